@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE ONLY — NumPy restatement of the Python front-ends that bracket the
+table ops in the reference (partition/stitch, unique/gather, sparse combiners, alltoall
+routing).  PY = /root/reference/tensorflow_recommenders_addons/dynamic_embedding/python/ops
+"""
+import numpy as np
+
+
+def default_partition_fn(keys, shard_num, gpu_mode=True):
+  """PY/dynamic_embedding_variable.py:165-197.  int64 keys on CUDA builds:
+  ``int32(key & 0x7fffffff) % N``; otherwise ``key % N`` (floor mod, like tf.math.mod)."""
+  keys = np.asarray(keys, dtype=np.int64)
+  if shard_num <= 1:
+    return np.zeros(keys.shape, dtype=np.int32)
+  if gpu_mode:
+    return ((keys & 0x7FFFFFFF).astype(np.int32) % np.int32(shard_num)).astype(np.int32)
+  return np.mod(keys, shard_num).astype(np.int32)
+
+
+def dynamic_partition(data, partitions, num):
+  """tf.dynamic_partition: stable split of rows by partition id."""
+  data = np.asarray(data)
+  return [data[partitions == p] for p in range(num)]
+
+
+def make_partition(data, partition_index, shard_num):
+  """PY/dynamic_embedding_variable.py:131-154 -> (partitions, indices)."""
+  if shard_num <= 1:
+    return [np.asarray(data)], None
+  parts = dynamic_partition(data, partition_index, shard_num)
+  idx = dynamic_partition(np.arange(len(data)), partition_index, shard_num)
+  return parts, idx
+
+
+def dynamic_stitch(indices, values):
+  """tf.dynamic_stitch: out[indices[p][i]] = values[p][i]  (PY/..._variable.py:157-162)."""
+  n = sum(len(i) for i in indices)
+  tail = values[0].shape[1:]
+  out = np.zeros((n,) + tail, dtype=values[0].dtype)
+  for i, v in zip(indices, values):
+    out[i] = v
+  return out
+
+
+def unique(ids):
+  """tf.unique: y in order of first occurrence, idx such that y[idx] == ids."""
+  ids = np.asarray(ids).reshape(-1)
+  _, first, inv = np.unique(ids, return_index=True, return_inverse=True)
+  order = np.argsort(first, kind="stable")
+  rank = np.empty_like(order)
+  rank[order] = np.arange(order.size)
+  return ids[np.sort(first)], rank[inv].astype(np.int32)
+
+
+def embedding_lookup_unique(table, ids, defaults):
+  """PY/dynamic_embedding_ops.py:64-117: unique -> lookup -> gather -> reshape."""
+  ids = np.asarray(ids)
+  u, idx = unique(ids)
+  rows = table.find(u, defaults)
+  return rows[idx].reshape(ids.shape + (rows.shape[1],))
+
+
+def embedding_lookup_sparse(table, sp_indices_row, sp_values, defaults, combiner="mean",
+                            sp_weights=None, num_rows=None):
+  """PY/dynamic_embedding_ops.py:120-293: unique ids -> lookup -> (weights) ->
+  segment sum / mean / sqrtn over the sparse row ids (sorted segment ids)."""
+  seg = np.asarray(sp_indices_row, dtype=np.int64)
+  ids = np.asarray(sp_values, dtype=np.int64)
+  u, idx = unique(ids)
+  emb = table.find(u, defaults).astype(np.float32)[idx]
+  w = np.ones(len(ids), np.float32) if sp_weights is None else np.asarray(sp_weights, np.float32)
+  n = int(seg.max()) + 1 if num_rows is None else num_rows
+  out = np.zeros((n, emb.shape[1]), np.float32)
+  np.add.at(out, seg, emb * w[:, None])
+  if combiner == "sum":
+    return out
+  wsum = np.zeros(n, np.float32)
+  if combiner == "mean":
+    np.add.at(wsum, seg, w)
+  elif combiner == "sqrtn":
+    np.add.at(wsum, seg, w * w)
+    wsum = np.sqrt(wsum)
+  else:
+    raise ValueError("combiner must be one of 'mean', 'sqrtn' or 'sum'")
+  with np.errstate(invalid="ignore", divide="ignore"):
+    res = out / wsum[:, None]
+  res[wsum == 0] = 0  # empty segments stay zero rows
+  return res
+
+
+def sharded_lookup(tables, ids, defaults_fn, partition_fn=default_partition_fn):
+  """Variable.lookup over N shards: partition -> per-shard find -> stitch
+  (PY/dynamic_embedding_variable.py:933-986)."""
+  ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+  n = len(tables)
+  part = partition_fn(ids, n)
+  kp, ki = make_partition(ids, part, n)
+  vals = [tables[i].find(kp[i], defaults_fn(len(kp[i]))) for i in range(n)]
+  if n == 1:
+    return vals[0]
+  return dynamic_stitch(ki, vals)
+
+
+def alltoall_lookup_model(rank_tables, ids_per_rank, defaults, partition_fn=default_partition_fn):
+  """Single-process model of HvdVariable.__alltoall_embedding_lookup__
+  (PY/shadow_embedding_ops.py:397-447): every rank partitions its ids by owner, owners look
+  the ids up in their local shard, rows return to the asking rank in input order."""
+  world = len(rank_tables)
+  out = []
+  for r in range(world):
+    ids = np.asarray(ids_per_rank[r], dtype=np.int64).reshape(-1)
+    part = partition_fn(ids, world)
+    rows = np.zeros((ids.size, rank_tables[0].dim), dtype=rank_tables[0].dtype)
+    for owner in range(world):
+      sel = np.nonzero(part == owner)[0]
+      if sel.size:
+        rows[sel] = rank_tables[owner].find(ids[sel], defaults)
+    out.append(rows)
+  return out
