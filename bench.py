@@ -1,0 +1,302 @@
+"""bench.py — dynamic-embedding hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--keys N_KEYS] [--batch B]
+
+One "step" = one pass of the hot path over one batch of synthetic ids, configuration
+BASELINE.json configs[1] ("1xMI355X: 100M keys, dim=64 fp32, Zipf-1.2 batch=131072,
+lookup+insert+sparse-Adam"):
+
+    forward : embedding lookup of the B Zipf ids  (find, default fill fused)         -> [B,64]
+    backward: gradients [B,64] -> duplicate ids summed -> fused sparse Adam on the unique keys,
+              which is also the write-back/insert of the batch's keys (rows are [p|m|v])
+
+`value` = ids looked up AND written back per second (lookup+insert pairs/s), whole job.  Inputs
+(id batches, gradients) are resident in HBM before the timed region.  N>1: one process per GPU,
+tables sharded by key hash, ids/rows/grads routed with alltoall over RCCL (weak scaling: per-GPU
+keys and batch fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+DIM = 64
+ZIPF_S = 1.2
+SEED = 20250205
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+# ------------------------------------------------------------------ synthetic inputs
+def zipf_bounded(rng, size, n, s=ZIPF_S):
+  """Bounded Zipf(s) over ranks 1..n by rejection-inversion (Hormann & Derflinger 1996)."""
+  one_s = 1.0 - s
+
+  def h_int(x):
+    return (np.power(x, one_s) - 1.0) / one_s
+
+  def h_int_inv(y):
+    return np.power(1.0 + y * one_s, 1.0 / one_s)
+
+  def h(x):
+    return np.power(x, -s)
+
+  hx1 = h_int(1.5) - 1.0
+  hn = h_int(n + 0.5)
+  sc = 2.0 - h_int_inv(h_int(2.5) - h(2.0))
+  out = np.empty(size, dtype=np.int64)
+  todo = np.arange(size)
+  while todo.size:
+    u = hn + rng.random(todo.size) * (hx1 - hn)
+    x = h_int_inv(u)
+    k = np.clip(np.floor(x + 0.5), 1, n)
+    ok = (k - x <= sc) | (u >= h_int(k + 0.5) - h(k))
+    out[todo[ok]] = k[ok].astype(np.int64)
+    todo = todo[~ok]
+  return out
+
+
+def fmix64_np(x):
+  x = x.astype(np.uint64)
+  x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd)
+  x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53)
+  x ^= x >> np.uint64(33)
+  return x
+
+
+def keys_of_ranks(ranks):
+  """Bijective scramble rank -> int64 key so hot keys are not adjacent."""
+  with np.errstate(over="ignore"):
+    return fmix64_np(ranks.astype(np.uint64) ^ np.uint64(SEED)).view(np.int64)
+
+
+def keys_of_ranks_torch(torch, ranks):
+  """Same scramble on the device (int64 two's-complement arithmetic, logical shifts emulated)."""
+  def lsr33(v):
+    return (v >> 33) & 0x7FFFFFFF
+  x = ranks ^ SEED
+  x = x ^ lsr33(x)
+  x = x * (-49064778989728563)        # 0xff51afd7ed558ccd as int64
+  x = x ^ lsr33(x)
+  x = x * (-4265267296055464877)      # 0xc4ceb9fe1a85ec53 as int64
+  x = x ^ lsr33(x)
+  return x
+
+
+# ------------------------------------------------------------------ CPU baseline (reference engine)
+def cpu_baseline(batch, budget_s=15.0):
+  """The reference's CPU path timed on this box's host cores: cuckoohash_map.hh (oracle/_ref,
+  compiled in place from the reference) driven through the reference's write-back sequence
+  (PY/dynamic_embedding_optimizer.py:165-204): unique -> 3 finds -> dense Adam -> 3 upserts."""
+  import oracle
+  from oracle import optimizers as oopt
+  kind = "reference" if oracle.available("reference") else "port"
+  cores = os.cpu_count() or 1
+  threads = cores if kind == "reference" else 1
+  n_keys = 4_000_000
+  rng = np.random.default_rng(SEED)
+  tabs = [oracle.CpuTable(DIM, np.float32, kind=kind, init_size=n_keys, threads=threads) for _ in range(3)]
+  chunk = 500_000
+  for lo in range(1, n_keys + 1, chunk):
+    r = np.arange(lo, min(n_keys, lo + chunk - 1) + 1, dtype=np.int64)
+    k = keys_of_ranks(r)
+    tabs[0].insert(k, (rng.standard_normal((k.size, DIM)) * 0.01).astype(np.float32))
+    z = np.zeros((k.size, DIM), np.float32)
+    tabs[1].insert(k, z); tabs[2].insert(k, z)
+  grads = (rng.standard_normal((batch, DIM)) * 0.01).astype(np.float32)
+  zero = np.zeros(DIM, np.float32)
+  done, t_total, step = 0, 0.0, 0
+  while t_total < budget_s and step < 200:
+    ids = keys_of_ranks(zipf_bounded(rng, batch, n_keys))
+    t0 = time.perf_counter()
+    uniq, idx = np.unique(ids, return_inverse=True)
+    g = np.zeros((uniq.size, DIM), np.float32)
+    np.add.at(g, idx, grads)
+    p = tabs[0].find(uniq, zero); m = tabs[1].find(uniq, zero); v = tabs[2].find(uniq, zero)
+    step += 1
+    p, m, v = oopt.adam(p, m, v, g, 1e-3, 0.9, 0.999, 1e-8, step)
+    tabs[0].insert(uniq, p); tabs[1].insert(uniq, m); tabs[2].insert(uniq, v)
+    t_total += time.perf_counter() - t0
+    done += batch
+  return {
+      "value": done / t_total, "unit": "lookup+insert pairs/s", "cores": threads, "kind": kind,
+      "sample": "%d steps of batch %d (Zipf-1.2 over %d resident keys, dim 64 fp32, unique->3 finds->numpy Adam->3 "
+                "upserts, %.1f s of CPU work)" % (step, batch, n_keys, t_total),
+  }
+
+
+# ------------------------------------------------------------------ main
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--keys", type=int, default=100_000_000, help="resident keys PER GPU")
+  ap.add_argument("--batch", type=int, default=131072, help="ids per GPU per step")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.gpus > 1 or world > 1:
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+  dev = torch.device("cuda", local_rank)
+  torch.cuda.set_device(dev)
+  B, K, W = args.batch, args.steps, args.warmup
+  n_local = args.keys
+  n_total = n_local * world
+
+  # ---- table: rows [p|m|v] co-located, sized so that no rehash happens -------------------------
+  opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=n_local,
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  emb = AllToAllEmbedding(var, partition_mode=0) if world > 1 else None
+  table = var.tables[0]
+
+  # ---- pre-fill: every key this rank owns (ranks 1..n_total, owner = default_partition_fn) ------
+  gen = torch.Generator(device=dev).manual_seed(SEED + rank)
+  chunk = 4_000_000
+  t_fill = time.perf_counter()
+  for lo in range(1, n_total + 1, chunk):
+    r = torch.arange(lo, min(n_total, lo + chunk - 1) + 1, dtype=torch.int64, device=dev)
+    k = keys_of_ranks_torch(torch, r)
+    if world > 1:
+      k = k[((k & 0x7FFFFFFF) % world) == rank]
+    v = torch.randn((k.numel(), DIM), generator=gen, device=dev) * 0.01
+    table._table.upsert(k, v, unique_keys=True)
+  resident = int(table.size().item())
+  t_fill = time.perf_counter() - t_fill
+
+  # ---- inputs resident in HBM: all id batches + one gradient buffer -----------------------------
+  rng = np.random.default_rng(SEED + 1000 * rank)
+  ids_np = keys_of_ranks(zipf_bounded(rng, (K + W) * B, n_total)).reshape(K + W, B)
+  ids_all = torch.from_numpy(ids_np).to(dev)
+  uniq_ratio = float(np.mean([np.unique(ids_np[i]).size / B for i in range(min(8, K + W))]))
+  grads = torch.randn((B, DIM), generator=gen, device=dev) * 0.01
+
+  ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+  ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+  ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+
+  def step(i, timed_idx=None):
+    ids = ids_all[i]
+    if timed_idx is not None:
+      ev_a[timed_idx].record()
+    if emb is None:
+      out = var.lookup(ids)
+    else:
+      out = emb.lookup(ids)
+    if timed_idx is not None:
+      ev_b[timed_idx].record()
+    if emb is None:
+      deo.apply_sparse(var, ids, grads)
+    else:
+      emb.apply_gradients(deo, grads)
+    if timed_idx is not None:
+      ev_c[timed_idx].record()
+    return out
+
+  for i in range(W):
+    step(i)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(K):
+    step(W + i, i)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  fwd_ms = float(np.mean([ev_a[i].elapsed_time(ev_b[i]) for i in range(K)]))
+  bwd_ms = float(np.mean([ev_b[i].elapsed_time(ev_c[i]) for i in range(K)]))
+
+  # ---- dominant-kernel roofline: find kernel alone, HIP events around back-to-back launches ------
+  # algorithmic bytes per lookup = 8 (key) + Rb (row read) + Rb (out write) = 520 B at dim 64 fp32
+  # (SURVEY.md §8d); one launch processes B ids.
+  reps = 50
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  ids0 = ids_all[W]
+  for _ in range(5):
+    table.lookup(ids0)
+  e0.record()
+  for _ in range(reps):
+    table.lookup(ids0)
+  e1.record()
+  torch.cuda.synchronize()
+  find_us = e0.elapsed_time(e1) * 1e3 / reps
+  find_bytes = B * (8 + 2 * DIM * 4)
+  # the fused optimizer kernel alone on the batch's unique keys: 8 + 7*Rb = 1800 B per unique key
+  uniq, idx, cnt = de.device_ops.unique(ids0)
+  gsum = torch.randn((uniq.numel(), DIM), generator=gen, device=dev) * 0.01
+  p = opt.params(1)
+  for _ in range(5):
+    table._table.apply_optimizer(p, uniq, gsum, table._default_value)
+  e0.record()
+  for _ in range(reps):
+    table._table.apply_optimizer(p, uniq, gsum, table._default_value)
+  e1.record()
+  torch.cuda.synchronize()
+  apply_us = e0.elapsed_time(e1) * 1e3 / reps
+  apply_bytes = uniq.numel() * (8 + 7 * DIM * 4)
+
+  if rank == 0:
+    ms = elapsed / K * 1e3
+    value = world * B * K / elapsed
+    ach = find_bytes / (find_us * 1e-6) / 1e9
+    res = {
+        "metric": "embedding lookup+insert pairs/s (dim=64 fp32, Zipf-1.2, lookup + sparse-Adam write-back)",
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: %d resident keys/GPU (%d total), dim=64 fp32 rows [p|m|v], Zipf-1.2 "
+                        "batch=%d/GPU, lookup + dedup + fused sparse Adam (insert/write-back)" % (resident, n_total, B),
+            "global_batch": B * world, "keys_per_gpu": resident, "unique_ratio": round(uniq_ratio, 4),
+            "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
+            "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "find_kernel<16,4>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
+        },
+        "phases": {
+            "forward_ms": fwd_ms, "backward_ms": bwd_ms,
+            "apply_kernel": {"avg_launch_us": apply_us, "algorithmic_bytes_per_launch": apply_bytes,
+                             "achieved_GBps": apply_bytes / (apply_us * 1e-6) / 1e9, "unique_keys": int(uniq.numel())},
+        },
+    }
+    if not args.no_cpu_baseline:
+      res["cpu_baseline"] = cpu_baseline(B)
+    print(json.dumps(res))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

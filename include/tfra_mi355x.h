@@ -1,0 +1,225 @@
+/* tfra_mi355x.h — C ABI of the MI355X-native dynamic-embedding table engine.
+ *
+ * This is the drop-in boundary: exactly the surface TFRA's GPU adapter
+ * (`gpu::TableWrapper<K,V>`) needs from its storage engine, plus the fused extras that
+ * replace multi-op sequences of the reference.  Plain pointers and sizes only; all device
+ * pointers are HIP device pointers on the table's device; `stream` is a `hipStream_t`
+ * passed as `void*`.  Every entry point returns 0 on success or a negative tfra_status and
+ * never throws; `tfra_last_error()` returns a thread-local message.  All table operations
+ * are STREAM-ORDERED and do not synchronise the host unless documented.
+ *
+ * Reference files (R = /root/reference/tensorflow_recommenders_addons/dynamic_embedding/core):
+ *   R/kernels/lookup_impl/lookup_table_op_hkv.h   gpu::TableWrapper  (what calls the engine)
+ *   R/kernels/hkv_hashtable_op_gpu.cu.cc          HkvHashTableOfTensorsGpu (TF op kernels)
+ *   R/kernels/cuckoo_hashtable_op.cc              CuckooHashTableOfTensors (CPU semantics =
+ *                                                 the result oracle)
+ *   R/ops/hkv_hashtable_ops.cc                    op names / attrs
+ */
+#ifndef TFRA_MI355X_H_
+#define TFRA_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFRA_ABI_VERSION 1
+
+typedef struct tfra_table tfra_table_t;
+typedef void* tfra_stream_t; /* hipStream_t */
+
+typedef enum {
+  TFRA_OK = 0,
+  TFRA_ERR_INVALID = -1,   /* bad argument / shape / dtype (TF: InvalidArgument)          */
+  TFRA_ERR_OOM = -2,       /* allocation failed                                            */
+  TFRA_ERR_HIP = -3,       /* HIP runtime error (TF: Internal)                             */
+  TFRA_ERR_FULL = -4,      /* table at max_capacity and key could not be placed            */
+  TFRA_ERR_IO = -5,        /* KV-file save/load failed                                     */
+  TFRA_ERR_UNSUPPORTED = -6
+} tfra_status;
+
+/* value dtypes registered for the GPU ops: K=int64 x V in {float, int8, int32, int64, half,
+ * bfloat16} (R/kernels/hkv_hashtable_op_gpu.cu.cc:1133-1138); double is the CPU table's extra
+ * (R/kernels/cuckoo_hashtable_op.cc:995-1014). */
+typedef enum {
+  TFRA_F32 = 0, TFRA_F16 = 1, TFRA_BF16 = 2, TFRA_I8 = 3, TFRA_I32 = 4, TFRA_I64 = 5, TFRA_F64 = 6
+} tfra_dtype;
+
+/* eviction strategy enum 0..4 as in R/kernels/lookup_impl/lookup_table_op_hkv.h:454-475 and
+ * PY/dynamic_embedding_creator.py:141-146; -1 = never evict (libcuckoo semantics: grow). */
+typedef enum {
+  TFRA_EVICT_NONE = -1, TFRA_EVICT_LRU = 0, TFRA_EVICT_LFU = 1, TFRA_EVICT_EPOCHLRU = 2,
+  TFRA_EVICT_EPOCHLFU = 3, TFRA_EVICT_CUSTOMIZED = 4
+} tfra_evict_strategy;
+
+/* Mirrors TableWrapperInitOptions (R/kernels/lookup_impl/lookup_table_op_hkv.h:304-315) and
+ * the creator-op attrs (R/ops/hkv_hashtable_ops.cc:318-339).  POD, versioned by struct_size. */
+typedef struct {
+  uint32_t struct_size;           /* = sizeof(tfra_table_opts)                               */
+  int32_t value_dtype;            /* tfra_dtype                                              */
+  int32_t dim;                    /* value_shape[0]                                          */
+  int32_t aux_fields;             /* S co-located per-key state vectors of `dim` elements
+                                     (optimizer slots m,v / accum,linear); 0 for a plain table */
+  uint64_t init_capacity;         /* attr init_capacity / init_size; 0 -> 1 Mi
+                                     (hkv_hashtable_op_gpu.cu.cc:53) or 8192 for cuckoo flavour */
+  uint64_t max_capacity;          /* attr max_capacity; 0 = unbounded (libcuckoo flavour)   */
+  uint64_t max_hbm_for_vectors;   /* accepted for attr parity; this engine is pure-HBM       */
+  float max_load_factor;          /* growth trigger; 0 -> 0.5 like lookup_table_op_hkv.h:449
+                                     when max_capacity>0, 0.75 for the unbounded flavour     */
+  int32_t strategy;               /* tfra_evict_strategy                                     */
+  int64_t step_per_epoch;         /* EPOCH* strategies (lookup_table_op_hkv.h:528-536)       */
+  int32_t reserved_key_start_bit; /* accepted for attr parity: this engine stores EVERY int64
+                                     key (libcuckoo parity), nothing is reserved             */
+  int32_t device;                 /* HIP device ordinal; -1 = current                        */
+  float aux_init[4];              /* initial value of aux field f for a newly inserted key   */
+} tfra_table_opts;
+
+/* Allocation bridge = TFOrDefaultAllocator (lookup_table_op_hkv.h:329-426): lets the host
+ * framework own the bytes.  NULL -> hipMalloc/hipFree. kind: 0 device, 1 pinned host, 2 host. */
+typedef struct {
+  void* (*alloc)(void* user, int kind, size_t bytes, tfra_stream_t stream);
+  void (*free)(void* user, int kind, void* ptr, tfra_stream_t stream);
+  void* user;
+} tfra_allocator;
+
+/* flags for insert / accum */
+#define TFRA_FLAG_UNIQUE_KEYS 1u /* caller guarantees no duplicate keys in this call (HKV's
+                                    contract, PY/dynamic_embedding_variable.py:1377-1378):
+                                    single-pass fast path. Without it duplicates resolve like the
+                                    single-threaded reference: the LAST occurrence wins.        */
+
+const char* tfra_last_error(void);
+int tfra_abi_version(void);
+
+/* -- lifetime: HashTableGpuOp / ResourceMgr own one handle per (shard, variable)
+ *    (R/kernels/cuckoo_hashtable_op_gpu.h:43-139); init = lookup_table_op_hkv.h:435-520 ------ */
+int tfra_table_create(const tfra_table_opts* opts, const tfra_allocator* alloc, tfra_table_t** out);
+int tfra_table_destroy(tfra_table_t* t);
+
+/* -- find = TableWrapper::get (lookup_table_op_hkv.h:719-732) with the default pre-fill FUSED:
+ *    values[i,:] = hit ? row : (default_is_full ? defaults[i,:] : defaults[0,:]);
+ *    exists[i] (may be NULL) = hit.  Duplicate keys allowed.  Never inserts.
+ *    Result oracle: TableWrapperOptimized::find (lookup_table_op_cpu.h:188-217).           */
+int tfra_table_find(tfra_table_t* t, size_t n, const int64_t* keys, void* values, uint8_t* exists,
+                    const void* defaults, int default_is_full, tfra_stream_t stream);
+
+/* -- insert_or_assign = TableWrapper::upsert (lookup_table_op_hkv.h:522-537); scores NULL or
+ *    [n] (HkvHashTableInsert's `scores` input, empty tensor -> NULL).  Advances the epoch
+ *    counter for EPOCH* strategies.  Oracle: LaunchTensorsInsert (cuckoo_hashtable_op.cc:111). */
+int tfra_table_insert_or_assign(tfra_table_t* t, size_t n, const int64_t* keys, const void* values,
+                                const uint64_t* scores, uint32_t flags, tfra_stream_t stream);
+
+/* -- accum_or_assign = TableWrapper::accum (lookup_table_op_hkv.h:539-546):
+ *    absent & !exists -> insert row; present & exists -> row += delta (element order 0..dim-1,
+ *    one add each); otherwise no-op.  Oracle: accumrase_fn (lib/cuckoo/cuckoohash_map.hh:619). */
+int tfra_table_accum_or_assign(tfra_table_t* t, size_t n, const int64_t* keys,
+                               const void* values_or_deltas, const uint8_t* exists,
+                               const uint64_t* scores, uint32_t flags, tfra_stream_t stream);
+
+/* -- erase / clear / size / capacity (lookup_table_op_hkv.h:745-756) ---------------------- */
+int tfra_table_erase(tfra_table_t* t, size_t n, const int64_t* keys, tfra_stream_t stream);
+int tfra_table_clear(tfra_table_t* t, tfra_stream_t stream);
+/* host result: synchronises `stream` (HkvHashTableOfTensorsGpu::size, :162-170) */
+int tfra_table_size(tfra_table_t* t, size_t* out, tfra_stream_t stream);
+/* device scalar result, no host sync (size_i64, :172-179) */
+int tfra_table_size_to_device(tfra_table_t* t, int64_t* d_out, tfra_stream_t stream);
+/* number of slots export_batch scans (= value to loop `offset` up to) */
+int tfra_table_capacity(tfra_table_t* t, size_t* out);
+/* grow (rehash) so that at least `min_slots` slots exist; no-op if already that large */
+int tfra_table_reserve(tfra_table_t* t, size_t min_slots, tfra_stream_t stream);
+
+/* -- export_batch(n, offset, d_counter, keys, values, scores) (lookup_table_op_hkv.h:548-594):
+ *    scans slots [offset, offset+n) and appends live (key, row[, score]) triples at
+ *    *d_counter (device size_t, caller zeroes it), order unspecified.  values/scores may be
+ *    NULL.  Output buffers must hold every live entry of the range.                        */
+int tfra_table_export_batch(tfra_table_t* t, size_t n, size_t offset, size_t* d_counter,
+                            int64_t* keys, void* values, uint64_t* scores, tfra_stream_t stream);
+
+/* -- set_global_epoch (lookup_table_op_hkv.h:499,507,533) --------------------------------- */
+int tfra_table_set_global_epoch(tfra_table_t* t, uint64_t epoch);
+
+/* -- KV files: <prefix>-keys (raw int64[]) and <prefix>-values (raw V[n*dim]), native endian
+ *    (cuckoo_hashtable_op.cc:310-505; lookup_table_op_hkv.h:602-717).  buffer_keys = keys per
+ *    I/O chunk.  load does NOT clear (the GPU op clears first, the CPU op does not).       */
+int tfra_table_save(tfra_table_t* t, const char* prefix, size_t buffer_keys, int append,
+                    tfra_stream_t stream, size_t* n_saved);
+int tfra_table_load(tfra_table_t* t, const char* prefix, size_t buffer_keys, tfra_stream_t stream,
+                    size_t* n_loaded);
+
+/* ============================ fused extras (beyond HKV's surface) ========================= */
+
+/* Field access for tables created with aux_fields > 0: same as find / insert_or_assign but on
+ * state vector `field` (0 = the embedding itself).  Lets `<param>/<opt>/<slot>` variables of
+ * create_slots (PY/dynamic_embedding_optimizer.py:870-958) be views of one physical table.   */
+int tfra_table_find_field(tfra_table_t* t, int field, size_t n, const int64_t* keys, void* values,
+                          uint8_t* exists, const void* defaults, int default_is_full,
+                          tfra_stream_t stream);
+int tfra_table_insert_field(tfra_table_t* t, int field, size_t n, const int64_t* keys,
+                            const void* values, uint32_t flags, tfra_stream_t stream);
+
+/* Fused sparse optimizer write-back: replaces (1+S) finds + dense apply + (1+S) upserts
+ * (PY/dynamic_embedding_optimizer.py:165-204) with one pass over rows laid out [p|slot..].
+ * keys [n] UNIQUE (use tfra_segment_sum first), grads [n,dim] fp32.  Missing keys are inserted
+ * with p = param_defaults (full [n,dim] or broadcast [dim], like find) and slots = aux_init.
+ * Requires value_dtype F32 and aux_fields >= the optimizer's slot count.                     */
+typedef enum { TFRA_OPT_SGD = 0, TFRA_OPT_ADAM = 1, TFRA_OPT_ADAGRAD = 2, TFRA_OPT_FTRL = 3 } tfra_opt_kind;
+typedef struct {
+  int32_t kind;     /* tfra_opt_kind */
+  float lr;         /* Adam: pass lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host (global step) */
+  float beta1, beta2, eps;          /* Adam; Adagrad: eps<0 -> TF1 rule (no eps)             */
+  float l1, l2, lr_power;           /* FTRL                                                  */
+} tfra_opt_params;
+/* d_n: optional DEVICE int64 scalar; when non-NULL only the first min(n, *d_n) keys are applied,
+ * so a caller can chain tfra_unique -> tfra_segment_sum -> apply without reading the unique count
+ * on the host (n is then the buffer length). */
+int tfra_table_apply_optimizer(tfra_table_t* t, const tfra_opt_params* p, size_t n,
+                               const int64_t* keys, const float* grads, const void* param_defaults,
+                               int default_is_full, const int64_t* d_n, tfra_stream_t stream);
+
+/* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
+
+/* Scratch for unique/partition; grows on demand, reusable across calls on one stream. */
+typedef struct tfra_workspace tfra_workspace_t;
+int tfra_workspace_create(int device, tfra_workspace_t** out);
+int tfra_workspace_destroy(tfra_workspace_t* ws);
+
+/* tf.unique: unique_out[0..*d_num_unique) in order of first occurrence, idx_out[i] = position of
+ * ids[i] in unique_out (PY/dynamic_embedding_ops.py:99; PY/shadow_embedding_ops.py:316).
+ * d_num_unique is a device int64 scalar (no host sync). */
+int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* unique_out,
+                int32_t* idx_out, int64_t* d_num_unique, tfra_stream_t stream);
+
+/* out[idx[i],:] += in[i,:] in index order per segment is NOT guaranteed; sums are accumulated in
+ * fp32 with a fixed tree per segment => deterministic. out is [num_segments, dim], zeroed here. */
+int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, const int32_t* idx,
+                     const int64_t* d_num_segments, size_t max_segments, float* out,
+                     tfra_stream_t stream);
+
+/* out[i,:] = rows[idx[i],:] (tf.gather after unique). row_bytes = dim*sizeof(V). */
+int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out,
+                     tfra_stream_t stream);
+
+/* default_partition_fn (PY/dynamic_embedding_variable.py:165-197) + dynamic_partition in one
+ * pass: owner[i] = mode 0: (key & 0x7fffffff) % num_shards (CUDA-build branch)
+ *                  mode 1: floor_mod(key, num_shards)       (CPU-build branch)
+ *                  mode 2: fmix64(key) % num_shards         (opt-in, Zipf-balanced)
+ * Produces owner-major keys_out, perm_out (original index of each output element, i.e. the
+ * dynamic_partition of range(n)) and d_counts[num_shards] (device int64).                 */
+int tfra_partition(tfra_workspace_t* ws, size_t n, const int64_t* keys, int num_shards, int mode,
+                   int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream);
+
+/* Same, for a caller-computed owner[i] in [0,num_shards) (custom `partitioner=` functions,
+ * PY/dynamic_embedding_variable.py:484-500): only perm_out and d_counts are produced. */
+int tfra_partition_by_owner(tfra_workspace_t* ws, size_t n, const int32_t* owner, int num_shards,
+                            int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream);
+
+/* dynamic_stitch for one flat permutation: out[perm[i],:] = in[i,:]. */
+int tfra_scatter_rows(size_t n, size_t row_bytes, const void* in, const int32_t* perm, void* out,
+                      tfra_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFRA_MI355X_H_ */

@@ -1,0 +1,179 @@
+// Device-side layout and probe primitives of the MI355X dynamic-embedding table.
+//
+// Layout in HBM:
+//   keys   : nb buckets x 16 x int64.  One bucket = ONE 128-byte line = 15 key slots + 1
+//            meta word (bit0 = OVERFLOW: some key whose probe sequence passes through this
+//            bucket was placed further along).  A probe is one coalesced 128-B read by the 16
+//            lanes of a key group; 4 key groups per wave64.
+//   rows   : (nb*15 + 2) rows x row_stride bytes, row_stride = 16-B multiple of
+//            (1+aux_fields)*dim*sizeof(V): [embedding | slot1 | slot2 ...] co-located so a fused
+//            optimizer touches one contiguous segment.  Last 2 rows = side store for the two
+//            key values used as sentinels.
+//   scores : nb x 16 x uint64 (optional, eviction strategies only), same indexing as keys.
+//
+// Probe sequence of key k: b0 = mulhi(fmix64(k), nb); b1 = mulhi(fmix64(h^C), nb) (!= b0);
+// then b1+1, b1+2, ... (mod nb).  First-fit insertion + the monotone OVERFLOW flag mean a find
+// stops at the first bucket that holds the key or is not flagged: 1 line for nearly every
+// key at load factor <= 0.5, no tombstones (erase simply empties the slot).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfra {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+constexpr i64 EMPTY_KEY = (i64)0x8000000000000000ULL;   // INT64_MIN
+constexpr i64 LOCKED_KEY = (i64)0x8000000000000001ULL;  // slot being replaced (eviction)
+constexpr int SLOTS = 15;                               // key slots per 128-B bucket line
+constexpr int NUM_RESERVED = 2;                         // side rows for EMPTY_KEY / LOCKED_KEY
+constexpr u64 META_OVERFLOW = 1ULL;
+constexpr int SIZE_SHARDS = 256;       // size counter sharded over 256 lines (one per channel-ish)
+constexpr int SIZE_SHARD_STRIDE = 16;  // u64 words between shards (128 B)
+
+struct TableView {
+  i64* keys;
+  unsigned char* rows;
+  u64* scores;
+  u64 nb;
+  unsigned field_bytes;  // dim*sizeof(V)
+  unsigned row_stride;   // bytes between rows
+  unsigned n_fields;     // 1 + aux_fields
+  unsigned* reserved_present;  // [NUM_RESERVED]
+  u64* size_shards;            // [SIZE_SHARDS*SIZE_SHARD_STRIDE], wrapping signed deltas
+  int* winner;                 // [nb*15+2] scratch for duplicate resolution (may be null)
+  unsigned* err_count;         // keys that could not be placed (table full)
+};
+
+__device__ __forceinline__ u64 fmix64(u64 k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+__device__ __forceinline__ u64 bucket0(i64 key, u64 nb, u64& h) {
+  h = fmix64((u64)key);
+  return __umul64hi(h, nb);
+}
+__device__ __forceinline__ u64 bucket1(u64 h, u64 b0, u64 nb) {
+  u64 b1 = __umul64hi(fmix64(h ^ 0x9e3779b97f4a7c15ULL), nb);
+  if (b1 == b0) b1 = (b0 + 1 == nb) ? 0 : b0 + 1;
+  return b1;
+}
+__device__ __forceinline__ u64 next_bucket(u64 b, u64 nb) { return (b + 1 == nb) ? 0 : b + 1; }
+__device__ __forceinline__ bool is_reserved_key(i64 k) { return k <= LOCKED_KEY; }
+__device__ __forceinline__ int reserved_index(i64 k) { return (int)(k - EMPTY_KEY); }
+
+// Keys are read with agent-scope relaxed atomics (sc1: served by L2, never a stale L1 line) in
+// every kernel that can race with slot claims of the same launch.
+__device__ __forceinline__ i64 load_key_coherent(const i64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ i64 shfl_i64(i64 v, int src) {
+  int lo = __shfl((int)(u64)v, src), hi = __shfl((int)((u64)v >> 32), src);
+  return (i64)(((u64)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// ---- find: continue a probe whose first line `k` (bucket b) is already in registers --------
+// Returns the row index (b*15+slot) or -1.  All 16 lanes of the group call with the same key.
+template <bool COHERENT>
+__device__ __forceinline__ i64 probe_find_from(const TableView& v, i64 key, u64 h, u64 b, i64 k,
+                                               int sub, int gshift) {
+  if (is_reserved_key(key)) {
+    int r = reserved_index(key);
+    return v.reserved_present[r] ? (i64)(v.nb * SLOTS + r) : -1;
+  }
+  u64 b1 = bucket1(h, b, v.nb);
+  for (u64 step = 0;; ++step) {
+    u64 m = __ballot(sub < SLOTS && k == key);
+    unsigned hit = (unsigned)(m >> gshift) & 0x7fffu;
+    if (hit) return (i64)(b * SLOTS + (__ffs(hit) - 1));
+    i64 meta = shfl_i64(k, gshift + 15);
+    if (!((u64)meta & META_OVERFLOW) || step >= v.nb) return -1;
+    b = (step == 0) ? b1 : next_bucket(b, v.nb);
+    k = COHERENT ? load_key_coherent(&v.keys[b * 16 + sub]) : v.keys[b * 16 + sub];
+  }
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, int gshift) {
+  u64 h;
+  u64 b = bucket0(key, v.nb, h);
+  i64 k = COHERENT ? load_key_coherent(&v.keys[b * 16 + sub]) : v.keys[b * 16 + sub];
+  return probe_find_from<COHERENT>(v, key, h, b, k, sub, gshift);
+}
+
+// ---- insert: find the key or claim the FIRST empty slot of its probe sequence -------------
+// Within one launch slots only go EMPTY -> key, and every inserter takes the first empty slot
+// in probe order with a CAS, so two groups inserting the same key can never end up in two
+// different slots.  Returns row index, or -1 when no slot could be found.
+__device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int sub, int gshift,
+                                               bool& is_new) {
+  is_new = false;
+  if (is_reserved_key(key)) {
+    int r = reserved_index(key);
+    unsigned old = 0;
+    if (sub == 0) old = atomicExch(&v.reserved_present[r], 1u);
+    old = __shfl(old, gshift);
+    is_new = (old == 0);
+    return (i64)(v.nb * SLOTS + r);
+  }
+  u64 h;
+  const u64 b0 = bucket0(key, v.nb, h);
+  const u64 b1 = bucket1(h, b0, v.nb);
+  for (int attempt = 0; attempt < 1024; ++attempt) {
+    u64 b = b0;
+    i64 fe = -1;  // word index (b*16+slot) of the first empty slot seen
+    for (u64 step = 0; step <= v.nb; ++step) {
+      i64 k = load_key_coherent(&v.keys[b * 16 + sub]);
+      u64 m = __ballot(sub < SLOTS && k == key);
+      unsigned hit = (unsigned)(m >> gshift) & 0x7fffu;
+      if (hit) return (i64)(b * SLOTS + (__ffs(hit) - 1));
+      u64 e = __ballot(sub < SLOTS && k == EMPTY_KEY);
+      unsigned emp = (unsigned)(e >> gshift) & 0x7fffu;
+      if (fe < 0 && emp) fe = (i64)(b * 16 + (__ffs(emp) - 1));
+      i64 meta = shfl_i64(k, gshift + 15);
+      if (!((u64)meta & META_OVERFLOW)) {
+        if (fe >= 0) break;  // the key cannot live further along; claim the first empty slot
+        // bucket full and never overflowed: extend the chain through it
+        if (sub == 15) atomicOr((u64*)&v.keys[b * 16 + 15], META_OVERFLOW);
+      }
+      b = (step == 0) ? b1 : next_bucket(b, v.nb);
+    }
+    if (fe < 0) return -1;
+    i64 old = 0;
+    if (sub == 0) old = (i64)atomicCAS((u64*)&v.keys[fe], (u64)EMPTY_KEY, (u64)key);
+    old = shfl_i64(old, gshift);
+    u64 bb = (u64)fe >> 4;
+    i64 row = (i64)(bb * SLOTS + ((u64)fe & 15));
+    if (old == EMPTY_KEY) { is_new = true; return row; }
+    if (old == key) return row;  // an identical key won the race for this very slot
+    // another key took it: rescan
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void size_add(const TableView& v, u64 wave_id, long long delta) {
+  atomicAdd(&v.size_shards[(wave_id % SIZE_SHARDS) * SIZE_SHARD_STRIDE], (u64)delta);
+}
+
+// ---- row movement: G = copy granule in bytes (largest power of two <=16 dividing the row
+// bytes and every base pointer); 16 lanes move 16*G bytes per step, fully coalesced -----------
+template <int G> struct Granule;
+template <> struct Granule<16> { typedef uint4 T; };
+template <> struct Granule<8> { typedef uint2 T; };
+template <> struct Granule<4> { typedef unsigned T; };
+template <> struct Granule<2> { typedef unsigned short T; };
+template <> struct Granule<1> { typedef unsigned char T; };
+
+template <int G>
+__device__ __forceinline__ void copy_bytes16(unsigned char* dst, const unsigned char* src,
+                                             unsigned bytes, int sub) {
+  typedef typename Granule<G>::T T;
+  for (unsigned off = sub * G; off < bytes; off += 16 * G)
+    *reinterpret_cast<T*>(dst + off) = *reinterpret_cast<const T*>(src + off);
+}
+
+}  // namespace tfra

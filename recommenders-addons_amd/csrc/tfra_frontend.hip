@@ -1,0 +1,486 @@
+// Front-end helpers that bracket the table ops in the reference:
+//   tfra_unique        tf.unique                      PY/dynamic_embedding_ops.py:99
+//   tfra_gather_rows   tf.gather(unique_rows, idx)    PY/dynamic_embedding_ops.py:111
+//   tfra_segment_sum   unsorted_segment_sum of grads  PY/dynamic_embedding_optimizer.py:177-190
+//   tfra_partition     default_partition_fn + dynamic_partition  PY/dynamic_embedding_variable.py:131-197
+//   tfra_scatter_rows  dynamic_stitch                 PY/dynamic_embedding_variable.py:157-162
+// All stream-ordered, counts stay on the device (no host sync), results deterministic.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/tfra_mi355x.h"
+#include "tfra_device.h"
+#include "tfra_host.h"
+
+using namespace tfra;
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return set_error(_e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP,                \
+                       std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+  } while (0)
+
+struct tfra_workspace {
+  int device = 0;
+  void* buf = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need, hipStream_t s) {
+    if (need <= bytes) return TFRA_OK;
+    if (buf) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(buf)); buf = nullptr; bytes = 0; }
+    size_t want = std::max(need, (size_t)1 << 20);
+    HIP_TRY(hipMalloc(&buf, want));
+    bytes = want;
+    return TFRA_OK;
+  }
+};
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// carve helper
+struct Carver {
+  unsigned char* p;
+  size_t used = 0;
+  template <class T> T* take(size_t n) {
+    T* r = reinterpret_cast<T*>(p + used);
+    used += align_up(n * sizeof(T));
+    return r;
+  }
+};
+
+// ------------------------------------ unique --------------------------------------------------
+constexpr int UNQ_ITEMS = 4;                   // contiguous ids per thread
+constexpr int UNQ_TILE = 256 * UNQ_ITEMS;      // ids per block
+
+__global__ void unq_fill_kernel(i64* hkeys, int* hfirst, size_t cap1) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap1; i += (size_t)gridDim.x * blockDim.x) {
+    hkeys[i] = EMPTY_KEY;
+    hfirst[i] = 0x7fffffff;
+  }
+}
+
+// scratch open-addressing set: CAS the id in, remember the smallest input index per distinct id
+__global__ void unq_insert_kernel(size_t n, const i64* __restrict__ ids, i64* hkeys, int* hfirst, int* slot_of,
+                                  size_t cap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  i64 id = ids[i];
+  size_t s;
+  if (id == EMPTY_KEY) {
+    s = cap;  // side slot for the sentinel value itself
+  } else {
+    s = fmix64((u64)id) & (cap - 1);
+    for (;;) {
+      i64 cur = load_key_coherent(&hkeys[s]);
+      if (cur == id) break;
+      if (cur == EMPTY_KEY) {
+        i64 old = (i64)atomicCAS((u64*)&hkeys[s], (u64)EMPTY_KEY, (u64)id);
+        if (old == EMPTY_KEY || old == id) break;
+      }
+      s = (s + 1) & (cap - 1);
+    }
+  }
+  atomicMin(&hfirst[s], (int)i);
+  slot_of[i] = (int)s;
+}
+
+__device__ __forceinline__ int block_sum_256(int v, int* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void unq_count_kernel(size_t n, const int* __restrict__ hfirst,
+                                                        const int* __restrict__ slot_of, int* block_counts) {
+  __shared__ int sh[4];
+  size_t base = (size_t)blockIdx.x * UNQ_TILE + threadIdx.x * UNQ_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < UNQ_ITEMS; ++k) {
+    size_t i = base + k;
+    if (i < n) c += hfirst[slot_of[i]] == (int)i;
+  }
+  int t = block_sum_256(c, sh);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = t;
+}
+
+// single-block exclusive scan of per-tile counts (in place) + grand total
+__global__ __launch_bounds__(1024) void scan_counts_kernel(int* counts, size_t m, i64* total_out) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < m; base += 1024) {
+    size_t i = base + threadIdx.x;
+    int v = i < m ? counts[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    int incl = sh[threadIdx.x];
+    if (i < m) counts[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void unq_scatter_kernel(size_t n, const i64* __restrict__ ids,
+                                                          const int* __restrict__ hfirst, const int* __restrict__ slot_of,
+                                                          const int* __restrict__ block_off, i64* unique_out, int* hrank) {
+  __shared__ int wsum[4];
+  size_t base = (size_t)blockIdx.x * UNQ_TILE + threadIdx.x * UNQ_ITEMS;
+  int flag[UNQ_ITEMS], c = 0;
+#pragma unroll
+  for (int k = 0; k < UNQ_ITEMS; ++k) {
+    size_t i = base + k;
+    flag[k] = (i < n) && hfirst[slot_of[i]] == (int)i;
+    c += flag[k];
+  }
+  // exclusive scan of c over the block in thread order (= input order)
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6, incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int k = 0; k < w; ++k) woff += wsum[k];
+  int pos = block_off[blockIdx.x] + woff + incl - c;
+#pragma unroll
+  for (int k = 0; k < UNQ_ITEMS; ++k) {
+    if (flag[k]) {
+      size_t i = base + k;
+      unique_out[pos] = ids[i];
+      hrank[slot_of[i]] = pos;
+      ++pos;
+    }
+  }
+}
+
+__global__ void unq_idx_kernel(size_t n, const int* __restrict__ slot_of, const int* __restrict__ hrank, int* idx_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx_out[i] = hrank[slot_of[i]];
+}
+
+// ------------------------------------ row gather / scatter ------------------------------------
+template <int G, bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(size_t n, unsigned row_bytes, const unsigned char* __restrict__ in,
+                                                        const int* __restrict__ idx, unsigned char* __restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  const size_t i = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  if (i >= n) return;
+  size_t j = (size_t)idx[i];
+  const unsigned char* src = in + (SCATTER ? i : j) * (size_t)row_bytes;
+  unsigned char* dst = out + (SCATTER ? j : i) * (size_t)row_bytes;
+  copy_bytes16<G>(dst, src, row_bytes, sub);
+}
+
+template <bool SCATTER>
+int move_rows(size_t n, size_t row_bytes, const void* in, const int32_t* idx, void* out, hipStream_t s) {
+  if (n == 0) return TFRA_OK;
+  if (!in || !idx || !out) return set_error(TFRA_ERR_INVALID, "gather/scatter: null buffer");
+  size_t x = row_bytes | (size_t)(uintptr_t)in | (size_t)(uintptr_t)out | 16;
+  int g = (int)(x & (~x + 1));
+  dim3 grid((unsigned)((n * 16 + 255) / 256)), block(256);
+  const unsigned char* i8 = (const unsigned char*)in;
+  unsigned char* o8 = (unsigned char*)out;
+  unsigned rb = (unsigned)row_bytes;
+  switch (g) {
+    case 16: move_rows_kernel<16, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;
+    case 8: move_rows_kernel<8, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;
+    case 4: move_rows_kernel<4, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;
+    case 2: move_rows_kernel<2, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;
+    default: move_rows_kernel<1, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+// ------------------------------------ segment sum ---------------------------------------------
+__global__ void iota_kernel(int* p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int)i;
+}
+
+// seg_sorted ascending (stable => member indices ascending inside a segment).  One 16-lane group
+// per segment walks its members in index order: out[seg,:] = sum_i in[i,:], ONE fp32 add per
+// element per member, i.e. exactly the order of a sequential CPU unsorted_segment_sum
+// (bit-exact vs the oracle).
+
+__global__ void seg_bounds_kernel(size_t n, const int* __restrict__ seg_sorted, int* seg_start, size_t max_segments) {
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int s = seg_sorted[p];
+  if ((size_t)s >= max_segments) return;
+  if (p == 0 || seg_sorted[p - 1] != s) seg_start[s] = (int)p;
+  if (p == n - 1 || seg_sorted[p + 1] != s) seg_start[max_segments + s] = (int)p + 1;  // end
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void seg_sum_kernel(size_t nseg_cap, const i64* __restrict__ d_nseg, int dim,
+                                                      const float* __restrict__ in, const int* __restrict__ member,
+                                                      const int* __restrict__ seg_start, float* __restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  size_t nseg = (size_t)*d_nseg;
+  if (nseg > nseg_cap) nseg = nseg_cap;
+  if (g >= nseg) return;
+  int b = seg_start[g], e = seg_start[nseg_cap + g];
+  float* o = out + g * (size_t)dim;
+  if (VEC4) {
+    for (int c = sub * 4; c < dim; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = b; p < e; ++p) {
+        float4 x = *reinterpret_cast<const float4*>(in + (size_t)member[p] * dim + c);
+        acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+      }
+      *reinterpret_cast<float4*>(o + c) = acc;
+    }
+  } else {
+    for (int c = sub; c < dim; c += 16) {
+      float acc = 0.f;
+      for (int p = b; p < e; ++p) acc += in[(size_t)member[p] * dim + c];
+      o[c] = acc;
+    }
+  }
+}
+
+// ------------------------------------ partition ------------------------------------------------
+__device__ __forceinline__ int owner_of(i64 key, int num, int mode) {
+  if (mode == 0) return (int)(key & 0x7fffffff) % num;
+  if (mode == 1) { i64 m = key % num; return (int)(m < 0 ? m + num : m); }
+  return (int)__umul64hi(fmix64((u64)key), (u64)num);
+}
+
+// pass 1: per-tile (256 ids) histogram -> hist[tile][shard]
+__global__ __launch_bounds__(256) void part_hist_kernel(size_t n, const i64* __restrict__ keys, const int* __restrict__ owner,
+                                                        int num, int mode, int* hist) {
+  extern __shared__ int cnt[];
+  for (int s = threadIdx.x; s < num; s += 256) cnt[s] = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[owner ? min(max(owner[i], 0), num - 1) : owner_of(keys[i], num, mode)], 1);
+  __syncthreads();
+  for (int s = threadIdx.x; s < num; s += 256) hist[(size_t)blockIdx.x * num + s] = cnt[s];
+}
+
+// pass 2 (single block): shard-major exclusive scan over (shard, tile); totals -> d_counts
+__global__ __launch_bounds__(1024) void part_scan_kernel(int* hist, size_t tiles, int num, i64* d_counts) {
+  __shared__ int sh[1024];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int s = 0; s < num; ++s) {
+    long long start = carry;
+    __syncthreads();
+    for (size_t base = 0; base < tiles; base += 1024) {
+      size_t tix = base + threadIdx.x;
+      int v = tix < tiles ? hist[tix * num + s] : 0;
+      sh[threadIdx.x] = v;
+      __syncthreads();
+      for (int o = 1; o < 1024; o <<= 1) {
+        int add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+      }
+      int incl = sh[threadIdx.x];
+      if (tix < tiles) hist[tix * num + s] = (int)(carry + incl - v);
+      __syncthreads();
+      if (threadIdx.x == 1023) carry += incl;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) d_counts[s] = carry - start;
+    __syncthreads();
+  }
+}
+
+// pass 3: stable scatter.  Rank inside the tile = (same-owner ids in earlier waves) + (same-owner
+// ids in lower lanes of this wave), found with a ballot per distinct owner present in the wave.
+__global__ __launch_bounds__(256) void part_scatter_kernel(size_t n, const i64* __restrict__ keys, const int* __restrict__ owner,
+                                                           int num, int mode, const int* __restrict__ hist, i64* keys_out,
+                                                           int* perm_out) {
+  extern __shared__ int wcnt[];  // [4][num]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int s = threadIdx.x; s < 4 * num; s += 256) wcnt[s] = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  bool ok = i < n;
+  i64 key = (ok && keys) ? keys[i] : 0;
+  int own = ok ? (owner ? min(max(owner[i], 0), num - 1) : owner_of(key, num, mode)) : -1;
+  int rank = 0;
+  u64 todo = __ballot(ok);
+  while (todo) {
+    int leader = __ffsll((unsigned long long)todo) - 1;
+    int o = __shfl(own, leader);
+    u64 m = __ballot(own == o);
+    if (own == o) rank = __popcll(m & ((1ULL << lane) - 1));
+    if (lane == leader) wcnt[w * num + o] = __popcll(m);
+    todo &= ~m;
+  }
+  __syncthreads();
+  if (ok) {
+    int before = 0;
+    for (int k = 0; k < w; ++k) before += wcnt[k * num + own];
+    size_t pos = (size_t)hist[(size_t)blockIdx.x * num + own] + before + rank;
+    if (keys_out) keys_out[pos] = key;
+    perm_out[pos] = (int)i;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfra_workspace_create(int device, tfra_workspace_t** out) {
+  if (!out) return set_error(TFRA_ERR_INVALID, "null out");
+  tfra_workspace* ws = new tfra_workspace();
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) { delete ws; return set_error(TFRA_ERR_HIP, "no HIP device"); }
+  ws->device = device;
+  *out = ws;
+  return TFRA_OK;
+}
+
+int tfra_workspace_destroy(tfra_workspace_t* ws) {
+  if (!ws) return TFRA_OK;
+  (void)hipSetDevice(ws->device);
+  if (ws->buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->buf); }
+  delete ws;
+  return TFRA_OK;
+}
+
+int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* unique_out, int32_t* idx_out,
+                int64_t* d_num_unique, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_num_unique) return set_error(TFRA_ERR_INVALID, "unique: null argument");
+  HIP_TRY(hipSetDevice(ws->device));
+  if (n == 0) { HIP_TRY(hipMemsetAsync(d_num_unique, 0, sizeof(int64_t), s)); return TFRA_OK; }
+  if (!ids || !unique_out || !idx_out) return set_error(TFRA_ERR_INVALID, "unique: null buffer");
+  if (n >= (1ULL << 30)) return set_error(TFRA_ERR_INVALID, "unique: more than 2^30 ids per call");
+  size_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  size_t tiles = (n + UNQ_TILE - 1) / UNQ_TILE;
+  size_t need = align_up((cap + 1) * 8) + 2 * align_up((cap + 1) * 4) + align_up(n * 4) + align_up(tiles * 4);
+  int rc = ws->ensure(need, s);
+  if (rc) return rc;
+  Carver c{(unsigned char*)ws->buf};
+  i64* hkeys = c.take<i64>(cap + 1);
+  int* hfirst = c.take<int>(cap + 1);
+  int* hrank = c.take<int>(cap + 1);
+  int* slot_of = c.take<int>(n);
+  int* bcnt = c.take<int>(tiles);
+  unq_fill_kernel<<<(unsigned)std::min<size_t>(2048, (cap + 256) / 256), 256, 0, s>>>(hkeys, hfirst, cap + 1);
+  unq_insert_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, (const i64*)ids, hkeys, hfirst, slot_of, cap);
+  unq_count_kernel<<<(unsigned)tiles, 256, 0, s>>>(n, hfirst, slot_of, bcnt);
+  scan_counts_kernel<<<1, 1024, 0, s>>>(bcnt, tiles, (i64*)d_num_unique);
+  unq_scatter_kernel<<<(unsigned)tiles, 256, 0, s>>>(n, (const i64*)ids, hfirst, slot_of, bcnt, (i64*)unique_out, hrank);
+  unq_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, slot_of, hrank, idx_out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out, tfra_stream_t stream) {
+  return move_rows<false>(n, row_bytes, rows, idx, out, (hipStream_t)stream);
+}
+
+int tfra_scatter_rows(size_t n, size_t row_bytes, const void* in, const int32_t* perm, void* out, tfra_stream_t stream) {
+  return move_rows<true>(n, row_bytes, in, perm, out, (hipStream_t)stream);
+}
+
+int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, const int32_t* idx,
+                     const int64_t* d_num_segments, size_t max_segments, float* out, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_num_segments || !out || dim <= 0) return set_error(TFRA_ERR_INVALID, "segment_sum: bad argument");
+  HIP_TRY(hipSetDevice(ws->device));
+  if (max_segments == 0) return TFRA_OK;
+  if (n == 0) { HIP_TRY(hipMemsetAsync(out, 0, max_segments * (size_t)dim * sizeof(float), s)); return TFRA_OK; }
+  if (!in || !idx) return set_error(TFRA_ERR_INVALID, "segment_sum: null buffer");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "segment_sum: too many rows");
+  unsigned bits = 1;
+  while ((1ULL << bits) < max_segments && bits < 32) ++bits;
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, (const int*)idx, (int*)nullptr, (const int*)nullptr,
+                                    (int*)nullptr, n, 0u, bits, s));
+  size_t need = 3 * align_up(n * 4) + align_up(2 * max_segments * 4) + align_up(tmp_bytes);
+  int rc = ws->ensure(need, s);
+  if (rc) return rc;
+  Carver c{(unsigned char*)ws->buf};
+  int* iota = c.take<int>(n);
+  int* seg_sorted = c.take<int>(n);
+  int* member = c.take<int>(n);
+  int* seg_start = c.take<int>(2 * max_segments);
+  void* tmp = c.take<unsigned char>(tmp_bytes);
+  iota_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(iota, n);
+  HIP_TRY(hipMemsetAsync(seg_start, 0, 2 * max_segments * sizeof(int), s));  // empty segments: start=end=0
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const int*)idx, seg_sorted, (const int*)iota, member, n, 0u, bits, s));
+  seg_bounds_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, seg_sorted, seg_start, max_segments);
+  dim3 grid((unsigned)((max_segments * 16 + 255) / 256));
+  bool vec4 = (dim % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
+  if (vec4) seg_sum_kernel<true><<<grid, 256, 0, s>>>(max_segments, (const i64*)d_num_segments, dim, in, member, seg_start, out);
+  else seg_sum_kernel<false><<<grid, 256, 0, s>>>(max_segments, (const i64*)d_num_segments, dim, in, member, seg_start, out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_partition(tfra_workspace_t* ws, size_t n, const int64_t* keys, int num_shards, int mode, int64_t* keys_out,
+                   int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_counts || num_shards <= 0 || num_shards > 2048 || mode < 0 || mode > 2)
+    return set_error(TFRA_ERR_INVALID, "partition: bad argument (1 <= num_shards <= 2048, mode in 0..2)");
+  HIP_TRY(hipSetDevice(ws->device));
+  if (n == 0) { HIP_TRY(hipMemsetAsync(d_counts, 0, num_shards * sizeof(int64_t), s)); return TFRA_OK; }
+  if (!keys || !keys_out || !perm_out) return set_error(TFRA_ERR_INVALID, "partition: null buffer");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "partition: too many keys");
+  size_t tiles = (n + 255) / 256;
+  int rc = ws->ensure(align_up(tiles * num_shards * 4), s);
+  if (rc) return rc;
+  int* hist = (int*)ws->buf;
+  part_hist_kernel<<<(unsigned)tiles, 256, num_shards * sizeof(int), s>>>(n, (const i64*)keys, nullptr, num_shards, mode, hist);
+  part_scan_kernel<<<1, 1024, 0, s>>>(hist, tiles, num_shards, (i64*)d_counts);
+  part_scatter_kernel<<<(unsigned)tiles, 256, 4 * num_shards * sizeof(int), s>>>(n, (const i64*)keys, nullptr, num_shards, mode,
+                                                                                  hist, (i64*)keys_out, perm_out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_partition_by_owner(tfra_workspace_t* ws, size_t n, const int32_t* owner, int num_shards, int32_t* perm_out,
+                            int64_t* d_counts, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_counts || num_shards <= 0 || num_shards > 2048)
+    return set_error(TFRA_ERR_INVALID, "partition_by_owner: bad argument (1 <= num_shards <= 2048)");
+  HIP_TRY(hipSetDevice(ws->device));
+  if (n == 0) { HIP_TRY(hipMemsetAsync(d_counts, 0, num_shards * sizeof(int64_t), s)); return TFRA_OK; }
+  if (!owner || !perm_out) return set_error(TFRA_ERR_INVALID, "partition_by_owner: null buffer");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "partition_by_owner: too many keys");
+  size_t tiles = (n + 255) / 256;
+  int rc = ws->ensure(align_up(tiles * num_shards * 4), s);
+  if (rc) return rc;
+  int* hist = (int*)ws->buf;
+  part_hist_kernel<<<(unsigned)tiles, 256, num_shards * sizeof(int), s>>>(n, nullptr, owner, num_shards, 0, hist);
+  part_scan_kernel<<<1, 1024, 0, s>>>(hist, tiles, num_shards, (i64*)d_counts);
+  part_scatter_kernel<<<(unsigned)tiles, 256, 4 * num_shards * sizeof(int), s>>>(n, nullptr, owner, num_shards, 0, hist, nullptr,
+                                                                                  perm_out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Host-side table object behind the opaque tfra_table_t handle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/tfra_mi355x.h"
+#include "tfra_device.h"
+
+namespace tfra {
+
+extern thread_local std::string g_last_error;
+int set_error(int code, const std::string& msg);
+
+struct Storage {
+  i64* keys = nullptr;
+  unsigned char* rows = nullptr;
+  u64* scores = nullptr;
+  u64 nb = 0;
+};
+
+struct AuxInitPod {
+  unsigned elem_bytes;
+  unsigned pattern[4];
+};
+
+struct Table {
+  tfra_table_opts opts{};
+  tfra_allocator alloc{nullptr, nullptr, nullptr};
+  int device = 0;
+  unsigned field_bytes = 0, row_stride = 0;
+  Storage cur;
+  u64* size_shards = nullptr;
+  unsigned* reserved_present = nullptr;  // [2] + err_count + d_scalar in one 64-B block
+  unsigned* err_count = nullptr;
+  i64* d_scalar = nullptr;
+  i64* h_scalar = nullptr;  // pinned
+  int* winner = nullptr;
+  size_t winner_len = 0;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  AuxInitPod aux{};
+  // host bookkeeping
+  std::mutex mu;
+  size_t size_ub = 0;  // upper bound of the live-key count (exact after read_size)
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
+  hipEvent_t chain_event = nullptr;
+  uint64_t global_epoch = 0;
+  int64_t curr_step = 1;
+  int n_rehash = 0;
+
+  void* dalloc(size_t bytes, hipStream_t s);
+  void dfree(void* p, hipStream_t s);
+  int alloc_storage(u64 nb, Storage* st, hipStream_t s);
+  TableView view_of(const Storage& st) const;
+  int enter(hipStream_t s);
+  int read_size(hipStream_t s, size_t* out);
+  int check_errors(hipStream_t s);
+  int ensure_winner(hipStream_t s);
+  int ensure_scratch(size_t bytes, hipStream_t s);
+  int grow(u64 min_nb, hipStream_t s);
+  int prepare_insert(size_t n, hipStream_t s);
+};
+
+}  // namespace tfra

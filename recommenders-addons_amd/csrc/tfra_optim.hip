@@ -1,0 +1,176 @@
+// Fused sparse-optimizer write-back on co-located rows [p | slot1 | slot2].
+//
+// The reference runs, per step and per embedding variable, (1+S) table finds, ONE stock
+// TensorFlow dense apply kernel on the local [U,dim] buffers and (1+S) table upserts
+// (PY/dynamic_embedding_optimizer.py:165-204; slots are separate hash tables, create_slots
+// :870-958).  Here one kernel does it per unique key: locate-or-insert the row once, read
+// p/slots, apply, write back = 8 + 7*Rb algorithmic bytes for Adam/FTRL instead of 4936 B.
+// Update rules = TF's ResourceApply{GradientDescent,Adam,Adagrad[V2],Ftrl} (restated in
+// oracle/optimizers.py), evaluated in fp32 in the same operation order
+// (this file is compiled with -ffp-contract=off so no FMA contraction changes roundings).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/tfra_mi355x.h"
+#include "tfra_device.h"
+#include "tfra_host.h"
+
+using namespace tfra;
+
+namespace {
+
+struct OptP {
+  int kind;
+  float lr, beta1, beta2, eps, l1, l2, lr_power;
+};
+
+__device__ __forceinline__ float sgnf(float z) { return (z > 0.f) ? 1.f : ((z < 0.f) ? -1.f : 0.f); }
+
+template <int KIND>
+__device__ __forceinline__ void apply_one(const OptP& o, float g, float& p, float& s1, float& s2) {
+  if (KIND == TFRA_OPT_SGD) {
+    p = p - o.lr * g;
+  } else if (KIND == TFRA_OPT_ADAM) {
+    // m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps)
+    s1 = s1 + (g - s1) * (1.f - o.beta1);
+    s2 = s2 + (g * g - s2) * (1.f - o.beta2);
+    p = p - (s1 * o.lr) / (sqrtf(s2) + o.eps);
+  } else if (KIND == TFRA_OPT_ADAGRAD) {
+    s1 = s1 + g * g;
+    if (o.eps < 0.f) p = p - o.lr * g / sqrtf(s1);
+    else p = p - o.lr * g / (sqrtf(s1) + o.eps);
+  } else {  // FTRL: s1 = accum, s2 = linear
+    float a_new = s1 + g * g;
+    float pa_new, pa;
+    if (o.lr_power == -0.5f) { pa_new = sqrtf(a_new); pa = sqrtf(s1); }
+    else { pa_new = powf(a_new, -o.lr_power); pa = powf(s1, -o.lr_power); }
+    float sigma = (pa_new - pa) / o.lr;
+    s2 = s2 + g - sigma * p;
+    float q = pa_new / o.lr + 2.f * o.l2;
+    p = (fabsf(s2) > o.l1) ? (sgnf(s2) * o.l1 - s2) / q : 0.f;
+    s1 = a_new;
+  }
+}
+
+template <int KIND> struct NSlots { static constexpr int v = KIND == TFRA_OPT_SGD ? 0 : (KIND == TFRA_OPT_ADAGRAD ? 1 : 2); };
+
+// 16 lanes per key; lane `sub` owns elements sub*4..sub*4+3 (+64 per step): float4 everywhere
+// when dim % 4 == 0 (VEC4), scalar otherwise.
+template <int KIND, bool VEC4>
+__global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
+                                                    const float* __restrict__ grads,
+                                                    const float* __restrict__ defaults, int full, int dim,
+                                                    float aux0, float aux1, const i64* __restrict__ d_n) {
+  constexpr int S = NSlots<KIND>::v;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  int fresh = 0, failed = 0;
+  if (d_n) { size_t dn = (size_t)*d_n; if (dn < n) n = dn; }
+  if (g < n) {
+    const i64 key = keys[g];
+    bool is_new;
+    i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+    if (row < 0) {
+      failed = (sub == 0);
+    } else {
+      fresh = (is_new && sub == 0);
+      float* pr = reinterpret_cast<float*>(v.rows + (size_t)row * v.row_stride);
+      const float* gr = grads + g * (size_t)dim;
+      const float* df = defaults + (full ? g * (size_t)dim : 0);
+      if (VEC4) {
+        for (int c = sub * 4; c < dim; c += 64) {
+          float4 gg = *reinterpret_cast<const float4*>(gr + c);
+          float4 p, s1 = make_float4(aux0, aux0, aux0, aux0), s2 = make_float4(aux1, aux1, aux1, aux1);
+          if (is_new) {
+            p = *reinterpret_cast<const float4*>(df + c);
+          } else {
+            p = *reinterpret_cast<const float4*>(pr + c);
+            if (S >= 1) s1 = *reinterpret_cast<const float4*>(pr + dim + c);
+            if (S >= 2) s2 = *reinterpret_cast<const float4*>(pr + 2 * dim + c);
+          }
+          apply_one<KIND>(o, gg.x, p.x, s1.x, s2.x);
+          apply_one<KIND>(o, gg.y, p.y, s1.y, s2.y);
+          apply_one<KIND>(o, gg.z, p.z, s1.z, s2.z);
+          apply_one<KIND>(o, gg.w, p.w, s1.w, s2.w);
+          *reinterpret_cast<float4*>(pr + c) = p;
+          if (S >= 1) *reinterpret_cast<float4*>(pr + dim + c) = s1;
+          if (S >= 2) *reinterpret_cast<float4*>(pr + 2 * dim + c) = s2;
+        }
+      } else {
+        for (int c = sub; c < dim; c += 16) {
+          float p, s1 = aux0, s2 = aux1;
+          if (is_new) {
+            p = df[c];
+          } else {
+            p = pr[c];
+            if (S >= 1) s1 = pr[dim + c];
+            if (S >= 2) s2 = pr[2 * dim + c];
+          }
+          apply_one<KIND>(o, gr[c], p, s1, s2);
+          pr[c] = p;
+          if (S >= 1) pr[dim + c] = s1;
+          if (S >= 2) pr[2 * dim + c] = s2;
+        }
+      }
+      // aux fields the optimizer does not own (table created with more slots than it uses)
+      if (is_new && (int)v.n_fields - 1 > S) {
+        for (int f = S + 1; f < (int)v.n_fields; ++f)
+          for (int c = sub; c < dim; c += 16) pr[f * dim + c] = (f == 1 ? aux0 : aux1);
+      }
+      if (v.scores && sub == 0 && row < (i64)(v.nb * SLOTS)) v.scores[((u64)row / SLOTS) * 16 + (u64)row % SLOTS] = wall_clock64();
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, g >> 2, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+template <int KIND>
+void launch_apply(bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
+                  const float* d, int full, int dim, float a0, float a1, const i64* dn) {
+  if (vec4) apply_kernel<KIND, true><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn);
+  else apply_kernel<KIND, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn);
+}
+
+}  // namespace
+
+extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_params* p, size_t n, const int64_t* keys,
+                                          const float* grads, const void* param_defaults, int default_is_full,
+                                          const int64_t* d_n, tfra_stream_t stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !p) return set_error(TFRA_ERR_INVALID, "apply_optimizer: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(t->mu);
+  int rc = t->enter(s);
+  if (rc) return rc;
+  if (n == 0) return TFRA_OK;
+  if (!keys || !grads || !param_defaults) return set_error(TFRA_ERR_INVALID, "apply_optimizer: null buffer");
+  if (t->opts.value_dtype != TFRA_F32) return set_error(TFRA_ERR_UNSUPPORTED, "apply_optimizer: value_dtype must be float32");
+  int need = p->kind == TFRA_OPT_SGD ? 0 : (p->kind == TFRA_OPT_ADAGRAD ? 1 : 2);
+  if (p->kind < 0 || p->kind > TFRA_OPT_FTRL) return set_error(TFRA_ERR_INVALID, "apply_optimizer: unknown kind");
+  if (t->opts.aux_fields < need)
+    return set_error(TFRA_ERR_INVALID, "apply_optimizer: table has " + std::to_string(t->opts.aux_fields) +
+                                           " aux fields, optimizer needs " + std::to_string(need));
+  rc = t->prepare_insert(n, s);
+  if (rc) return rc;
+  TableView v = t->view_of(t->cur);
+  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power};
+  int dim = t->opts.dim;
+  bool vec4 = dim % 4 == 0 && (((uintptr_t)grads | (uintptr_t)param_defaults) % 16 == 0);
+  dim3 grid((unsigned)((n * 16 + 255) / 256));
+  const i64* k = (const i64*)keys;
+  const float* d = (const float*)param_defaults;
+  float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
+  switch (p->kind) {
+    case TFRA_OPT_SGD: launch_apply<TFRA_OPT_SGD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
+    case TFRA_OPT_ADAM: launch_apply<TFRA_OPT_ADAM>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
+    case TFRA_OPT_ADAGRAD: launch_apply<TFRA_OPT_ADAGRAD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
+    default: launch_apply<TFRA_OPT_FTRL>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
+  }
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_optimizer: launch failed");
+  return TFRA_OK;
+}

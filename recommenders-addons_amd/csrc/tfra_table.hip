@@ -1,0 +1,1002 @@
+// MI355X (gfx950) dynamic-embedding table: kernels + C ABI (include/tfra_mi355x.h).
+//
+// Replaces, behind TFRA's own op surface, what `gpu::TableWrapper` gets from HierarchicalKV
+// (R/kernels/lookup_impl/lookup_table_op_hkv.h:515-756) with results defined by the
+// reference's CPU table (R/kernels/cuckoo_hashtable_op.cc, lib/cuckoo/cuckoohash_map.hh).
+// Work mapping everywhere: 16 lanes per key (one 128-B bucket line per probe, one 16-B
+// granule per lane per row step), 4 keys per wave64, U independent keys in flight per group.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tfra_mi355x.h"
+#include "tfra_device.h"
+#include "tfra_host.h"
+
+using namespace tfra;
+typedef tfra::AuxInitPod AuxInit;  // elem_bytes = sizeof(V); pattern[f] = aux_init[f] as V, replicated to 32 bits
+
+// =============================== kernels ====================================================
+
+// ---- find (+ fused default fill, + exists) -------------------------------------------------
+template <int G, int U>
+__global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const i64* __restrict__ keys,
+                                                   unsigned char* __restrict__ out,
+                                                   uint8_t* __restrict__ exists,
+                                                   const unsigned char* __restrict__ defaults,
+                                                   int full, unsigned field_off) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const int grp = lane >> 4;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  constexpr int KPW = 4 * U;
+  const size_t base = wave * KPW;
+  if (base >= n) return;
+  i64 kreg = (lane < KPW && base + lane < n) ? keys[base + lane] : 0;
+  i64 key[U];
+  u64 h[U], b[U];
+  i64 k0[U];
+  bool valid[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = u * 4 + grp;
+    key[u] = shfl_i64(kreg, j);
+    valid[u] = base + j < n;
+    b[u] = bucket0(key[u], v.nb, h[u]);
+    k0[u] = valid[u] ? v.keys[b[u] * 16 + sub] : EMPTY_KEY;  // U probes in flight
+  }
+  const unsigned char* src[U];
+  unsigned char* dst[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    size_t i = base + u * 4 + grp;
+    i64 row = valid[u] ? probe_find_from<false>(v, key[u], h[u], b[u], k0[u], sub, gshift) : -1;
+    if (valid[u] && exists && sub == 0) exists[i] = row >= 0;
+    src[u] = row >= 0 ? v.rows + (size_t)row * v.row_stride + field_off
+                      : defaults + (full ? i * (size_t)v.field_bytes : 0);
+    dst[u] = out + i * (size_t)v.field_bytes;
+  }
+  typedef typename Granule<G>::T T;
+  for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
+    T tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (valid[u]) tmp[u] = *reinterpret_cast<const T*>(src[u] + off);  // U rows in flight
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (valid[u]) *reinterpret_cast<T*>(dst[u] + off) = tmp[u];
+  }
+}
+
+// ---- aux-field initialisation for a newly claimed row --------------------------------------
+
+__device__ __forceinline__ void init_aux_fields(const TableView& v, const AuxInit& ai, i64 row,
+                                                int sub, unsigned skip_field) {
+  unsigned char* r = v.rows + (size_t)row * v.row_stride;
+  for (unsigned f = 0; f < v.n_fields; ++f) {
+    if (f == skip_field) continue;
+    unsigned pat = f == 0 ? 0u : ai.pattern[(f - 1) & 3];
+    unsigned char* p = r + f * v.field_bytes;
+    if ((v.field_bytes & 3) == 0) {
+      for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(p + off) = pat;
+    } else {
+      for (unsigned off = sub; off < v.field_bytes; off += 16) p[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
+    }
+  }
+}
+
+__device__ __forceinline__ void update_score(const TableView& v, i64 row, bool is_new, int strategy,
+                                             u64 in_score, u64 epoch, int sub) {
+  if (!v.scores || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
+  u64 b = (u64)row / SLOTS, s = (u64)row % SLOTS;
+  u64* p = &v.scores[b * 16 + s];
+  u64 old = is_new ? 0 : *p;
+  u64 ns;
+  switch (strategy) {
+    case TFRA_EVICT_LFU: atomicAdd(p, in_score); return;  // slots are zeroed on clear/erase
+    case TFRA_EVICT_EPOCHLRU: ns = (epoch << 32) | (wall_clock64() & 0xffffffffULL); break;
+    case TFRA_EVICT_EPOCHLFU: {
+      u64 cnt = (old & 0xffffffffULL) + in_score;
+      if (cnt > 0xffffffffULL) cnt = 0xffffffffULL;
+      ns = (epoch << 32) | cnt;
+    } break;
+    case TFRA_EVICT_CUSTOMIZED: ns = in_score; break;
+    default: ns = wall_clock64(); break;  // LRU: device-wide monotonic clock
+  }
+  *p = ns;
+}
+
+// ---- insert_or_assign, unique-keys fast path (single pass) ---------------------------------
+template <int G, int U>
+__global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t n,
+                                                            const i64* __restrict__ keys,
+                                                            const unsigned char* __restrict__ vals,
+                                                            const u64* __restrict__ scores,
+                                                            unsigned field, AuxInit ai, int strategy,
+                                                            u64 epoch) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  constexpr int KPW = 4 * U;
+  const size_t base = wave * KPW;
+  if (base >= n) return;
+  i64 kreg = (lane < KPW && base + lane < n) ? keys[base + lane] : 0;
+  int fresh = 0, failed = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = u * 4 + grp;
+    size_t i = base + j;
+    i64 key = shfl_i64(kreg, j);
+    if (i < n) {
+      bool is_new;
+      i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+      if (row >= 0) {
+        copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes,
+                        vals + i * (size_t)v.field_bytes, v.field_bytes, sub);
+        if (is_new && v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
+        update_score(v, row, is_new, strategy, scores ? scores[i] : 1, epoch, sub);
+        fresh += (is_new && sub == 0);
+      } else {
+        failed += (sub == 0);
+      }
+    }
+  }
+  // one size update per wave
+  for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
+  if (lane == 0) {
+    if (fresh) size_add(v, wave, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// ---- insert_or_assign with duplicates: pass 1 locate/claim + elect the LAST index ----------
+template <int U>
+__global__ __launch_bounds__(256) void insert_locate_kernel(TableView v, size_t n,
+                                                            const i64* __restrict__ keys,
+                                                            i64* __restrict__ slot_of, unsigned field,
+                                                            AuxInit ai) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  constexpr int KPW = 4 * U;
+  const size_t base = wave * KPW;
+  if (base >= n) return;
+  i64 kreg = (lane < KPW && base + lane < n) ? keys[base + lane] : 0;
+  int fresh = 0, failed = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = u * 4 + grp;
+    size_t i = base + j;
+    i64 key = shfl_i64(kreg, j);
+    if (i < n) {
+      bool is_new;
+      i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+      if (row >= 0) {
+        if (is_new && v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
+        if (sub == 0) { atomicMax(&v.winner[row], (int)i); slot_of[i] = row | (is_new ? (i64)1 << 62 : 0); }
+        fresh += (is_new && sub == 0);
+      } else {
+        if (sub == 0) slot_of[i] = -1;
+        failed += (sub == 0);
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
+  if (lane == 0) {
+    if (fresh) size_add(v, wave, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// pass 2: only the elected occurrence writes the row (sequential "last writer wins" of
+// LaunchTensorsInsert with one thread), then re-arms the election word.
+template <int G>
+__global__ __launch_bounds__(256) void insert_write_kernel(TableView v, size_t n,
+                                                           const unsigned char* __restrict__ vals,
+                                                           const u64* __restrict__ scores,
+                                                           const i64* __restrict__ slot_of,
+                                                           unsigned field, int strategy, u64 epoch) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const size_t i = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  if (i >= n) return;
+  (void)lane;
+  i64 so = slot_of[i];
+  if (so < 0) return;
+  bool is_new = (so >> 62) & 1;
+  i64 row = so & (((i64)1 << 62) - 1);
+  if (v.winner[row] != (int)i) {
+    // LFU counts every upsert, also the overwritten duplicates
+    if (strategy == TFRA_EVICT_LFU) update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
+    return;
+  }
+  copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes,
+                  vals + i * (size_t)v.field_bytes, v.field_bytes, sub);
+  update_score(v, row, is_new, strategy, scores ? scores[i] : 1, epoch, sub);
+}
+
+__global__ void rearm_winner_kernel(TableView v, size_t n, const i64* __restrict__ slot_of) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  i64 so = slot_of[i];
+  if (so >= 0) v.winner[so & (((i64)1 << 62) - 1)] = -1;
+}
+
+// ---- typed accumulate: row[j] += delta[j], one add per element (ValueArray::operator+=) ----
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <int DT>
+__device__ __forceinline__ void row_add(unsigned char* row, const unsigned char* delta, unsigned dim, int sub) {
+  for (unsigned j = sub; j < dim; j += 16) {
+    if (DT == TFRA_F32) reinterpret_cast<float*>(row)[j] += reinterpret_cast<const float*>(delta)[j];
+    else if (DT == TFRA_F64) reinterpret_cast<double*>(row)[j] += reinterpret_cast<const double*>(delta)[j];
+    else if (DT == TFRA_I8) reinterpret_cast<signed char*>(row)[j] = (signed char)(reinterpret_cast<signed char*>(row)[j] + reinterpret_cast<const signed char*>(delta)[j]);
+    else if (DT == TFRA_I32) reinterpret_cast<unsigned*>(row)[j] += reinterpret_cast<const unsigned*>(delta)[j];
+    else if (DT == TFRA_I64) reinterpret_cast<u64*>(row)[j] += reinterpret_cast<const u64*>(delta)[j];
+    else if (DT == TFRA_F16) {
+      _Float16 a = reinterpret_cast<_Float16*>(row)[j], b = reinterpret_cast<const _Float16*>(delta)[j];
+      reinterpret_cast<_Float16*>(row)[j] = (_Float16)((float)a + (float)b);
+    } else {
+      unsigned short* r = reinterpret_cast<unsigned short*>(row);
+      r[j] = f32_to_bf16(bf16_to_f32(r[j]) + bf16_to_f32(reinterpret_cast<const unsigned short*>(delta)[j]));
+    }
+  }
+}
+
+// ---- accum_or_assign.  ROUND >= 0: duplicate-safe mode, processes only the occurrence that is
+// currently first-in-line for its key (election word), see host loop. -------------------------
+template <int DT, int G>
+__global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const i64* __restrict__ keys,
+                                                    const unsigned char* __restrict__ vod,
+                                                    const uint8_t* __restrict__ exists,
+                                                    const u64* __restrict__ scores, unsigned dim,
+                                                    AuxInit ai, int strategy, u64 epoch,
+                                                    const int* __restrict__ order, size_t n_order) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  const size_t wave = g >> 2;
+  const size_t cnt = order ? n_order : n;
+  int fresh = 0, failed = 0;
+  if (g < cnt) {
+    const size_t i = order ? (size_t)order[g] : g;
+    const i64 key = keys[i];
+    const bool ex = exists[i] != 0;
+    const unsigned char* src = vod + i * (size_t)v.field_bytes;
+    if (!ex) {
+      bool is_new;
+      i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+      if (row < 0) failed = (sub == 0);
+      else if (is_new) {
+        copy_bytes16<G>(v.rows + (size_t)row * v.row_stride, src, v.field_bytes, sub);
+        if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, 0);
+        update_score(v, row, true, strategy, scores ? scores[i] : 1, epoch, sub);
+        fresh = (sub == 0);
+      }  // present & !exists: dropped
+    } else {
+      i64 row = probe_find<true>(v, key, sub, gshift);
+      if (row >= 0) {
+        row_add<DT>(v.rows + (size_t)row * v.row_stride, src, dim, sub);
+        update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
+      }  // absent & exists: dropped
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
+  if (lane == 0) {
+    if (fresh) size_add(v, wave, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// ---- erase ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void erase_kernel(TableView v, size_t n, const i64* __restrict__ keys) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  int gone = 0;
+  if (g < n) {
+    i64 key = keys[g];
+    if (is_reserved_key(key)) {
+      if (sub == 0) gone = atomicExch(&v.reserved_present[reserved_index(key)], 0u) != 0;
+    } else {
+      i64 row = probe_find<true>(v, key, sub, gshift);
+      if (row >= 0 && sub == 0) {
+        u64 w = ((u64)row / SLOTS) * 16 + (u64)row % SLOTS;
+        // CAS so that duplicate keys in one call decrement the size once
+        gone = atomicCAS((u64*)&v.keys[w], (u64)key, (u64)EMPTY_KEY) == (u64)key;
+        if (gone && v.scores) v.scores[w] = 0;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) gone += __shfl_xor(gone, o);
+  if (lane == 0 && gone) size_add(v, g >> 2, -(long long)gone);
+}
+
+// ---- clear / fill ---------------------------------------------------------------------------
+__global__ void clear_kernel(TableView v, int reset_counters) {
+  size_t total = v.nb * 16;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+    v.keys[w] = ((w & 15) == 15) ? 0 : EMPTY_KEY;
+    if (v.scores) v.scores[w] = 0;
+  }
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!reset_counters) return;
+  if (t < SIZE_SHARDS) v.size_shards[t * SIZE_SHARD_STRIDE] = 0;
+  if (t < NUM_RESERVED) v.reserved_present[t] = 0;
+  if (t == 0) *v.err_count = 0;
+}
+
+__global__ void fill_i32_kernel(int* p, size_t n, int val) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = val;
+}
+
+__global__ void size_kernel(TableView v, i64* out) {
+  __shared__ long long part[SIZE_SHARDS];
+  part[threadIdx.x] = (long long)v.size_shards[threadIdx.x * SIZE_SHARD_STRIDE];
+  __syncthreads();
+  for (int s = SIZE_SHARDS / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = part[0];
+}
+
+// ---- export_batch: slots [offset, offset+n) -> compact (key,row,score) at *counter ----------
+// One block = 64 buckets; one returned atomic per block (not per wave) reserves the output run.
+template <int G>
+__global__ __launch_bounds__(256) void export_kernel(TableView v, u64 first_bucket, u64 last_bucket,
+                                                     u64 lo, u64 hi, u64* counter, i64* __restrict__ keys_out,
+                                                     unsigned char* __restrict__ vals_out,
+                                                     u64* __restrict__ scores_out) {
+  __shared__ unsigned cnt[64];
+  __shared__ u64 base_s;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const int grp_in_block = threadIdx.x >> 4;  // 0..15
+  i64 k[4];
+  unsigned live[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    u64 b = first_bucket + (u64)blockIdx.x * 64 + it * 16 + grp_in_block;
+    bool ok = b < last_bucket;
+    k[it] = ok ? v.keys[b * 16 + sub] : EMPTY_KEY;
+    u64 slot = b * SLOTS + sub;
+    bool l = ok && sub < SLOTS && k[it] != EMPTY_KEY && k[it] != LOCKED_KEY && slot >= lo && slot < hi;
+    live[it] = (unsigned)(__ballot(l) >> gshift) & 0x7fffu;
+    if (sub == 0) cnt[it * 16 + grp_in_block] = __popc(live[it]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int i = 0; i < 64; ++i) { unsigned c = cnt[i]; cnt[i] = run; run += c; }
+    base_s = run ? atomicAdd(counter, (u64)run) : 0;
+  }
+  __syncthreads();
+  const u64 base = base_s;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    u64 b = first_bucket + (u64)blockIdx.x * 64 + it * 16 + grp_in_block;
+    u64 pos0 = base + cnt[it * 16 + grp_in_block];
+    unsigned m = live[it];
+    if (m & (1u << sub)) {
+      u64 pos = pos0 + __popc(m & ((1u << sub) - 1));
+      keys_out[pos] = k[it];
+      if (scores_out) scores_out[pos] = v.scores ? v.scores[b * 16 + sub] : 0;
+    }
+    if (vals_out) {
+      unsigned r = 0;
+      while (m) {
+        int s = __ffs(m) - 1;
+        m &= m - 1;
+        copy_bytes16<G>(vals_out + (pos0 + r) * (size_t)v.field_bytes,
+                        v.rows + (size_t)(b * SLOTS + s) * v.row_stride, v.field_bytes, sub);
+        ++r;
+      }
+    }
+  }
+}
+
+// the two side rows (keys INT64_MIN, INT64_MIN+1) are slots nb*15 and nb*15+1
+__global__ void export_reserved_kernel(TableView v, u64 lo, u64 hi, u64* counter, i64* keys_out,
+                                       unsigned char* vals_out, u64* scores_out) {
+  for (int r = 0; r < NUM_RESERVED; ++r) {
+    u64 slot = v.nb * SLOTS + r;
+    if (slot < lo || slot >= hi || !v.reserved_present[r]) continue;
+    __shared__ u64 pos_s;
+    if (threadIdx.x == 0) pos_s = atomicAdd(counter, 1ULL);
+    __syncthreads();
+    u64 pos = pos_s;
+    if (threadIdx.x == 0) { keys_out[pos] = EMPTY_KEY + r; if (scores_out) scores_out[pos] = ~0ULL; }
+    if (vals_out)
+      for (unsigned off = threadIdx.x; off < v.field_bytes; off += blockDim.x)
+        vals_out[pos * (size_t)v.field_bytes + off] = v.rows[slot * (size_t)v.row_stride + off];
+    __syncthreads();
+  }
+}
+
+// ---- rehash (growth): move every live row of `o` into `v` -----------------------------------
+__global__ __launch_bounds__(256) void rehash_kernel(TableView o, TableView v) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const u64 b = (((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  int failed = 0;
+  if (b < o.nb) {
+    i64 k = o.keys[b * 16 + sub];
+    unsigned m = (unsigned)(__ballot(sub < SLOTS && k != EMPTY_KEY && k != LOCKED_KEY) >> gshift) & 0x7fffu;
+    while (m) {
+      int s = __ffs(m) - 1;
+      m &= m - 1;
+      i64 key = shfl_i64(k, gshift + s);
+      bool is_new;
+      i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+      if (row < 0) { failed += (sub == 0); continue; }
+      copy_bytes16<16>(v.rows + (size_t)row * v.row_stride,
+                       o.rows + (size_t)(b * SLOTS + s) * o.row_stride, o.row_stride, sub);
+      if (v.scores && o.scores && sub == 0)
+        v.scores[((u64)row / SLOTS) * 16 + (u64)row % SLOTS] = o.scores[b * 16 + s];
+    }
+  }
+  if (b == 0) {  // side rows
+    for (int r = 0; r < NUM_RESERVED; ++r)
+      copy_bytes16<16>(v.rows + (size_t)(v.nb * SLOTS + r) * v.row_stride,
+                       o.rows + (size_t)(o.nb * SLOTS + r) * o.row_stride, o.row_stride, sub);
+  }
+  for (int off = 32; off > 0; off >>= 1) failed += __shfl_xor(failed, off);
+  if (lane == 0 && failed) atomicAdd(v.err_count, (unsigned)failed);
+}
+
+// =============================== host side ==================================================
+
+namespace tfra {
+thread_local std::string g_last_error;
+int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+}  // namespace tfra
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return set_error(_e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP,                \
+                       std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+  } while (0)
+
+static size_t dtype_size(int dt) {
+  switch (dt) {
+    case TFRA_F32: case TFRA_I32: return 4;
+    case TFRA_F16: case TFRA_BF16: return 2;
+    case TFRA_I8: return 1;
+    case TFRA_I64: case TFRA_F64: return 8;
+    default: return 0;
+  }
+}
+
+static unsigned short host_f2h(float f) {
+  _Float16 h = (_Float16)f;
+  unsigned short u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+static unsigned short host_f2b(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+static AuxInit make_aux_init(const tfra_table_opts& o) {
+  AuxInit ai;
+  ai.elem_bytes = (unsigned)dtype_size(o.value_dtype);
+  for (int f = 0; f < 4; ++f) {
+    float x = o.aux_init[f];
+    unsigned pat = 0;
+    switch (o.value_dtype) {
+      case TFRA_F32: memcpy(&pat, &x, 4); break;
+      case TFRA_I32: { int v = (int)x; memcpy(&pat, &v, 4); } break;
+      case TFRA_F16: { unsigned short h = host_f2h(x); pat = h | ((unsigned)h << 16); } break;
+      case TFRA_BF16: { unsigned short h = host_f2b(x); pat = h | ((unsigned)h << 16); } break;
+      case TFRA_I8: { unsigned char c = (unsigned char)(signed char)x; pat = c * 0x01010101u; } break;
+      default: pat = 0; break;  // 8-byte types: aux fields start at 0
+    }
+    ai.pattern[f] = pat;
+  }
+  return ai;
+}
+
+static int granule_of(size_t bytes, const void* a, const void* b) {
+  size_t x = bytes | (size_t)(uintptr_t)a | (size_t)(uintptr_t)b | 16;
+  int g = (int)(x & (~x + 1));
+  return g > 16 ? 16 : g;
+}
+
+namespace tfra {
+
+void* Table::dalloc(size_t bytes, hipStream_t s) {
+  if (alloc.alloc) return alloc.alloc(alloc.user, 0, bytes, (tfra_stream_t)s);
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  return p;
+}
+void Table::dfree(void* p, hipStream_t s) {
+  if (!p) return;
+  if (alloc.alloc) alloc.free(alloc.user, 0, p, (tfra_stream_t)s);
+  else (void)hipFree(p);
+}
+
+int Table::alloc_storage(u64 nb, Storage* st, hipStream_t s) {
+  st->nb = nb;
+  size_t nrows = nb * SLOTS + NUM_RESERVED;
+  st->keys = (i64*)dalloc(nb * 16 * sizeof(i64), s);
+  st->rows = (unsigned char*)dalloc(nrows * (size_t)row_stride, s);
+  st->scores = opts.strategy >= 0 ? (u64*)dalloc(nb * 16 * sizeof(u64), s) : nullptr;
+  if (!st->keys || !st->rows || (opts.strategy >= 0 && !st->scores)) {
+    dfree(st->keys, s); dfree(st->rows, s); dfree(st->scores, s);
+    *st = Storage();
+    return set_error(TFRA_ERR_OOM, "table storage allocation failed (" + std::to_string(nrows) + " rows x " +
+                                       std::to_string(row_stride) + " B)");
+  }
+  return TFRA_OK;
+}
+
+TableView Table::view_of(const Storage& st) const {
+  TableView v;
+  v.keys = st.keys; v.rows = st.rows; v.scores = st.scores; v.nb = st.nb;
+  v.field_bytes = field_bytes; v.row_stride = row_stride; v.n_fields = 1 + opts.aux_fields;
+  v.reserved_present = reserved_present; v.size_shards = size_shards; v.winner = winner;
+  v.err_count = err_count;
+  return v;
+}
+
+// serialise against work queued on another stream (the reference blocks on a per-table mutex and
+// a stream sync per op, R/kernels/hkv_hashtable_op_gpu.cu.cc:192-213; here: event chaining).
+int Table::enter(hipStream_t s) {
+  if (hipSetDevice(device) != hipSuccess) return set_error(TFRA_ERR_HIP, "hipSetDevice failed");
+  if (has_last && s != last_stream) {
+    HIP_TRY(hipEventRecord(chain_event, last_stream));
+    HIP_TRY(hipStreamWaitEvent(s, chain_event, 0));
+  }
+  last_stream = s;
+  has_last = true;
+  return TFRA_OK;
+}
+
+int Table::read_size(hipStream_t s, size_t* out) {
+  size_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar);
+  HIP_TRY(hipMemcpyAsync(h_scalar, d_scalar, sizeof(i64), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  i64 v = *h_scalar;
+  *out = v < 0 ? 0 : (size_t)v;
+  size_ub = *out;
+  return TFRA_OK;
+}
+
+int Table::check_errors(hipStream_t s) {
+  unsigned e = 0;
+  HIP_TRY(hipMemcpyAsync(h_scalar, err_count, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  memcpy(&e, h_scalar, sizeof(unsigned));
+  if (e) {
+    HIP_TRY(hipMemsetAsync(err_count, 0, sizeof(unsigned), s));
+    return set_error(TFRA_ERR_FULL, std::to_string(e) + " keys could not be placed: table full at max_capacity");
+  }
+  return TFRA_OK;
+}
+
+int Table::ensure_winner(hipStream_t s) {
+  size_t need = cur.nb * SLOTS + NUM_RESERVED;
+  if (winner && winner_len >= need) return TFRA_OK;
+  dfree(winner, s);
+  winner = (int*)dalloc(need * sizeof(int), s);
+  if (!winner) return set_error(TFRA_ERR_OOM, "winner scratch allocation failed");
+  winner_len = need;
+  fill_i32_kernel<<<2048, 256, 0, s>>>(winner, need, -1);
+  return TFRA_OK;
+}
+
+int Table::ensure_scratch(size_t bytes, hipStream_t s) {
+  if (scratch_bytes >= bytes) return TFRA_OK;
+  if (scratch) { HIP_TRY(hipStreamSynchronize(s)); dfree(scratch, s); }
+  size_t want = std::max(bytes, scratch_bytes * 2);
+  scratch = dalloc(want, s);
+  if (!scratch) { scratch_bytes = 0; return set_error(TFRA_ERR_OOM, "scratch allocation failed"); }
+  scratch_bytes = want;
+  return TFRA_OK;
+}
+
+// grow to at least min_nb buckets: new arrays, rehash kernel, free the old ones.
+int Table::grow(u64 min_nb, hipStream_t s) {
+  if (min_nb <= cur.nb) return TFRA_OK;
+  Storage nw;
+  int rc = alloc_storage(min_nb, &nw, s);
+  if (rc) return rc;
+  Storage old = cur;
+  int* old_winner = winner;
+  winner = nullptr; winner_len = 0;  // sized per storage; rebuilt lazily
+  TableView nv = view_of(nw);
+  // fresh key lines; keep counters (rehash moves, it does not insert)
+  clear_kernel<<<2048, 256, 0, s>>>(nv, 0);
+  u64 groups = old.nb;
+  rehash_kernel<<<(unsigned)((groups * 16 + 255) / 256), 256, 0, s>>>(view_of(old), nv);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));  // old arrays are freed below
+  dfree(old.keys, s); dfree(old.rows, s); dfree(old.scores, s); dfree(old_winner, s);
+  cur = nw;
+  n_rehash++;
+  return TFRA_OK;
+}
+
+// called before inserting up to n new keys
+int Table::prepare_insert(size_t n, hipStream_t s) {
+  double lf = opts.max_load_factor;
+  size_t slots = cur.nb * SLOTS;
+  if ((double)(size_ub + n) <= lf * (double)slots) { size_ub += n; return TFRA_OK; }
+  size_t sz;
+  int rc = read_size(s, &sz);
+  if (rc) return rc;
+  if ((double)(sz + n) > lf * (double)slots) {
+    u64 max_nb = opts.max_capacity ? (opts.max_capacity + SLOTS - 1) / SLOTS : ~0ULL;
+    if (cur.nb < max_nb) {
+      u64 want = (u64)((double)(sz + n) / lf / SLOTS) + 1;
+      want = std::max(want, cur.nb * 2);
+      want = std::min(want, max_nb);
+      rc = grow(want, s);
+      if (rc) return rc;
+    }
+  }
+  size_ub = sz + n;
+  return TFRA_OK;
+}
+
+}  // namespace tfra
+
+static int find_impl(Table* t, hipStream_t s, int field, size_t n, const int64_t* keys, void* values,
+                     uint8_t* exists, const void* defaults, int full) {
+  if (n == 0) return TFRA_OK;
+  if (!keys || !values || !defaults) return set_error(TFRA_ERR_INVALID, "find: null buffer");
+  if (field < 0 || field > t->opts.aux_fields) return set_error(TFRA_ERR_INVALID, "find: bad field");
+  TableView v = t->view_of(t->cur);
+  unsigned fo = field * t->field_bytes;
+  int g = granule_of(t->field_bytes, values, defaults);
+  if (fo) g = std::min(g, granule_of(fo, nullptr, nullptr));
+  constexpr int U = 4;
+  size_t waves = (n + 4 * U - 1) / (4 * U);
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  const i64* k = (const i64*)keys;
+  unsigned char* o = (unsigned char*)values;
+  const unsigned char* d = (const unsigned char*)defaults;
+  switch (g) {
+    case 16: find_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+    case 8: find_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+    case 4: find_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+    case 2: find_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+    default: find_kernel<1, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64_t* keys, const void* values,
+                       const uint64_t* scores, uint32_t flags) {
+  if (n == 0) return TFRA_OK;
+  if (!keys || !values) return set_error(TFRA_ERR_INVALID, "insert: null buffer");
+  if (field < 0 || field > t->opts.aux_fields) return set_error(TFRA_ERR_INVALID, "insert: bad field");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "insert: more than 2^31-1 keys per call");
+  int rc = t->prepare_insert(n, s);
+  if (rc) return rc;
+  // TableWrapper::upsert epoch stepping (lookup_table_op_hkv.h:528-536)
+  u64 epoch = t->global_epoch;
+  unsigned fo = field * t->field_bytes;
+  int g = granule_of(t->field_bytes, values, nullptr);
+  if (fo) g = std::min(g, granule_of(fo, nullptr, nullptr));
+  const i64* k = (const i64*)keys;
+  const unsigned char* vals = (const unsigned char*)values;
+  const u64* sc = (const u64*)scores;
+  int strat = t->opts.strategy;
+  constexpr int U = 4;
+  size_t waves = (n + 4 * U - 1) / (4 * U);
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (flags & TFRA_FLAG_UNIQUE_KEYS) {
+    TableView v = t->view_of(t->cur);
+    switch (g) {
+      case 16: insert_unique_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
+      case 8: insert_unique_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
+      case 4: insert_unique_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
+      case 2: insert_unique_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
+      default: insert_unique_kernel<1, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
+    }
+  } else {
+    rc = t->ensure_winner(s);
+    if (rc) return rc;
+    rc = t->ensure_scratch(n * sizeof(i64), s);
+    if (rc) return rc;
+    TableView v = t->view_of(t->cur);
+    i64* slot_of = (i64*)t->scratch;
+    insert_locate_kernel<U><<<grid, block, 0, s>>>(v, n, k, slot_of, field, t->aux);
+    dim3 grid2((unsigned)((n * 16 + 255) / 256));
+    switch (g) {
+      case 16: insert_write_kernel<16><<<grid2, block, 0, s>>>(v, n, vals, sc, slot_of, field, strat, epoch); break;
+      case 8: insert_write_kernel<8><<<grid2, block, 0, s>>>(v, n, vals, sc, slot_of, field, strat, epoch); break;
+      case 4: insert_write_kernel<4><<<grid2, block, 0, s>>>(v, n, vals, sc, slot_of, field, strat, epoch); break;
+      case 2: insert_write_kernel<2><<<grid2, block, 0, s>>>(v, n, vals, sc, slot_of, field, strat, epoch); break;
+      default: insert_write_kernel<1><<<grid2, block, 0, s>>>(v, n, vals, sc, slot_of, field, strat, epoch); break;
+    }
+    rearm_winner_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(v, n, slot_of);
+  }
+  HIP_TRY(hipGetLastError());
+  if (strat == TFRA_EVICT_EPOCHLRU || strat == TFRA_EVICT_EPOCHLFU) {
+    t->curr_step += 1;
+    if (t->opts.step_per_epoch > 0 && t->curr_step > t->opts.step_per_epoch) { t->global_epoch += 1; t->curr_step = 1; }
+  }
+  return TFRA_OK;
+}
+
+template <int DT>
+static void launch_accum(int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k, const unsigned char* vod,
+                         const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai, int strat, u64 epoch,
+                         const int* order, size_t n_order) {
+  dim3 block(256);
+  switch (g) {
+    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+  }
+}
+
+static void launch_accum_dt(int dt, int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k,
+                            const unsigned char* vod, const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai,
+                            int strat, u64 epoch, const int* order, size_t n_order) {
+  switch (dt) {
+    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+  }
+}
+
+// ------------------------------------ C ABI --------------------------------------------------
+extern "C" {
+
+const char* tfra_last_error(void) { return g_last_error.c_str(); }
+int tfra_abi_version(void) { return TFRA_ABI_VERSION; }
+
+int tfra_table_create(const tfra_table_opts* o, const tfra_allocator* alloc, tfra_table_t** out) {
+  if (!o || !out) return set_error(TFRA_ERR_INVALID, "null argument");
+  if (o->struct_size != sizeof(tfra_table_opts)) return set_error(TFRA_ERR_INVALID, "tfra_table_opts size mismatch (ABI)");
+  size_t es = dtype_size(o->value_dtype);
+  if (!es) return set_error(TFRA_ERR_INVALID, "unsupported value_dtype");
+  if (o->dim <= 0) return set_error(TFRA_ERR_INVALID, "dim must be positive");
+  if (o->aux_fields < 0 || o->aux_fields > 4) return set_error(TFRA_ERR_INVALID, "aux_fields must be in [0,4]");
+  if (o->strategy < -1 || o->strategy > 4) return set_error(TFRA_ERR_INVALID, "unknown eviction strategy");
+  Table* t = new Table();
+  t->opts = *o;
+  if (alloc) t->alloc = *alloc;
+  int dev = o->device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { delete t; return set_error(TFRA_ERR_HIP, "no HIP device"); }
+  t->device = dev;
+  if (hipSetDevice(dev) != hipSuccess) { delete t; return set_error(TFRA_ERR_HIP, "hipSetDevice failed"); }
+  // hkv_hashtable_op_gpu.cu.cc:121-133: init 0 -> default, max < init -> max = init
+  if (t->opts.init_capacity == 0) t->opts.init_capacity = t->opts.max_capacity ? (1ULL << 20) : 8192;
+  if (t->opts.max_capacity && t->opts.max_capacity < t->opts.init_capacity) t->opts.max_capacity = t->opts.init_capacity;
+  if (t->opts.max_load_factor <= 0.f || t->opts.max_load_factor > 1.f)
+    t->opts.max_load_factor = t->opts.max_capacity ? 0.5f : 0.75f;
+  t->field_bytes = (unsigned)(o->dim * es);
+  t->row_stride = (unsigned)(((size_t)t->field_bytes * (1 + o->aux_fields) + 15) / 16 * 16);
+  t->aux = make_aux_init(t->opts);
+  hipStream_t s = nullptr;
+  auto fail = [&](int rc) { tfra_table_destroy(reinterpret_cast<tfra_table_t*>(t)); return rc; };
+  size_t ctr_bytes = (SIZE_SHARDS * SIZE_SHARD_STRIDE) * sizeof(u64);
+  t->size_shards = (u64*)t->dalloc(ctr_bytes, s);
+  t->reserved_present = (unsigned*)t->dalloc(64, s);
+  if (!t->size_shards || !t->reserved_present) return fail(set_error(TFRA_ERR_OOM, "counter allocation failed"));
+  t->err_count = t->reserved_present + 8;
+  t->d_scalar = (i64*)(t->reserved_present + 12);
+  if (hipHostMalloc((void**)&t->h_scalar, 64) != hipSuccess) return fail(set_error(TFRA_ERR_OOM, "pinned scalar"));
+  if (hipEventCreateWithFlags(&t->chain_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
+  u64 nb = std::max<u64>(2, (u64)((double)t->opts.init_capacity / t->opts.max_load_factor / SLOTS) + 1);
+  if (t->opts.max_capacity) nb = std::min<u64>(nb, std::max<u64>(2, (t->opts.max_capacity + SLOTS - 1) / SLOTS));
+  int rc = t->alloc_storage(nb, &t->cur, s);
+  if (rc) return fail(rc);
+  clear_kernel<<<2048, 256, 0, s>>>(t->view_of(t->cur), 1);
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "clear failed"));
+  *out = reinterpret_cast<tfra_table_t*>(t);
+  return TFRA_OK;
+}
+
+int tfra_table_destroy(tfra_table_t* tp) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t) return TFRA_OK;
+  (void)hipSetDevice(t->device);
+  (void)hipDeviceSynchronize();
+  hipStream_t s = nullptr;
+  t->dfree(t->cur.keys, s); t->dfree(t->cur.rows, s); t->dfree(t->cur.scores, s);
+  t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
+  t->dfree(t->winner, s); t->dfree(t->scratch, s);
+  if (t->h_scalar) (void)hipHostFree(t->h_scalar);
+  if (t->chain_event) (void)hipEventDestroy(t->chain_event);
+  delete t;
+  return TFRA_OK;
+}
+
+#define TABLE_ENTER()                                         \
+  Table* t = reinterpret_cast<Table*>(tp);                    \
+  if (!t) return set_error(TFRA_ERR_INVALID, "null table");   \
+  hipStream_t s = (hipStream_t)stream;                        \
+  std::lock_guard<std::mutex> lock(t->mu);                    \
+  { int _rc = t->enter(s); if (_rc) return _rc; }
+
+int tfra_table_find(tfra_table_t* tp, size_t n, const int64_t* keys, void* values, uint8_t* exists,
+                    const void* defaults, int default_is_full, tfra_stream_t stream) {
+  TABLE_ENTER();
+  return find_impl(t, s, 0, n, keys, values, exists, defaults, default_is_full);
+}
+
+int tfra_table_find_field(tfra_table_t* tp, int field, size_t n, const int64_t* keys, void* values,
+                          uint8_t* exists, const void* defaults, int default_is_full, tfra_stream_t stream) {
+  TABLE_ENTER();
+  return find_impl(t, s, field, n, keys, values, exists, defaults, default_is_full);
+}
+
+int tfra_table_insert_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, const void* values,
+                                const uint64_t* scores, uint32_t flags, tfra_stream_t stream) {
+  TABLE_ENTER();
+  return insert_impl(t, s, 0, n, keys, values, scores, flags);
+}
+
+int tfra_table_insert_field(tfra_table_t* tp, int field, size_t n, const int64_t* keys, const void* values,
+                            uint32_t flags, tfra_stream_t stream) {
+  TABLE_ENTER();
+  return insert_impl(t, s, field, n, keys, values, nullptr, flags);
+}
+
+int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, const void* vod,
+                               const uint8_t* exists, const uint64_t* scores, uint32_t flags, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (n == 0) return TFRA_OK;
+  if (!keys || !vod || !exists) return set_error(TFRA_ERR_INVALID, "accum: null buffer");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "accum: more than 2^31-1 keys per call");
+  int rc = t->prepare_insert(n, s);
+  if (rc) return rc;
+  int g = granule_of(t->field_bytes, vod, nullptr);
+  TableView v = t->view_of(t->cur);
+  const i64* k = (const i64*)keys;
+  if (flags & TFRA_FLAG_UNIQUE_KEYS) {
+    dim3 grid((unsigned)((n * 16 + 255) / 256));
+    launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    return TFRA_OK;
+  }
+  // Duplicate-safe mode: the reference applies duplicates sequentially in index order
+  // (LaunchTensorsAccum on one thread).  Group occurrences by key on the host and run one
+  // launch per "occurrence rank": launch r handles the r-th occurrence of every key, so adds to
+  // one row happen in index order.  Costs a D2H copy of the keys; the unique-keys flag is the
+  // production path (TFRA de-duplicates before accum).
+  std::vector<i64> hk(n);
+  HIP_TRY(hipMemcpyAsync(hk.data(), keys, n * sizeof(i64), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int> idx(n);
+  for (size_t i = 0; i < n; ++i) idx[i] = (int)i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hk[a] < hk[b]; });
+  std::vector<int> rank(n);
+  int max_rank = 0;
+  for (size_t p = 0; p < n; ++p) {
+    rank[p] = (p > 0 && hk[idx[p]] == hk[idx[p - 1]]) ? rank[p - 1] + 1 : 0;
+    max_rank = std::max(max_rank, rank[p]);
+  }
+  std::vector<std::vector<int>> rounds(max_rank + 1);
+  for (size_t p = 0; p < n; ++p) rounds[rank[p]].push_back(idx[p]);
+  rc = t->ensure_scratch(n * sizeof(int), s);
+  if (rc) return rc;
+  int* d_order = (int*)t->scratch;
+  size_t off = 0;
+  for (auto& r : rounds) {
+    HIP_TRY(hipMemcpyAsync(d_order + off, r.data(), r.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    off += r.size();
+  }
+  off = 0;
+  for (auto& r : rounds) {
+    dim3 grid((unsigned)((r.size() * 16 + 255) / 256));
+    launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, d_order + off, r.size());
+    off += r.size();
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));  // host vectors feeding the H2D copies die here
+  return TFRA_OK;
+}
+
+int tfra_table_erase(tfra_table_t* tp, size_t n, const int64_t* keys, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (n == 0) return TFRA_OK;
+  if (!keys) return set_error(TFRA_ERR_INVALID, "erase: null keys");
+  erase_kernel<<<(unsigned)((n * 16 + 255) / 256), 256, 0, s>>>(t->view_of(t->cur), n, (const i64*)keys);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_table_clear(tfra_table_t* tp, tfra_stream_t stream) {
+  TABLE_ENTER();
+  clear_kernel<<<2048, 256, 0, s>>>(t->view_of(t->cur), 1);
+  HIP_TRY(hipGetLastError());
+  t->size_ub = 0;
+  return TFRA_OK;
+}
+
+int tfra_table_size(tfra_table_t* tp, size_t* out, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (!out) return set_error(TFRA_ERR_INVALID, "size: null out");
+  int rc = t->read_size(s, out);
+  if (rc) return rc;
+  return t->check_errors(s);
+}
+
+int tfra_table_size_to_device(tfra_table_t* tp, int64_t* d_out, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (!d_out) return set_error(TFRA_ERR_INVALID, "size: null out");
+  size_kernel<<<1, SIZE_SHARDS, 0, s>>>(t->view_of(t->cur), (i64*)d_out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_table_capacity(tfra_table_t* tp, size_t* out) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !out) return set_error(TFRA_ERR_INVALID, "capacity: null argument");
+  std::lock_guard<std::mutex> lock(t->mu);
+  *out = t->cur.nb * SLOTS + NUM_RESERVED;
+  return TFRA_OK;
+}
+
+int tfra_table_reserve(tfra_table_t* tp, size_t min_slots, tfra_stream_t stream) {
+  TABLE_ENTER();
+  u64 nb = (min_slots + SLOTS - 1) / SLOTS;
+  if (t->opts.max_capacity) nb = std::min<u64>(nb, (t->opts.max_capacity + SLOTS - 1) / SLOTS);
+  return t->grow(nb, s);
+}
+
+int tfra_table_export_batch(tfra_table_t* tp, size_t n, size_t offset, size_t* d_counter, int64_t* keys,
+                            void* values, uint64_t* scores, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (!d_counter || !keys) return set_error(TFRA_ERR_INVALID, "export: null buffer");
+  TableView v = t->view_of(t->cur);
+  u64 lo = offset, hi = offset + n, total = v.nb * SLOTS;
+  if (n == 0 || lo >= total + NUM_RESERVED) return TFRA_OK;
+  u64 fb = lo / SLOTS, lb = std::min<u64>(v.nb, (std::min<u64>(hi, total) + SLOTS - 1) / SLOTS);
+  int g = granule_of(t->field_bytes, values, nullptr);
+  if (lb > fb) {
+    dim3 grid((unsigned)((lb - fb + 63) / 64)), block(256);
+    u64* c = (u64*)d_counter;
+    unsigned char* vo = (unsigned char*)values;
+    switch (g) {
+      case 16: export_kernel<16><<<grid, block, 0, s>>>(v, fb, lb, lo, hi, c, (i64*)keys, vo, (u64*)scores); break;
+      case 8: export_kernel<8><<<grid, block, 0, s>>>(v, fb, lb, lo, hi, c, (i64*)keys, vo, (u64*)scores); break;
+      case 4: export_kernel<4><<<grid, block, 0, s>>>(v, fb, lb, lo, hi, c, (i64*)keys, vo, (u64*)scores); break;
+      case 2: export_kernel<2><<<grid, block, 0, s>>>(v, fb, lb, lo, hi, c, (i64*)keys, vo, (u64*)scores); break;
+      default: export_kernel<1><<<grid, block, 0, s>>>(v, fb, lb, lo, hi, c, (i64*)keys, vo, (u64*)scores); break;
+    }
+  }
+  if (hi > total)
+    export_reserved_kernel<<<1, 64, 0, s>>>(v, lo, hi, (u64*)d_counter, (i64*)keys, (unsigned char*)values, (u64*)scores);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_table_set_global_epoch(tfra_table_t* tp, uint64_t epoch) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t) return set_error(TFRA_ERR_INVALID, "null table");
+  std::lock_guard<std::mutex> lock(t->mu);
+  t->global_epoch = epoch;
+  return TFRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""ctypes binding of include/tfra_mi355x.h — the only door from Python to the HIP engine.
+
+There is NO CPU fallback: if the shared library is missing or no MI355X is visible the
+product path raises (TFRA's GPU ops likewise refuse to run without their .so,
+R/tensorflow_recommenders_addons/utils/resource_loader.py:104-120).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtfra_mi355x.so")
+
+TFRA_F32, TFRA_F16, TFRA_BF16, TFRA_I8, TFRA_I32, TFRA_I64, TFRA_F64 = range(7)
+FLAG_UNIQUE_KEYS = 1
+OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_FTRL = range(4)
+
+
+class TfraError(RuntimeError):
+  def __init__(self, code, msg):
+    super().__init__("tfra_mi355x error %d: %s" % (code, msg))
+    self.code = code
+
+
+class TableOpts(ctypes.Structure):
+  _fields_ = [
+      ("struct_size", ctypes.c_uint32),
+      ("value_dtype", ctypes.c_int32),
+      ("dim", ctypes.c_int32),
+      ("aux_fields", ctypes.c_int32),
+      ("init_capacity", ctypes.c_uint64),
+      ("max_capacity", ctypes.c_uint64),
+      ("max_hbm_for_vectors", ctypes.c_uint64),
+      ("max_load_factor", ctypes.c_float),
+      ("strategy", ctypes.c_int32),
+      ("step_per_epoch", ctypes.c_int64),
+      ("reserved_key_start_bit", ctypes.c_int32),
+      ("device", ctypes.c_int32),
+      ("aux_init", ctypes.c_float * 4),
+  ]
+
+
+class OptParams(ctypes.Structure):
+  _fields_ = [
+      ("kind", ctypes.c_int32),
+      ("lr", ctypes.c_float),
+      ("beta1", ctypes.c_float),
+      ("beta2", ctypes.c_float),
+      ("eps", ctypes.c_float),
+      ("l1", ctypes.c_float),
+      ("l2", ctypes.c_float),
+      ("lr_power", ctypes.c_float),
+  ]
+
+
+_P = ctypes.c_void_p
+_SZ = ctypes.c_size_t
+_I = ctypes.c_int
+_SIGS = {
+    "tfra_table_create": [ctypes.POINTER(TableOpts), _P, ctypes.POINTER(_P)],
+    "tfra_table_destroy": [_P],
+    "tfra_table_find": [_P, _SZ, _P, _P, _P, _P, _I, _P],
+    "tfra_table_find_field": [_P, _I, _SZ, _P, _P, _P, _P, _I, _P],
+    "tfra_table_insert_or_assign": [_P, _SZ, _P, _P, _P, ctypes.c_uint32, _P],
+    "tfra_table_insert_field": [_P, _I, _SZ, _P, _P, ctypes.c_uint32, _P],
+    "tfra_table_accum_or_assign": [_P, _SZ, _P, _P, _P, _P, ctypes.c_uint32, _P],
+    "tfra_table_erase": [_P, _SZ, _P, _P],
+    "tfra_table_clear": [_P, _P],
+    "tfra_table_size": [_P, ctypes.POINTER(_SZ), _P],
+    "tfra_table_size_to_device": [_P, _P, _P],
+    "tfra_table_capacity": [_P, ctypes.POINTER(_SZ)],
+    "tfra_table_reserve": [_P, _SZ, _P],
+    "tfra_table_export_batch": [_P, _SZ, _SZ, _P, _P, _P, _P, _P],
+    "tfra_table_set_global_epoch": [_P, ctypes.c_uint64],
+    "tfra_table_save": [_P, ctypes.c_char_p, _SZ, _I, _P, ctypes.POINTER(_SZ)],
+    "tfra_table_load": [_P, ctypes.c_char_p, _SZ, _P, ctypes.POINTER(_SZ)],
+    "tfra_table_apply_optimizer": [_P, ctypes.POINTER(OptParams), _SZ, _P, _P, _P, _I, _P, _P],
+    "tfra_workspace_create": [_I, ctypes.POINTER(_P)],
+    "tfra_workspace_destroy": [_P],
+    "tfra_unique": [_P, _SZ, _P, _P, _P, _P, _P],
+    "tfra_segment_sum": [_P, _SZ, _I, _P, _P, _P, _SZ, _P, _P],
+    "tfra_gather_rows": [_SZ, _SZ, _P, _P, _P, _P],
+    "tfra_partition": [_P, _SZ, _P, _I, _I, _P, _P, _P, _P],
+    "tfra_partition_by_owner": [_P, _SZ, _P, _I, _P, _P, _P],
+    "tfra_scatter_rows": [_SZ, _SZ, _P, _P, _P, _P],
+}
+
+_lib = None
+
+
+def lib():
+  """Loads the HIP library (fails loudly when it was not built)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise ImportError(
+          "%s not found: run `python recommenders-addons_amd/build.py` (hipcc, gfx950). "
+          "There is no CPU fallback." % LIB_PATH)
+    l = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+      f = getattr(l, name)
+      f.argtypes = args
+      f.restype = ctypes.c_int
+    l.tfra_last_error.restype = ctypes.c_char_p
+    l.tfra_last_error.argtypes = []
+    l.tfra_abi_version.restype = ctypes.c_int
+    l.tfra_abi_version.argtypes = []
+    _lib = l
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    raise TfraError(rc, lib().tfra_last_error().decode("utf-8", "replace"))
+
+
+def call(name, *args):
+  check(getattr(lib(), name)(*args))

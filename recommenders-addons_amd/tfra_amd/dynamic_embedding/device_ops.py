@@ -1,0 +1,115 @@
+"""Device front-end ops that bracket the table calls (N1/N3 of SURVEY.md §8f), as torch-tensor
+functions over the C ABI: unique, gather, segment_sum, partition (+stitch)."""
+import ctypes
+
+import torch
+
+from .. import _capi
+from .table_ops import _ptr, _stream
+
+_WS = {}
+
+
+def _workspace(device):
+  key = device.index
+  if key not in _WS:
+    h = ctypes.c_void_p()
+    _capi.call("tfra_workspace_create", device.index, ctypes.byref(h))
+    _WS[key] = h
+  return _WS[key]
+
+
+def unique(ids):
+  """tf.unique (first-occurrence order): returns (unique[U], idx[n] int32, num_unique device scalar).
+
+  `unique` is returned as a length-n buffer view trimmed with ONE host read of the count — the
+  same sync TF's `tf.unique` output-shape inference imposes (PY/dynamic_embedding_ops.py:99)."""
+  ids = ids.contiguous()
+  flat = ids.reshape(-1)
+  n = flat.numel()
+  dev = flat.device
+  uniq = torch.empty(n, dtype=torch.int64, device=dev)
+  idx = torch.empty(n, dtype=torch.int32, device=dev)
+  cnt = torch.zeros((), dtype=torch.int64, device=dev)
+  _capi.call("tfra_unique", _workspace(dev), n, _ptr(flat), _ptr(uniq), _ptr(idx), _ptr(cnt), _stream(dev))
+  u = int(cnt.item())
+  return uniq[:u], idx, cnt
+
+
+def unique_no_sync(ids):
+  """Like `unique` but never reads the count on the host: returns the full-length buffer."""
+  flat = ids.contiguous().reshape(-1)
+  n = flat.numel()
+  dev = flat.device
+  uniq = torch.empty(n, dtype=torch.int64, device=dev)
+  idx = torch.empty(n, dtype=torch.int32, device=dev)
+  cnt = torch.zeros((), dtype=torch.int64, device=dev)
+  _capi.call("tfra_unique", _workspace(dev), n, _ptr(flat), _ptr(uniq), _ptr(idx), _ptr(cnt), _stream(dev))
+  return uniq, idx, cnt
+
+
+def gather_rows(rows, idx):
+  """out[i,:] = rows[idx[i],:]  (tf.gather after unique, PY/dynamic_embedding_ops.py:111)."""
+  rows = rows.contiguous()
+  idx = idx.contiguous()
+  n = idx.numel()
+  row_bytes = rows.shape[-1] * rows.element_size()
+  out = torch.empty((n, rows.shape[-1]), dtype=rows.dtype, device=rows.device)
+  _capi.call("tfra_gather_rows", n, row_bytes, _ptr(rows), _ptr(idx), _ptr(out), _stream(rows.device))
+  return out
+
+
+def scatter_rows(rows, perm, n_out=None):
+  """out[perm[i],:] = rows[i,:]  (dynamic_stitch with one flat permutation)."""
+  rows = rows.contiguous()
+  perm = perm.contiguous()
+  n = perm.numel()
+  two_d = rows.reshape(n, -1)
+  row_bytes = two_d.shape[1] * rows.element_size()
+  out = torch.empty((n if n_out is None else n_out, two_d.shape[1]), dtype=rows.dtype, device=rows.device)
+  _capi.call("tfra_scatter_rows", n, row_bytes, _ptr(two_d), _ptr(perm), _ptr(out), _stream(rows.device))
+  return out
+
+
+def segment_sum(grads, idx, num_segments_dev, max_segments):
+  """unsorted_segment_sum(grads, idx) -> [max_segments, dim]; rows >= *num_segments_dev are unspecified.
+  Members of a segment are added in input order, one fp32 add each (sequential CPU order)."""
+  grads = grads.contiguous()
+  idx = idx.contiguous()
+  n = idx.numel()
+  dim = grads.shape[-1]
+  out = torch.empty((max_segments, dim), dtype=torch.float32, device=grads.device)
+  _capi.call("tfra_segment_sum", _workspace(grads.device), n, dim, _ptr(grads), _ptr(idx), _ptr(num_segments_dev),
+             max_segments, _ptr(out), _stream(grads.device))
+  return out
+
+
+PARTITION_MASK_MOD = 0  # int32(key & 0x7fffffff) % N   (CUDA-build branch of default_partition_fn)
+PARTITION_FLOOR_MOD = 1  # key % N                       (CPU-build branch)
+PARTITION_HASH = 2  # fmix64(key) % N               (opt-in, Zipf-balanced)
+
+
+def partition(keys, num_shards, mode=PARTITION_MASK_MOD):
+  """default_partition_fn + dynamic_partition in one pass (PY/dynamic_embedding_variable.py:131-197).
+  Returns owner-major keys, perm (original index of each output element) and device counts[num_shards]."""
+  flat = keys.contiguous().reshape(-1)
+  n = flat.numel()
+  dev = flat.device
+  keys_out = torch.empty(n, dtype=torch.int64, device=dev)
+  perm = torch.empty(n, dtype=torch.int32, device=dev)
+  counts = torch.zeros(num_shards, dtype=torch.int64, device=dev)
+  _capi.call("tfra_partition", _workspace(dev), n, _ptr(flat), num_shards, mode, _ptr(keys_out), _ptr(perm),
+             _ptr(counts), _stream(dev))
+  return keys_out, perm, counts
+
+
+def partition_by_owner(owner, num_shards):
+  """dynamic_partition of range(n) by a caller-computed owner tensor (custom partitioners)."""
+  owner = owner.reshape(-1).to(torch.int32).contiguous()
+  n = owner.numel()
+  dev = owner.device
+  perm = torch.empty(n, dtype=torch.int32, device=dev)
+  counts = torch.zeros(num_shards, dtype=torch.int64, device=dev)
+  _capi.call("tfra_partition_by_owner", _workspace(dev), n, _ptr(owner), num_shards, _ptr(perm), _ptr(counts),
+             _stream(dev))
+  return perm, counts

@@ -1,0 +1,186 @@
+"""Sparse optimizers for `de.Variable` — the write-back half of the hot path.
+
+Reference: `DynamicEmbeddingOptimizer` patches a stock TF optimizer so that, per step and per
+embedding variable, it runs (1+S) table finds -> the stock dense apply kernel on the local
+[U,dim] buffers -> (1+S) table upserts, the S slots living in S extra hash tables
+(PY/dynamic_embedding_optimizer.py:134-242, create_slots :870-958).  Here the S slot vectors are
+co-located with the embedding row (`Variable(aux_fields=S)`) and the whole sequence is ONE HIP
+kernel per shard (`tfra_table_apply_optimizer`), preceded by the duplicate-id reduction the
+reference gets from `_resource_apply_sparse_duplicate_indices` (:177-190): gradients of
+duplicate ids are summed, then one update per key.  Update rules = TF's
+ResourceApply{GradientDescent,Adam,Adagrad[V2],Ftrl}.  Slots of unseen keys start from the
+slot initial value (zeros / `initial_accumulator_value`), state is per key (lazy), the step
+counter for Adam's bias correction is global (PY/...optimizer.py:870-931).
+"""
+import math
+
+import torch
+
+from .. import _capi
+from . import device_ops
+from .variable import TrainableWrapper, Variable
+
+
+class _Opt:
+  slots = ()
+  kind = None
+
+  def aux_init(self):
+    return (0.0, 0.0, 0.0, 0.0)
+
+  def params(self, step):
+    raise NotImplementedError
+
+
+class SGD(_Opt):
+  """tf.train.GradientDescentOptimizer / keras SGD (no momentum)."""
+  kind = _capi.OPT_SGD
+  slots = ()
+
+  def __init__(self, learning_rate=0.01):
+    self.lr = learning_rate
+
+  def params(self, step):
+    p = _capi.OptParams()
+    p.kind, p.lr = self.kind, self.lr
+    return p
+
+
+class Adam(_Opt):
+  """tf.train.AdamOptimizer (epsilon-hat form): slots m, v."""
+  kind = _capi.OPT_ADAM
+  slots = ("m", "v")
+
+  def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
+    self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
+
+  def params(self, step):
+    import numpy as np
+    f32 = np.float32
+    # lr_t = lr*sqrt(1-b2^t)/(1-b1^t), evaluated in fp32 like TF's kernel prologue
+    b1p = f32(np.power(f32(self.b1), f32(step)))
+    b2p = f32(np.power(f32(self.b2), f32(step)))
+    lr_t = f32(f32(self.lr) * np.sqrt(f32(1) - b2p) / (f32(1) - b1p))
+    p = _capi.OptParams()
+    p.kind, p.lr, p.beta1, p.beta2, p.eps = self.kind, float(lr_t), self.b1, self.b2, self.eps
+    return p
+
+
+class Adagrad(_Opt):
+  """tf.train.AdagradOptimizer (epsilon=None) or keras Adagrad (epsilon=1e-7): slot accumulator."""
+  kind = _capi.OPT_ADAGRAD
+  slots = ("accumulator",)
+
+  def __init__(self, learning_rate=0.001, initial_accumulator_value=0.1, epsilon=None):
+    self.lr, self.init_acc, self.eps = learning_rate, initial_accumulator_value, epsilon
+
+  def aux_init(self):
+    return (self.init_acc, 0.0, 0.0, 0.0)
+
+  def params(self, step):
+    p = _capi.OptParams()
+    p.kind, p.lr, p.eps = self.kind, self.lr, (-1.0 if self.eps is None else self.eps)
+    return p
+
+
+class Ftrl(_Opt):
+  """tf.train.FtrlOptimizer: slots accum, linear."""
+  kind = _capi.OPT_FTRL
+  slots = ("accum", "linear")
+
+  def __init__(self, learning_rate=0.001, learning_rate_power=-0.5, initial_accumulator_value=0.1,
+               l1_regularization_strength=0.0, l2_regularization_strength=0.0):
+    self.lr, self.lr_power, self.init_acc = learning_rate, learning_rate_power, initial_accumulator_value
+    self.l1, self.l2 = l1_regularization_strength, l2_regularization_strength
+
+  def aux_init(self):
+    return (self.init_acc, 0.0, 0.0, 0.0)
+
+  def params(self, step):
+    p = _capi.OptParams()
+    p.kind, p.lr, p.l1, p.l2, p.lr_power = self.kind, self.lr, self.l1, self.l2, self.lr_power
+    return p
+
+
+class SlotView:
+  """`optimizer.get_slot(var, name)`: a read view on one co-located state vector; plays the role of
+  the `<param>/<opt>/<slot>` de.Variable of create_slots (PY/...optimizer.py:870-904)."""
+
+  def __init__(self, var, field, init):
+    self.var, self.field, self.init = var, field, init
+
+  def lookup(self, keys):
+    keys = torch.as_tensor(keys, device=self.var._primary)
+    kp, perm, counts = self.var._partition(keys)
+    outs = []
+    for i, t in enumerate(self.var._tables):
+      d = torch.full((self.var.dim,), self.init, dtype=self.var.value_dtype, device=t._device)
+      outs.append(t._table.find(kp[i].to(t._device), d, field=self.field).to(self.var._primary))
+    v = outs[0] if perm is None else device_ops.scatter_rows(torch.cat(outs, 0), perm)
+    return v.reshape(tuple(keys.shape) + (self.var.dim,))
+
+
+class DynamicEmbeddingOptimizer:
+  """`de.DynamicEmbeddingOptimizer(opt)` (PY/dynamic_embedding_optimizer.py:807-867)."""
+
+  def __init__(self, opt, bp_v2=None, synchronous=False):
+    if not isinstance(opt, _Opt):
+      raise TypeError("optimizer must be one of tfra_amd.dynamic_embedding.optimizers.{SGD,Adam,Adagrad,Ftrl}")
+    self.opt = opt
+    self.iterations = 0
+
+  @staticmethod
+  def variable_kwargs(opt):
+    """kwargs for de.Variable / get_variable so rows carry this optimizer's slots."""
+    return {"aux_fields": len(opt.slots), "aux_init": opt.aux_init()}
+
+  def get_slot(self, var, name):
+    f = self.opt.slots.index(name) + 1
+    return SlotView(var, f, self.opt.aux_init()[f - 1])
+
+  def _check(self, var):
+    if var.aux_fields < len(self.opt.slots):
+      raise ValueError(
+          "Variable %r was created with aux_fields=%d but %s needs %d co-located slot vectors: create it with "
+          "**DynamicEmbeddingOptimizer.variable_kwargs(opt)" %
+          (var.name, var.aux_fields, type(self.opt).__name__, len(self.opt.slots)))
+
+  def apply_gradients(self, grads_and_vars, name=None):
+    """grads_and_vars: iterable of (grad[N,dim], TrainableWrapper) — one global step for all pairs."""
+    self.iterations += 1
+    p = self.opt.params(self.iterations)
+    for grad, tw in grads_and_vars:
+      if not isinstance(tw, TrainableWrapper):
+        raise TypeError("expected the TrainableWrapper returned by embedding_lookup(..., return_trainable=True)")
+      self.apply_sparse(tw.params, tw.ids, grad, p)
+
+  def apply_sparse(self, var, ids, grad, p=None):
+    """Sum gradients of duplicate ids, then one fused update per unique key and shard."""
+    if p is None:
+      self.iterations += 1
+      p = self.opt.params(self.iterations)
+    self._check(var)
+    ids = torch.as_tensor(ids, device=var._primary).reshape(-1)
+    grad = grad.reshape(-1, var.dim).to(torch.float32)
+    n = ids.numel()
+    if n == 0:
+      return
+    uniq_buf, idx, cnt = device_ops.unique_no_sync(ids)
+    gsum = device_ops.segment_sum(grad, idx, cnt, n)
+    if var.shard_num == 1 and not callable(var.initializer):
+      # one shard: no partition, so the unique count never has to reach the host
+      t = var._tables[0]
+      t._table.apply_optimizer(p, uniq_buf, gsum, t._default_value.to(torch.float32), n_dev=cnt)
+      return
+    u = int(cnt.item())
+    uniq, gsum = uniq_buf[:u], gsum[:u]
+    kp, perm, counts = var._partition(uniq)
+    gp = var._split_rows(gsum, perm, counts)
+    for i, t in enumerate(var._tables):
+      k = kp[i].to(t._device)
+      if k.numel() == 0:
+        continue
+      dd = var._create_default_values_by_initializer(k.numel(), t._device)
+      if dd is None:
+        dd = t._default_value
+      t._table.apply_optimizer(p, k, gp[i].to(t._device), dd.to(torch.float32))

@@ -1,0 +1,462 @@
+"""KV-table wrappers: `CuckooHashTable` / `HkvHashTable` with the reference's method surface.
+
+Mirrors PY/cuckoo_hashtable_ops.py:45-575 and PY/hkv_hashtable_ops.py:47-560
+(PY = /root/reference/tensorflow_recommenders_addons/dynamic_embedding/python/ops): same
+constructor arguments, same methods (`size, lookup, insert, accum, remove, clear, export,
+save_to_file_system, load_from_file_system`; Hkv adds `export_with_scores,
+export_keys_and_scores`), same argument meaning and error behaviour.  Tensors are torch
+tensors on the table's MI355X; every method is one call through the C ABI
+(include/tfra_mi355x.h) on torch's current HIP stream — no per-op host sync (the reference
+syncs 1-3x per op, R/kernels/hkv_hashtable_op_gpu.cu.cc:192-213).
+
+In the reference `CuckooHashTable` on a GPU device silently issues the Hkv ops
+(PY/cuckoo_hashtable_ops.py:153-165,309-338); here both classes are the same HIP engine:
+`CuckooHashTable` = unbounded, growing, never-evicting flavour (libcuckoo semantics),
+`HkvHashTable` = bounded `max_capacity` flavour with scores.
+"""
+import ctypes
+import enum
+import os
+import sys
+
+import torch
+
+from .. import _capi
+
+_TORCH2DT = {
+    torch.float32: _capi.TFRA_F32,
+    torch.float16: _capi.TFRA_F16,
+    torch.bfloat16: _capi.TFRA_BF16,
+    torch.int8: _capi.TFRA_I8,
+    torch.int32: _capi.TFRA_I32,
+    torch.int64: _capi.TFRA_I64,
+    torch.float64: _capi.TFRA_F64,
+}
+
+KHkvHashTableInitCapacity = 1024 * 1024  # PY/hkv_hashtable_ops.py:40-44
+KHkvHashTableMaxCapacity = 1024 * 1024
+KHkvHashTableMaxHbmForValuesByBytes = 1024 * 1024 * 1024
+
+
+class HkvEvictStrategy(enum.IntEnum):
+  """PY/dynamic_embedding_creator.py:141-146"""
+  LRU = 0
+  LFU = 1
+  EPOCHLRU = 2
+  EPOCHLFU = 3
+  CUSTOMIZED = 4
+
+
+def _stream(device):
+  return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _as_device(device):
+  if device is None or device == "" or device == []:
+    device = "cuda:0"
+  if isinstance(device, (list, tuple)):
+    device = device[0]
+  if isinstance(device, str):
+    d = device.strip().lower().replace("/", "")
+    # TF-style '/GPU:0' / '/device:GPU:0'
+    if "gpu" in d:
+      device = "cuda:" + d.split(":")[-1]
+  dev = torch.device(device)
+  if dev.type != "cuda":
+    raise RuntimeError(
+        "tfra_amd tables live on an MI355X (device %r requested); there is no CPU fallback" %
+        (device,))
+  if not torch.cuda.is_available():
+    raise RuntimeError("no HIP device visible: tfra_amd has no CPU fallback")
+  return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class _DeviceTable:
+  """Owns one tfra_table_t and exposes the table ops on torch tensors."""
+
+  def __init__(self, key_dtype, value_dtype, default_value, name, device, dim=None, aux_fields=0,
+               init_capacity=0, max_capacity=0, max_hbm_for_values=0, strategy=-1, step_per_epoch=0,
+               reserved_key_start_bit=0, max_load_factor=0.0, aux_init=(0.0, 0.0, 0.0, 0.0)):
+    if key_dtype != torch.int64:
+      # GPU ops are registered for K=int64 only (R/kernels/hkv_hashtable_op_gpu.cu.cc:1133-1138)
+      raise TypeError("key_dtype must be torch.int64 on GPU tables, got %s" % key_dtype)
+    if value_dtype not in _TORCH2DT:
+      raise TypeError("unsupported value_dtype %s" % value_dtype)
+    self._key_dtype = key_dtype
+    self._value_dtype = value_dtype
+    self._device = _as_device(device)
+    self._name = name
+    dv = torch.as_tensor(default_value, dtype=value_dtype).reshape(-1)
+    if dim is None:
+      dim = dv.numel()
+    elif dv.numel() == 1 and dim != 1:
+      dv = dv.repeat(dim)
+    if dv.numel() != dim:
+      raise ValueError("default_value must be a vector of dim %d, got shape %s" % (dim, tuple(dv.shape)))
+    self._dim = int(dim)
+    self._default_value = dv.to(self._device).contiguous()
+    o = _capi.TableOpts()
+    o.struct_size = ctypes.sizeof(_capi.TableOpts)
+    o.value_dtype = _TORCH2DT[value_dtype]
+    o.dim = self._dim
+    o.aux_fields = aux_fields
+    o.init_capacity = int(init_capacity)
+    o.max_capacity = int(max_capacity)
+    o.max_hbm_for_vectors = int(max_hbm_for_values)
+    o.max_load_factor = float(max_load_factor)
+    o.strategy = int(strategy)
+    o.step_per_epoch = int(step_per_epoch)
+    o.reserved_key_start_bit = int(reserved_key_start_bit)
+    o.device = self._device.index
+    for i in range(4):
+      o.aux_init[i] = float(aux_init[i]) if i < len(aux_init) else 0.0
+    self._aux_fields = aux_fields
+    h = ctypes.c_void_p()
+    _capi.call("tfra_table_create", ctypes.byref(o), None, ctypes.byref(h))
+    self._h = h
+
+  def __del__(self):
+    h = getattr(self, "_h", None)
+    if h:
+      try:
+        _capi.lib().tfra_table_destroy(h)
+      except Exception:  # interpreter shutdown
+        pass
+      self._h = None
+
+  # ---- helpers -----------------------------------------------------------------------------
+  @property
+  def dim(self):
+    return self._dim
+
+  @property
+  def device(self):
+    return self._device
+
+  @property
+  def key_dtype(self):
+    return self._key_dtype
+
+  @property
+  def value_dtype(self):
+    return self._value_dtype
+
+  def _keys(self, keys):
+    keys = torch.as_tensor(keys, device=self._device) if not torch.is_tensor(keys) else keys
+    if keys.dtype != self._key_dtype:
+      raise TypeError("Signature mismatch. Keys must be dtype %s, got %s." % (self._key_dtype, keys.dtype))
+    return keys.to(self._device).contiguous()
+
+  def _values_for(self, keys, values, what="values"):
+    values = torch.as_tensor(values, device=self._device) if not torch.is_tensor(values) else values
+    if values.dtype != self._value_dtype:
+      raise TypeError("Signature mismatch. %s must be dtype %s, got %s." % (what, self._value_dtype, values.dtype))
+    want = tuple(keys.shape) + (self._dim,)
+    if tuple(values.shape) != want:
+      # CheckKeyAndValueTensorsForInsert (R/kernels/cuckoo_hashtable_op.cc:640-660), KAT K6
+      raise ValueError("Expected shape %s for %s, got %s" % (list(want), what, list(values.shape)))
+    return values.to(self._device).contiguous()
+
+  # ---- ops ---------------------------------------------------------------------------------
+  def find(self, keys, dynamic_default_values=None, return_exists=False, field=0):
+    keys = self._keys(keys)
+    n = keys.numel()
+    d = self._default_value if dynamic_default_values is None else dynamic_default_values
+    d = torch.as_tensor(d, device=self._device) if not torch.is_tensor(d) else d.to(self._device)
+    if d.dtype != self._value_dtype:
+      raise TypeError("default values must be dtype %s, got %s" % (self._value_dtype, d.dtype))
+    d = d.contiguous()
+    out = torch.empty(tuple(keys.shape) + (self._dim,), dtype=self._value_dtype, device=self._device)
+    # is_full_default = (value_flat.size() == default_flat.size())
+    # (R/kernels/hkv_hashtable_op_gpu.cu.cc:188-190, cuckoo_hashtable_op.cc:48-50)
+    full = int(out.numel() == d.numel())
+    if not full and d.numel() < self._dim:
+      raise ValueError("default value needs at least dim=%d elements, got %d" % (self._dim, d.numel()))
+    exists = torch.empty(keys.shape, dtype=torch.bool, device=self._device) if return_exists else None
+    if n:
+      if field:
+        _capi.call("tfra_table_find_field", self._h, field, n, _ptr(keys), _ptr(out), _ptr(exists), _ptr(d), full,
+                   _stream(self._device))
+      else:
+        _capi.call("tfra_table_find", self._h, n, _ptr(keys), _ptr(out), _ptr(exists), _ptr(d), full,
+                   _stream(self._device))
+    return (out, exists) if return_exists else out
+
+  def upsert(self, keys, values, scores=None, unique_keys=False, field=0):
+    keys = self._keys(keys)
+    values = self._values_for(keys, values)
+    n = keys.numel()
+    if n == 0:
+      return
+    flags = _capi.FLAG_UNIQUE_KEYS if unique_keys else 0
+    if scores is not None and scores.numel() == 0:
+      scores = None  # HkvHashTableInsert: empty scores tensor == no scores
+    if scores is not None:
+      scores = scores.to(self._device, torch.int64).contiguous()
+      if scores.numel() != n:
+        raise ValueError("scores must have one entry per key")
+    if field:
+      _capi.call("tfra_table_insert_field", self._h, field, n, _ptr(keys), _ptr(values), flags, _stream(self._device))
+    else:
+      _capi.call("tfra_table_insert_or_assign", self._h, n, _ptr(keys), _ptr(values), _ptr(scores), flags,
+                 _stream(self._device))
+
+  def accum_or_assign(self, keys, values_or_deltas, exists, scores=None, unique_keys=False):
+    keys = self._keys(keys)
+    vod = self._values_for(keys, values_or_deltas, "values_or_deltas")
+    exists = torch.as_tensor(exists, device=self._device)
+    if exists.dtype != torch.bool:
+      raise TypeError("exists must be a bool tensor")
+    if exists.numel() != keys.numel():
+      raise ValueError("exists must have the same number of elements as keys")
+    exists = exists.contiguous()
+    n = keys.numel()
+    if n == 0:
+      return
+    if scores is not None and scores.numel() == 0:
+      scores = None
+    if scores is not None:
+      scores = scores.to(self._device, torch.int64).contiguous()
+    _capi.call("tfra_table_accum_or_assign", self._h, n, _ptr(keys), _ptr(vod), _ptr(exists), _ptr(scores),
+               _capi.FLAG_UNIQUE_KEYS if unique_keys else 0, _stream(self._device))
+
+  def erase(self, keys):
+    keys = self._keys(keys)
+    if keys.numel():
+      _capi.call("tfra_table_erase", self._h, keys.numel(), _ptr(keys), _stream(self._device))
+
+  def clear_all(self):
+    _capi.call("tfra_table_clear", self._h, _stream(self._device))
+
+  def size_host(self):
+    out = ctypes.c_size_t()
+    _capi.call("tfra_table_size", self._h, ctypes.byref(out), _stream(self._device))
+    return out.value
+
+  def size_device(self):
+    out = torch.empty((), dtype=torch.int64, device=self._device)
+    _capi.call("tfra_table_size_to_device", self._h, _ptr(out), _stream(self._device))
+    return out
+
+  def capacity(self):
+    out = ctypes.c_size_t()
+    _capi.call("tfra_table_capacity", self._h, ctypes.byref(out))
+    return out.value
+
+  def reserve(self, n_slots):
+    _capi.call("tfra_table_reserve", self._h, int(n_slots), _stream(self._device))
+
+  def export_all(self, with_scores=False, values=True, split_size=None):
+    """Export = size, then export_batch over the capacity (hkv_hashtable_op_gpu.cu.cc:425-470)."""
+    n = self.size_host()
+    cap = self.capacity()
+    keys = torch.empty(n, dtype=torch.int64, device=self._device)
+    vals = torch.empty((n, self._dim), dtype=self._value_dtype, device=self._device) if values else None
+    scores = torch.empty(n, dtype=torch.int64, device=self._device) if with_scores else None
+    counter = torch.zeros(1, dtype=torch.int64, device=self._device)
+    step = cap if not split_size else int(split_size)
+    for off in range(0, cap, step):
+      _capi.call("tfra_table_export_batch", self._h, min(step, cap - off), off, _ptr(counter), _ptr(keys), _ptr(vals),
+                 _ptr(scores), _stream(self._device))
+    got = int(counter.item())
+    if got != n:
+      raise RuntimeError("export: table changed during export (%d vs %d)" % (got, n))
+    return keys, vals, scores
+
+  def save(self, prefix, buffer_size=4194304, append_to_file=False):
+    out = ctypes.c_size_t()
+    _capi.call("tfra_table_save", self._h, prefix.encode(), int(buffer_size), int(bool(append_to_file)),
+               _stream(self._device), ctypes.byref(out))
+    return out.value
+
+  def load(self, prefix, buffer_size=4194304):
+    out = ctypes.c_size_t()
+    _capi.call("tfra_table_load", self._h, prefix.encode(), int(buffer_size), _stream(self._device), ctypes.byref(out))
+    return out.value
+
+  def apply_optimizer(self, params, keys, grads, param_defaults, n_dev=None):
+    """n_dev: optional device int64 scalar = number of leading (key, grad) pairs that are valid."""
+    keys = self._keys(keys)
+    grads = grads.to(self._device, torch.float32).contiguous()
+    if tuple(grads.shape) != tuple(keys.shape) + (self._dim,):
+      raise ValueError("Expected shape %s for grads, got %s" % (list(keys.shape) + [self._dim], list(grads.shape)))
+    d = param_defaults.to(self._device, torch.float32).contiguous()
+    full = int(d.numel() == grads.numel())
+    _capi.call("tfra_table_apply_optimizer", self._h, ctypes.byref(params), keys.numel(), _ptr(keys), _ptr(grads), _ptr(d),
+               full, _ptr(n_dev), _stream(self._device))
+
+
+class _LookupInterfaceMirror:
+  """Shared method surface of CuckooHashTable / HkvHashTable (tf LookupInterface subclasses)."""
+
+  _table: _DeviceTable
+
+  @property
+  def name(self):
+    return self._name
+
+  @property
+  def key_dtype(self):
+    return self._key_dtype
+
+  @property
+  def value_dtype(self):
+    return self._value_dtype
+
+  @property
+  def resource_handle(self):
+    return self._table
+
+  def size(self, name=None):
+    """Scalar int64 DEVICE tensor (GPU `size_i64`, hkv_hashtable_op_gpu.cu.cc:172-179)."""
+    return self._table.size_device()
+
+  def remove(self, keys, name=None):
+    """PY/cuckoo_hashtable_ops.py:219-246: absent keys are silently ignored."""
+    self._table.erase(keys)
+
+  def clear(self, name=None):
+    self._table.clear_all()
+
+  def lookup(self, keys, dynamic_default_values=None, return_exists=False, name=None):
+    """PY/cuckoo_hashtable_ops.py:272-340"""
+    return self._table.find(keys, dynamic_default_values, return_exists)
+
+  def export(self, name=None):
+    k, v, _ = self._table.export_all()
+    return k, v
+
+  def _file_prefix(self, dirpath, file_name, dirpath_env):
+    # PY/cuckoo_hashtable_ops.py:437-480: env var wins over dirpath; file name defaults to table name
+    if dirpath_env:
+      dirpath = os.environ.get(dirpath_env, dirpath)
+    if not dirpath:
+      raise ValueError("dirpath is required")
+    os.makedirs(dirpath, exist_ok=True)
+    return os.path.join(dirpath, file_name if file_name else self._name)
+
+  def save_to_file_system(self, dirpath, file_name=None, dirpath_env="TFRA_SAVED_KV", append_to_file=False,
+                          buffer_size=4194304, name=None):
+    return self._table.save(self._file_prefix(dirpath, file_name, dirpath_env), buffer_size, append_to_file)
+
+  def load_from_file_system(self, dirpath, file_name=None, dirpath_env="TFRA_SAVED_KV", load_entire_dir=False,
+                            buffer_size=4194304, name=None):
+    """load_entire_dir: load every `*-keys` file of the directory (PY/cuckoo_hashtable_ops.py:482-523).
+    The GPU op clears the table first (hkv_hashtable_op_gpu.cu.cc:619)."""
+    prefix = self._file_prefix(dirpath, file_name, dirpath_env)
+    self._table.clear_all()
+    if load_entire_dir:
+      d = os.path.dirname(prefix)
+      total = 0
+      for f in sorted(os.listdir(d)):
+        if f.endswith("-keys"):
+          total += self._table.load(os.path.join(d, f[:-len("-keys")]), buffer_size)
+      return total
+    return self._table.load(prefix, buffer_size)
+
+
+class CuckooHashTable(_LookupInterfaceMirror):
+  """PY/cuckoo_hashtable_ops.py:45-145.  Growing, never-evicting table (libcuckoo semantics)."""
+
+  def __init__(self, key_dtype, value_dtype, default_value, name="CuckooHashTable", checkpoint=True, init_size=0,
+               config=None, device="", shard_saveable_object_fn=None, dim=None, aux_fields=0, aux_init=(0.0,) * 4):
+    self._key_dtype = key_dtype
+    self._value_dtype = value_dtype
+    self._name = name
+    self._checkpoint = checkpoint
+    self._init_size = init_size
+    self._max_capacity = sys.maxsize
+    if init_size == 0:
+      # K/cuckoo_hashtable_op.cc:199-207: TF_HASHTABLE_INIT_SIZE, default 8192
+      init_size = int(os.environ.get("TF_HASHTABLE_INIT_SIZE", 8192))
+    self._table = _DeviceTable(key_dtype, value_dtype, default_value, name, device, dim=dim, aux_fields=aux_fields,
+                               init_capacity=init_size, max_capacity=0, strategy=-1, aux_init=aux_init)
+    self._default_value = self._table._default_value
+    self._device = self._table.device
+
+  def insert(self, keys, values, name=None):
+    """PY/cuckoo_hashtable_ops.py:342-373.  Duplicate keys: last one wins (sequential CPU order)."""
+    self._table.upsert(keys, values)
+
+  def accum(self, keys, values_or_deltas, exists, name=None):
+    """PY/cuckoo_hashtable_ops.py:375-412"""
+    self._table.accum_or_assign(keys, values_or_deltas, exists)
+
+
+class HkvHashTable(_LookupInterfaceMirror):
+  """PY/hkv_hashtable_ops.py:47-175.  Bounded table with per-key scores and in-bucket eviction."""
+
+  def __init__(self, key_dtype, value_dtype, default_value, name="HkvHashTable", checkpoint=True,
+               init_capacity=KHkvHashTableInitCapacity, max_capacity=KHkvHashTableMaxCapacity,
+               max_hbm_for_values=KHkvHashTableMaxHbmForValuesByBytes, config=None, device="",
+               shard_saveable_object_fn=None, evict_strategy=HkvEvictStrategy.LRU, step_per_epoch=0, gen_scores_fn=None,
+               reserved_key_start_bit=0, dim=None, aux_fields=0, aux_init=(0.0,) * 4):
+    if config:
+      init_capacity = config.init_capacity
+      max_capacity = config.max_capacity
+      max_hbm_for_values = config.max_hbm_for_values
+      evict_strategy = config.evict_strategy
+      step_per_epoch = config.step_per_epoch
+      gen_scores_fn = config.gen_scores_fn
+      reserved_key_start_bit = config.reserved_key_start_bit
+    self._key_dtype = key_dtype
+    self._value_dtype = value_dtype
+    self._scores_dtype = torch.int64
+    self._name = name
+    self._checkpoint = checkpoint
+    self._init_capacity = init_capacity
+    self._max_capacity = max_capacity
+    self._max_hbm_for_values = max_hbm_for_values
+    self._evict_strategy = HkvEvictStrategy(evict_strategy)
+    self._step_per_epoch = step_per_epoch
+    self._gen_scores_fn = gen_scores_fn
+    self._reserved_key_start_bit = reserved_key_start_bit
+    if max_capacity == 0:
+      # hkv_hashtable_op_gpu.cu.cc:104-120
+      env = os.environ.get("TFRA_GPU_HASHTABLE_UPLIMIT_SIZE")
+      if env is None:
+        raise ValueError("max_capaicty=0 and TFRA_GPU_HASHTABLE_UPLIMIT_SIZE not set is not valid.")
+      max_capacity = int(env)
+    self._table = _DeviceTable(key_dtype, value_dtype, default_value, name, device, dim=dim, aux_fields=aux_fields,
+                               init_capacity=init_capacity, max_capacity=max_capacity,
+                               max_hbm_for_values=max_hbm_for_values, strategy=int(self._evict_strategy),
+                               step_per_epoch=step_per_epoch, reserved_key_start_bit=reserved_key_start_bit,
+                               aux_init=aux_init)
+    self._default_value = self._table._default_value
+    self._device = self._table.device
+
+  def _gen_scores(self, keys):
+    """PY/hkv_hashtable_ops.py:209-217"""
+    if self._evict_strategy == HkvEvictStrategy.CUSTOMIZED:
+      assert self._gen_scores_fn is not None, "You must set gen_scores_fn when set evict strategy to CUSTOMIZED"
+      return self._gen_scores_fn(keys)
+    if self._evict_strategy in (HkvEvictStrategy.LFU, HkvEvictStrategy.EPOCHLFU):
+      return torch.ones(keys.shape, dtype=torch.int64, device=keys.device)
+    return None
+
+  def insert(self, keys, values, name=None):
+    """PY/hkv_hashtable_ops.py:339-367"""
+    keys = self._table._keys(keys)
+    self._table.upsert(keys, values, scores=self._gen_scores(keys))
+
+  def accum(self, keys, values_or_deltas, exists, name=None):
+    """PY/hkv_hashtable_ops.py:369-402"""
+    keys = self._table._keys(keys)
+    self._table.accum_or_assign(keys, values_or_deltas, exists, scores=self._gen_scores(keys))
+
+  def export_keys_and_scores(self, split_size, name=None):
+    """PY/hkv_hashtable_ops.py:421-434"""
+    if not (isinstance(split_size, int) and split_size > 0):
+      raise ValueError("split_size must be positive integer.")
+    k, _, s = self._table.export_all(with_scores=True, values=False, split_size=split_size)
+    return k, s
+
+  def export_with_scores(self, split_size, name=None):
+    """PY/hkv_hashtable_ops.py:436-450"""
+    if not (isinstance(split_size, int) and split_size > 0):
+      raise ValueError("split_size must be positive integer.")
+    return self._table.export_all(with_scores=True, values=True, split_size=split_size)

@@ -1,0 +1,389 @@
+"""`Variable`, `get_variable`, `embedding_lookup*` — host-side mirror of the reference API.
+
+PY = /root/reference/tensorflow_recommenders_addons/dynamic_embedding/python/ops
+  Variable ............... PY/dynamic_embedding_variable.py:453-1262
+  default_partition_fn ... PY/dynamic_embedding_variable.py:165-197
+  get_variable ........... PY/dynamic_embedding_variable.py:1265-1359
+  embedding_lookup ....... PY/dynamic_embedding_variable.py:1362-1530
+  embedding_lookup_unique / _sparse / safe_..._sparse  PY/dynamic_embedding_ops.py:64-430
+  TrainableWrapper ....... PY/embedding_weights.py:38-540 (prefetch_values / update_op)
+
+A logical table = N physical tables (`devices=[...]`, one shard per entry); every call is
+partition -> per-shard table op -> stitch, the partition/stitch being device kernels
+(tfra_partition / tfra_scatter_rows) instead of tf.dynamic_partition/dynamic_stitch.
+"""
+import torch
+
+from . import device_ops
+from .table_ops import CuckooHashTable, HkvHashTable, HkvEvictStrategy, _as_device
+
+
+def default_partition_fn(keys, shard_num):
+  """PY/dynamic_embedding_variable.py:165-197 (int64 keys, accelerator build):
+  ``int32(key & 0x7fffffff) % shard_num``.  Kept as a python callable for API parity; the
+  Variable recognises it and runs the fused device partition instead."""
+  if shard_num <= 1:
+    return torch.zeros(keys.shape, dtype=torch.int32, device=keys.device)
+  return ((keys & 0x7FFFFFFF).to(torch.int32) % shard_num).to(torch.int32)
+
+
+class KVCreator:
+  """PY/dynamic_embedding_creator.py:36-78"""
+
+  def __init__(self, config=None):
+    self.config = config
+
+  def create(self, **kw):
+    raise NotImplementedError
+
+
+class CuckooHashTableConfig:
+  """PY/dynamic_embedding_creator.py:80-88 (empty in the reference too)."""
+
+
+class CuckooHashTableCreator(KVCreator):
+  """PY/dynamic_embedding_creator.py:91-138"""
+
+  def create(self, key_dtype=None, value_dtype=None, default_value=None, name=None, checkpoint=None, init_size=None,
+             config=None, device=None, shard_saveable_object_fn=None, **kw):
+    return CuckooHashTable(key_dtype=key_dtype, value_dtype=value_dtype, default_value=default_value, name=name,
+                           checkpoint=checkpoint, init_size=init_size or 0, config=config or self.config, device=device,
+                           **kw)
+
+
+class HkvHashTableConfig:
+  """PY/dynamic_embedding_creator.py:149-169"""
+
+  def __init__(self, init_capacity=1024 * 1024, max_capacity=1024 * 1024, max_hbm_for_values=1024 * 1024 * 1024,
+               evict_strategy=HkvEvictStrategy.LRU, step_per_epoch=0, gen_scores_fn=None, reserved_key_start_bit=0):
+    self.init_capacity = init_capacity
+    self.max_capacity = max_capacity
+    self.max_hbm_for_values = max_hbm_for_values
+    self.evict_strategy = evict_strategy
+    self.step_per_epoch = step_per_epoch
+    self.gen_scores_fn = gen_scores_fn
+    self.reserved_key_start_bit = reserved_key_start_bit
+
+
+class HkvHashTableCreator(KVCreator):
+  """PY/dynamic_embedding_creator.py:172-230"""
+
+  def create(self, key_dtype=None, value_dtype=None, default_value=None, name=None, checkpoint=None, init_size=None,
+             config=None, device=None, shard_saveable_object_fn=None, **kw):
+    cfg = config or self.config or HkvHashTableConfig()
+    return HkvHashTable(key_dtype=key_dtype, value_dtype=value_dtype, default_value=default_value, name=name,
+                        checkpoint=checkpoint, config=cfg, device=device, **kw)
+
+
+class Variable:
+  """A sharded dynamic-embedding table (PY/dynamic_embedding_variable.py:453-692)."""
+
+  def __init__(self, key_dtype=torch.int64, value_dtype=torch.float32, dim=1, devices=None,
+               partitioner=default_partition_fn, shared_name=None, name="DynamicEmbedding_Variable", initializer=None,
+               trainable=True, checkpoint=True, init_size=0, kv_creator=None, restrict_policy=None, bp_v2=False,
+               short_file_name=False, aux_fields=0, aux_init=(0.0, 0.0, 0.0, 0.0)):
+    self.key_dtype = key_dtype
+    self.value_dtype = value_dtype
+    self.dim = int(dim)
+    self.bp_v2 = bp_v2
+    self.name = name
+    self.trainable = trainable
+    self.checkpoint = checkpoint
+    self.aux_fields = aux_fields
+    self.devices = list(devices) if devices else ["cuda:%d" % torch.cuda.current_device()]
+    self.shard_num = len(self.devices)
+    self.partition_fn = partitioner
+    self.init_size = int(init_size / self.shard_num)  # PY/..._variable.py:597
+    self.initializer = initializer
+    self.kv_creator = kv_creator if kv_creator else CuckooHashTableCreator()
+    # static default row: first element of the initializer (PY/..._variable.py:723-765)
+    if initializer is None:
+      static_default = 0
+    elif callable(initializer):
+      static_default = initializer([1, self.dim]).reshape(-1)[0].item()
+    else:
+      static_default = torch.as_tensor(initializer).reshape(-1)[0].item()
+    self._static_default = static_default
+    default_value = torch.full((self.dim,), static_default, dtype=value_dtype)
+    self._tables = []
+    for idx, dev in enumerate(self.devices):
+      self._tables.append(
+          self.kv_creator.create(key_dtype=key_dtype, value_dtype=value_dtype, default_value=default_value,
+                                 name=self._make_name(idx), checkpoint=checkpoint, init_size=self.init_size, device=dev,
+                                 dim=self.dim, aux_fields=aux_fields, aux_init=aux_init))
+    self._primary = _as_device(self.devices[0])
+
+  def _make_name(self, table_idx):
+    """PY/dynamic_embedding_variable.py:768-770"""
+    return "{}_mht_{}of{}".format(self.name.replace("/", "_"), table_idx + 1, self.shard_num)
+
+  @property
+  def tables(self):
+    return self._tables
+
+  # ---- partition / stitch ------------------------------------------------------------------
+  def _partition(self, keys):
+    """-> (keys_per_shard, perm, counts_host). perm is None for 1 shard."""
+    flat = keys.reshape(-1)
+    if self.shard_num <= 1:
+      return [flat], None, [flat.numel()]
+    if self.partition_fn is default_partition_fn:
+      owner_major, perm, counts = device_ops.partition(flat, self.shard_num, device_ops.PARTITION_MASK_MOD)
+    else:
+      owner = self.partition_fn(flat, self.shard_num)
+      perm, counts = device_ops.partition_by_owner(owner, self.shard_num)
+      owner_major = device_ops.gather_rows(flat.reshape(-1, 1), perm).reshape(-1)
+    c = counts.tolist()  # data-dependent shapes: one host read, like tf.dynamic_partition
+    return list(torch.split(owner_major, c)), perm, c
+
+  def _split_rows(self, rows, perm, counts):
+    if perm is None:
+      return [rows]
+    return list(torch.split(device_ops.gather_rows(rows, perm), counts))
+
+  # ---- table ops ---------------------------------------------------------------------------
+  def upsert(self, keys, values, name=None):
+    """PY/dynamic_embedding_variable.py:772-804"""
+    keys = torch.as_tensor(keys, device=self._primary)
+    values = torch.as_tensor(values, device=self._primary)
+    want = tuple(keys.shape) + (self.dim,)
+    if tuple(values.shape) != want:
+      raise ValueError("Expected shape %s for values, got %s" % (list(want), list(values.shape)))
+    kp, perm, counts = self._partition(keys)
+    vp = self._split_rows(values.reshape(-1, self.dim), perm, counts)
+    for i, t in enumerate(self._tables):
+      t.insert(kp[i].to(t._device), vp[i].to(t._device))
+
+  def accum(self, keys, old_values, new_values, exists, name=None):
+    """PY/dynamic_embedding_variable.py:806-855: where(exists, new-old, new) then per-shard accum."""
+    keys = torch.as_tensor(keys, device=self._primary)
+    exists = torch.as_tensor(exists, device=self._primary).reshape(-1).to(torch.bool)
+    old_values = old_values.reshape(-1, self.dim)
+    new_values = new_values.reshape(-1, self.dim)
+    vod = torch.where(exists[:, None], new_values - old_values, new_values)
+    kp, perm, counts = self._partition(keys)
+    vp = self._split_rows(vod, perm, counts)
+    ep = [exists] if perm is None else list(
+        torch.split(device_ops.gather_rows(exists.reshape(-1, 1).to(torch.uint8), perm).reshape(-1).to(torch.bool),
+                    counts))
+    for i, t in enumerate(self._tables):
+      t.accum(kp[i].to(t._device), vp[i].to(t._device), ep[i].to(t._device))
+
+  def remove(self, keys, name=None):
+    """PY/dynamic_embedding_variable.py:877-902"""
+    kp, _, _ = self._partition(torch.as_tensor(keys, device=self._primary))
+    for i, t in enumerate(self._tables):
+      t.remove(kp[i].to(t._device))
+
+  def clear(self, name=None):
+    for t in self._tables:
+      t.clear()
+
+  def _create_default_values_by_initializer(self, n, device):
+    """PY/dynamic_embedding_variable.py:919-931: full-size [n,dim] defaults from the initializer."""
+    if self.initializer is None or not callable(self.initializer):
+      return None
+    return self.initializer([n, self.dim]).to(device=device, dtype=self.value_dtype)
+
+  def lookup(self, keys, return_exists=False, name=None):
+    """PY/dynamic_embedding_variable.py:933-986"""
+    keys = torch.as_tensor(keys, device=self._primary)
+    kp, perm, counts = self._partition(keys)
+    vals, exs = [], []
+    for i, t in enumerate(self._tables):
+      k = kp[i].to(t._device)
+      dd = self._create_default_values_by_initializer(k.numel(), t._device)
+      r = t.lookup(k, dynamic_default_values=dd, return_exists=return_exists)
+      if return_exists:
+        vals.append(r[0].to(self._primary))
+        exs.append(r[1].to(self._primary))
+      else:
+        vals.append(r.to(self._primary))
+    if perm is None:
+      v = vals[0]
+      e = exs[0] if return_exists else None
+    else:
+      v = device_ops.scatter_rows(torch.cat(vals, 0), perm)
+      e = None
+      if return_exists:
+        e = device_ops.scatter_rows(torch.cat(exs, 0).reshape(-1, 1).to(torch.uint8), perm).reshape(-1).to(torch.bool)
+    v = v.reshape(tuple(keys.shape) + (self.dim,))
+    if return_exists:
+      return v, e.reshape(keys.shape)
+    return v
+
+  def export(self, name=None):
+    """PY/dynamic_embedding_variable.py:988-1007"""
+    ks, vs = [], []
+    for t in self._tables:
+      k, v = t.export()
+      ks.append(k.to(self._primary))
+      vs.append(v.to(self._primary))
+    return torch.cat(ks, 0), torch.cat(vs, 0)
+
+  def size(self, index=None, name=None):
+    """PY/dynamic_embedding_variable.py:1133-1155"""
+    if index is not None:
+      return self._tables[index].size()
+    return torch.stack([t.size().to(self._primary) for t in self._tables]).sum()
+
+  def save_to_file_system(self, dirpath, proc_size=1, proc_rank=0, buffer_size=4194304):
+    """Per-shard files `<name>_mht_<i>of<N>[_rank<r>_size<s>]-keys/-values`
+    (PY/dynamic_embedding_variable.py:1009-1060)."""
+    for idx, t in enumerate(self._tables):
+      fname = self._make_name(idx)
+      if proc_size > 1:
+        fname += "_rank{}_size{}".format(proc_rank, proc_size)
+      t.save_to_file_system(dirpath, file_name=fname, dirpath_env=None, buffer_size=buffer_size)
+
+  def load_from_file_system(self, dirpath, proc_size=1, proc_rank=0, buffer_size=4194304):
+    """Reload; when the shard count changed, every `_mht_` file is re-read and re-partitioned
+    through partition_fn (PY/dynamic_embedding_variable.py:200-450, 1062-1131)."""
+    import os
+    files = sorted(f[:-len("-keys")] for f in os.listdir(dirpath)
+                   if f.endswith("-keys") and f.startswith(self.name.replace("/", "_") + "_mht_"))
+    same = all(self._make_name(i) in files for i in range(self.shard_num)) and len(files) == self.shard_num
+    if same and proc_size == 1:
+      for idx, t in enumerate(self._tables):
+        t.load_from_file_system(dirpath, file_name=self._make_name(idx), dirpath_env=None, buffer_size=buffer_size)
+      return
+    import numpy as np
+    self.clear()
+    for f in files:
+      keys = np.fromfile(os.path.join(dirpath, f + "-keys"), dtype=np.int64)
+      vals = torch.from_numpy(np.fromfile(os.path.join(dirpath, f + "-values"), dtype=np.uint8)).view(
+          self.value_dtype).reshape(-1, self.dim)
+      self.upsert(torch.from_numpy(keys).to(self._primary), vals.to(self._primary))
+
+
+_VARIABLES = {}
+
+
+def get_variable(name, key_dtype=torch.int64, value_dtype=torch.float32, dim=1, devices=None,
+                 partitioner=default_partition_fn, shared_name="get_variable", initializer=None, trainable=True,
+                 checkpoint=True, init_size=0, kv_creator=None, restrict_policy=None, bp_v2=False, **kw):
+  """PY/dynamic_embedding_variable.py:1265-1359: create-or-reuse by name."""
+  if name in _VARIABLES:
+    return _VARIABLES[name]
+  v = Variable(key_dtype=key_dtype, value_dtype=value_dtype, dim=dim, devices=devices, partitioner=partitioner,
+               shared_name=shared_name, name=name, initializer=initializer, trainable=trainable, checkpoint=checkpoint,
+               init_size=init_size, kv_creator=kv_creator, restrict_policy=restrict_policy, bp_v2=bp_v2, **kw)
+  _VARIABLES[name] = v
+  return v
+
+
+class TrainableWrapper:
+  """The local [N,dim] "shadow" of the rows of one lookup (PY/embedding_weights.py:38-540):
+  refilled from the table on read (`prefetch_values`), written back by `update_op`."""
+
+  def __init__(self, params, ids, max_norm=None):
+    self.params = params
+    self.ids = ids
+    self.max_norm = max_norm
+    self._values = None
+    self.exists = None
+    self.prefetch_values()
+
+  def prefetch_values(self):
+    """PY/embedding_weights.py:163-170"""
+    if self.params.bp_v2:
+      r, self.exists = self.params.lookup(self.ids, return_exists=True)
+    else:
+      r = self.params.lookup(self.ids)
+    self._values = self.transform(r)
+    return self._values
+
+  def transform(self, result):
+    """PY/embedding_weights.py:497-521: optional clip_by_norm over the embedding axis."""
+    if self.max_norm is None:
+      return result
+    norm = result.to(torch.float32).norm(dim=-1, keepdim=True)
+    scale = self.max_norm / torch.maximum(norm, torch.full_like(norm, self.max_norm))
+    return (result * scale).to(result.dtype)
+
+  def read_value(self):
+    return self._values
+
+  def update_op(self, new_values, old_values=None):
+    """PY/embedding_weights.py:434-444: upsert (or accum when bp_v2) the post-optimizer rows."""
+    if self.params.bp_v2:
+      old = self._values if old_values is None else old_values
+      self.params.accum(self.ids, old, new_values, self.exists)
+    else:
+      self.params.upsert(self.ids, new_values)
+    self._values = new_values
+
+
+def embedding_lookup(params, ids, partition_strategy=None, name=None, validate_indices=None, max_norm=None,
+                     return_trainable=False):
+  """PY/dynamic_embedding_variable.py:1362-1530.  A miss returns the initializer row and does NOT
+  insert (keys enter the table on the optimizer write-back)."""
+  ids = torch.as_tensor(ids, device=params._primary)
+  tw = TrainableWrapper(params, ids.reshape(-1), max_norm=max_norm)
+  emb = tw.read_value().reshape(tuple(ids.shape) + (params.dim,))
+  return (emb, tw) if return_trainable else emb
+
+
+def embedding_lookup_unique(params, ids, partition_strategy=None, name=None, validate_indices=None, max_norm=None,
+                            return_trainable=False):
+  """PY/dynamic_embedding_ops.py:64-117: unique -> lookup -> gather."""
+  ids = torch.as_tensor(ids, device=params._primary)
+  uniq, idx, _ = device_ops.unique(ids)
+  r = embedding_lookup(params, uniq, max_norm=max_norm, return_trainable=return_trainable)
+  ue, tw = r if return_trainable else (r, None)
+  emb = device_ops.gather_rows(ue, idx).reshape(tuple(ids.shape) + (params.dim,))
+  return (emb, tw) if return_trainable else emb
+
+
+def embedding_lookup_sparse(params, sp_ids, sp_weights=None, partition_strategy=None, name="embedding_lookup_sparse",
+                            combiner="mean", max_norm=None, return_trainable=False, num_rows=None):
+  """PY/dynamic_embedding_ops.py:120-293.  `sp_ids` = (indices[nnz,2] or row_ids[nnz], values[nnz]);
+  `sp_weights` = matching weight values or None.  Segment combine sum / mean / sqrtn over rows."""
+  if combiner not in ("mean", "sqrtn", "sum"):
+    raise ValueError("combiner must be one of 'mean', 'sqrtn' or 'sum'")
+  indices, ids = sp_ids
+  indices = torch.as_tensor(indices, device=params._primary)
+  seg = (indices[:, 0] if indices.dim() == 2 else indices).to(torch.int64)
+  ids = torch.as_tensor(ids, device=params._primary)
+  uniq, idx, _ = device_ops.unique(ids)
+  r = embedding_lookup(params, uniq, max_norm=max_norm, return_trainable=return_trainable)
+  ue, tw = r if return_trainable else (r, None)
+  emb = device_ops.gather_rows(ue, idx).to(torch.float32)
+  n = int(seg.max().item()) + 1 if num_rows is None else num_rows
+  w = torch.ones(ids.numel(), dtype=torch.float32, device=emb.device) if sp_weights is None else torch.as_tensor(
+      sp_weights, dtype=torch.float32, device=emb.device)
+  out = torch.zeros((n, params.dim), dtype=torch.float32, device=emb.device)
+  out.index_add_(0, seg, emb * w[:, None])
+  if combiner != "sum":
+    ws = torch.zeros(n, dtype=torch.float32, device=emb.device)
+    ws.index_add_(0, seg, w if combiner == "mean" else w * w)
+    if combiner == "sqrtn":
+      ws = ws.sqrt()
+    out = torch.where(ws[:, None] > 0, out / ws[:, None], torch.zeros_like(out))
+  return (out, tw) if return_trainable else out
+
+
+def safe_embedding_lookup_sparse(params, sp_ids, sparse_weights=None, combiner="mean", default_id=None,
+                                 name="safe_embedding_lookup_sparse", partition_strategy=None, max_norm=None,
+                                 return_trainable=False, num_rows=None):
+  """PY/dynamic_embedding_ops.py:296-430: drop ids < 0 and non-positive weights; empty rows yield
+  zeros (or the `default_id` embedding)."""
+  indices, ids = sp_ids
+  indices = torch.as_tensor(indices, device=params._primary)
+  ids = torch.as_tensor(ids, device=params._primary)
+  keep = ids >= 0
+  w = None
+  if sparse_weights is not None:
+    w = torch.as_tensor(sparse_weights, dtype=torch.float32, device=params._primary)
+    keep &= w > 0
+  rows = indices[:, 0] if indices.dim() == 2 else indices
+  n = int(rows.max().item()) + 1 if num_rows is None else num_rows
+  out = embedding_lookup_sparse(params, (rows[keep], ids[keep]), None if w is None else w[keep], combiner=combiner,
+                                max_norm=max_norm, return_trainable=return_trainable, num_rows=n)
+  res, tw = out if return_trainable else (out, None)
+  if default_id is not None:
+    empty = torch.ones(n, dtype=torch.bool, device=res.device)
+    empty[rows[keep].to(torch.int64)] = False
+    d = params.lookup(torch.tensor([default_id], dtype=torch.int64, device=params._primary)).to(torch.float32)
+    res = torch.where(empty[:, None], d, res)
+  return (res, tw) if return_trainable else res

@@ -1,0 +1,231 @@
+"""GPU parity: front-end device ops, sharded Variable, embedding_lookup*, fused optimizers — all
+through the C ABI — against the numpy restatements in oracle/."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import frontends as ofe
+from oracle import optimizers as oopt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  return torch, de
+
+
+def T(torch, a):
+  return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n,hi", [(1, 5), (7, 3), (1000, 50), (131072, 20000), (300001, 10**12)])
+def test_unique_is_tf_unique(env, n, hi):
+  torch, de = env
+  rng = np.random.default_rng(n)
+  ids = rng.integers(-hi, hi, size=n).astype(np.int64)
+  ids[0] = np.iinfo(np.int64).min  # the scratch set's sentinel value is a legal id
+  u, idx, cnt = de.device_ops.unique(T(torch, ids))
+  eu, eidx = ofe.unique(ids)
+  assert int(cnt.item()) == eu.size
+  np.testing.assert_array_equal(u.cpu().numpy(), eu)
+  np.testing.assert_array_equal(idx.cpu().numpy(), eidx)
+
+
+def test_gather_scatter_rows(env):
+  torch, de = env
+  rng = np.random.default_rng(1)
+  for dim, dt in [(64, np.float32), (3, np.float32), (5, np.int8), (1, np.int64), (7, np.float16)]:
+    rows = (rng.standard_normal((500, dim)) * 50).astype(dt)
+    idx = rng.integers(0, 500, size=2000).astype(np.int32)
+    out = de.device_ops.gather_rows(T(torch, rows), T(torch, idx))
+    np.testing.assert_array_equal(out.cpu().numpy(), rows[idx])
+    perm = rng.permutation(500).astype(np.int32)
+    out = de.device_ops.scatter_rows(T(torch, rows), T(torch, perm))
+    exp = np.empty_like(rows); exp[perm] = rows
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("dim", [64, 10, 1])
+def test_segment_sum_is_sequential_fp32(env, dim):
+  torch, de = env
+  rng = np.random.default_rng(dim)
+  n = 50000
+  ids = (rng.zipf(1.3, size=n) % 4000).astype(np.int64)
+  g = rng.standard_normal((n, dim)).astype(np.float32)
+  eu, esum, eidx = oopt.segment_sum_by_key(ids, g)
+  u, idx, cnt = de.device_ops.unique_no_sync(T(torch, ids))
+  out = de.device_ops.segment_sum(T(torch, g), idx, cnt, n)
+  U = int(cnt.item())
+  assert U == eu.size
+  # same summation order as the sequential CPU loop => bit-exact
+  np.testing.assert_array_equal(out[:U].cpu().numpy(), esum)
+
+
+@pytest.mark.parametrize("shards,mode", [(2, 0), (8, 0), (3, 1), (8, 2), (64, 0)])
+def test_partition_matches_default_partition_fn(env, shards, mode):
+  torch, de = env
+  rng = np.random.default_rng(shards)
+  n = 70001
+  keys = rng.integers(-2**62, 2**62, size=n).astype(np.int64)
+  ko, perm, counts = de.device_ops.partition(T(torch, keys), shards, mode)
+  if mode == 2:
+    # hash mode has no reference twin: check it is a stable partition by SOME owner function
+    perm_np = perm.cpu().numpy(); c = counts.cpu().numpy()
+    assert c.sum() == n and sorted(perm_np.tolist()) == list(range(n))
+    np.testing.assert_array_equal(ko.cpu().numpy(), keys[perm_np])
+    off = 0
+    for s in range(shards):
+      seg = perm_np[off:off + c[s]]
+      assert np.all(np.diff(seg) > 0)
+      off += c[s]
+    return
+  owner = ofe.default_partition_fn(keys, shards, gpu_mode=(mode == 0))
+  parts, idxs = ofe.make_partition(keys, owner, shards)
+  np.testing.assert_array_equal(counts.cpu().numpy(), [len(p) for p in parts])
+  np.testing.assert_array_equal(ko.cpu().numpy(), np.concatenate(parts))
+  np.testing.assert_array_equal(perm.cpu().numpy(), np.concatenate(idxs))
+
+
+def test_k7_k8_sharding(env):
+  """K7: default partitioner over 2 shards (T/dynamic_embedding_ops_test.py:324-349);
+  K8: custom partitioner keys%2 over 3 shards (:382-408)."""
+  torch, de = env
+  ids = torch.arange(5, dtype=torch.int64).cuda()
+  v = de.Variable(dim=2, devices=["cuda:0", "cuda:0"], name="k7", initializer=0.0)
+  emb, tw = de.embedding_lookup(v, ids, return_trainable=True)
+  tw.update_op(emb)
+  assert int(v.size().item()) == 5 and int(v.size(0).item()) == 3 and int(v.size(1).item()) == 2
+  v8 = de.Variable(dim=1, devices=["cuda:0"] * 3, name="k8", partitioner=lambda k, n: (k % 2).to(torch.int32))
+  v8.upsert(ids, torch.tensor([[0.], [1.], [2.], [3.], [4.]]).cuda())
+  out = v8.lookup(torch.tensor([1, 3, 2, 3, 0], dtype=torch.int64).cuda())
+  np.testing.assert_array_equal(out.cpu().numpy(), [[1], [3], [2], [3], [0]])
+  assert [int(v8.size(i).item()) for i in range(3)] == [3, 2, 0]
+
+
+def test_k5_high_rank_and_k9_max_norm(env):
+  torch, de = env
+  v = de.Variable(dim=1, name="k5", initializer=-1.0)
+  v.upsert(torch.tensor([0, 1, 2]).cuda(), torch.tensor([[0.], [1.], [2.]]).cuda())
+  out = v.lookup(torch.tensor([[0, 1], [2, 4]]).cuda())
+  assert tuple(out.shape) == (2, 2, 1)
+  np.testing.assert_array_equal(out.cpu().numpy(), [[[0], [1]], [[2], [-1]]])
+  v9 = de.Variable(dim=1, name="k9", initializer=2.0)
+  out = de.embedding_lookup(v9, torch.tensor([0]).cuda(), max_norm=1.0)
+  np.testing.assert_allclose(out.cpu().numpy(), [[1.0]])
+  v92 = de.Variable(dim=2, name="k92", initializer=2.0)
+  v92.upsert(torch.tensor([7]).cuda(), torch.tensor([[3.0, 4.0]]).cuda())
+  out = de.embedding_lookup(v92, torch.tensor([7]).cuda(), max_norm=2.0)
+  np.testing.assert_allclose(out.cpu().numpy(), [[1.2, 1.6]], rtol=1e-6)
+
+
+def test_k10_initializer_statistics(env):
+  """T/dynamic_embedding_variable_test.py:565-588: defaults of 2^17 missing keys follow the
+  initializer (random_normal(0, 0.01))."""
+  torch, de = env
+  gen = torch.Generator(device="cuda").manual_seed(2)
+  init = lambda shape: torch.randn(shape, generator=gen, device="cuda") * 0.01
+  v = de.Variable(dim=10, name="k10", initializer=init)
+  out = v.lookup(torch.arange(2**17, dtype=torch.int64).cuda())
+  assert abs(out.mean().item()) < 1e-4 and abs(out.std().item() - 0.01) < 1e-4
+  assert int(v.size().item()) == 0  # lookup never inserts
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_embedding_lookup_unique_and_sparse(env, shards):
+  torch, de = env
+  rng = np.random.default_rng(4)
+  dim = 8
+  v = de.Variable(dim=dim, devices=["cuda:0"] * shards, name="els%d" % shards, initializer=-2.0)
+  cpu = oracle.CpuTable(dim)
+  keys = np.arange(0, 300, dtype=np.int64)
+  vals = rng.standard_normal((300, dim)).astype(np.float32)
+  v.upsert(T(torch, keys), T(torch, vals)); cpu.insert(keys, vals)
+  ids = rng.integers(0, 400, size=(7, 31)).astype(np.int64)
+  default = np.full(dim, -2.0, np.float32)
+  out = de.embedding_lookup_unique(v, T(torch, ids))
+  np.testing.assert_array_equal(out.cpu().numpy(), ofe.embedding_lookup_unique(cpu, ids, default))
+  rows = np.sort(rng.integers(0, 50, size=600)).astype(np.int64)
+  sid = rng.integers(0, 400, size=600).astype(np.int64)
+  w = rng.random(600).astype(np.float32) + 0.1
+  for comb in ("sum", "mean", "sqrtn"):
+    for weights in (None, w):
+      got = de.embedding_lookup_sparse(v, (T(torch, rows), T(torch, sid)), None if weights is None else T(torch, weights),
+                                       combiner=comb, num_rows=50)
+      exp = ofe.embedding_lookup_sparse(cpu, rows, sid, default, comb, weights, num_rows=50)
+      np.testing.assert_allclose(got.cpu().numpy(), exp, rtol=2e-6, atol=2e-6)
+  with pytest.raises(ValueError, match="combiner"):
+    de.embedding_lookup_sparse(v, (T(torch, rows), T(torch, sid)), combiner="max")
+
+
+OPTS = {
+    "sgd": (lambda de: de.optimizers.SGD(0.1), dict(lr=0.1)),
+    "adam": (lambda de: de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8), dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)),
+    "adagrad": (lambda de: de.optimizers.Adagrad(0.05, 0.1), dict(lr=0.05, init_acc=0.1)),
+    "adagrad_v2": (lambda de: de.optimizers.Adagrad(0.05, 0.1, 1e-7), dict(lr=0.05, init_acc=0.1, eps=1e-7)),
+    "ftrl": (lambda de: de.optimizers.Ftrl(0.05, -0.5, 0.1, 1e-3, 1e-3), dict(lr=0.05, l1=1e-3, l2=1e-3, init_acc=0.1)),
+    "ftrl_pow": (lambda de: de.optimizers.Ftrl(0.05, -0.3, 0.1, 0.0, 1e-3), dict(lr=0.05, l1=0.0, l2=1e-3, init_acc=0.1, lr_power=-0.3)),
+}
+
+
+@pytest.mark.parametrize("name", list(OPTS))
+@pytest.mark.parametrize("dim,shards", [(1, 1), (10, 2), (64, 1)])
+def test_k13_fused_optimizer_matches_reference_sequence(env, name, dim, shards):
+  """K13 (T/dynamic_embedding_optimizer_test.py:546-641): ids [0,1,1,2,3,4,4] with duplicates
+  summed, 10 steps, shards {1,2}, dim {1,10} — fused HIP update vs the reference's
+  (1+S) finds + dense apply + (1+S) upserts over CPU tables.  Tolerance 1e-6 (north_star)."""
+  torch, de = env
+  kind = name.split("_")[0]
+  mk, hyper = OPTS[name]
+  opt = mk(de)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  v = de.Variable(dim=dim, devices=["cuda:0"] * shards, name="k13_%s_%d_%d" % (name, dim, shards), initializer=0.25,
+                  **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  rng = np.random.default_rng(13)
+  base_keys = np.arange(5, dtype=np.int64)
+  base = rng.random((5, dim)).astype(np.float32)
+  v.upsert(T(torch, base_keys), T(torch, base))
+  nslots = len(opt.slots)
+  tabs = [oracle.CpuTable(dim) for _ in range(1 + nslots)]
+  tabs[0].insert(base_keys, base)
+  ora = oopt.SparseOptimizerOracle(kind, tabs[0], tabs[1:], hyper, 0.25)
+  ids = np.array([0, 1, 1, 2, 3, 4, 4, 9], dtype=np.int64)  # 9 is unseen: inserted by the write-back
+  for step in range(10):
+    emb, tw = de.embedding_lookup(v, T(torch, ids), return_trainable=True)
+    exp = tabs[0].find(ids, np.full(dim, 0.25, np.float32))
+    np.testing.assert_allclose(emb.cpu().numpy(), exp, rtol=1e-6, atol=1e-6)
+    g = (2.0 * exp * rng.random((ids.size, 1)).astype(np.float32)).astype(np.float32)  # d/dE (E x)^2-like
+    deo.apply_gradients([(T(torch, g), tw)])
+    ora.apply(ids, g)
+  k, val = v.export()
+  o = np.argsort(k.cpu().numpy())
+  ek, ev = tabs[0].export_sorted()
+  np.testing.assert_array_equal(k.cpu().numpy()[o], ek)
+  np.testing.assert_allclose(val.cpu().numpy()[o], ev, rtol=1e-6, atol=1e-6)
+  for si, sname in enumerate(opt.slots):
+    got = deo.get_slot(v, sname).lookup(T(torch, ek)).cpu().numpy()
+    exp = tabs[1 + si].find(ek, np.zeros(dim, np.float32))
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6)
+
+
+def test_optimizer_requires_slots(env):
+  torch, de = env
+  v = de.Variable(dim=4, name="noslots")
+  deo = de.DynamicEmbeddingOptimizer(de.optimizers.Adam())
+  with pytest.raises(ValueError, match="aux_fields"):
+    deo.apply_sparse(v, torch.tensor([1]).cuda(), torch.zeros(1, 4).cuda())
+
+
+def test_bp_v2_accum_write_back(env):
+  """bp_v2: update_op sends where(exists, new-old, new) through accum (PY/embedding_weights.py:434-444)."""
+  torch, de = env
+  v = de.Variable(dim=3, name="bpv2", initializer=1.0, bp_v2=True)
+  v.upsert(torch.tensor([1, 2]).cuda(), torch.tensor([[1., 1, 1], [2, 2, 2]]).cuda())
+  emb, tw = de.embedding_lookup(v, torch.tensor([1, 2, 3]).cuda(), return_trainable=True)
+  np.testing.assert_array_equal(tw.exists.cpu().numpy(), [True, True, False])
+  v.upsert(torch.tensor([1]).cuda(), torch.tensor([[10., 10, 10]]).cuda())  # someone else moved key 1
+  tw.update_op(emb + 0.5)
+  out = v.lookup(torch.tensor([1, 2, 3]).cuda()).cpu().numpy()
+  np.testing.assert_array_equal(out, [[10.5] * 3, [2.5] * 3, [1.5] * 3])

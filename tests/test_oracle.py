@@ -73,3 +73,13 @@ def test_port_matches_reference_engine_random_ops(dim, dtype):
       break
     got.append(k); off += k.size
   assert np.array_equal(np.sort(np.concatenate(got)), ka)
+
+
+def test_port_replays_golden_vectors_from_reference_engine():
+  """The committed fixtures were produced by the real reference engine; the port must replay them."""
+  import glob, os
+  from tests.golden.replay import replay
+  files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_ops_*.npz")))
+  assert len(files) >= 5
+  for f in files:
+    replay(f, lambda dim, dtype: oracle.CpuTable(dim, dtype, kind="port"))
