@@ -165,7 +165,7 @@ def main():
   # ---- table: rows [p|m|v] co-located, sized so that no rehash happens -------------------------
   opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
   deo = de.DynamicEmbeddingOptimizer(opt)
-  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=n_local,
+  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05),
                     **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
   emb = AllToAllEmbedding(var, partition_mode=0) if world > 1 else None
   table = var.tables[0]

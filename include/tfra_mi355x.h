@@ -178,6 +178,14 @@ int tfra_table_apply_optimizer(tfra_table_t* t, const tfra_opt_params* p, size_t
                                const int64_t* keys, const float* grads, const void* param_defaults,
                                int default_is_full, const int64_t* d_n, tfra_stream_t stream);
 
+/* The whole backward half of a training step in two kernels: ids [n] MAY repeat (a raw Zipf batch);
+ * gradients of equal ids are summed in a fixed order (deterministic), then one fused update per
+ * unique key as above.  = _resource_apply_sparse_duplicate_indices + the write-back sequence
+ * (PY/dynamic_embedding_optimizer.py:165-204).  param_default_row: [dim] fp32, used for unseen keys.
+ * Requires float32 values, dim % 4 == 0, dim <= 256. */
+int tfra_table_apply_sparse(tfra_table_t* t, const tfra_opt_params* p, size_t n, const int64_t* ids,
+                            const float* grads, const float* param_default_row, tfra_stream_t stream);
+
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 
 /* Scratch for unique/partition; grows on demand, reusable across calls on one stream. */

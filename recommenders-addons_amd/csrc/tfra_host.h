@@ -47,6 +47,11 @@ struct Table {
   hipStream_t last_stream = nullptr;
   bool has_last = false;
   hipEvent_t chain_event = nullptr;
+  hipEvent_t size_event = nullptr;  // async size refresh (prepare_insert)
+  bool size_pending = false;
+  size_t n_since_read = 0;
+  i64* h_size = nullptr;  // pinned, inside the h_scalar block
+  bool growth_blocked = false;
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
   int n_rehash = 0;

@@ -16,45 +16,11 @@
 #include "../../include/tfra_mi355x.h"
 #include "tfra_device.h"
 #include "tfra_host.h"
+#include "tfra_optim_device.h"
 
 using namespace tfra;
 
 namespace {
-
-struct OptP {
-  int kind;
-  float lr, beta1, beta2, eps, l1, l2, lr_power;
-};
-
-__device__ __forceinline__ float sgnf(float z) { return (z > 0.f) ? 1.f : ((z < 0.f) ? -1.f : 0.f); }
-
-template <int KIND>
-__device__ __forceinline__ void apply_one(const OptP& o, float g, float& p, float& s1, float& s2) {
-  if (KIND == TFRA_OPT_SGD) {
-    p = p - o.lr * g;
-  } else if (KIND == TFRA_OPT_ADAM) {
-    // m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t*m/(sqrt(v)+eps)
-    s1 = s1 + (g - s1) * (1.f - o.beta1);
-    s2 = s2 + (g * g - s2) * (1.f - o.beta2);
-    p = p - (s1 * o.lr) / (sqrtf(s2) + o.eps);
-  } else if (KIND == TFRA_OPT_ADAGRAD) {
-    s1 = s1 + g * g;
-    if (o.eps < 0.f) p = p - o.lr * g / sqrtf(s1);
-    else p = p - o.lr * g / (sqrtf(s1) + o.eps);
-  } else {  // FTRL: s1 = accum, s2 = linear
-    float a_new = s1 + g * g;
-    float pa_new, pa;
-    if (o.lr_power == -0.5f) { pa_new = sqrtf(a_new); pa = sqrtf(s1); }
-    else { pa_new = powf(a_new, -o.lr_power); pa = powf(s1, -o.lr_power); }
-    float sigma = (pa_new - pa) / o.lr;
-    s2 = s2 + g - sigma * p;
-    float q = pa_new / o.lr + 2.f * o.l2;
-    p = (fabsf(s2) > o.l1) ? (sgnf(s2) * o.l1 - s2) / q : 0.f;
-    s1 = a_new;
-  }
-}
-
-template <int KIND> struct NSlots { static constexpr int v = KIND == TFRA_OPT_SGD ? 0 : (KIND == TFRA_OPT_ADAGRAD ? 1 : 2); };
 
 // 16 lanes per key; lane `sub` owns elements sub*4..sub*4+3 (+64 per step): float4 everywhere
 // when dim % 4 == 0 (VEC4), scalar otherwise.

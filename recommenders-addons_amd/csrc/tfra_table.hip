@@ -632,21 +632,56 @@ int Table::grow(u64 min_nb, hipStream_t s) {
 }
 
 // called before inserting up to n new keys
+// Called before an op that may insert up to n new keys.  Growth policy:
+//   * `size_ub` is a host-side UPPER BOUND of the live-key count (every insert-type call adds its
+//     n; exact after a size read).  While size_ub + n <= max_load_factor*slots nothing happens.
+//   * Past that soft threshold a steady-state training loop (upserts of resident keys) must not
+//     pay a host sync per call: an ASYNC size read (size kernel + 8-B D2H into pinned memory +
+//     event) refreshes the bound; the call proceeds optimistically while the bound stays under
+//     the hard threshold (92 % of the slots, where first-fit probing still terminates quickly).
+//   * Only when the bound passes the hard threshold do we synchronise, and grow if the TRUE size
+//     needs it.  An out-of-memory during growth is not an error unless the keys cannot fit at all.
 int Table::prepare_insert(size_t n, hipStream_t s) {
-  double lf = opts.max_load_factor;
-  size_t slots = cur.nb * SLOTS;
-  if ((double)(size_ub + n) <= lf * (double)slots) { size_ub += n; return TFRA_OK; }
+  const double slots = (double)(cur.nb * SLOTS);
+  const double soft = opts.max_load_factor * slots, hard = 0.92 * slots;
+  if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
+  // at max_capacity (eviction takes over) or after a failed growth there is nothing to decide
+  const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb < (opts.max_capacity + SLOTS - 1) / SLOTS);
+  if (!can_grow) return TFRA_OK;
+  if (size_pending && hipEventQuery(size_event) == hipSuccess) {
+    i64 v = *h_size;
+    size_ub = (v < 0 ? 0 : (size_t)v) + n_since_read;
+    size_pending = false;
+    if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
+  }
+  if ((double)(size_ub + n) <= hard) {
+    if (!size_pending) {
+      size_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1);
+      HIP_TRY(hipMemcpyAsync(h_size, d_scalar + 1, sizeof(i64), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(size_event, s));
+      size_pending = true;
+      n_since_read = 0;
+    }
+    size_ub += n;
+    n_since_read += n;
+    return TFRA_OK;
+  }
   size_t sz;
   int rc = read_size(s, &sz);
   if (rc) return rc;
-  if ((double)(sz + n) > lf * (double)slots) {
+  size_pending = false;
+  if ((double)(sz + n) > soft && can_grow) {
     u64 max_nb = opts.max_capacity ? (opts.max_capacity + SLOTS - 1) / SLOTS : ~0ULL;
-    if (cur.nb < max_nb) {
-      u64 want = (u64)((double)(sz + n) / lf / SLOTS) + 1;
-      want = std::max(want, cur.nb * 2);
-      want = std::min(want, max_nb);
-      rc = grow(want, s);
-      if (rc) return rc;
+    u64 need = (u64)((double)(sz + n) / opts.max_load_factor / SLOTS) + 1;
+    u64 tries[2] = {std::min(std::max(need, cur.nb * 2), max_nb), std::min(std::max(need, cur.nb + cur.nb / 4), max_nb)};
+    rc = TFRA_ERR_OOM;
+    for (int i = 0; i < 2 && rc == TFRA_ERR_OOM; ++i) rc = grow(tries[i], s);
+    if (rc == TFRA_ERR_OOM) {
+      if ((double)(sz + n) > 0.98 * slots) return rc;  // cannot fit: report the allocation failure
+      growth_blocked = true;                            // keep running denser instead
+      g_last_error.clear();
+    } else if (rc) {
+      return rc;
     }
   }
   size_ub = sz + n;
@@ -803,6 +838,8 @@ int tfra_table_create(const tfra_table_opts* o, const tfra_allocator* alloc, tfr
   t->d_scalar = (i64*)(t->reserved_present + 12);
   if (hipHostMalloc((void**)&t->h_scalar, 64) != hipSuccess) return fail(set_error(TFRA_ERR_OOM, "pinned scalar"));
   if (hipEventCreateWithFlags(&t->chain_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
+  if (hipEventCreateWithFlags(&t->size_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
+  t->h_size = t->h_scalar + 4;
   u64 nb = std::max<u64>(2, (u64)((double)t->opts.init_capacity / t->opts.max_load_factor / SLOTS) + 1);
   if (t->opts.max_capacity) nb = std::min<u64>(nb, std::max<u64>(2, (t->opts.max_capacity + SLOTS - 1) / SLOTS));
   int rc = t->alloc_storage(nb, &t->cur, s);
@@ -824,6 +861,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   t->dfree(t->winner, s); t->dfree(t->scratch, s);
   if (t->h_scalar) (void)hipHostFree(t->h_scalar);
   if (t->chain_event) (void)hipEventDestroy(t->chain_event);
+  if (t->size_event) (void)hipEventDestroy(t->size_event);
   delete t;
   return TFRA_OK;
 }
@@ -930,6 +968,8 @@ int tfra_table_clear(tfra_table_t* tp, tfra_stream_t stream) {
   clear_kernel<<<2048, 256, 0, s>>>(t->view_of(t->cur), 1);
   HIP_TRY(hipGetLastError());
   t->size_ub = 0;
+  t->size_pending = false;
+  t->n_since_read = 0;
   return TFRA_OK;
 }
 

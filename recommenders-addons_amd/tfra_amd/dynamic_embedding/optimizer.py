@@ -123,11 +123,15 @@ class SlotView:
 class DynamicEmbeddingOptimizer:
   """`de.DynamicEmbeddingOptimizer(opt)` (PY/dynamic_embedding_optimizer.py:807-867)."""
 
-  def __init__(self, opt, bp_v2=None, synchronous=False):
+  def __init__(self, opt, bp_v2=None, synchronous=False, exact_order=False):
+    """exact_order=True sums duplicate gradients strictly in input order (bit-exact vs a sequential
+    CPU unsorted_segment_sum) through unique + segment_sum + apply; the default uses the fused
+    two-kernel path whose fixed summation tree is deterministic but not the sequential order."""
     if not isinstance(opt, _Opt):
       raise TypeError("optimizer must be one of tfra_amd.dynamic_embedding.optimizers.{SGD,Adam,Adagrad,Ftrl}")
     self.opt = opt
     self.iterations = 0
+    self.exact_order = exact_order
 
   @staticmethod
   def variable_kwargs(opt):
@@ -164,6 +168,12 @@ class DynamicEmbeddingOptimizer:
     grad = grad.reshape(-1, var.dim).to(torch.float32)
     n = ids.numel()
     if n == 0:
+      return
+    if (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and
+        not self.exact_order):
+      # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic
+      t = var._tables[0]
+      t._table.apply_sparse(p, ids, grad, t._default_value.to(torch.float32))
       return
     uniq_buf, idx, cnt = device_ops.unique_no_sync(ids)
     gsum = device_ops.segment_sum(grad, idx, cnt, n)

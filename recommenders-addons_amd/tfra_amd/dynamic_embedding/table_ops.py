@@ -290,6 +290,21 @@ class _DeviceTable:
                full, _ptr(n_dev), _stream(self._device))
 
 
+  # method of _DeviceTable (appended below the class body by assignment)
+def _apply_sparse(self, params, ids, grads, default_row):
+  """ids may repeat: duplicate gradients are summed (fixed order), one fused update per unique key."""
+  ids = self._keys(ids).reshape(-1)
+  grads = grads.to(self._device, torch.float32).contiguous()
+  if grads.numel() != ids.numel() * self._dim:
+    raise ValueError("Expected shape %s for grads, got %s" % ([ids.numel(), self._dim], list(grads.shape)))
+  d = default_row.to(self._device, torch.float32).contiguous()
+  _capi.call("tfra_table_apply_sparse", self._h, ctypes.byref(params), ids.numel(), _ptr(ids), _ptr(grads), _ptr(d),
+             _stream(self._device))
+
+
+_DeviceTable.apply_sparse = _apply_sparse
+
+
 class _LookupInterfaceMirror:
   """Shared method surface of CuckooHashTable / HkvHashTable (tf LookupInterface subclasses)."""
 

@@ -232,3 +232,67 @@ def test_bp_v2_accum_write_back(env):
   tw.update_op(emb + 0.5)
   out = v.lookup(torch.tensor([1, 2, 3]).cuda()).cpu().numpy()
   np.testing.assert_array_equal(out, [[10.5] * 3, [2.5] * 3, [1.5] * 3])
+
+
+@pytest.mark.parametrize("dim", [64, 8, 128, 200])
+@pytest.mark.parametrize("kind", ["adam", "ftrl", "adagrad", "sgd"])
+def test_apply_sparse_two_kernel_path_zipf(env, dim, kind):
+  """The fused tile-reduce + bucket-apply path on Zipf batches with heavy duplication (hot key
+  ~18 % of the batch) vs the reference sequence over CPU tables.  Sums of duplicates use a fixed
+  tree instead of the sequential order => compare at 1e-6 relative to the summed-gradient scale
+  (fp64 oracle sums), and require bit-identical results across two runs (determinism)."""
+  torch, de = env
+  from bench import zipf_bounded, keys_of_ranks
+  mk, hyper = OPTS[kind]
+  rng = np.random.default_rng(dim)
+  n_keys, B = 50000, 20000 + dim  # not a multiple of the 1024 tile
+  results = []
+  for run in range(2):
+    opt = mk(de)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    v = de.Variable(dim=dim, name="as_%s_%d_%d" % (kind, dim, run), initializer=0.1,
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    tabs = [oracle.CpuTable(dim) for _ in range(1 + len(opt.slots))]
+    ora = oopt.SparseOptimizerOracle(kind, tabs[0], tabs[1:], hyper, 0.1)
+    r2 = np.random.default_rng(1000 + dim)
+    for step in range(3):
+      ids = keys_of_ranks(zipf_bounded(r2, B, n_keys))
+      g = (r2.standard_normal((B, dim)) * 0.01).astype(np.float32)
+      deo.apply_sparse(v, T(torch, ids), T(torch, g))
+      if run == 0:
+        # oracle with fp64 duplicate sums (order-free), rounded once to fp32
+        uniq, inv = np.unique(ids, return_inverse=True)
+        gs = np.zeros((uniq.size, dim), np.float64); np.add.at(gs, inv, g.astype(np.float64))
+        ora.apply(uniq, gs.astype(np.float32))
+    k, val = v.export()
+    o = np.argsort(k.cpu().numpy())
+    results.append((k.cpu().numpy()[o], val.cpu().numpy()[o]))
+    if run == 0:
+      ek, ev = tabs[0].export_sorted()
+      np.testing.assert_array_equal(results[0][0], ek)
+      # Adam/FTRL normalise the update: errors of the gradient sum shrink further; 2e-6 abs covers
+      # the hot key whose 3600-term sum differs from the fp64 sum by ~1e-6 relative
+      np.testing.assert_allclose(results[0][1], ev, rtol=2e-6, atol=2e-6)
+      assert int(v.size().item()) == ek.size
+  np.testing.assert_array_equal(results[0][0], results[1][0])
+  np.testing.assert_array_equal(results[0][1], results[1][1])
+
+
+def test_apply_sparse_matches_exact_order_path_without_duplicates(env):
+  """With unique ids there is nothing to sum: fused path == exact path bit for bit."""
+  torch, de = env
+  rng = np.random.default_rng(8)
+  dim = 64
+  ids = rng.permutation(10**6)[:30000].astype(np.int64)
+  g = (rng.standard_normal((ids.size, dim)) * 0.01).astype(np.float32)
+  outs = []
+  for exact in (False, True):
+    opt = de.optimizers.Adam(1e-3)
+    deo = de.DynamicEmbeddingOptimizer(opt, exact_order=exact)
+    v = de.Variable(dim=dim, name="ex%d" % exact, initializer=0.3, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    for _ in range(2):
+      deo.apply_sparse(v, T(torch, ids), T(torch, g))
+    k, val = v.export()
+    o = np.argsort(k.cpu().numpy())
+    outs.append(val.cpu().numpy()[o])
+  np.testing.assert_array_equal(outs[0], outs[1])
