@@ -24,17 +24,24 @@ namespace {
 
 // 16 lanes per key; lane `sub` owns elements sub*4..sub*4+3 (+64 per step): float4 everywhere
 // when dim % 4 == 0 (VEC4), scalar otherwise.
-template <int KIND, bool VEC4>
+// INDIRECT: gradient row of entry g is named by src[g] (tfra_sparse_apply.hip): src < alt_base ->
+// grads row src, else alt_rows row (src-alt_base); src == 0xffffffff -> hole, skipped.
+template <int KIND, bool VEC4, bool INDIRECT>
 __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
                                                     const float* __restrict__ grads,
                                                     const float* __restrict__ defaults, int full, int dim,
-                                                    float aux0, float aux1, const i64* __restrict__ d_n) {
+                                                    float aux0, float aux1, const i64* __restrict__ d_n,
+                                                    const unsigned* __restrict__ src, const float* __restrict__ alt_rows,
+                                                    unsigned alt_base) {
   constexpr int S = NSlots<KIND>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   int fresh = 0, failed = 0;
   if (d_n) { size_t dn = (size_t)*d_n; if (dn < n) n = dn; }
-  if (g < n) {
+  unsigned sidx = 0;
+  bool active = g < n;
+  if (INDIRECT && active) { sidx = src[g]; active = sidx != 0xffffffffu; }
+  if (active) {
     const i64 key = keys[g];
     bool is_new;
     i64 row = locate_or_claim(v, key, sub, gshift, is_new);
@@ -43,7 +50,8 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
     } else {
       fresh = (is_new && sub == 0);
       float* pr = reinterpret_cast<float*>(v.rows + (size_t)row * v.row_stride);
-      const float* gr = grads + g * (size_t)dim;
+      const float* gr = INDIRECT ? (sidx < alt_base ? grads + (size_t)sidx * dim : alt_rows + (size_t)(sidx - alt_base) * dim)
+                                 : grads + g * (size_t)dim;
       const float* df = defaults + (full ? g * (size_t)dim : 0);
       if (VEC4) {
         for (int c = sub * 4; c < dim; c += 64) {
@@ -98,11 +106,32 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
 template <int KIND>
 void launch_apply(bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
                   const float* d, int full, int dim, float a0, float a1, const i64* dn) {
-  if (vec4) apply_kernel<KIND, true><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn);
-  else apply_kernel<KIND, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn);
+  if (vec4) apply_kernel<KIND, true, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0);
+  else apply_kernel<KIND, false, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0);
 }
 
 }  // namespace
+
+namespace tfra {
+// third kernel of tfra_table_apply_sparse: caller holds the table lock and has run prepare_insert
+int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, size_t max_n, const i64* keys,
+                          const unsigned* src, const float* grads, const float* alt_rows, unsigned alt_base,
+                          const float* default_row, const i64* d_n) {
+  TableView v = t->view_of(t->cur);
+  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power};
+  const int dim = t->opts.dim;
+  const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
+  dim3 grid((unsigned)((max_n * 16 + 255) / 256));
+  switch (p->kind) {
+    case TFRA_OPT_SGD: apply_kernel<TFRA_OPT_SGD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
+    case TFRA_OPT_ADAM: apply_kernel<TFRA_OPT_ADAM, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
+    case TFRA_OPT_ADAGRAD: apply_kernel<TFRA_OPT_ADAGRAD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
+    default: apply_kernel<TFRA_OPT_FTRL, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
+  }
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
+  return TFRA_OK;
+}
+}  // namespace tfra
 
 extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_params* p, size_t n, const int64_t* keys,
                                           const float* grads, const void* param_defaults, int default_is_full,
