@@ -109,8 +109,10 @@ __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, 
 // Within one launch slots only go EMPTY -> key, and every inserter takes the first empty slot
 // in probe order with a CAS, so two groups inserting the same key can never end up in two
 // different slots.  Returns row index, or -1 when no slot could be found.
-__device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int sub, int gshift,
-                                               bool& is_new) {
+// `k_first` = the key's first bucket line (b0), already loaded by the caller (coherently) so that
+// a kernel can put the first probes of several keys in flight before resolving any of them.
+__device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key, u64 h, u64 b0, i64 k_first,
+                                                    int sub, int gshift, bool& is_new) {
   is_new = false;
   if (is_reserved_key(key)) {
     int r = reserved_index(key);
@@ -120,14 +122,12 @@ __device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int 
     is_new = (old == 0);
     return (i64)(v.nb * SLOTS + r);
   }
-  u64 h;
-  const u64 b0 = bucket0(key, v.nb, h);
   const u64 b1 = bucket1(h, b0, v.nb);
   for (int attempt = 0; attempt < 1024; ++attempt) {
     u64 b = b0;
     i64 fe = -1;  // word index (b*16+slot) of the first empty slot seen
     for (u64 step = 0; step <= v.nb; ++step) {
-      i64 k = load_key_coherent(&v.keys[b * 16 + sub]);
+      i64 k = (attempt == 0 && step == 0) ? k_first : load_key_coherent(&v.keys[b * 16 + sub]);
       u64 m = __ballot(sub < SLOTS && k == key);
       unsigned hit = (unsigned)(m >> gshift) & 0x7fffu;
       if (hit) return (i64)(b * SLOTS + (__ffs(hit) - 1));
@@ -153,6 +153,14 @@ __device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int 
     // another key took it: rescan
   }
   return -1;
+}
+
+__device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int sub, int gshift,
+                                               bool& is_new) {
+  u64 h;
+  const u64 b0 = bucket0(key, v.nb, h);
+  i64 k = load_key_coherent(&v.keys[b0 * 16 + sub]);
+  return locate_or_claim_from(v, key, h, b0, k, sub, gshift, is_new);
 }
 
 __device__ __forceinline__ void size_add(const TableView& v, u64 wave_id, long long delta) {

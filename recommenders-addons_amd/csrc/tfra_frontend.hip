@@ -372,7 +372,7 @@ int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* uni
                 int64_t* d_num_unique, tfra_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!ws || !d_num_unique) return set_error(TFRA_ERR_INVALID, "unique: null argument");
-  HIP_TRY(hipSetDevice(ws->device));
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) HIP_TRY(hipSetDevice(ws->device)); }
   if (n == 0) { HIP_TRY(hipMemsetAsync(d_num_unique, 0, sizeof(int64_t), s)); return TFRA_OK; }
   if (!ids || !unique_out || !idx_out) return set_error(TFRA_ERR_INVALID, "unique: null buffer");
   if (n >= (1ULL << 30)) return set_error(TFRA_ERR_INVALID, "unique: more than 2^30 ids per call");
@@ -410,7 +410,7 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
                      const int64_t* d_num_segments, size_t max_segments, float* out, tfra_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!ws || !d_num_segments || !out || dim <= 0) return set_error(TFRA_ERR_INVALID, "segment_sum: bad argument");
-  HIP_TRY(hipSetDevice(ws->device));
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) HIP_TRY(hipSetDevice(ws->device)); }
   if (max_segments == 0) return TFRA_OK;
   if (n == 0) { HIP_TRY(hipMemsetAsync(out, 0, max_segments * (size_t)dim * sizeof(float), s)); return TFRA_OK; }
   if (!in || !idx) return set_error(TFRA_ERR_INVALID, "segment_sum: null buffer");
@@ -446,7 +446,7 @@ int tfra_partition(tfra_workspace_t* ws, size_t n, const int64_t* keys, int num_
   hipStream_t s = (hipStream_t)stream;
   if (!ws || !d_counts || num_shards <= 0 || num_shards > 2048 || mode < 0 || mode > 2)
     return set_error(TFRA_ERR_INVALID, "partition: bad argument (1 <= num_shards <= 2048, mode in 0..2)");
-  HIP_TRY(hipSetDevice(ws->device));
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) HIP_TRY(hipSetDevice(ws->device)); }
   if (n == 0) { HIP_TRY(hipMemsetAsync(d_counts, 0, num_shards * sizeof(int64_t), s)); return TFRA_OK; }
   if (!keys || !keys_out || !perm_out) return set_error(TFRA_ERR_INVALID, "partition: null buffer");
   if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "partition: too many keys");
@@ -467,7 +467,7 @@ int tfra_partition_by_owner(tfra_workspace_t* ws, size_t n, const int32_t* owner
   hipStream_t s = (hipStream_t)stream;
   if (!ws || !d_counts || num_shards <= 0 || num_shards > 2048)
     return set_error(TFRA_ERR_INVALID, "partition_by_owner: bad argument (1 <= num_shards <= 2048)");
-  HIP_TRY(hipSetDevice(ws->device));
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) HIP_TRY(hipSetDevice(ws->device)); }
   if (n == 0) { HIP_TRY(hipMemsetAsync(d_counts, 0, num_shards * sizeof(int64_t), s)); return TFRA_OK; }
   if (!owner || !perm_out) return set_error(TFRA_ERR_INVALID, "partition_by_owner: null buffer");
   if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "partition_by_owner: too many keys");

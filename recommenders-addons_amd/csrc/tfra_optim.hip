@@ -55,15 +55,15 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
       const float* df = defaults + (full ? g * (size_t)dim : 0);
       if (VEC4) {
         for (int c = sub * 4; c < dim; c += 64) {
+          // all loads unconditional and issued together (a brand-new row reads its own not yet
+          // initialised bytes and discards them)
           float4 gg = *reinterpret_cast<const float4*>(gr + c);
-          float4 p, s1 = make_float4(aux0, aux0, aux0, aux0), s2 = make_float4(aux1, aux1, aux1, aux1);
-          if (is_new) {
-            p = *reinterpret_cast<const float4*>(df + c);
-          } else {
-            p = *reinterpret_cast<const float4*>(pr + c);
-            if (S >= 1) s1 = *reinterpret_cast<const float4*>(pr + dim + c);
-            if (S >= 2) s2 = *reinterpret_cast<const float4*>(pr + 2 * dim + c);
-          }
+          float4 p = *reinterpret_cast<const float4*>((is_new ? df : pr) + c);
+          float4 s1 = *reinterpret_cast<const float4*>(pr + (S >= 1 ? dim : 0) + c);
+          float4 s2 = *reinterpret_cast<const float4*>(pr + (S >= 2 ? 2 * dim : 0) + c);
+          __builtin_amdgcn_sched_barrier(0);
+          if (is_new || S < 1) s1 = make_float4(aux0, aux0, aux0, aux0);
+          if (is_new || S < 2) s2 = make_float4(aux1, aux1, aux1, aux1);
           apply_one<KIND>(o, gg.x, p.x, s1.x, s2.x);
           apply_one<KIND>(o, gg.y, p.y, s1.y, s2.y);
           apply_one<KIND>(o, gg.z, p.z, s1.z, s2.z);

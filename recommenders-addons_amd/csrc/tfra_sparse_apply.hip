@@ -102,7 +102,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT/64]*/, int* 
 //   row_of(p)  -> const float* of position p's row        out_of(p_head) -> float* for the run sum
 template <int NCH, class RowOf, class OutOf>
 __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const unsigned char* s_flag,
-                                                 float (*s_left)[64 * MAXCH], unsigned char* s_cont,
+                                                 float (*s_left)[64 * NCH], unsigned char* s_cont,
                                                  unsigned char* s_hashead, RowOf row_of, OutOf out_of) {
   constexpr int BATCH = Batch<NCH>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, g = threadIdx.x >> 4;
@@ -129,17 +129,20 @@ __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const
   if (has_any) {
     for (int p0 = gs; p0 < ge; p0 += BATCH) {
       float4 x[BATCH][NCH];
+      // unconditional loads (skipped positions re-read the chunk's first row, an L2 hit) so that the
+      // BATCH row fetches are all in flight before the first add; see find_kernel for why
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         int p = p0 + j;
         bool need = p < ge && !(s_flag[p] & F_SINGLE);
-        const float* row = need ? row_of(p) : nullptr;
+        const float* row = row_of(need ? p : gs);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
           int col = k * 64 + sub * 4;
-          x[j][k] = (need && col < dim) ? *reinterpret_cast<const float4*>(row + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[j][k] = *reinterpret_cast<const float4*>(row + (col < dim ? col : 0));
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         int p = p0 + j;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(NT) void tile_reduce_kernel(size_t n, const i64* __
   __shared__ unsigned short s_u[TILE];       // unique rank (within the tile) of each head position
   __shared__ unsigned char s_flag[TILE + 1];
   __shared__ unsigned s_hist[2048];          // P <= 2048
-  __shared__ float s_left[16][64 * MAXCH];
+  __shared__ float s_left[16][64 * NCH];
   __shared__ unsigned char s_cont[16], s_hashead[16];
   __shared__ int s_scan[NT / 64];
   const size_t tile = blockIdx.x, base = tile * TILE;
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(NT) void tile_reduce_kernel(size_t n, const i64* __
 // kernel C.  Output: bucket b owns u_keys/u_src[off_b .. off_b+n_b) with n_b = its descriptor count
 // and off_b = sum_t tile_start[t][b]; the first (#unique in bucket) entries are filled, the rest are
 // SKIP.  Summed rows go to scratch row (sum_base - rows_base + index).  The last bucket publishes
-// the total entry count.
+// the total entry count.  A bucket holding more than CMAX descriptors (several very hot keys
+// hashing together) is processed in 2^k passes, pass q taking the keys with (hash & (2^k-1)) == q.
 template <int NCH>
 __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned ntiles, int dim, unsigned rows_base,
                                                           unsigned sum_base, const float* __restrict__ grads,
@@ -275,77 +279,109 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
                                                           i64* __restrict__ d_total, unsigned* overflow) {
   __shared__ u64 e_key[CMAX];        // key with the sign bit flipped (unsigned order)
   __shared__ unsigned e_ord[CMAX];   // descriptor index t*TILE+u: ascending = tile order
+  __shared__ unsigned s_src[CMAX];   // part_src of each sorted position
   __shared__ unsigned char s_flag[CMAX + 1];
-  __shared__ unsigned short s_rank[CMAX];  // unique rank (within the bucket) of each head position
-  __shared__ float s_left[16][64 * MAXCH];
+  __shared__ unsigned short s_rank[CMAX];  // unique rank (within the pass) of each head position
+  __shared__ float s_left[16][64 * NCH];
   __shared__ unsigned char s_cont[16], s_hashead[16];
   __shared__ int s_scan[NT / 64];
   const unsigned b = blockIdx.x;
-  int carry = 0;
+  // bucket totals: n_b descriptors starting at output offset off_b
+  int n_b = 0;
   long long off = 0;
-  bool too_many = false;
   for (unsigned t0 = 0; t0 < ntiles; t0 += NT) {
     unsigned t = t0 + threadIdx.x;
-    int cnt = 0, st = 0, tot;
+    int cnt = 0, st = 0;
     if (t < ntiles) { cnt = tile_hist[(size_t)t * P + b]; st = tile_start[(size_t)t * P + b]; }
-    // off_b = sum over tiles of (descriptors of smaller buckets in that tile)
-    int st_sum = st;
-    for (int o2 = 32; o2 > 0; o2 >>= 1) st_sum += __shfl_xor(st_sum, o2);
-    int ex = block_excl_scan(cnt, s_scan, &tot);
-    if ((threadIdx.x & 63) == 0) s_scan[threadIdx.x >> 6] = st_sum;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { cnt += __shfl_xor(cnt, o2); st += __shfl_xor(st, o2); }
+    if ((threadIdx.x & 63) == 0) { s_scan[threadIdx.x >> 6] = cnt; s_rank[threadIdx.x >> 6] = 0; e_ord[threadIdx.x >> 6] = (unsigned)st; }
     __syncthreads();
-    off += (long long)s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    n_b += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    off += (long long)e_ord[0] + e_ord[1] + e_ord[2] + e_ord[3];
     __syncthreads();
-    if (carry + tot > CMAX) too_many = true;  // keep counting: the region must still be marked
-    for (int j = 0; j < cnt && !too_many; ++j) {
-      unsigned d = t * TILE + st + j;
-      e_ord[carry + ex + j] = d;
-      e_key[carry + ex + j] = (u64)part_keys[d] ^ 0x8000000000000000ULL;
+  }
+  if (b == P - 1 && threadIdx.x == 0) *d_total = off + n_b;
+  if (n_b == 0) return;
+  unsigned npass = 1;
+  while ((unsigned)n_b > (CMAX / 2) * npass && npass < 64) npass <<= 1;
+  if (n_b <= CMAX) npass = 1;
+  int out_used = 0;  // unique keys emitted so far (over all passes)
+  for (unsigned pass = 0; pass < npass; ++pass) {
+    // gather this pass's descriptors from every tile, tile order
+    int carry = 0;
+    bool too_many = false;
+    for (unsigned t0 = 0; t0 < ntiles; t0 += NT) {
+      unsigned t = t0 + threadIdx.x;
+      int cnt = 0, st = 0, mine = 0, tot;
+      if (t < ntiles) { cnt = tile_hist[(size_t)t * P + b]; st = tile_start[(size_t)t * P + b]; }
+      if (npass == 1) {
+        mine = cnt;
+      } else {
+        for (int j = 0; j < cnt; ++j)
+          mine += ((unsigned)fmix64((u64)part_keys[t * TILE + st + j]) & (npass - 1)) == pass;
+      }
+      int ex = block_excl_scan(mine, s_scan, &tot);
+      if (carry + tot > CMAX) too_many = true;
+      if (!too_many) {
+        int w = carry + ex;
+        for (int j = 0; j < cnt; ++j) {
+          unsigned d = t * TILE + st + j;
+          i64 key = part_keys[d];
+          if (npass == 1 || ((unsigned)fmix64((u64)key) & (npass - 1)) == pass) {
+            e_ord[w] = d;
+            e_key[w] = (u64)key ^ 0x8000000000000000ULL;
+            ++w;
+          }
+        }
+      }
+      carry += tot;
     }
-    carry += tot;
-  }
-  const int n = carry;
-  if (b == P - 1 && threadIdx.x == 0) *d_total = off + n;
-  if (too_many) {  // pathological hash skew (> CMAX descriptors in one of P buckets): reported, not applied
-    if (threadIdx.x == 0) atomicAdd(overflow, 1u);
-    for (int i = threadIdx.x; i < n; i += NT) u_src[off + i] = SKIP;
-    return;
-  }
-  if (n == 0) return;
-  int n2 = 2;
-  while (n2 < n) n2 <<= 1;
-  for (int p = n + threadIdx.x; p < n2; p += NT) { e_key[p] = ~0ULL; e_ord[p] = 0xffffffffu; }
-  __syncthreads();
-  bitonic_sort<unsigned>(e_key, e_ord, n2);
-  // flags + unique ranks; outputs for pass-through runs (exactly one part) need no row traffic
-  int ccarry = 0;
-  for (int pb = 0; pb < n; pb += NT) {
-    int p = pb + threadIdx.x;
-    bool hd = p < n && (p == 0 || e_key[p] != e_key[p - 1]);
-    bool single = hd && (p + 1 >= n || e_key[p + 1] != e_key[p]);
-    int tot;
-    int ex = block_excl_scan(hd ? 1 : 0, s_scan, &tot);
-    if (p < n) s_flag[p] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
-    if (hd) {
-      long long o = off + ccarry + ex;
-      u_keys[o] = (i64)(e_key[p] ^ 0x8000000000000000ULL);
-      u_src[o] = single ? part_src[e_ord[p]] : sum_base + (unsigned)o;
-      s_rank[p] = (unsigned short)(ccarry + ex);
+    if (too_many) {  // one key alone exceeds CMAX parts (n > 2^20 ids per call): reported, not applied
+      if (threadIdx.x == 0) atomicAdd(overflow, 1u);
+      continue;
     }
-    ccarry += tot;
-  }
-  const int nuniq = ccarry;
-  for (int i = nuniq + threadIdx.x; i < n; i += NT) u_src[off + i] = SKIP;
-  if (threadIdx.x == 0) s_flag[n] = F_HEAD;
-  __syncthreads();
-  const int span = (n + 15) / 16;
-  ordered_run_sums<NCH>(
-      n, span, dim, s_flag, s_left, s_cont, s_hashead,
-      [&](int p) {
+    const int n = carry;
+    if (n == 0) continue;
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    for (int p = n + threadIdx.x; p < n2; p += NT) { e_key[p] = ~0ULL; e_ord[p] = 0xffffffffu; }
+    __syncthreads();
+    bitonic_sort<unsigned>(e_key, e_ord, n2);
+    // flags + unique ranks; pass-through runs (exactly one part) need no row traffic
+    int ccarry = 0;
+    for (int pb = 0; pb < n; pb += NT) {
+      int p = pb + threadIdx.x;
+      bool hd = p < n && (p == 0 || e_key[p] != e_key[p - 1]);
+      bool single = hd && (p + 1 >= n || e_key[p + 1] != e_key[p]);
+      int tot;
+      int ex = block_excl_scan(hd ? 1 : 0, s_scan, &tot);
+      if (p < n) {
         unsigned src = part_src[e_ord[p]];
-        return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
-      },
-      [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(off + s_rank[ph])) * dim; });
+        s_src[p] = src;
+        s_flag[p] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
+        if (hd) {
+          long long o = off + out_used + ccarry + ex;
+          u_keys[o] = (i64)(e_key[p] ^ 0x8000000000000000ULL);
+          u_src[o] = single ? src : sum_base + (unsigned)o;
+          s_rank[p] = (unsigned short)(ccarry + ex);
+        }
+      }
+      ccarry += tot;
+    }
+    if (threadIdx.x == 0) s_flag[n] = F_HEAD;
+    __syncthreads();
+    const long long obase = off + out_used;
+    ordered_run_sums<NCH>(
+        n, (n + 15) / 16, dim, s_flag, s_left, s_cont, s_hashead,
+        [&](int p) {
+          unsigned src = s_src[p];
+          return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
+        },
+        [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(obase + s_rank[ph])) * dim; });
+    out_used += ccarry;
+    __syncthreads();
+  }
+  for (int i = out_used + threadIdx.x; i < n_b; i += NT) u_src[off + i] = SKIP;
 }
 
 }  // namespace
@@ -368,12 +404,14 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   if (dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)param_default_row) & 15))
     return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
                                            "(use tfra_unique + tfra_segment_sum + tfra_table_apply_optimizer otherwise)");
-  if (n >= (1ULL << 30)) return set_error(TFRA_ERR_INVALID, "apply_sparse: more than 2^30 ids per call");
+  if (n > (1ULL << 20))
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^20 ids per call (one key may hold ntiles <= CMAX "
+                                           "partial rows); split the batch or use the unique + segment_sum path");
   rc = t->prepare_insert(n, s);
   if (rc) return rc;
   const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
   unsigned P = 64;
-  while (P < 2048 && (size_t)P * 256 < n) P <<= 1;
+  while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   // scratch: part_keys | part_src | u_keys | u_src | tile_hist | tile_start | d_total | rows[2*npad]
   size_t bytes = 2 * al(npad * 8) + 2 * al(npad * 4) + 2 * al(ntiles * P * 2) + 256 + 2 * al(npad * (size_t)dim * 4);

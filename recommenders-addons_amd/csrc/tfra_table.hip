@@ -37,39 +37,42 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
   constexpr int KPW = 4 * U;
   const size_t base = wave * KPW;
   if (base >= n) return;
-  i64 kreg = (lane < KPW && base + lane < n) ? keys[base + lane] : 0;
+  // Loads are kept UNCONDITIONAL (tail keys are clamped to the last valid index): a load inside an
+  // `if (valid)` block gets its own `s_waitcnt vmcnt(0)` and the U probes / U rows would be fetched
+  // one latency after the other instead of all in flight (measured 23 us -> 11 us per 131072 keys).
+  const size_t last = n - 1;
+  i64 kreg = keys[min(base + (size_t)(lane & (KPW - 1)), last)];
   i64 key[U];
   u64 h[U], b[U];
   i64 k0[U];
-  bool valid[U];
+  size_t idx[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int j = u * 4 + grp;
     key[u] = shfl_i64(kreg, j);
-    valid[u] = base + j < n;
+    idx[u] = min(base + j, last);
     b[u] = bucket0(key[u], v.nb, h[u]);
-    k0[u] = valid[u] ? v.keys[b[u] * 16 + sub] : EMPTY_KEY;  // U probes in flight
+    k0[u] = v.keys[b[u] * 16 + sub];  // U probes in flight
   }
+  __builtin_amdgcn_sched_barrier(0);  // keep the U loads ahead of their first use
   const unsigned char* src[U];
   unsigned char* dst[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    size_t i = base + u * 4 + grp;
-    i64 row = valid[u] ? probe_find_from<false>(v, key[u], h[u], b[u], k0[u], sub, gshift) : -1;
-    if (valid[u] && exists && sub == 0) exists[i] = row >= 0;
+    i64 row = probe_find_from<false>(v, key[u], h[u], b[u], k0[u], sub, gshift);
+    if (exists && sub == 0) exists[idx[u]] = row >= 0;
     src[u] = row >= 0 ? v.rows + (size_t)row * v.row_stride + field_off
-                      : defaults + (full ? i * (size_t)v.field_bytes : 0);
-    dst[u] = out + i * (size_t)v.field_bytes;
+                      : defaults + (full ? idx[u] * (size_t)v.field_bytes : 0);
+    dst[u] = out + idx[u] * (size_t)v.field_bytes;
   }
   typedef typename Granule<G>::T T;
   for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
     T tmp[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (valid[u]) tmp[u] = *reinterpret_cast<const T*>(src[u] + off);  // U rows in flight
+    for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(src[u] + off);  // U rows in flight
+    __builtin_amdgcn_sched_barrier(0);  // ... and do not let the scheduler pair each load with its store
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (valid[u]) *reinterpret_cast<T*>(dst[u] + off) = tmp[u];
+    for (int u = 0; u < U; ++u) *reinterpret_cast<T*>(dst[u] + off) = tmp[u];  // clamped tail: same bytes twice
   }
 }
 
@@ -124,16 +127,25 @@ __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t 
   constexpr int KPW = 4 * U;
   const size_t base = wave * KPW;
   if (base >= n) return;
-  i64 kreg = (lane < KPW && base + lane < n) ? keys[base + lane] : 0;
+  const size_t last = n - 1;
+  i64 kreg = keys[min(base + (size_t)(lane & (KPW - 1)), last)];
   int fresh = 0, failed = 0;
+  i64 key[U], k0[U];
+  u64 h[U], b0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {  // U first probes in flight (unconditional, tail clamped)
+    key[u] = shfl_i64(kreg, u * 4 + grp);
+    b0[u] = bucket0(key[u], v.nb, h[u]);
+    k0[u] = load_key_coherent(&v.keys[b0[u] * 16 + sub]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int j = u * 4 + grp;
     size_t i = base + j;
-    i64 key = shfl_i64(kreg, j);
     if (i < n) {
       bool is_new;
-      i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+      i64 row = locate_or_claim_from(v, key[u], h[u], b0[u], k0[u], sub, gshift, is_new);
       if (row >= 0) {
         copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes,
                         vals + i * (size_t)v.field_bytes, v.field_bytes, sub);
@@ -176,7 +188,12 @@ __global__ __launch_bounds__(256) void insert_locate_kernel(TableView v, size_t 
       i64 row = locate_or_claim(v, key, sub, gshift, is_new);
       if (row >= 0) {
         if (is_new && v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
-        if (sub == 0) { atomicMax(&v.winner[row], (int)i); slot_of[i] = row | (is_new ? (i64)1 << 62 : 0); }
+        if (sub == 0) {
+          // hot keys (Zipf) repeat thousands of times: only occurrences that can still raise the
+          // maximum pay for the contended atomic
+          if (__hip_atomic_load(&v.winner[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)i) atomicMax(&v.winner[row], (int)i);
+          slot_of[i] = row | (is_new ? (i64)1 << 62 : 0);
+        }
         fresh += (is_new && sub == 0);
       } else {
         if (sub == 0) slot_of[i] = -1;
@@ -556,7 +573,12 @@ TableView Table::view_of(const Storage& st) const {
 // serialise against work queued on another stream (the reference blocks on a per-table mutex and
 // a stream sync per op, R/kernels/hkv_hashtable_op_gpu.cu.cc:192-213; here: event chaining).
 int Table::enter(hipStream_t s) {
-  if (hipSetDevice(device) != hipSuccess) return set_error(TFRA_ERR_HIP, "hipSetDevice failed");
+  // hipSetDevice costs tens of microseconds on ROCm 7.2 — more than the find kernel itself — so
+  // it is only issued when the calling thread is on another device.
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device) {
+    if (hipSetDevice(device) != hipSuccess) return set_error(TFRA_ERR_HIP, "hipSetDevice failed");
+  }
   if (has_last && s != last_stream) {
     HIP_TRY(hipEventRecord(chain_event, last_stream));
     HIP_TRY(hipStreamWaitEvent(s, chain_event, 0));

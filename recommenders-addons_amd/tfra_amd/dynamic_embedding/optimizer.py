@@ -170,7 +170,7 @@ class DynamicEmbeddingOptimizer:
     if n == 0:
       return
     if (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and
-        not self.exact_order):
+        n <= (1 << 20) and not self.exact_order):
       # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic
       t = var._tables[0]
       t._table.apply_sparse(p, ids, grad, t._default_value.to(torch.float32))

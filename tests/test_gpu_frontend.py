@@ -296,3 +296,38 @@ def test_apply_sparse_matches_exact_order_path_without_duplicates(env):
     o = np.argsort(k.cpu().numpy())
     outs.append(val.cpu().numpy()[o])
   np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_apply_sparse_hot_bucket_multipass(env):
+  """100 hot keys that all hash into ONE merge bucket and occur in every tile: the bucket holds
+  more descriptors than fit in LDS and is merged in several hash-split passes."""
+  torch, de = env
+  from bench import fmix64_np
+  rng = np.random.default_rng(77)
+  n, dim = 20064, 8
+  P = 64
+  while P < 2048 and P * 128 < n:
+    P *= 2
+  cand = rng.integers(1, 2**62, size=200000).astype(np.int64)
+  h = fmix64_np(cand.astype(np.uint64))
+  bucket = ((h >> np.uint64(32)).astype(np.uint64) * np.uint64(P)) >> np.uint64(32)  # ~ mulhi(h, P)
+  hot = cand[bucket == 7][:100]
+  assert hot.size == 100
+  ids = np.concatenate([np.tile(hot, n // 100), hot[: n % 100]])
+  rng.shuffle(ids)
+  g = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
+  opt = de.optimizers.Adagrad(0.05, 0.1)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  v = de.Variable(dim=dim, name="hotbucket", initializer=0.2, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  deo.apply_sparse(v, T(torch, ids), T(torch, g))
+  tabs = [oracle.CpuTable(dim), oracle.CpuTable(dim)]
+  ora = oopt.SparseOptimizerOracle("adagrad", tabs[0], tabs[1:], dict(lr=0.05, init_acc=0.1), 0.2)
+  uniq, inv = np.unique(ids, return_inverse=True)
+  gs = np.zeros((uniq.size, dim), np.float64); np.add.at(gs, inv, g.astype(np.float64))
+  ora.apply(uniq, gs.astype(np.float32))
+  assert int(v.size().item()) == 100
+  k, val = v.export()
+  o = np.argsort(k.cpu().numpy())
+  ek, ev = tabs[0].export_sorted()
+  np.testing.assert_array_equal(k.cpu().numpy()[o], ek)
+  np.testing.assert_allclose(val.cpu().numpy()[o], ev, rtol=2e-6, atol=2e-6)
