@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
           float4 p = *reinterpret_cast<const float4*>((is_new ? df : pr) + c);
           float4 s1 = *reinterpret_cast<const float4*>(pr + (S >= 1 ? dim : 0) + c);
           float4 s2 = *reinterpret_cast<const float4*>(pr + (S >= 2 ? 2 * dim : 0) + c);
-          __builtin_amdgcn_sched_barrier(0);
+          keep_live(gg, p, s1, s2);
           if (is_new || S < 1) s1 = make_float4(aux0, aux0, aux0, aux0);
           if (is_new || S < 2) s2 = make_float4(aux1, aux1, aux1, aux1);
           apply_one<KIND>(o, gg.x, p.x, s1.x, s2.x);

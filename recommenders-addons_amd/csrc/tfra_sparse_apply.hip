@@ -142,7 +142,6 @@ __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const
           x[j][k] = *reinterpret_cast<const float4*>(row + (col < dim ? col : 0));
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         int p = p0 + j;

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
     b[u] = bucket0(key[u], v.nb, h[u]);
     k0[u] = v.keys[b[u] * 16 + sub];  // U probes in flight
   }
-  __builtin_amdgcn_sched_barrier(0);  // keep the U loads ahead of their first use
+  static_assert(U == 4, "keep_live is written for U == 4");
+  keep_live(k0[0], k0[1], k0[2], k0[3]);
   const unsigned char* src[U];
   unsigned char* dst[U];
 #pragma unroll
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
     T tmp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(src[u] + off);  // U rows in flight
-    __builtin_amdgcn_sched_barrier(0);  // ... and do not let the scheduler pair each load with its store
+    keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
 #pragma unroll
     for (int u = 0; u < U; ++u) *reinterpret_cast<T*>(dst[u] + off) = tmp[u];  // clamped tail: same bytes twice
   }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t 
     b0[u] = bucket0(key[u], v.nb, h[u]);
     k0[u] = load_key_coherent(&v.keys[b0[u] * 16 + sub]);
   }
-  __builtin_amdgcn_sched_barrier(0);
+  keep_live(k0[0], k0[1], k0[2], k0[3]);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int j = u * 4 + grp;

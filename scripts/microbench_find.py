@@ -23,9 +23,9 @@ obuf = torch.empty((B, 64), device=dev); dflt = torch.zeros(64, device=dev); st 
 src = torch.randn((B, 64), device=dev)
 print("torch copy 33.5MB: %.1fus" % timeit(lambda: obuf.copy_(src), reps=100))
 for name, ids in [("zipf", zipf), ("uniform", uni)]:
-  for mode, mname in [(0, "full"), (1, "gather+store,no probe"), (2, "probe only"), (3, "store zeros"), (4, "first line only")]:
+  for mode, mname in [(0, "full"), (1, "gather+store,no probe"), (2, "probe only"), (3, "store zeros"), (4, "first line only"), (7, "prod copy")] + [(10 + i, "fk clamp=%d bar=%d ex=%d" % (i & 1, (i >> 1) & 1, (i >> 2) & 1)) for i in range(8)]:
     r = []
-    for U in (1, 2, 4, 8):
+    for U in ((1, 2, 4, 8) if mode < 7 else (4,)):
       args = (t._table._h, mode, U, B, _ptr(ids), _ptr(obuf), _ptr(dflt), st)
       r.append("U%d=%.1f" % (U, timeit(lambda: dbg(*args), reps=200)))
     print("%-8s %-24s %s" % (name, mname, "  ".join(r)), flush=True)
