@@ -45,8 +45,9 @@ int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, siz
 namespace {
 
 constexpr int TILE = 512;    // ids per kernel-A block
-constexpr int NT = 256;      // threads per block (16 groups of 16 lanes)
-constexpr int CMAX = 2048;   // descriptors one kernel-C block can hold in LDS
+constexpr int NTA = 512;     // kernel-A threads (32 groups of 16 lanes: 8 waves keep a CU busy)
+constexpr int NT = 256;      // kernel-C threads (16 groups)
+constexpr int CMAX = 1024;   // descriptors one kernel-C block can hold in LDS
 constexpr int MAXCH = 4;     // D <= 256 (one float4 per lane per 64-column chunk)
 constexpr unsigned SKIP = 0xffffffffu;
 constexpr unsigned char F_HEAD = 1, F_SINGLE = 2;
@@ -56,19 +57,26 @@ template <int NCH> struct Batch { static constexpr int v = NCH == 1 ? 8 : (NCH =
 __device__ __forceinline__ bool less_hi(u64 ha, unsigned ia, u64 hb, unsigned ib) {
   return ha != hb ? ha < hb : ia < ib;
 }
+__device__ __forceinline__ bool less_hi(u64 ha, unsigned short ia, u64 hb, unsigned short ib) {
+  return ha != hb ? ha < hb : ia < ib;
+}
 
-// in-LDS bitonic sort of n2 (power of two) composite (h, i) pairs by NT threads
-template <class I>
+__device__ __forceinline__ bool less_hi(u64 ha, u64 ia, u64 hb, u64 ib) {
+  return ha != hb ? ha < hb : ia < ib;
+}
+
+// in-LDS bitonic sort of n2 (power of two) composite (h, i) pairs by NTH threads
+template <int NTH, class I>
 __device__ __forceinline__ void bitonic_sort(u64* h, I* ix, int n2) {
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int q = threadIdx.x; q < (n2 >> 1); q += NT) {
+      for (int q = threadIdx.x; q < (n2 >> 1); q += NTH) {
         int i = ((q / j) * (j << 1)) + (q % j);
         int l = i + j;
         bool up = ((i & k) == 0);
         u64 hi_ = h[i], hl = h[l];
         I ii = ix[i], il = ix[l];
-        bool sw = up ? less_hi(hl, (unsigned)il, hi_, (unsigned)ii) : less_hi(hi_, (unsigned)ii, hl, (unsigned)il);
+        bool sw = up ? less_hi(hl, il, hi_, ii) : less_hi(hi_, ii, hl, il);
         if (sw) { h[i] = hl; h[l] = hi_; ix[i] = il; ix[l] = ii; }
       }
       __syncthreads();
@@ -76,8 +84,9 @@ __device__ __forceinline__ void bitonic_sort(u64* h, I* ix, int n2) {
   }
 }
 
-// exclusive scan of one int per thread over the NT-thread block
-__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT/64]*/, int* total) {
+// exclusive scan of one int per thread over the NTH-thread block
+template <int NTH>
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NTH/64]*/, int* total) {
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6, incl = v;
   for (int o = 1; o < 64; o <<= 1) {
     int t = __shfl_up(incl, o);
@@ -86,7 +95,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT/64]*/, int* 
   if (lane == 63) sh[w] = incl;
   __syncthreads();
   int woff = 0, tot = 0;
-  for (int k = 0; k < NT / 64; ++k) { if (k < w) woff += sh[k]; tot += sh[k]; }
+  for (int k = 0; k < NTH / 64; ++k) { if (k < w) woff += sh[k]; tot += sh[k]; }
   __syncthreads();
   *total = tot;
   return woff + incl - v;
@@ -100,7 +109,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NT/64]*/, int* 
 //   is finished by the group that holds its head ("owner"): later chunks leave their share in
 //   s_left and the owner adds those in chunk order after one barrier.
 //   row_of(p)  -> const float* of position p's row        out_of(p_head) -> float* for the run sum
-template <int NCH, class RowOf, class OutOf>
+template <int NCH, int NG, class RowOf, class OutOf>
 __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const unsigned char* s_flag,
                                                  float (*s_left)[64 * NCH], unsigned char* s_cont,
                                                  unsigned char* s_hashead, RowOf row_of, OutOf out_of) {
@@ -171,7 +180,7 @@ __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const
   if (sub == 0) { s_cont[g] = cont_in; s_hashead[g] = seen_head; }
   __syncthreads();
   if (owner_open) {
-    for (int g2 = g + 1; g2 < 16 && s_cont[g2]; ++g2) {
+    for (int g2 = g + 1; g2 < NG && s_cont[g2]; ++g2) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         float4 x = *reinterpret_cast<const float4*>(&s_left[g2][k * 64 + sub * 4]);
@@ -187,55 +196,50 @@ __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const
 // kernel A.  Descriptor u of tile t lives at index t*TILE+u: part_keys[], part_src[] where
 // src < rows_base -> gradient row `src` of the caller's buffer, else scratch row (src-rows_base).
 template <int NCH>
-__global__ __launch_bounds__(NT) void tile_reduce_kernel(size_t n, const i64* __restrict__ ids,
-                                                         const float* __restrict__ grads, int dim, unsigned P,
-                                                         unsigned rows_base, i64* __restrict__ part_keys,
-                                                         unsigned* __restrict__ part_src, float* __restrict__ scratch_rows,
-                                                         unsigned short* __restrict__ tile_hist,
-                                                         unsigned short* __restrict__ tile_start) {
+__global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* __restrict__ ids,
+                                                          const float* __restrict__ grads, int dim, unsigned P,
+                                                          unsigned rows_base, i64* __restrict__ part_keys,
+                                                          unsigned* __restrict__ part_src, float* __restrict__ scratch_rows,
+                                                          unsigned short* __restrict__ tile_hist,
+                                                          unsigned short* __restrict__ tile_start) {
+  constexpr int NG = NTA / 16;
   __shared__ u64 s_h[TILE];
+  __shared__ i64 s_key[TILE];                // ids of the tile, input order
   __shared__ unsigned short s_ix[TILE];
   __shared__ unsigned short s_u[TILE];       // unique rank (within the tile) of each head position
   __shared__ unsigned char s_flag[TILE + 1];
   __shared__ unsigned s_hist[2048];          // P <= 2048
-  __shared__ float s_left[16][64 * NCH];
-  __shared__ unsigned char s_cont[16], s_hashead[16];
-  __shared__ int s_scan[NT / 64];
+  __shared__ float s_left[NG][64 * NCH];
+  __shared__ unsigned char s_cont[NG], s_hashead[NG];
+  __shared__ int s_scan[NTA / 64];
   const size_t tile = blockIdx.x, base = tile * TILE;
   const int nvalid = (int)min((size_t)TILE, n - base);
-  for (int p = threadIdx.x; p < TILE; p += NT) {
+  static_assert(TILE == NTA, "one id per thread");
+  {
+    const int p = threadIdx.x;
     bool ok = p < nvalid;
-    s_h[p] = ok ? fmix64((u64)ids[base + p]) : ~0ULL;
+    i64 key = ok ? ids[base + p] : 0;
+    s_key[p] = key;
+    s_h[p] = ok ? fmix64((u64)key) : ~0ULL;
     s_ix[p] = ok ? (unsigned short)p : (unsigned short)0xffff;
   }
-  for (unsigned b = threadIdx.x; b < P; b += NT) s_hist[b] = 0;
+  for (unsigned b = threadIdx.x; b < P; b += NTA) s_hist[b] = 0;
   __syncthreads();
-  bitonic_sort<unsigned short>(s_h, s_ix, TILE);
-  // heads / singles / unique ranks: 2 consecutive positions per thread
-  constexpr int PPT = TILE / NT;
-  const int p0 = threadIdx.x * PPT;
-  int c = 0;
-  bool head[PPT];
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    int p = p0 + k;
-    head[k] = p < nvalid && (p == 0 || s_h[p] != s_h[p - 1]);
-    c += head[k];
-  }
+  bitonic_sort<NTA, unsigned short>(s_h, s_ix, TILE);
+  // heads / singles / unique ranks: one position per thread
+  const int p = threadIdx.x;
+  const bool head = p < nvalid && (p == 0 || s_h[p] != s_h[p - 1]);
   int ntile_unique;
-  int u = block_excl_scan(c, s_scan, &ntile_unique);
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    int p = p0 + k;
-    bool single = head[k] && (p + 1 >= nvalid || s_h[p + 1] != s_h[p]);
-    s_flag[p] = (head[k] ? F_HEAD : 0) | (single ? F_SINGLE : 0);
-    if (head[k]) {
+  const int u = block_excl_scan<NTA>(head ? 1 : 0, s_scan, &ntile_unique);
+  {
+    bool single = head && (p + 1 >= nvalid || s_h[p + 1] != s_h[p]);
+    s_flag[p] = (head ? F_HEAD : 0) | (single ? F_SINGLE : 0);
+    if (head) {
       atomicAdd(&s_hist[(unsigned)__umul64hi(s_h[p], (u64)P)], 1u);
       s_u[p] = (unsigned short)u;
       size_t d = base + (size_t)u;
-      part_keys[d] = ids[base + s_ix[p]];
+      part_keys[d] = s_key[s_ix[p]];
       part_src[d] = single ? (unsigned)(base + s_ix[p]) : rows_base + (unsigned)d;
-      ++u;
     }
   }
   if (threadIdx.x == 0) s_flag[TILE] = F_HEAD;
@@ -243,10 +247,10 @@ __global__ __launch_bounds__(NT) void tile_reduce_kernel(size_t n, const i64* __
   // per-bucket count and first unique rank (buckets ascend with the hash)
   {
     int carry = 0;
-    for (unsigned b0 = 0; b0 < P; b0 += NT) {
+    for (unsigned b0 = 0; b0 < P; b0 += NTA) {
       unsigned b = b0 + threadIdx.x;
       int v = b < P ? (int)s_hist[b] : 0, tot;
-      int ex = block_excl_scan(v, s_scan, &tot);
+      int ex = block_excl_scan<NTA>(v, s_scan, &tot);
       if (b < P) {
         tile_hist[tile * P + b] = (unsigned short)v;
         tile_start[tile * P + b] = (unsigned short)(carry + ex);
@@ -254,9 +258,9 @@ __global__ __launch_bounds__(NT) void tile_reduce_kernel(size_t n, const i64* __
       carry += tot;
     }
   }
-  ordered_run_sums<NCH>(
-      nvalid, TILE / 16, dim, s_flag, s_left, s_cont, s_hashead,
-      [&](int p) { return grads + (base + s_ix[p]) * (size_t)dim; },
+  ordered_run_sums<NCH, NG>(
+      nvalid, TILE / NG, dim, s_flag, s_left, s_cont, s_hashead,
+      [&](int q) { return grads + (base + s_ix[q]) * (size_t)dim; },
       [&](int ph) { return scratch_rows + (base + (size_t)s_u[ph]) * (size_t)dim; });
 }
 
@@ -276,38 +280,24 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
                                                           const unsigned short* __restrict__ tile_start,
                                                           i64* __restrict__ u_keys, unsigned* __restrict__ u_src,
                                                           i64* __restrict__ d_total, unsigned* overflow) {
+  constexpr int NG = NT / 16;
   __shared__ u64 e_key[CMAX];        // key with the sign bit flipped (unsigned order)
-  __shared__ unsigned e_ord[CMAX];   // descriptor index t*TILE+u: ascending = tile order
-  __shared__ unsigned s_src[CMAX];   // part_src of each sorted position
+  __shared__ u64 e_pay[CMAX];        // (descriptor index t*TILE+u) << 32 | part_src: ascending = tile order
   __shared__ unsigned char s_flag[CMAX + 1];
   __shared__ unsigned short s_rank[CMAX];  // unique rank (within the pass) of each head position
-  __shared__ float s_left[16][64 * NCH];
-  __shared__ unsigned char s_cont[16], s_hashead[16];
+  __shared__ float s_left[NG][64 * NCH];
+  __shared__ unsigned char s_cont[NG], s_hashead[NG];
   __shared__ int s_scan[NT / 64];
+  __shared__ long long s_off[NT / 64];
   const unsigned b = blockIdx.x;
-  // bucket totals: n_b descriptors starting at output offset off_b
-  int n_b = 0;
-  long long off = 0;
-  for (unsigned t0 = 0; t0 < ntiles; t0 += NT) {
-    unsigned t = t0 + threadIdx.x;
-    int cnt = 0, st = 0;
-    if (t < ntiles) { cnt = tile_hist[(size_t)t * P + b]; st = tile_start[(size_t)t * P + b]; }
-    for (int o2 = 32; o2 > 0; o2 >>= 1) { cnt += __shfl_xor(cnt, o2); st += __shfl_xor(st, o2); }
-    if ((threadIdx.x & 63) == 0) { s_scan[threadIdx.x >> 6] = cnt; s_rank[threadIdx.x >> 6] = 0; e_ord[threadIdx.x >> 6] = (unsigned)st; }
-    __syncthreads();
-    n_b += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-    off += (long long)e_ord[0] + e_ord[1] + e_ord[2] + e_ord[3];
-    __syncthreads();
-  }
-  if (b == P - 1 && threadIdx.x == 0) *d_total = off + n_b;
-  if (n_b == 0) return;
   unsigned npass = 1;
-  while ((unsigned)n_b > (CMAX / 2) * npass && npass < 64) npass <<= 1;
-  if (n_b <= CMAX) npass = 1;
-  int out_used = 0;  // unique keys emitted so far (over all passes)
+  int n_b = 0, out_used = 0;
+  long long off = 0;
   for (unsigned pass = 0; pass < npass; ++pass) {
-    // gather this pass's descriptors from every tile, tile order
-    int carry = 0;
+    // gather this pass's descriptors from every tile, tile order; the first pass also finds the
+    // bucket's totals (n_b descriptors, output offset off_b) and decides how many passes it needs
+    int carry = 0, all = 0;
+    long long off_acc = 0;
     bool too_many = false;
     for (unsigned t0 = 0; t0 < ntiles; t0 += NT) {
       unsigned t = t0 + threadIdx.x;
@@ -319,7 +309,13 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
         for (int j = 0; j < cnt; ++j)
           mine += ((unsigned)fmix64((u64)part_keys[t * TILE + st + j]) & (npass - 1)) == pass;
       }
-      int ex = block_excl_scan(mine, s_scan, &tot);
+      if (pass == 0) {  // off_b = sum over tiles of (descriptors of smaller buckets in that tile)
+        int st_sum = st;
+        for (int o2 = 32; o2 > 0; o2 >>= 1) st_sum += __shfl_xor(st_sum, o2);
+        if ((threadIdx.x & 63) == 0) s_off[threadIdx.x >> 6] = st_sum;
+      }
+      int ex = block_excl_scan<NT>(mine, s_scan, &tot);  // (barriers inside also publish s_off)
+      if (pass == 0) off_acc += s_off[0] + s_off[1] + s_off[2] + s_off[3];
       if (carry + tot > CMAX) too_many = true;
       if (!too_many) {
         int w = carry + ex;
@@ -327,15 +323,28 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
           unsigned d = t * TILE + st + j;
           i64 key = part_keys[d];
           if (npass == 1 || ((unsigned)fmix64((u64)key) & (npass - 1)) == pass) {
-            e_ord[w] = d;
+            e_pay[w] = ((u64)d << 32) | part_src[d];
             e_key[w] = (u64)key ^ 0x8000000000000000ULL;
             ++w;
           }
         }
       }
       carry += tot;
+      all += tot;
+      __syncthreads();
     }
-    if (too_many) {  // one key alone exceeds CMAX parts (n > 2^20 ids per call): reported, not applied
+    if (pass == 0) {
+      n_b = all;
+      off = off_acc;
+      if (b == P - 1 && threadIdx.x == 0) *d_total = off + n_b;
+      if (n_b == 0) return;
+      if (too_many && npass == 1) {  // restart with the bucket split by key hash
+        while ((unsigned)n_b > (CMAX / 2) * npass && npass < 64) npass <<= 1;
+        pass = (unsigned)-1;  // ++ -> 0
+        continue;
+      }
+    }
+    if (too_many) {  // one key alone exceeds CMAX parts: reported, not applied
       if (threadIdx.x == 0) atomicAdd(overflow, 1u);
       continue;
     }
@@ -343,26 +352,24 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     if (n == 0) continue;
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
-    for (int p = n + threadIdx.x; p < n2; p += NT) { e_key[p] = ~0ULL; e_ord[p] = 0xffffffffu; }
+    for (int q = n + threadIdx.x; q < n2; q += NT) { e_key[q] = ~0ULL; e_pay[q] = ~0ULL; }
     __syncthreads();
-    bitonic_sort<unsigned>(e_key, e_ord, n2);
+    bitonic_sort<NT, u64>(e_key, e_pay, n2);
     // flags + unique ranks; pass-through runs (exactly one part) need no row traffic
     int ccarry = 0;
     for (int pb = 0; pb < n; pb += NT) {
-      int p = pb + threadIdx.x;
-      bool hd = p < n && (p == 0 || e_key[p] != e_key[p - 1]);
-      bool single = hd && (p + 1 >= n || e_key[p + 1] != e_key[p]);
+      int q = pb + threadIdx.x;
+      bool hd = q < n && (q == 0 || e_key[q] != e_key[q - 1]);
+      bool single = hd && (q + 1 >= n || e_key[q + 1] != e_key[q]);
       int tot;
-      int ex = block_excl_scan(hd ? 1 : 0, s_scan, &tot);
-      if (p < n) {
-        unsigned src = part_src[e_ord[p]];
-        s_src[p] = src;
-        s_flag[p] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
+      int ex = block_excl_scan<NT>(hd ? 1 : 0, s_scan, &tot);
+      if (q < n) {
+        s_flag[q] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
         if (hd) {
           long long o = off + out_used + ccarry + ex;
-          u_keys[o] = (i64)(e_key[p] ^ 0x8000000000000000ULL);
-          u_src[o] = single ? src : sum_base + (unsigned)o;
-          s_rank[p] = (unsigned short)(ccarry + ex);
+          u_keys[o] = (i64)(e_key[q] ^ 0x8000000000000000ULL);
+          u_src[o] = single ? (unsigned)e_pay[q] : sum_base + (unsigned)o;
+          s_rank[q] = (unsigned short)(ccarry + ex);
         }
       }
       ccarry += tot;
@@ -370,10 +377,10 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     if (threadIdx.x == 0) s_flag[n] = F_HEAD;
     __syncthreads();
     const long long obase = off + out_used;
-    ordered_run_sums<NCH>(
-        n, (n + 15) / 16, dim, s_flag, s_left, s_cont, s_hashead,
-        [&](int p) {
-          unsigned src = s_src[p];
+    ordered_run_sums<NCH, NG>(
+        n, (n + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
+        [&](int q) {
+          unsigned src = (unsigned)e_pay[q];
           return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
         },
         [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(obase + s_rank[ph])) * dim; });
@@ -410,7 +417,7 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   if (rc) return rc;
   const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
   unsigned P = 64;
-  while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
+  while (P < 2048 && (size_t)P * 64 < n) P <<= 1;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   // scratch: part_keys | part_src | u_keys | u_src | tile_hist | tile_start | d_total | rows[2*npad]
   size_t bytes = 2 * al(npad * 8) + 2 * al(npad * 4) + 2 * al(ntiles * P * 2) + 256 + 2 * al(npad * (size_t)dim * 4);
@@ -430,10 +437,10 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   const i64* k = (const i64*)ids;
   dim3 ga((unsigned)ntiles), gc(P);
   switch (nch) {
-    case 1: tile_reduce_kernel<1><<<ga, NT, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
-    case 2: tile_reduce_kernel<2><<<ga, NT, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
-    case 3: tile_reduce_kernel<3><<<ga, NT, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
-    default: tile_reduce_kernel<4><<<ga, NT, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
+    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
+    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
+    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
+    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
   }
   switch (nch) {
     case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count); break;
