@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 
@@ -54,33 +55,48 @@ constexpr unsigned char F_HEAD = 1, F_SINGLE = 2;
 
 template <int NCH> struct Batch { static constexpr int v = NCH == 1 ? 8 : (NCH == 2 ? 4 : 2); };
 
-__device__ __forceinline__ bool less_hi(u64 ha, unsigned ia, u64 hb, unsigned ib) {
-  return ha != hb ? ha < hb : ia < ib;
-}
-__device__ __forceinline__ bool less_hi(u64 ha, unsigned short ia, u64 hb, unsigned short ib) {
-  return ha != hb ? ha < hb : ia < ib;
-}
-
-__device__ __forceinline__ bool less_hi(u64 ha, u64 ia, u64 hb, u64 ib) {
-  return ha != hb ? ha < hb : ia < ib;
-}
-
-// in-LDS bitonic sort of n2 (power of two) composite (h, i) pairs by NTH threads
-template <int NTH, class I>
-__device__ __forceinline__ void bitonic_sort(u64* h, I* ix, int n2) {
+// in-LDS bitonic sort of n2 (power of two) 32-bit keys by NTH threads.
+// Pair q of a stage touches elements i = 2j*(q/j) + q%j and i+j.  Thread t owns pairs t, t+NTH, ...
+// so for j <= 64 every wave works inside its own 128-element windows: those stages need no block
+// barrier (LDS operations of one wave execute in order) — only stages with distance >= 128 do.
+// History: sorting (u64 hash, index) PAIRS with a __syncthreads per stage cost 14 us (512 keys) to
+// 20 us (kernel C) per launch; grouping by an LDS hash first and sorting one packed u32 is ~5x less.
+template <int NTH>
+__device__ __forceinline__ void bitonic_sort_u32(unsigned* a, int n2) {
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
+      const int jm = j - 1;
       for (int q = threadIdx.x; q < (n2 >> 1); q += NTH) {
-        int i = ((q / j) * (j << 1)) + (q % j);
+        int i = ((q & ~jm) << 1) | (q & jm);
         int l = i + j;
+        unsigned x = a[i], y = a[l];
+        unsigned lo = min(x, y), hi = max(x, y);
         bool up = ((i & k) == 0);
-        u64 hi_ = h[i], hl = h[l];
-        I ii = ix[i], il = ix[l];
-        bool sw = up ? less_hi(hl, il, hi_, ii) : less_hi(hi_, ii, hl, il);
-        if (sw) { h[i] = hl; h[l] = hi_; ix[i] = il; ix[l] = ii; }
+        a[i] = up ? lo : hi;
+        a[l] = up ? hi : lo;
       }
-      __syncthreads();
+      // block barrier iff this stage or the next one exchanges across waves (distance >= 128);
+      // the stage after (k, 1) is (2k, k)
+      if (j >= 128 || (j == 1 && (k >= 128 || k == n2))) __syncthreads();
+      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // same-wave LDS ordering only
     }
+  }
+}
+
+// Group equal 64-bit keys of an LDS array: returns a slot id in [0, cap) that is the same for equal
+// keys and different for different keys.  owner[] (cap entries, zeroed) holds 1 + the index of the
+// element that claimed the slot; keys are compared through keys[owner-1].
+__device__ __forceinline__ unsigned lds_group_slot(const i64* keys, unsigned* owner, unsigned cap, int me, u64 hash) {
+  const i64 key = keys[me];
+  unsigned slot = (unsigned)(hash >> 17) & (cap - 1);
+  for (;;) {
+    unsigned o = owner[slot];
+    if (o == 0) {
+      o = atomicCAS(&owner[slot], 0u, (unsigned)me + 1u);
+      if (o == 0) return slot;
+    }
+    if (keys[o - 1] == key) return slot;
+    slot = (slot + 1) & (cap - 1);
   }
 }
 
@@ -195,17 +211,20 @@ __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const
 // ---------------------------------------------------------------------------------------------
 // kernel A.  Descriptor u of tile t lives at index t*TILE+u: part_keys[], part_src[] where
 // src < rows_base -> gradient row `src` of the caller's buffer, else scratch row (src-rows_base).
+// Sort key (31 bits) = bucket(11) | group slot(11) | position in tile(9): groups the tile by merge
+// bucket, then by key, ascending input position inside a key.
 template <int NCH>
 __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* __restrict__ ids,
                                                           const float* __restrict__ grads, int dim, unsigned P,
                                                           unsigned rows_base, i64* __restrict__ part_keys,
                                                           unsigned* __restrict__ part_src, float* __restrict__ scratch_rows,
                                                           unsigned short* __restrict__ tile_hist,
-                                                          unsigned short* __restrict__ tile_start) {
+                                                          unsigned short* __restrict__ tile_start, int stop) {
   constexpr int NG = NTA / 16;
-  __shared__ u64 s_h[TILE];
+  constexpr unsigned GCAP = 2048;            // group table: 4x the tile => short probe chains
   __shared__ i64 s_key[TILE];                // ids of the tile, input order
-  __shared__ unsigned short s_ix[TILE];
+  __shared__ unsigned s_sort[TILE];          // packed sort keys
+  __shared__ unsigned s_owner[GCAP];
   __shared__ unsigned short s_u[TILE];       // unique rank (within the tile) of each head position
   __shared__ unsigned char s_flag[TILE + 1];
   __shared__ unsigned s_hist[2048];          // P <= 2048
@@ -214,37 +233,45 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
   __shared__ int s_scan[NTA / 64];
   const size_t tile = blockIdx.x, base = tile * TILE;
   const int nvalid = (int)min((size_t)TILE, n - base);
-  static_assert(TILE == NTA, "one id per thread");
-  {
-    const int p = threadIdx.x;
-    bool ok = p < nvalid;
-    i64 key = ok ? ids[base + p] : 0;
-    s_key[p] = key;
-    s_h[p] = ok ? fmix64((u64)key) : ~0ULL;
-    s_ix[p] = ok ? (unsigned short)p : (unsigned short)0xffff;
-  }
-  for (unsigned b = threadIdx.x; b < P; b += NTA) s_hist[b] = 0;
-  __syncthreads();
-  bitonic_sort<NTA, unsigned short>(s_h, s_ix, TILE);
-  // heads / singles / unique ranks: one position per thread
+  static_assert(TILE == NTA && TILE == 512, "one id per thread; 9 position bits");
   const int p = threadIdx.x;
-  const bool head = p < nvalid && (p == 0 || s_h[p] != s_h[p - 1]);
+  const bool ok = p < nvalid;
+  const i64 key = ok ? ids[base + p] : 0;
+  s_key[p] = key;
+  for (unsigned b = threadIdx.x; b < P; b += NTA) s_hist[b] = 0;
+  for (unsigned b = threadIdx.x; b < GCAP; b += NTA) s_owner[b] = 0;
+  __syncthreads();
+  if (stop == 1) return;  // (tuning ablation, TFRA_DBG_STOP_A)
+  const u64 h = fmix64((u64)key);
+  unsigned packed = 0xffffffffu;
+  if (ok) {
+    unsigned slot = lds_group_slot(s_key, s_owner, GCAP, p, h);
+    packed = ((unsigned)__umul64hi(h, (u64)P) << 20) | (slot << 9) | (unsigned)p;
+  }
+  s_sort[p] = packed;
+  __syncthreads();
+  bitonic_sort_u32<NTA>(s_sort, TILE);
+  if (stop == 2) return;
+  // heads / singles / unique ranks: one sorted position per thread
+  const unsigned me = s_sort[p];
+  const bool head = p < nvalid && (p == 0 || (s_sort[p - 1] >> 9) != (me >> 9));
   int ntile_unique;
   const int u = block_excl_scan<NTA>(head ? 1 : 0, s_scan, &ntile_unique);
   {
-    bool single = head && (p + 1 >= nvalid || s_h[p + 1] != s_h[p]);
+    bool single = head && (p + 1 >= nvalid || (s_sort[p + 1] >> 9) != (me >> 9));
     s_flag[p] = (head ? F_HEAD : 0) | (single ? F_SINGLE : 0);
     if (head) {
-      atomicAdd(&s_hist[(unsigned)__umul64hi(s_h[p], (u64)P)], 1u);
+      atomicAdd(&s_hist[me >> 20], 1u);
       s_u[p] = (unsigned short)u;
       size_t d = base + (size_t)u;
-      part_keys[d] = s_key[s_ix[p]];
-      part_src[d] = single ? (unsigned)(base + s_ix[p]) : rows_base + (unsigned)d;
+      part_keys[d] = s_key[me & 511];
+      part_src[d] = single ? (unsigned)(base + (me & 511)) : rows_base + (unsigned)d;
     }
   }
   if (threadIdx.x == 0) s_flag[TILE] = F_HEAD;
   __syncthreads();
-  // per-bucket count and first unique rank (buckets ascend with the hash)
+  if (stop == 3) return;
+  // per-bucket count and first unique rank (buckets ascend with the sort key)
   {
     int carry = 0;
     for (unsigned b0 = 0; b0 < P; b0 += NTA) {
@@ -258,9 +285,10 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
       carry += tot;
     }
   }
+  if (stop == 4) return;
   ordered_run_sums<NCH, NG>(
       nvalid, TILE / NG, dim, s_flag, s_left, s_cont, s_hashead,
-      [&](int q) { return grads + (base + s_ix[q]) * (size_t)dim; },
+      [&](int q) { return grads + (base + (s_sort[q] & 511)) * (size_t)dim; },
       [&](int ph) { return scratch_rows + (base + (size_t)s_u[ph]) * (size_t)dim; });
 }
 
@@ -268,8 +296,10 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
 // kernel C.  Output: bucket b owns u_keys/u_src[off_b .. off_b+n_b) with n_b = its descriptor count
 // and off_b = sum_t tile_start[t][b]; the first (#unique in bucket) entries are filled, the rest are
 // SKIP.  Summed rows go to scratch row (sum_base - rows_base + index).  The last bucket publishes
-// the total entry count.  A bucket holding more than CMAX descriptors (several very hot keys
-// hashing together) is processed in 2^k passes, pass q taking the keys with (hash & (2^k-1)) == q.
+// the total entry count.  Descriptors are gathered in tile order, grouped by key with an LDS hash
+// and sorted on (group slot(11) | gather position(10)), so a key's parts stay in tile order.
+// A bucket holding more than CMAX descriptors (several very hot keys hashing together) is
+// processed in 2^k passes, pass q taking the keys with (hash & (2^k-1)) == q.
 template <int NCH>
 __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned ntiles, int dim, unsigned rows_base,
                                                           unsigned sum_base, const float* __restrict__ grads,
@@ -279,10 +309,14 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
                                                           const unsigned short* __restrict__ tile_hist,
                                                           const unsigned short* __restrict__ tile_start,
                                                           i64* __restrict__ u_keys, unsigned* __restrict__ u_src,
-                                                          i64* __restrict__ d_total, unsigned* overflow) {
+                                                          i64* __restrict__ d_total, unsigned* overflow, int stop) {
   constexpr int NG = NT / 16;
-  __shared__ u64 e_key[CMAX];        // key with the sign bit flipped (unsigned order)
-  __shared__ u64 e_pay[CMAX];        // (descriptor index t*TILE+u) << 32 | part_src: ascending = tile order
+  constexpr unsigned GCAP = 2 * CMAX;
+  static_assert(CMAX == 1024, "10 position bits");
+  __shared__ i64 e_key[CMAX];         // gathered keys, tile order
+  __shared__ unsigned e_src[CMAX];    // their part_src
+  __shared__ unsigned s_sort[CMAX];   // packed sort keys
+  __shared__ unsigned s_owner[GCAP];
   __shared__ unsigned char s_flag[CMAX + 1];
   __shared__ unsigned short s_rank[CMAX];  // unique rank (within the pass) of each head position
   __shared__ float s_left[NG][64 * NCH];
@@ -310,12 +344,16 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
           mine += ((unsigned)fmix64((u64)part_keys[t * TILE + st + j]) & (npass - 1)) == pass;
       }
       if (pass == 0) {  // off_b = sum over tiles of (descriptors of smaller buckets in that tile)
-        int st_sum = st;
-        for (int o2 = 32; o2 > 0; o2 >>= 1) st_sum += __shfl_xor(st_sum, o2);
-        if ((threadIdx.x & 63) == 0) s_off[threadIdx.x >> 6] = st_sum;
+        int st_sum = st, cnt_sum = cnt;
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { st_sum += __shfl_xor(st_sum, o2); cnt_sum += __shfl_xor(cnt_sum, o2); }
+        if ((threadIdx.x & 63) == 0) s_off[threadIdx.x >> 6] = ((long long)cnt_sum << 40) | (long long)st_sum;
       }
       int ex = block_excl_scan<NT>(mine, s_scan, &tot);  // (barriers inside also publish s_off)
-      if (pass == 0) off_acc += s_off[0] + s_off[1] + s_off[2] + s_off[3];
+      if (pass == 0) {
+        long long both = s_off[0] + s_off[1] + s_off[2] + s_off[3];  // st sums < 2^40: no carry into cnt
+        off_acc += both & ((1LL << 40) - 1);
+        all += (int)(both >> 40);
+      }
       if (carry + tot > CMAX) too_many = true;
       if (!too_many) {
         int w = carry + ex;
@@ -323,14 +361,13 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
           unsigned d = t * TILE + st + j;
           i64 key = part_keys[d];
           if (npass == 1 || ((unsigned)fmix64((u64)key) & (npass - 1)) == pass) {
-            e_pay[w] = ((u64)d << 32) | part_src[d];
-            e_key[w] = (u64)key ^ 0x8000000000000000ULL;
+            e_src[w] = part_src[d];
+            e_key[w] = key;
             ++w;
           }
         }
       }
       carry += tot;
-      all += tot;
       __syncthreads();
     }
     if (pass == 0) {
@@ -350,25 +387,34 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     }
     const int n = carry;
     if (n == 0) continue;
+    if (stop == 1) continue;  // (tuning ablation, TFRA_DBG_STOP_C)
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
-    for (int q = n + threadIdx.x; q < n2; q += NT) { e_key[q] = ~0ULL; e_pay[q] = ~0ULL; }
+    for (unsigned q = threadIdx.x; q < GCAP; q += NT) s_owner[q] = 0;
     __syncthreads();
-    bitonic_sort<NT, u64>(e_key, e_pay, n2);
+    for (int q = threadIdx.x; q < n2; q += NT) {
+      unsigned packed = 0xffffffffu;
+      if (q < n) packed = (lds_group_slot(e_key, s_owner, GCAP, q, fmix64((u64)e_key[q])) << 10) | (unsigned)q;
+      s_sort[q] = packed;
+    }
+    __syncthreads();
+    bitonic_sort_u32<NT>(s_sort, n2);
+    if (stop == 2) continue;
     // flags + unique ranks; pass-through runs (exactly one part) need no row traffic
     int ccarry = 0;
     for (int pb = 0; pb < n; pb += NT) {
       int q = pb + threadIdx.x;
-      bool hd = q < n && (q == 0 || e_key[q] != e_key[q - 1]);
-      bool single = hd && (q + 1 >= n || e_key[q + 1] != e_key[q]);
+      unsigned me = q < n ? s_sort[q] : 0;
+      bool hd = q < n && (q == 0 || (s_sort[q - 1] >> 10) != (me >> 10));
+      bool single = hd && (q + 1 >= n || (s_sort[q + 1] >> 10) != (me >> 10));
       int tot;
       int ex = block_excl_scan<NT>(hd ? 1 : 0, s_scan, &tot);
       if (q < n) {
         s_flag[q] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
         if (hd) {
           long long o = off + out_used + ccarry + ex;
-          u_keys[o] = (i64)(e_key[q] ^ 0x8000000000000000ULL);
-          u_src[o] = single ? (unsigned)e_pay[q] : sum_base + (unsigned)o;
+          u_keys[o] = e_key[me & 1023];
+          u_src[o] = single ? e_src[me & 1023] : sum_base + (unsigned)o;
           s_rank[q] = (unsigned short)(ccarry + ex);
         }
       }
@@ -377,10 +423,11 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     if (threadIdx.x == 0) s_flag[n] = F_HEAD;
     __syncthreads();
     const long long obase = off + out_used;
+    if (stop == 3) { out_used += ccarry; continue; }
     ordered_run_sums<NCH, NG>(
         n, (n + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
         [&](int q) {
-          unsigned src = (unsigned)e_pay[q];
+          unsigned src = e_src[s_sort[q] & 1023];
           return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
         },
         [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(obase + s_rank[ph])) * dim; });
@@ -436,17 +483,19 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   const int nch = (dim + 63) / 64;
   const i64* k = (const i64*)ids;
   dim3 ga((unsigned)ntiles), gc(P);
+  static const int stop_a = getenv("TFRA_DBG_STOP_A") ? atoi(getenv("TFRA_DBG_STOP_A")) : 0;
+  static const int stop_c = getenv("TFRA_DBG_STOP_C") ? atoi(getenv("TFRA_DBG_STOP_C")) : 0;
   switch (nch) {
-    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
-    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
-    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
-    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts); break;
+    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
+    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
+    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
+    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count); break;
+    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   return launch_apply_indirect(t, s, p, npad, u_keys, u_src, grads, rows, rows_base, param_default_row, d_total);
