@@ -40,6 +40,8 @@ struct Table {
   size_t winner_len = 0;
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  unsigned apply_P = 0;      // bucket count the cursor area at the head of `scratch` is armed for (0 = not armed)
+  unsigned apply_parity = 0; // which cursor array the next tfra_table_apply_sparse call appends to
   AuxInitPod aux{};
   // host bookkeeping
   std::mutex mu;

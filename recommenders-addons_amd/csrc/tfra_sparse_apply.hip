@@ -1,5 +1,5 @@
 // Sparse optimizer write-back WITH duplicate ids: tfra_table_apply_sparse(ids[B], grads[B,D]).
-// Three kernels, no global sort passes, no atomics on gradient data, deterministic.
+// Three kernels, no global sort passes, no atomics on gradient data, results bit-reproducible.
 //
 // Reference: gradients of duplicate ids are summed, then ONE update per key
 // (`_resource_apply_sparse_duplicate_indices` = unique + unsorted_segment_sum,
@@ -7,21 +7,23 @@
 // upserts (:165-204).  A Zipf-1.2 batch of 131 072 ids has ~22 K unique keys and the hottest key
 // repeats ~24 000 times, so the reduction must be parallel per key yet order-fixed:
 //
-//   A  tile_reduce   one block per TILE=512 ids: bitonic-sort (fmix64(id), idx) in LDS — equal ids
-//      become adjacent with ascending idx, and because bucket = mulhi(hash, P) is monotone in the
-//      hash the tile's unique keys come out grouped by bucket.  One descriptor (key, src) per
-//      unique key per tile: ids occurring once in the tile point straight at their gradient row
-//      (nothing is copied); runs of >= 2 are summed by 16-lane groups into a scratch row.
-//   C  bucket_merge  one block per bucket: gathers the bucket's descriptors from all tiles (tile
-//      order), bitonic-sorts (key, tile-order) in LDS, sums each key's partial rows in tile order
-//      -> ONE (key, src) per unique key of the batch (again pass-through when there is one part).
+//   A  tile_reduce   one block per TILE=512 ids (one id per thread): equal ids are grouped with an
+//      LDS hash, a packed (group, position) u32 is bitonic-sorted in REGISTERS (shuffles inside a
+//      wave, LDS only across waves).  One descriptor (key, src, tile) per unique key per tile is
+//      appended to the key's merge bucket (bucket = mulhi(fmix64(key), P), one returning atomic
+//      per descriptor on a per-bucket cursor): ids occurring once in the tile point straight at
+//      their gradient row (nothing is copied); runs of >= 2 are summed by 16-lane groups into a
+//      scratch row, ascending input position.
+//   C  bucket_merge  one block per bucket: loads its descriptors (one coalesced read), groups by key
+//      (LDS hash), sorts (group, tile), sums each key's parts in TILE ORDER -> ONE (key, src) per
+//      unique key of the batch (pass-through again when there is a single part).
 //   apply_kernel<INDIRECT> (tfra_optim.hip) one 16-lane group per unique key: locate-or-insert
 //      the row, read [p|m|v], apply, write back.
 //
 // Row reads are issued in batches of independent loads before the order-dependent adds, so the
 // kernels are bound by memory-level parallelism, not by one latency per row.
 // Summation tree per key = [ascending idx inside a (tile, position-chunk)] -> [chunks of the tile
-// in order] -> [tiles in order (chunked the same way)]: fixed by the input => bit-reproducible.
+// in order] -> [tiles in order (chunked the same way)]: a function of the input alone.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -45,42 +47,90 @@ int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, siz
 
 namespace {
 
-constexpr int TILE = 512;    // ids per kernel-A block
-constexpr int NTA = 512;     // kernel-A threads (32 groups of 16 lanes: 8 waves keep a CU busy)
+constexpr int TILE = 512;    // ids per kernel-A block = threads per block
+constexpr int NTA = 512;     // kernel-A threads (32 groups of 16 lanes)
 constexpr int NT = 256;      // kernel-C threads (16 groups)
-constexpr int CMAX = 1024;   // descriptors one kernel-C block can hold in LDS
+constexpr int CMAX = 1024;   // descriptors one kernel-C pass holds in LDS = capacity of a bucket region
 constexpr int MAXCH = 4;     // D <= 256 (one float4 per lane per 64-column chunk)
 constexpr unsigned SKIP = 0xffffffffu;
 constexpr unsigned char F_HEAD = 1, F_SINGLE = 2;
+constexpr unsigned CSTRIDE = 32;  // u32 words between bucket cursors: one 128-B line each (atomics on
+                                  // neighbouring words of one line serialise: 18 us -> 3 us in kernel A)
 
 template <int NCH> struct Batch { static constexpr int v = NCH == 1 ? 8 : (NCH == 2 ? 4 : 2); };
 
-// in-LDS bitonic sort of n2 (power of two) 32-bit keys by NTH threads.
-// Pair q of a stage touches elements i = 2j*(q/j) + q%j and i+j.  Thread t owns pairs t, t+NTH, ...
-// so for j <= 64 every wave works inside its own 128-element windows: those stages need no block
-// barrier (LDS operations of one wave execute in order) — only stages with distance >= 128 do.
-// History: sorting (u64 hash, index) PAIRS with a __syncthreads per stage cost 14 us (512 keys) to
-// 20 us (kernel C) per launch; grouping by an LDS hash first and sorting one packed u32 is ~5x less.
-template <int NTH>
-__device__ __forceinline__ void bitonic_sort_u32(unsigned* a, int n2) {
+// ---------------------------------------------------------------------------------------------
+// Bitonic sort of NTH*EPT 32-bit keys held in registers (element index i = thread*EPT + r).
+// Distances < EPT stay inside a thread, < 64*EPT inside a wave (ds_bpermute shuffles, no barrier),
+// only the last log2(NTH/64) distances of a round go through LDS with block barriers.
+// (An LDS-resident version with a __syncthreads per stage cost 14-20 us per launch here.)
+template <int NTH, int EPT, bool KV>
+__device__ __forceinline__ void reg_bitonic_impl(unsigned (&x)[EPT], unsigned (&v)[EPT], unsigned* s_tmp, unsigned* s_tmpv,
+                                                 int n2) {
+  const int t = threadIdx.x;
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      const int jm = j - 1;
-      for (int q = threadIdx.x; q < (n2 >> 1); q += NTH) {
-        int i = ((q & ~jm) << 1) | (q & jm);
-        int l = i + j;
-        unsigned x = a[i], y = a[l];
-        unsigned lo = min(x, y), hi = max(x, y);
-        bool up = ((i & k) == 0);
-        a[i] = up ? lo : hi;
-        a[l] = up ? hi : lo;
+      if (EPT > 1 && j == 1) {  // constant register indices only (a runtime index would spill to scratch)
+#pragma unroll
+        for (int r = 0; r < EPT; r += 2) {
+          bool up = (((t * EPT + r) & k) == 0);
+          unsigned a = x[r], b = x[r + 1], av = v[r], bv = v[r + 1];
+          bool sw = up ? (b < a) : (a < b);
+          x[r] = sw ? b : a; x[r + 1] = sw ? a : b;
+          if (KV) { v[r] = sw ? bv : av; v[r + 1] = sw ? av : bv; }
+        }
+      } else if (EPT > 2 && j == 2) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          bool up = (((t * EPT + r) & k) == 0);
+          unsigned a = x[r], b = x[r + 2], av = v[r], bv = v[r + 2];
+          bool sw = up ? (b < a) : (a < b);
+          x[r] = sw ? b : a; x[r + 2] = sw ? a : b;
+          if (KV) { v[r] = sw ? bv : av; v[r + 2] = sw ? av : bv; }
+        }
+      } else if (j < 64 * EPT) {
+        const int dl = j / EPT;
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          int i = t * EPT + r;
+          unsigned y = (unsigned)__shfl_xor((int)x[r], dl);
+          unsigned yv = KV ? (unsigned)__shfl_xor((int)v[r], dl) : 0u;
+          bool keep_min = (((i & k) == 0) == ((i & j) == 0));
+          bool take = keep_min ? (y < x[r]) : (y > x[r]);
+          x[r] = take ? y : x[r];
+          if (KV) v[r] = take ? yv : v[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) { s_tmp[t * EPT + r] = x[r]; if (KV) s_tmpv[t * EPT + r] = v[r]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+          int i = t * EPT + r;
+          unsigned y = s_tmp[i ^ j];
+          unsigned yv = KV ? s_tmpv[i ^ j] : 0u;
+          bool keep_min = (((i & k) == 0) == ((i & j) == 0));
+          bool take = keep_min ? (y < x[r]) : (y > x[r]);
+          x[r] = take ? y : x[r];
+          if (KV) v[r] = take ? yv : v[r];
+        }
+        __syncthreads();
       }
-      // block barrier iff this stage or the next one exchanges across waves (distance >= 128);
-      // the stage after (k, 1) is (2k, k)
-      if (j >= 128 || (j == 1 && (k >= 128 || k == n2))) __syncthreads();
-      else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // same-wave LDS ordering only
     }
   }
+}
+
+template <int NTH, int EPT>
+__device__ __forceinline__ void reg_bitonic(unsigned (&x)[EPT], unsigned* s_tmp, int n2) {
+  unsigned dummy[EPT] = {};
+  reg_bitonic_impl<NTH, EPT, false>(x, dummy, s_tmp, nullptr, n2);
+}
+
+// key-value variant: keys must be unique (no tie-breaking on the payload)
+template <int NTH, int EPT>
+__device__ __forceinline__ void reg_bitonic_kv(unsigned (&x)[EPT], unsigned (&v)[EPT], unsigned* s_tmp, unsigned* s_tmpv,
+                                               int n2) {
+  reg_bitonic_impl<NTH, EPT, true>(x, v, s_tmp, s_tmpv, n2);
 }
 
 // Group equal 64-bit keys of an LDS array: returns a slot id in [0, cap) that is the same for equal
@@ -208,26 +258,37 @@ __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const
   }
 }
 
+// Descriptor store: bucket b owns entries [b*CMAX, b*CMAX+CMAX); cursor[b] counts every append,
+// appends beyond CMAX go to the overflow list (rare: several very hot keys hashing together).
+struct DescStore {
+  i64* key;
+  unsigned* src;
+  unsigned* ord;       // tile << 9 | unique rank inside the tile: a deterministic id of the descriptor
+  unsigned* cursor;    // [P] (this call's parity)
+  i64* ovf_key;
+  unsigned* ovf_src;
+  unsigned* ovf_ord;
+  unsigned* ovf_bucket;
+  unsigned* ovf_count;
+  unsigned ovf_cap;
+};
+
 // ---------------------------------------------------------------------------------------------
-// kernel A.  Descriptor u of tile t lives at index t*TILE+u: part_keys[], part_src[] where
-// src < rows_base -> gradient row `src` of the caller's buffer, else scratch row (src-rows_base).
-// Sort key (31 bits) = bucket(11) | group slot(11) | position in tile(9): groups the tile by merge
-// bucket, then by key, ascending input position inside a key.
+// kernel A.  src < rows_base -> gradient row `src` of the caller's buffer, else scratch row
+// (src-rows_base).  Sort key (20 bits) = group slot(11) | position in tile(9).
 template <int NCH>
 __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* __restrict__ ids,
                                                           const float* __restrict__ grads, int dim, unsigned P,
-                                                          unsigned rows_base, i64* __restrict__ part_keys,
-                                                          unsigned* __restrict__ part_src, float* __restrict__ scratch_rows,
-                                                          unsigned short* __restrict__ tile_hist,
-                                                          unsigned short* __restrict__ tile_start, int stop) {
+                                                          unsigned rows_base, DescStore ds,
+                                                          float* __restrict__ scratch_rows, unsigned* overflow, int stop) {
   constexpr int NG = NTA / 16;
   constexpr unsigned GCAP = 2048;            // group table: 4x the tile => short probe chains
   __shared__ i64 s_key[TILE];                // ids of the tile, input order
-  __shared__ unsigned s_sort[TILE];          // packed sort keys
+  __shared__ unsigned s_sort[TILE];          // packed sort keys, sorted
   __shared__ unsigned s_owner[GCAP];
+  __shared__ unsigned s_rep[GCAP];           // smallest input position of the group (deterministic id)
   __shared__ unsigned short s_u[TILE];       // unique rank (within the tile) of each head position
   __shared__ unsigned char s_flag[TILE + 1];
-  __shared__ unsigned s_hist[2048];          // P <= 2048
   __shared__ float s_left[NG][64 * NCH];
   __shared__ unsigned char s_cont[NG], s_hashead[NG];
   __shared__ int s_scan[NTA / 64];
@@ -238,22 +299,24 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
   const bool ok = p < nvalid;
   const i64 key = ok ? ids[base + p] : 0;
   s_key[p] = key;
-  for (unsigned b = threadIdx.x; b < P; b += NTA) s_hist[b] = 0;
-  for (unsigned b = threadIdx.x; b < GCAP; b += NTA) s_owner[b] = 0;
+  for (unsigned b = threadIdx.x; b < GCAP; b += NTA) { s_owner[b] = 0; s_rep[b] = 0xffffffffu; }
   __syncthreads();
   if (stop == 1) return;  // (tuning ablation, TFRA_DBG_STOP_A)
-  const u64 h = fmix64((u64)key);
-  unsigned packed = 0xffffffffu;
-  if (ok) {
-    unsigned slot = lds_group_slot(s_key, s_owner, GCAP, p, h);
-    packed = ((unsigned)__umul64hi(h, (u64)P) << 20) | (slot << 9) | (unsigned)p;
-  }
-  s_sort[p] = packed;
+  // Which hash slot a key lands in depends on the race between colliding keys, so the slot must not
+  // influence the order: groups are ordered by their first input position instead (also = the
+  // order tf.unique would emit them in).  Sort key (18 bits) = first position(9) | position(9).
+  unsigned slot = 0;
+  if (ok) { slot = lds_group_slot(s_key, s_owner, GCAP, p, fmix64((u64)key)); atomicMin(&s_rep[slot], (unsigned)p); }
   __syncthreads();
-  bitonic_sort_u32<NTA>(s_sort, TILE);
+  unsigned x[1] = {0xffffffffu};
+  if (ok) x[0] = (s_rep[slot] << 9) | (unsigned)p;
+  reg_bitonic<NTA, 1>(x, s_sort, TILE);
+  __syncthreads();
+  s_sort[p] = x[0];
+  __syncthreads();
   if (stop == 2) return;
   // heads / singles / unique ranks: one sorted position per thread
-  const unsigned me = s_sort[p];
+  const unsigned me = x[0];
   const bool head = p < nvalid && (p == 0 || (s_sort[p - 1] >> 9) != (me >> 9));
   int ntile_unique;
   const int u = block_excl_scan<NTA>(head ? 1 : 0, s_scan, &ntile_unique);
@@ -261,31 +324,24 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
     bool single = head && (p + 1 >= nvalid || (s_sort[p + 1] >> 9) != (me >> 9));
     s_flag[p] = (head ? F_HEAD : 0) | (single ? F_SINGLE : 0);
     if (head) {
-      atomicAdd(&s_hist[me >> 20], 1u);
       s_u[p] = (unsigned short)u;
-      size_t d = base + (size_t)u;
-      part_keys[d] = s_key[me & 511];
-      part_src[d] = single ? (unsigned)(base + (me & 511)) : rows_base + (unsigned)d;
+      const i64 k = s_key[me & 511];
+      const unsigned src = single ? (unsigned)(base + (me & 511)) : rows_base + (unsigned)(base + u);
+      const unsigned b = (unsigned)__umul64hi(fmix64((u64)k), (u64)P);
+      unsigned pos = atomicAdd(&ds.cursor[(size_t)b * CSTRIDE], 1u);
+      if (pos < CMAX) {
+        size_t d = (size_t)b * CMAX + pos;
+        ds.key[d] = k; ds.src[d] = src; ds.ord[d] = ((unsigned)tile << 9) | (unsigned)u;
+      } else {
+        unsigned o = atomicAdd(ds.ovf_count, 1u);
+        if (o < ds.ovf_cap) { ds.ovf_key[o] = k; ds.ovf_src[o] = src; ds.ovf_ord[o] = ((unsigned)tile << 9) | (unsigned)u; ds.ovf_bucket[o] = b; }
+        else atomicAdd(overflow, 1u);
+      }
     }
   }
   if (threadIdx.x == 0) s_flag[TILE] = F_HEAD;
   __syncthreads();
   if (stop == 3) return;
-  // per-bucket count and first unique rank (buckets ascend with the sort key)
-  {
-    int carry = 0;
-    for (unsigned b0 = 0; b0 < P; b0 += NTA) {
-      unsigned b = b0 + threadIdx.x;
-      int v = b < P ? (int)s_hist[b] : 0, tot;
-      int ex = block_excl_scan<NTA>(v, s_scan, &tot);
-      if (b < P) {
-        tile_hist[tile * P + b] = (unsigned short)v;
-        tile_start[tile * P + b] = (unsigned short)(carry + ex);
-      }
-      carry += tot;
-    }
-  }
-  if (stop == 4) return;
   ordered_run_sums<NCH, NG>(
       nvalid, TILE / NG, dim, s_flag, s_left, s_cont, s_hashead,
       [&](int q) { return grads + (base + (s_sort[q] & 511)) * (size_t)dim; },
@@ -293,128 +349,153 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel C.  Output: bucket b owns u_keys/u_src[off_b .. off_b+n_b) with n_b = its descriptor count
-// and off_b = sum_t tile_start[t][b]; the first (#unique in bucket) entries are filled, the rest are
-// SKIP.  Summed rows go to scratch row (sum_base - rows_base + index).  The last bucket publishes
-// the total entry count.  Descriptors are gathered in tile order, grouped by key with an LDS hash
-// and sorted on (group slot(11) | gather position(10)), so a key's parts stay in tile order.
-// A bucket holding more than CMAX descriptors (several very hot keys hashing together) is
-// processed in 2^k passes, pass q taking the keys with (hash & (2^k-1)) == q.
+// kernel C.  Output: bucket b owns u_keys/u_src[off_b .. off_b+n_b), n_b = cursor[b], off_b =
+// sum of the cursors of smaller buckets; the first (#unique in bucket) entries are filled, the rest
+// are SKIP.  Summed rows go to scratch row (sum_base - rows_base + index).  The last bucket
+// publishes the total entry count.
+// A bucket with more than CMAX descriptors is processed in 2^k passes, pass q taking the keys with
+// (hash & (2^k-1)) == q, reading its region plus its share of the overflow list.
 template <int NCH>
-__global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned ntiles, int dim, unsigned rows_base,
-                                                          unsigned sum_base, const float* __restrict__ grads,
-                                                          const i64* __restrict__ part_keys,
-                                                          const unsigned* __restrict__ part_src,
-                                                          float* __restrict__ scratch_rows,
-                                                          const unsigned short* __restrict__ tile_hist,
-                                                          const unsigned short* __restrict__ tile_start,
-                                                          i64* __restrict__ u_keys, unsigned* __restrict__ u_src,
-                                                          i64* __restrict__ d_total, unsigned* overflow, int stop) {
+__global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, unsigned rows_base, unsigned sum_base,
+                                                          const float* __restrict__ grads, DescStore ds,
+                                                          unsigned* __restrict__ cursor_next,
+                                                          float* __restrict__ scratch_rows, i64* __restrict__ u_keys,
+                                                          unsigned* __restrict__ u_src, i64* __restrict__ d_total,
+                                                          unsigned* overflow, int stop) {
   constexpr int NG = NT / 16;
   constexpr unsigned GCAP = 2 * CMAX;
-  static_assert(CMAX == 1024, "10 position bits");
-  __shared__ i64 e_key[CMAX];         // gathered keys, tile order
-  __shared__ unsigned e_src[CMAX];    // their part_src
-  __shared__ unsigned s_sort[CMAX];   // packed sort keys
+  static_assert(CMAX == 1024, "10 entry bits");
+  __shared__ i64 e_key[CMAX];
+  __shared__ unsigned e_src[CMAX];
+  __shared__ unsigned e_ord[CMAX];
+  __shared__ unsigned s_sort[CMAX];     // sorted: entry index of each position
+  __shared__ unsigned s_skey[CMAX];     // sorted: (group id << 11) | tile
   __shared__ unsigned s_owner[GCAP];
+  __shared__ unsigned s_rep[GCAP];      // smallest descriptor id of the group (deterministic)
   __shared__ unsigned char s_flag[CMAX + 1];
   __shared__ unsigned short s_rank[CMAX];  // unique rank (within the pass) of each head position
   __shared__ float s_left[NG][64 * NCH];
   __shared__ unsigned char s_cont[NG], s_hashead[NG];
   __shared__ int s_scan[NT / 64];
-  __shared__ long long s_off[NT / 64];
+  __shared__ long long s_red[NT / 64];
   const unsigned b = blockIdx.x;
-  unsigned npass = 1;
-  int n_b = 0, out_used = 0;
+  // output offset = sum of the cursors of the buckets before this one
   long long off = 0;
+  {
+    long long acc = 0;
+    for (unsigned i = threadIdx.x; i < b; i += NT) acc += ds.cursor[(size_t)i * CSTRIDE];
+    for (int o2 = 32; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    off = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  }
+  const int n_b = (int)ds.cursor[(size_t)b * CSTRIDE];
+  const unsigned n_ovf = n_b > CMAX ? min(*ds.ovf_count, ds.ovf_cap) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cursor_next[(size_t)b * CSTRIDE] = 0;  // re-arm the other parity for the next call
+    if (b == 0) cursor_next[(size_t)P * CSTRIDE] = 0;  // (its overflow counter)
+    if (b == P - 1) *d_total = off + n_b;
+  }
+  if (n_b == 0) return;
+  unsigned npass = 1;
+  if (n_b > CMAX) while ((unsigned)n_b > (unsigned)(CMAX / 2) * npass && npass < 64) npass <<= 1;
+  const int n_reg = min(n_b, CMAX);
+  int out_used = 0;
   for (unsigned pass = 0; pass < npass; ++pass) {
-    // gather this pass's descriptors from every tile, tile order; the first pass also finds the
-    // bucket's totals (n_b descriptors, output offset off_b) and decides how many passes it needs
-    int carry = 0, all = 0;
-    long long off_acc = 0;
-    bool too_many = false;
-    for (unsigned t0 = 0; t0 < ntiles; t0 += NT) {
-      unsigned t = t0 + threadIdx.x;
-      int cnt = 0, st = 0, mine = 0, tot;
-      if (t < ntiles) { cnt = tile_hist[(size_t)t * P + b]; st = tile_start[(size_t)t * P + b]; }
-      if (npass == 1) {
-        mine = cnt;
-      } else {
-        for (int j = 0; j < cnt; ++j)
-          mine += ((unsigned)fmix64((u64)part_keys[t * TILE + st + j]) & (npass - 1)) == pass;
+    int n = 0;
+    if (npass == 1) {  // the common case: one coalesced read of the bucket region
+      for (int q = threadIdx.x; q < n_reg; q += NT) {
+        size_t d = (size_t)b * CMAX + q;
+        e_key[q] = ds.key[d]; e_src[q] = ds.src[d]; e_ord[q] = ds.ord[d];
       }
-      if (pass == 0) {  // off_b = sum over tiles of (descriptors of smaller buckets in that tile)
-        int st_sum = st, cnt_sum = cnt;
-        for (int o2 = 32; o2 > 0; o2 >>= 1) { st_sum += __shfl_xor(st_sum, o2); cnt_sum += __shfl_xor(cnt_sum, o2); }
-        if ((threadIdx.x & 63) == 0) s_off[threadIdx.x >> 6] = ((long long)cnt_sum << 40) | (long long)st_sum;
-      }
-      int ex = block_excl_scan<NT>(mine, s_scan, &tot);  // (barriers inside also publish s_off)
-      if (pass == 0) {
-        long long both = s_off[0] + s_off[1] + s_off[2] + s_off[3];  // st sums < 2^40: no carry into cnt
-        off_acc += both & ((1LL << 40) - 1);
-        all += (int)(both >> 40);
-      }
-      if (carry + tot > CMAX) too_many = true;
-      if (!too_many) {
-        int w = carry + ex;
-        for (int j = 0; j < cnt; ++j) {
-          unsigned d = t * TILE + st + j;
-          i64 key = part_keys[d];
-          if (npass == 1 || ((unsigned)fmix64((u64)key) & (npass - 1)) == pass) {
-            e_src[w] = part_src[d];
-            e_key[w] = key;
-            ++w;
-          }
-        }
-      }
-      carry += tot;
+      n = n_reg;
       __syncthreads();
-    }
-    if (pass == 0) {
-      n_b = all;
-      off = off_acc;
-      if (b == P - 1 && threadIdx.x == 0) *d_total = off + n_b;
-      if (n_b == 0) return;
-      if (too_many && npass == 1) {  // restart with the bucket split by key hash
-        while ((unsigned)n_b > (CMAX / 2) * npass && npass < 64) npass <<= 1;
-        pass = (unsigned)-1;  // ++ -> 0
+    } else {  // filtered gather from the region and from the overflow list
+      int carry = 0;
+      bool too_many = false;
+      for (int q0 = 0; q0 < n_reg + (int)n_ovf; q0 += NT) {
+        int q = q0 + threadIdx.x;
+        i64 k = 0; unsigned sr = 0, od = 0; bool take = false;
+        if (q < n_reg) {
+          size_t d = (size_t)b * CMAX + q;
+          k = ds.key[d]; sr = ds.src[d]; od = ds.ord[d]; take = true;
+        } else if (q < n_reg + (int)n_ovf) {
+          unsigned o = q - n_reg;
+          if (ds.ovf_bucket[o] == b) { k = ds.ovf_key[o]; sr = ds.ovf_src[o]; od = ds.ovf_ord[o]; take = true; }
+        }
+        take = take && (((unsigned)(fmix64((u64)k) >> 40) & (npass - 1)) == pass);
+        int tot;
+        int ex = block_excl_scan<NT>(take ? 1 : 0, s_scan, &tot);
+        if (carry + tot > CMAX) too_many = true;
+        if (take && !too_many) { e_key[carry + ex] = k; e_src[carry + ex] = sr; e_ord[carry + ex] = od; }
+        carry += tot;
+      }
+      __syncthreads();
+      if (too_many) {  // one key alone exceeds CMAX parts: reported, not applied
+        if (threadIdx.x == 0) atomicAdd(overflow, 1u);
         continue;
       }
+      n = carry;
     }
-    if (too_many) {  // one key alone exceeds CMAX parts: reported, not applied
-      if (threadIdx.x == 0) atomicAdd(overflow, 1u);
-      continue;
-    }
-    const int n = carry;
     if (n == 0) continue;
     if (stop == 1) continue;  // (tuning ablation, TFRA_DBG_STOP_C)
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
-    for (unsigned q = threadIdx.x; q < GCAP; q += NT) s_owner[q] = 0;
+    for (unsigned q = threadIdx.x; q < GCAP; q += NT) { s_owner[q] = 0; s_rep[q] = 0xffffffffu; }
     __syncthreads();
-    for (int q = threadIdx.x; q < n2; q += NT) {
-      unsigned packed = 0xffffffffu;
-      if (q < n) packed = (lds_group_slot(e_key, s_owner, GCAP, q, fmix64((u64)e_key[q])) << 10) | (unsigned)q;
-      s_sort[q] = packed;
+    // group by key; a group's deterministic id = its smallest descriptor id (tile<<9|rank, 20 bits);
+    // the hash slot itself depends on arrival order and must not influence the order
+    for (int q = threadIdx.x; q < n; q += NT) {
+      unsigned slot = lds_group_slot(e_key, s_owner, GCAP, q, fmix64((u64)e_key[q]));
+      atomicMin(&s_rep[slot], e_ord[q]);
+      s_sort[q] = slot;
     }
     __syncthreads();
-    bitonic_sort_u32<NT>(s_sort, n2);
+    // sort key (31 bits) = group id(20) | tile(11), unique per entry; payload = entry index
+    auto key_of = [&](int q) { return q < n ? ((s_rep[s_sort[q]] << 11) | (e_ord[q] >> 9)) : 0xffffffffu; };
+    if (n2 <= NT) {
+      unsigned x[1] = {key_of(threadIdx.x)}, v[1] = {(unsigned)threadIdx.x};
+      __syncthreads();
+      reg_bitonic_kv<NT, 1>(x, v, s_skey, s_sort, n2);
+      __syncthreads();
+      s_skey[threadIdx.x] = x[0]; s_sort[threadIdx.x] = v[0];
+    } else if (n2 == 2 * NT) {
+      unsigned x[2], v[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { x[r] = key_of(threadIdx.x * 2 + r); v[r] = threadIdx.x * 2 + r; }
+      __syncthreads();
+      reg_bitonic_kv<NT, 2>(x, v, s_skey, s_sort, n2);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { s_skey[threadIdx.x * 2 + r] = x[r]; s_sort[threadIdx.x * 2 + r] = v[r]; }
+    } else {
+      unsigned x[4], v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { x[r] = key_of(threadIdx.x * 4 + r); v[r] = threadIdx.x * 4 + r; }
+      __syncthreads();
+      reg_bitonic_kv<NT, 4>(x, v, s_skey, s_sort, n2);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s_skey[threadIdx.x * 4 + r] = x[r]; s_sort[threadIdx.x * 4 + r] = v[r]; }
+    }
+    __syncthreads();
     if (stop == 2) continue;
     // flags + unique ranks; pass-through runs (exactly one part) need no row traffic
     int ccarry = 0;
     for (int pb = 0; pb < n; pb += NT) {
       int q = pb + threadIdx.x;
-      unsigned me = q < n ? s_sort[q] : 0;
-      bool hd = q < n && (q == 0 || (s_sort[q - 1] >> 10) != (me >> 10));
-      bool single = hd && (q + 1 >= n || (s_sort[q + 1] >> 10) != (me >> 10));
+      unsigned me = q < n ? s_sort[q] : 0, mk = q < n ? s_skey[q] : 0;
+      bool hd = q < n && (q == 0 || (s_skey[q - 1] >> 11) != (mk >> 11));
+      bool single = hd && (q + 1 >= n || (s_skey[q + 1] >> 11) != (mk >> 11));
       int tot;
       int ex = block_excl_scan<NT>(hd ? 1 : 0, s_scan, &tot);
       if (q < n) {
         s_flag[q] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
         if (hd) {
           long long o = off + out_used + ccarry + ex;
-          u_keys[o] = e_key[me & 1023];
-          u_src[o] = single ? e_src[me & 1023] : sum_base + (unsigned)o;
+          u_keys[o] = e_key[me];
+          u_src[o] = single ? e_src[me] : sum_base + (unsigned)o;
           s_rank[q] = (unsigned short)(ccarry + ex);
         }
       }
@@ -427,7 +508,7 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     ordered_run_sums<NCH, NG>(
         n, (n + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
         [&](int q) {
-          unsigned src = e_src[s_sort[q] & 1023];
+          unsigned src = e_src[s_sort[q]];
           return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
         },
         [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(obase + s_rank[ph])) * dim; });
@@ -458,27 +539,48 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
     return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
                                            "(use tfra_unique + tfra_segment_sum + tfra_table_apply_optimizer otherwise)");
   if (n > (1ULL << 20))
-    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^20 ids per call (one key may hold ntiles <= CMAX "
-                                           "partial rows); split the batch or use the unique + segment_sum path");
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^20 ids per call (tile index has 11 bits and one key "
+                                           "may hold ntiles <= CMAX parts); split the batch or use the unique + "
+                                           "segment_sum path");
   rc = t->prepare_insert(n, s);
   if (rc) return rc;
   const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
   unsigned P = 64;
-  while (P < 2048 && (size_t)P * 64 < n) P <<= 1;
+  while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  // scratch: part_keys | part_src | u_keys | u_src | tile_hist | tile_start | d_total | rows[2*npad]
-  size_t bytes = 2 * al(npad * 8) + 2 * al(npad * 4) + 2 * al(ntiles * P * 2) + 256 + 2 * al(npad * (size_t)dim * 4);
+  // scratch: cursors[2][P+1] | region key/src/ord [P*CMAX] | overflow key/src/ord/bucket [npad] |
+  //          u_keys/u_src [npad] | d_total | rows [2*npad][dim]
+  const size_t reg = (size_t)P * CMAX;
+  size_t bytes = al(2 * (size_t)(P + 1) * CSTRIDE * 4) + al(reg * 8) + 2 * al(reg * 4) + al(npad * 8) + 3 * al(npad * 4) + al(npad * 8) +
+                 al(npad * 4) + 256 + 2 * al(npad * (size_t)dim * 4);
+  const bool fresh = t->scratch_bytes < bytes || t->apply_P != P;
   rc = t->ensure_scratch(bytes, s);
   if (rc) return rc;
   unsigned char* w = (unsigned char*)t->scratch;
-  i64* part_keys = (i64*)w; w += al(npad * 8);
+  unsigned* cursors = (unsigned*)w; w += al(2 * (size_t)(P + 1) * CSTRIDE * 4);
+  if (fresh) {  // both cursor parities start at zero; afterwards kernel C re-arms the idle one
+    if (hipMemsetAsync(cursors, 0, 2 * (size_t)(P + 1) * CSTRIDE * 4, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: memset");
+    t->apply_P = P;
+    t->apply_parity = 0;
+  }
+  DescStore ds;
+  ds.key = (i64*)w; w += al(reg * 8);
+  ds.src = (unsigned*)w; w += al(reg * 4);
+  ds.ord = (unsigned*)w; w += al(reg * 4);
+  ds.ovf_key = (i64*)w; w += al(npad * 8);
+  ds.ovf_src = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_ord = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_bucket = (unsigned*)w; w += al(npad * 4);
   i64* u_keys = (i64*)w; w += al(npad * 8);
-  unsigned* part_src = (unsigned*)w; w += al(npad * 4);
   unsigned* u_src = (unsigned*)w; w += al(npad * 4);
-  unsigned short* th = (unsigned short*)w; w += al(ntiles * P * 2);
-  unsigned short* ts = (unsigned short*)w; w += al(ntiles * P * 2);
   i64* d_total = (i64*)w; w += 256;
   float* rows = (float*)w;
+  unsigned* cur = cursors + (size_t)t->apply_parity * (P + 1) * CSTRIDE;
+  unsigned* nxt = cursors + (size_t)(t->apply_parity ^ 1) * (P + 1) * CSTRIDE;
+  t->apply_parity ^= 1;
+  ds.cursor = cur;
+  ds.ovf_count = cur + (size_t)P * CSTRIDE;
+  ds.ovf_cap = (unsigned)npad;
   const unsigned rows_base = (unsigned)npad, sum_base = (unsigned)(2 * npad);
   const int nch = (dim + 63) / 64;
   const i64* k = (const i64*)ids;
@@ -486,16 +588,16 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   static const int stop_a = getenv("TFRA_DBG_STOP_A") ? atoi(getenv("TFRA_DBG_STOP_A")) : 0;
   static const int stop_c = getenv("TFRA_DBG_STOP_C") ? atoi(getenv("TFRA_DBG_STOP_C")) : 0;
   switch (nch) {
-    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
-    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
-    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
-    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, part_keys, part_src, rows, th, ts, stop_a); break;
+    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
+    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
+    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
+    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, part_keys, part_src, rows, th, ts, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   return launch_apply_indirect(t, s, p, npad, u_keys, u_src, grads, rows, rows_base, param_default_row, d_total);

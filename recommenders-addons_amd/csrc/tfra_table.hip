@@ -624,6 +624,7 @@ int Table::ensure_winner(hipStream_t s) {
 
 int Table::ensure_scratch(size_t bytes, hipStream_t s) {
   if (scratch_bytes >= bytes) return TFRA_OK;
+  apply_P = 0;  // the armed cursor area of tfra_table_apply_sparse does not survive a reallocation
   if (scratch) { HIP_TRY(hipStreamSynchronize(s)); dfree(scratch, s); }
   size_t want = std::max(bytes, scratch_bytes * 2);
   scratch = dalloc(want, s);
@@ -773,6 +774,7 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
     if (rc) return rc;
     rc = t->ensure_scratch(n * sizeof(i64), s);
     if (rc) return rc;
+    t->apply_P = 0;  // scratch head is overwritten below
     TableView v = t->view_of(t->cur);
     i64* slot_of = (i64*)t->scratch;
     insert_locate_kernel<U><<<grid, block, 0, s>>>(v, n, k, slot_of, field, t->aux);
@@ -959,6 +961,7 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
   for (size_t p = 0; p < n; ++p) rounds[rank[p]].push_back(idx[p]);
   rc = t->ensure_scratch(n * sizeof(int), s);
   if (rc) return rc;
+  t->apply_P = 0;  // scratch head is overwritten below
   int* d_order = (int*)t->scratch;
   size_t off = 0;
   for (auto& r : rounds) {

@@ -306,7 +306,7 @@ def test_apply_sparse_hot_bucket_multipass(env):
   rng = np.random.default_rng(77)
   n, dim = 40064, 8
   P = 64
-  while P < 2048 and P * 64 < n:
+  while P < 2048 and P * 128 < n:
     P *= 2
   cand = rng.integers(1, 2**62, size=200000).astype(np.int64)
   h = fmix64_np(cand.astype(np.uint64))
