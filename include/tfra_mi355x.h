@@ -137,6 +137,13 @@ int tfra_table_reserve(tfra_table_t* t, size_t min_slots, tfra_stream_t stream);
 int tfra_table_export_batch(tfra_table_t* t, size_t n, size_t offset, size_t* d_counter,
                             int64_t* keys, void* values, uint64_t* scores, tfra_stream_t stream);
 
+/* -- run-time options.  TFRA_OPTION_CAPTURE_SAFE = 1 makes every table entry point safe to call
+ *    while `stream` is being captured into a hipGraph (no host synchronisation, no event
+ *    record/query, no growth): the caller guarantees capacity (tfra_table_reserve beforehand) and
+ *    keeps using ONE stream.  Scratch buffers must have been sized by an identical warm-up call. */
+typedef enum { TFRA_OPTION_CAPTURE_SAFE = 1 } tfra_option;
+int tfra_table_set_option(tfra_table_t* t, int option, int64_t value);
+
 /* -- set_global_epoch (lookup_table_op_hkv.h:499,507,533) --------------------------------- */
 int tfra_table_set_global_epoch(tfra_table_t* t, uint64_t epoch);
 
@@ -170,6 +177,9 @@ typedef struct {
   float lr;         /* Adam: pass lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host (global step) */
   float beta1, beta2, eps;          /* Adam; Adagrad: eps<0 -> TF1 rule (no eps)             */
   float l1, l2, lr_power;           /* FTRL                                                  */
+  const float* d_lr;                /* optional DEVICE scalar overriding `lr` (read by the kernel):
+                                       lets a captured hipGraph follow a learning-rate schedule /
+                                       Adam's per-step lr_t without re-capturing                */
 } tfra_opt_params;
 /* d_n: optional DEVICE int64 scalar; when non-NULL only the first min(n, *d_n) keys are applied,
  * so a caller can chain tfra_unique -> tfra_segment_sum -> apply without reading the unique count

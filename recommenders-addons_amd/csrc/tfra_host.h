@@ -41,7 +41,6 @@ struct Table {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   unsigned apply_P = 0;      // bucket count the cursor area at the head of `scratch` is armed for (0 = not armed)
-  unsigned apply_parity = 0; // which cursor array the next tfra_table_apply_sparse call appends to
   AuxInitPod aux{};
   // host bookkeeping
   std::mutex mu;
@@ -54,6 +53,7 @@ struct Table {
   size_t n_since_read = 0;
   i64* h_size = nullptr;  // pinned, inside the h_scalar block
   bool growth_blocked = false;
+  bool capture_safe = false;  // TFRA_OPTION_CAPTURE_SAFE
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
   int n_rehash = 0;

@@ -32,11 +32,17 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
                                                     const float* __restrict__ defaults, int full, int dim,
                                                     float aux0, float aux1, const i64* __restrict__ d_n,
                                                     const unsigned* __restrict__ src, const float* __restrict__ alt_rows,
-                                                    unsigned alt_base) {
+                                                    unsigned alt_base, unsigned* __restrict__ rearm, unsigned rearm_count,
+                                                    unsigned rearm_stride) {
   constexpr int S = NSlots<KIND>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   int fresh = 0, failed = 0;
+  if (o.d_lr) o.lr = *o.d_lr;
+  if (INDIRECT && rearm) {  // zero the bucket cursors of tfra_table_apply_sparse for its next call
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < rearm_count) rearm[tid * rearm_stride] = 0;
+  }
   if (d_n) { size_t dn = (size_t)*d_n; if (dn < n) n = dn; }
   unsigned sidx = 0;
   bool active = g < n;
@@ -106,8 +112,8 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
 template <int KIND>
 void launch_apply(bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
                   const float* d, int full, int dim, float a0, float a1, const i64* dn) {
-  if (vec4) apply_kernel<KIND, true, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0);
-  else apply_kernel<KIND, false, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0);
+  if (vec4) apply_kernel<KIND, true, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0);
+  else apply_kernel<KIND, false, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0);
 }
 
 }  // namespace
@@ -116,17 +122,18 @@ namespace tfra {
 // third kernel of tfra_table_apply_sparse: caller holds the table lock and has run prepare_insert
 int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, size_t max_n, const i64* keys,
                           const unsigned* src, const float* grads, const float* alt_rows, unsigned alt_base,
-                          const float* default_row, const i64* d_n) {
+                          const float* default_row, const i64* d_n, unsigned* rearm, unsigned rearm_count,
+                          unsigned rearm_stride) {
   TableView v = t->view_of(t->cur);
-  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power};
+  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power, p->d_lr};
   const int dim = t->opts.dim;
   const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
   dim3 grid((unsigned)((max_n * 16 + 255) / 256));
   switch (p->kind) {
-    case TFRA_OPT_SGD: apply_kernel<TFRA_OPT_SGD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
-    case TFRA_OPT_ADAM: apply_kernel<TFRA_OPT_ADAM, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
-    case TFRA_OPT_ADAGRAD: apply_kernel<TFRA_OPT_ADAGRAD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
-    default: apply_kernel<TFRA_OPT_FTRL, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base); break;
+    case TFRA_OPT_SGD: apply_kernel<TFRA_OPT_SGD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
+    case TFRA_OPT_ADAM: apply_kernel<TFRA_OPT_ADAM, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
+    case TFRA_OPT_ADAGRAD: apply_kernel<TFRA_OPT_ADAGRAD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
+    default: apply_kernel<TFRA_OPT_FTRL, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   return TFRA_OK;
@@ -153,7 +160,7 @@ extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_param
   rc = t->prepare_insert(n, s);
   if (rc) return rc;
   TableView v = t->view_of(t->cur);
-  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power};
+  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power, p->d_lr};
   int dim = t->opts.dim;
   bool vec4 = dim % 4 == 0 && (((uintptr_t)grads | (uintptr_t)param_defaults) % 16 == 0);
   dim3 grid((unsigned)((n * 16 + 255) / 256));

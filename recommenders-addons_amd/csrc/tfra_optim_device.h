@@ -11,6 +11,7 @@ namespace tfra {
 struct OptP {
   int kind;
   float lr, beta1, beta2, eps, l1, l2, lr_power;
+  const float* d_lr;  // optional device scalar overriding lr
 };
 
 __device__ __forceinline__ float sgnf(float z) { return (z > 0.f) ? 1.f : ((z < 0.f) ? -1.f : 0.f); }

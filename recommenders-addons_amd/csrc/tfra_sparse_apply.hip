@@ -42,7 +42,8 @@ namespace tfra {
 // implemented in tfra_optim.hip
 int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, size_t max_n, const i64* keys,
                           const unsigned* src, const float* grads, const float* alt_rows, unsigned alt_base,
-                          const float* default_row, const i64* d_n);
+                          const float* default_row, const i64* d_n, unsigned* rearm, unsigned rearm_count,
+                          unsigned rearm_stride);
 }  // namespace tfra
 
 namespace {
@@ -358,7 +359,6 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
 template <int NCH>
 __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, unsigned rows_base, unsigned sum_base,
                                                           const float* __restrict__ grads, DescStore ds,
-                                                          unsigned* __restrict__ cursor_next,
                                                           float* __restrict__ scratch_rows, i64* __restrict__ u_keys,
                                                           unsigned* __restrict__ u_src, i64* __restrict__ d_total,
                                                           unsigned* overflow, int stop) {
@@ -392,11 +392,7 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, u
   const int n_b = (int)ds.cursor[(size_t)b * CSTRIDE];
   const unsigned n_ovf = n_b > CMAX ? min(*ds.ovf_count, ds.ovf_cap) : 0u;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    cursor_next[(size_t)b * CSTRIDE] = 0;  // re-arm the other parity for the next call
-    if (b == 0) cursor_next[(size_t)P * CSTRIDE] = 0;  // (its overflow counter)
-    if (b == P - 1) *d_total = off + n_b;
-  }
+  if (threadIdx.x == 0 && b == P - 1) *d_total = off + n_b;
   if (n_b == 0) return;
   unsigned npass = 1;
   if (n_b > CMAX) while ((unsigned)n_b > (unsigned)(CMAX / 2) * npass && npass < 64) npass <<= 1;
@@ -548,20 +544,19 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   unsigned P = 64;
   while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  // scratch: cursors[2][P+1] | region key/src/ord [P*CMAX] | overflow key/src/ord/bucket [npad] |
+  // scratch: cursors[P+1] | region key/src/ord [P*CMAX] | overflow key/src/ord/bucket [npad] |
   //          u_keys/u_src [npad] | d_total | rows [2*npad][dim]
   const size_t reg = (size_t)P * CMAX;
-  size_t bytes = al(2 * (size_t)(P + 1) * CSTRIDE * 4) + al(reg * 8) + 2 * al(reg * 4) + al(npad * 8) + 3 * al(npad * 4) + al(npad * 8) +
+  size_t bytes = al((size_t)(P + 1) * CSTRIDE * 4) + al(reg * 8) + 2 * al(reg * 4) + al(npad * 8) + 3 * al(npad * 4) + al(npad * 8) +
                  al(npad * 4) + 256 + 2 * al(npad * (size_t)dim * 4);
   const bool fresh = t->scratch_bytes < bytes || t->apply_P != P;
   rc = t->ensure_scratch(bytes, s);
   if (rc) return rc;
   unsigned char* w = (unsigned char*)t->scratch;
-  unsigned* cursors = (unsigned*)w; w += al(2 * (size_t)(P + 1) * CSTRIDE * 4);
-  if (fresh) {  // both cursor parities start at zero; afterwards kernel C re-arms the idle one
-    if (hipMemsetAsync(cursors, 0, 2 * (size_t)(P + 1) * CSTRIDE * 4, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: memset");
+  unsigned* cursors = (unsigned*)w; w += al((size_t)(P + 1) * CSTRIDE * 4);
+  if (fresh) {  // cursors start at zero; afterwards the apply kernel of every call re-arms them
+    if (hipMemsetAsync(cursors, 0, (size_t)(P + 1) * CSTRIDE * 4, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: memset");
     t->apply_P = P;
-    t->apply_parity = 0;
   }
   DescStore ds;
   ds.key = (i64*)w; w += al(reg * 8);
@@ -575,11 +570,8 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   unsigned* u_src = (unsigned*)w; w += al(npad * 4);
   i64* d_total = (i64*)w; w += 256;
   float* rows = (float*)w;
-  unsigned* cur = cursors + (size_t)t->apply_parity * (P + 1) * CSTRIDE;
-  unsigned* nxt = cursors + (size_t)(t->apply_parity ^ 1) * (P + 1) * CSTRIDE;
-  t->apply_parity ^= 1;
-  ds.cursor = cur;
-  ds.ovf_count = cur + (size_t)P * CSTRIDE;
+  ds.cursor = cursors;
+  ds.ovf_count = cursors + (size_t)P * CSTRIDE;
   ds.ovf_cap = (unsigned)npad;
   const unsigned rows_base = (unsigned)npad, sum_base = (unsigned)(2 * npad);
   const int nch = (dim + 63) / 64;
@@ -594,11 +586,14 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
     default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, nxt, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
-  return launch_apply_indirect(t, s, p, npad, u_keys, u_src, grads, rows, rows_base, param_default_row, d_total);
+  // the apply kernel runs after every merge block has read the cursors: it zeroes them for the next
+  // call (no host-side state, so the three launches can be captured into a HIP graph and replayed)
+  return launch_apply_indirect(t, s, p, npad, u_keys, u_src, grads, rows, rows_base, param_default_row, d_total, cursors,
+                               P + 1, CSTRIDE);
 }

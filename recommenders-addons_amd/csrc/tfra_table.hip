@@ -580,7 +580,7 @@ int Table::enter(hipStream_t s) {
   if (hipGetDevice(&cur) != hipSuccess || cur != device) {
     if (hipSetDevice(device) != hipSuccess) return set_error(TFRA_ERR_HIP, "hipSetDevice failed");
   }
-  if (has_last && s != last_stream) {
+  if (has_last && s != last_stream && !capture_safe) {
     HIP_TRY(hipEventRecord(chain_event, last_stream));
     HIP_TRY(hipStreamWaitEvent(s, chain_event, 0));
   }
@@ -666,6 +666,7 @@ int Table::grow(u64 min_nb, hipStream_t s) {
 //   * Only when the bound passes the hard threshold do we synchronise, and grow if the TRUE size
 //     needs it.  An out-of-memory during growth is not an error unless the keys cannot fit at all.
 int Table::prepare_insert(size_t n, hipStream_t s) {
+  if (capture_safe) return TFRA_OK;  // capacity is the caller's responsibility while capturing
   const double slots = (double)(cur.nb * SLOTS);
   const double soft = opts.max_load_factor * slots, hard = 0.92 * slots;
   if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
@@ -1055,6 +1056,14 @@ int tfra_table_export_batch(tfra_table_t* tp, size_t n, size_t offset, size_t* d
     export_reserved_kernel<<<1, 64, 0, s>>>(v, lo, hi, (u64*)d_counter, (i64*)keys, (unsigned char*)values, (u64*)scores);
   HIP_TRY(hipGetLastError());
   return TFRA_OK;
+}
+
+int tfra_table_set_option(tfra_table_t* tp, int option, int64_t value) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t) return set_error(TFRA_ERR_INVALID, "null table");
+  std::lock_guard<std::mutex> lock(t->mu);
+  if (option == TFRA_OPTION_CAPTURE_SAFE) { t->capture_safe = value != 0; return TFRA_OK; }
+  return set_error(TFRA_ERR_INVALID, "unknown option");
 }
 
 int tfra_table_set_global_epoch(tfra_table_t* tp, uint64_t epoch) {

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtfra_mi355x.so")
 TFRA_F32, TFRA_F16, TFRA_BF16, TFRA_I8, TFRA_I32, TFRA_I64, TFRA_F64 = range(7)
 FLAG_UNIQUE_KEYS = 1
 OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_FTRL = range(4)
+OPTION_CAPTURE_SAFE = 1
 
 
 class TfraError(RuntimeError):
@@ -49,6 +50,7 @@ class OptParams(ctypes.Structure):
       ("l1", ctypes.c_float),
       ("l2", ctypes.c_float),
       ("lr_power", ctypes.c_float),
+      ("d_lr", ctypes.c_void_p),
   ]
 
 
@@ -71,6 +73,7 @@ _SIGS = {
     "tfra_table_reserve": [_P, _SZ, _P],
     "tfra_table_export_batch": [_P, _SZ, _SZ, _P, _P, _P, _P, _P],
     "tfra_table_set_global_epoch": [_P, ctypes.c_uint64],
+    "tfra_table_set_option": [_P, _I, ctypes.c_int64],
     "tfra_table_save": [_P, ctypes.c_char_p, _SZ, _I, _P, ctypes.POINTER(_SZ)],
     "tfra_table_load": [_P, ctypes.c_char_p, _SZ, _P, ctypes.POINTER(_SZ)],
     "tfra_table_apply_optimizer": [_P, ctypes.POINTER(OptParams), _SZ, _P, _P, _P, _I, _P, _P],

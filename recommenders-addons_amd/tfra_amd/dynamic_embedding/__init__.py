@@ -2,7 +2,7 @@
 (`/root/reference/tensorflow_recommenders_addons/dynamic_embedding/__init__.py`) for the hot path."""
 from . import device_ops
 from . import optimizer as optimizers
-from .optimizer import DynamicEmbeddingOptimizer
+from .optimizer import CapturedTrainStep, DynamicEmbeddingOptimizer
 from .table_ops import (CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
                         KHkvHashTableMaxCapacity, KHkvHashTableMaxHbmForValuesByBytes)
 from .variable import (CuckooHashTableConfig, CuckooHashTableCreator, HkvHashTableConfig, HkvHashTableCreator,

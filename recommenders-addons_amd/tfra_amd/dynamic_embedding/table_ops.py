@@ -247,6 +247,10 @@ class _DeviceTable:
     _capi.call("tfra_table_capacity", self._h, ctypes.byref(out))
     return out.value
 
+  def set_capture_safe(self, on):
+    """While True every op on this table can be captured into a HIP graph (no host sync, no growth)."""
+    _capi.call("tfra_table_set_option", self._h, _capi.OPTION_CAPTURE_SAFE, int(bool(on)))
+
   def reserve(self, n_slots):
     _capi.call("tfra_table_reserve", self._h, int(n_slots), _stream(self._device))
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_opts_struct_layout_matches_header(built):
   # struct_size is checked by tfra_table_create; keep the python mirror in sync with the C struct
   assert ctypes.sizeof(built.TableOpts) == 80
-  assert ctypes.sizeof(built.OptParams) == 32
+  assert ctypes.sizeof(built.OptParams) == 40
 
 
 def test_product_path_has_no_cpu_fallback():
