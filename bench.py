@@ -250,34 +250,53 @@ def main():
     fwd_ms = float(np.mean([ev_a[i].elapsed_time(ev_b[i]) for i in range(K)]))
     bwd_ms = float(np.mean([ev_b[i].elapsed_time(ev_c[i]) for i in range(K)]))
 
-  # ---- dominant-kernel roofline: find kernel alone, HIP events around back-to-back launches ------
-  # algorithmic bytes per lookup = 8 (key) + Rb (row read) + Rb (out write) = 520 B at dim 64 fp32
-  # (SURVEY.md §8d); one launch processes B ids.
+  # ---- roofline inputs, measured live with HIP events on the stream the kernels run on ------------
+  # (1) lookup kernel find_kernel<16,4>: algorithmic bytes per lookup = 8 (key) + Rb (row read) + Rb
+  #     (out write) = 520 B at dim 64 fp32; one launch processes B ids.  Timed both
+  #     inside the timed region (ev_a..ev_b brackets exactly that launch each step) and back-to-back.
   reps = 50
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   ids0 = ids_all[W]
-  for _ in range(5):
-    table.lookup(ids0)
-  e0.record()
-  for _ in range(reps):
-    table.lookup(ids0)
-  e1.record()
-  torch.cuda.synchronize()
-  find_us = e0.elapsed_time(e1) * 1e3 / reps
+
+  def timed(fn):
+    for _ in range(5):
+      fn()
+    e0.record()
+    for _ in range(reps):
+      fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+  find_b2b_us = timed(lambda: table.lookup(ids0))
   find_bytes = B * (8 + 2 * DIM * 4)
-  # the fused optimizer kernel alone on the batch's unique keys: 8 + 7*Rb = 1800 B per unique key
+  find_us = fwd_ms * 1e3 if (fwd_ms is not None and world == 1) else find_b2b_us
+  # (2) write-back pipeline tile_reduce -> bucket_merge -> apply_kernel<INDIRECT> (one C-ABI call):
+  #     algorithmic bytes = B*(8 + Rb) (ids + gradient rows read once) + U*(8 + 7*Rb) (fused Adam on
+  #     the unique keys) — the dedup itself has no algorithmic traffic.
   uniq, idx, cnt = de.device_ops.unique(ids0)
-  gsum = torch.randn((uniq.numel(), DIM), generator=gen, device=dev) * 0.01
+  U = int(uniq.numel())
   p = opt.params(1)
-  for _ in range(5):
-    table._table.apply_optimizer(p, uniq, gsum, table._default_value)
-  e0.record()
-  for _ in range(reps):
-    table._table.apply_optimizer(p, uniq, gsum, table._default_value)
-  e1.record()
-  torch.cuda.synchronize()
-  apply_us = e0.elapsed_time(e1) * 1e3 / reps
-  apply_bytes = uniq.numel() * (8 + 7 * DIM * 4)
+  wb_us = timed(lambda: table._table.apply_sparse(p, ids0, grads, table._default_value))
+  wb_bytes = B * (8 + DIM * 4) + U * (8 + 7 * DIM * 4)
+  # (3) the fused optimizer kernel alone on pre-summed unique keys
+  gsum = torch.randn((U, DIM), generator=gen, device=dev) * 0.01
+  apply_us = timed(lambda: table._table.apply_optimizer(p, uniq, gsum, table._default_value))
+  apply_bytes = U * (8 + 7 * DIM * 4)
+  # measured HBM traffic of the same kernels (rocprofv3 PMC passes, profiles/rNN_summary.json)
+  prof = None
+  try:
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
+    if cands:
+      prof = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+  except OSError:
+    prof = None
+
+  def traffic_of(kname):
+    try:
+      return prof["kernels"][kname]["hbm_bytes_per_launch_corrected"]
+    except (TypeError, KeyError):
+      return None
 
   if rank == 0:
     ms = elapsed / K * 1e3
@@ -296,14 +315,27 @@ def main():
             "launch": "hipGraph replay" if use_graph else "eager",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "find_kernel<16,4>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",
+            "achieved": find_bytes / (find_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": find_bytes / (find_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("find_kernel"),
             "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
+            "avg_launch_us_back_to_back": find_b2b_us,
+            "timing": "HIP events around the launch inside the timed region" if fwd_ms is not None else "back-to-back",
+        },
+        "roofline_write_back": {
+            "bound": "hbm", "kernel": "tile_reduce_kernel + bucket_merge_kernel + apply_kernel<INDIRECT> "
+                                      "(duplicate-gradient reduction + fused sparse Adam, one C-ABI call)",
+            "achieved": wb_bytes / (wb_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": wb_bytes / (wb_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "traffic": (sum(traffic_of(k) for k in ("tile_reduce_kernel", "bucket_merge_kernel", "apply_kernel"))
+                        if all(traffic_of(k) for k in ("tile_reduce_kernel", "bucket_merge_kernel", "apply_kernel")) else None),
+            "algorithmic_bytes_per_launch": wb_bytes, "avg_launch_us": wb_us, "unique_keys": U,
+            "note": "latency/occupancy bound, not bandwidth bound: per-kernel split in profiles/",
         },
         "phases": {
             "forward_ms": fwd_ms, "backward_ms": bwd_ms,
-            "apply_kernel": {"avg_launch_us": apply_us, "algorithmic_bytes_per_launch": apply_bytes,
-                             "achieved_GBps": apply_bytes / (apply_us * 1e-6) / 1e9, "unique_keys": int(uniq.numel())},
+            "apply_kernel_alone": {"avg_launch_us": apply_us, "algorithmic_bytes_per_launch": apply_bytes,
+                                   "achieved_GBps": apply_bytes / (apply_us * 1e-6) / 1e9},
         },
     }
     if not args.no_cpu_baseline:

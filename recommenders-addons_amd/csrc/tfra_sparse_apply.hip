@@ -363,13 +363,13 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, u
                                                           unsigned* __restrict__ u_src, i64* __restrict__ d_total,
                                                           unsigned* overflow, int stop) {
   constexpr int NG = NT / 16;
-  constexpr unsigned GCAP = 2 * CMAX;
+  constexpr unsigned GCAP = CMAX;   // group table as large as the pass (LDS budget: 4 blocks per CU)
   static_assert(CMAX == 1024, "10 entry bits");
   __shared__ i64 e_key[CMAX];
   __shared__ unsigned e_src[CMAX];
-  __shared__ unsigned e_ord[CMAX];
-  __shared__ unsigned s_sort[CMAX];     // sorted: entry index of each position
-  __shared__ unsigned s_skey[CMAX];     // sorted: (group id << 11) | tile
+  __shared__ unsigned e_ord[CMAX];      // descriptor ids; reused as s_skey once the sort keys are built
+  __shared__ unsigned s_sort[CMAX];     // group slot, then (sorted) entry index of each position
+  unsigned* const s_skey = e_ord;       // sorted: (group id << 11) | tile
   __shared__ unsigned s_owner[GCAP];
   __shared__ unsigned s_rep[GCAP];      // smallest descriptor id of the group (deterministic)
   __shared__ unsigned char s_flag[CMAX + 1];

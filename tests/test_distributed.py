@@ -1,0 +1,144 @@
+"""CPU, gloo, world_size 2: the multi-process id-routing logic of AllToAllEmbedding
+(partition -> alltoall ids -> local lookup -> alltoall rows -> un-permute; backward mirror) with
+TEST DOUBLES for the two device pieces (the HIP table and the HIP front-end kernels cannot run
+without a GPU): the local shard is the CPU oracle, the partition/gather/scatter ops are numpy
+restatements.  Checks against the single-process model of the reference's
+`__alltoall_embedding_lookup__` (oracle/frontends.py, PY/shadow_embedding_ops.py:397-447)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+DIM = 6
+
+
+class _CpuOps:
+  """numpy stand-ins with the signatures of tfra_amd.dynamic_embedding.device_ops."""
+
+  def partition(self, ids, world, mode):
+    from oracle import frontends as ofe
+    k = ids.numpy()
+    owner = ofe.default_partition_fn(k, world, gpu_mode=(mode == 0))
+    perm = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]).astype(np.int32)
+    counts = np.array([(owner == r).sum() for r in range(world)], dtype=np.int64)
+    return torch.from_numpy(k[perm]), torch.from_numpy(perm), torch.from_numpy(counts)
+
+  def gather_rows(self, rows, idx):
+    return rows[idx.long()]
+
+  def scatter_rows(self, rows, perm):
+    out = torch.empty_like(rows)
+    out[perm.long()] = rows
+    return out
+
+
+class _OracleShard:
+  """de.Variable stand-in over the CPU oracle: lookup + SGD write-back with duplicate sums."""
+
+  def __init__(self, dim):
+    import oracle
+    self.t = oracle.CpuTable(dim)
+    self.dim = dim
+
+  def lookup(self, ids):
+    return torch.from_numpy(self.t.find(ids.numpy(), np.full(self.dim, -1.0, np.float32)))
+
+
+class _SgdOpt:
+  def __init__(self, lr):
+    self.lr = lr
+
+  def apply_sparse(self, shard, ids, grads):
+    from oracle import optimizers as oopt
+    uniq, g, _ = oopt.segment_sum_by_key(ids.numpy(), grads.numpy())
+    p = shard.t.find(uniq, np.full(shard.dim, -1.0, np.float32))
+    shard.t.insert(uniq, oopt.sgd(p, g, self.lr))
+
+
+def _all_keys():
+  return np.arange(0, 400, dtype=np.int64) * 7919 - 1000
+
+
+def _ids(rank):
+  rng = np.random.default_rng(100 + rank)
+  return rng.choice(np.concatenate([_all_keys(), np.arange(10**6, 10**6 + 50)]), size=(5, 37 + 11 * rank))
+
+
+def _grads(rank, n):
+  return np.random.default_rng(200 + rank).standard_normal((n, DIM)).astype(np.float32)
+
+
+def _worker(rank, world, port, q):
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from oracle import frontends as ofe
+  from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
+  shard = _OracleShard(DIM)
+  keys = _all_keys()
+  mine = keys[ofe.default_partition_fn(keys, world) == rank]
+  shard.t.insert(mine, np.tile(mine[:, None].astype(np.float32) * 0.5, (1, DIM)))
+  emb = AllToAllEmbedding(shard, partition_mode=0, ops=_CpuOps())
+  ids = torch.from_numpy(_ids(rank))
+  out = emb.lookup(ids)
+  g = _grads(rank, ids.numel())
+  emb.apply_gradients(_SgdOpt(0.1), torch.from_numpy(g))
+  dist.barrier()
+  k, v = shard.t.export_sorted()
+  q.put((rank, out.numpy(), k, v))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_alltoall_lookup_and_write_back_world2():
+  world, port = 2, 29511 + (os.getpid() % 200)
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = {}
+  for _ in range(world):
+    r, out, k, v = q.get(timeout=120)
+    res[r] = (out, k, v)
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  # single-process model
+  import oracle
+  from oracle import frontends as ofe
+  from oracle import optimizers as oopt
+  keys = _all_keys()
+  owner = ofe.default_partition_fn(keys, world)
+  tabs = [oracle.CpuTable(DIM) for _ in range(world)]
+  for r in range(world):
+    mine = keys[owner == r]
+    tabs[r].insert(mine, np.tile(mine[:, None].astype(np.float32) * 0.5, (1, DIM)))
+  ids = [_ids(r) for r in range(world)]
+  exp = ofe.alltoall_lookup_model(tabs, ids, np.full(DIM, -1.0, np.float32))
+  for r in range(world):
+    np.testing.assert_array_equal(res[r][0].reshape(-1, DIM), exp[r])
+    assert res[r][0].shape == ids[r].shape + (DIM,)
+  # write-back: each owner receives the grads of every rank for its keys, rank order = alltoall order
+  for owner_rank in range(world):
+    ks, gs = [], []
+    for src in range(world):
+      flat = ids[src].reshape(-1)
+      sel = ofe.default_partition_fn(flat, world) == owner_rank
+      ks.append(flat[sel]); gs.append(_grads(src, flat.size)[sel])
+    ks, gs = np.concatenate(ks), np.concatenate(gs)
+    uniq, gsum, _ = oopt.segment_sum_by_key(ks, gs)
+    p = tabs[owner_rank].find(uniq, np.full(DIM, -1.0, np.float32))
+    tabs[owner_rank].insert(uniq, oopt.sgd(p, gsum, 0.1))
+    ek, ev = tabs[owner_rank].export_sorted()
+    np.testing.assert_array_equal(res[owner_rank][1], ek)
+    np.testing.assert_allclose(res[owner_rank][2], ev, rtol=1e-6, atol=1e-6)
