@@ -40,6 +40,9 @@ def build(force=False, verbose=True):
   os.makedirs(OBJ, exist_ok=True)
   os.makedirs(LIBDIR, exist_ok=True)
   srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+  if os.environ.get("TFRA_WITH_TUNING"):  # kernel-ablation entry points for scripts/microbench_find.py
+    tdir = os.path.join(CSRC, "tuning")
+    srcs += sorted(os.path.join(tdir, f) for f in os.listdir(tdir) if f.endswith(".hip"))
   newest = _deps()
   with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
     res = list(ex.map(lambda s: _compile(s, force, newest), srcs))

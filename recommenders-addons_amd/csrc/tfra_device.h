@@ -103,6 +103,15 @@ __device__ __forceinline__ void keep_live(unsigned& a, unsigned& b, unsigned& c,
 __device__ __forceinline__ void keep_live(unsigned short&, unsigned short&, unsigned short&, unsigned short&) {}
 __device__ __forceinline__ void keep_live(unsigned char&, unsigned char&, unsigned char&, unsigned char&) {}
 
+// Write-through 16-B store (sc0 sc1): the line leaves the XCD's L2 while the kernel is still running
+// instead of staying dirty until the kernel boundary (MI355X_MICROARCH.md: a dependent kernel
+// boundary costs + B / 6 TB/s for B dirty bytes — 5.6 us behind find's 33.5 MB of output).
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt16(void* p, uint4 v) {
+  v4u_t x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+
 // ---- find: continue a probe whose first line `k` (bucket b) is already in registers --------
 // Returns the row index (b*15+slot) or -1.  All 16 lanes of the group call with the same key.
 template <bool COHERENT>
@@ -138,8 +147,13 @@ __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, 
 // different slots.  Returns row index, or -1 when no slot could be found.
 // `k_first` = the key's first bucket line (b0), already loaded by the caller (coherently) so that
 // a kernel can put the first probes of several keys in flight before resolving any of them.
+// bounded = the table cannot grow (Hkv flavour at max_capacity): the chain is never extended beyond
+// 4 buckets (b0, b1, b1+1, b1+2 — at load factor 0.5 the chance that all four are full is ~1e-8, so
+// nothing is evicted before the table is really full); when neither the key nor an empty slot exists
+// the function returns NEED_EVICT (-2).
+constexpr i64 NEED_EVICT = -2;
 __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key, u64 h, u64 b0, i64 k_first,
-                                                    int sub, int gshift, bool& is_new) {
+                                                    int sub, int gshift, bool& is_new, bool bounded = false) {
   is_new = false;
   if (is_reserved_key(key)) {
     int r = reserved_index(key);
@@ -164,12 +178,13 @@ __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key,
       i64 meta = shfl_i64(k, gshift + 15);
       if (!((u64)meta & META_OVERFLOW)) {
         if (fe >= 0) break;  // the key cannot live further along; claim the first empty slot
+        if (bounded && step >= 3) return NEED_EVICT;
         // bucket full and never overflowed: extend the chain through it
         if (sub == 15) atomicOr((u64*)&v.keys[b * 16 + 15], META_OVERFLOW);
       }
       b = (step == 0) ? b1 : next_bucket(b, v.nb);
     }
-    if (fe < 0) return -1;
+    if (fe < 0) return bounded ? NEED_EVICT : -1;
     i64 old = 0;
     if (sub == 0) old = (i64)atomicCAS((u64*)&v.keys[fe], (u64)EMPTY_KEY, (u64)key);
     old = shfl_i64(old, gshift);
@@ -188,6 +203,58 @@ __device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int 
   const u64 b0 = bucket0(key, v.nb, h);
   i64 k = load_key_coherent(&v.keys[b0 * 16 + sub]);
   return locate_or_claim_from(v, key, h, b0, k, sub, gshift, is_new);
+}
+
+// ---- eviction (Hkv strategies, table full): replace the minimum-score entry among the 30 slots
+// of the key's two home buckets — HKV's "in-bucket min-score eviction" (SURVEY.md appendix D;
+// behaviour pinned by T/hkv_hashtable_evict_test.py).  admit_always: LRU-type scores (a new key is
+// the most recent); otherwise the new key enters only if in_score >= the minimum score.
+// Returns the row whose key word now holds LOCKED_KEY (the caller writes row + score, then publishes
+// the key with publish_key), -1 when the key was not admitted, -3 when no victim could be taken.
+__device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 in_score, bool admit_always, int sub,
+                                              int gshift, u64* victim_word, bool& claimed_empty) {
+  u64 h;
+  const u64 b0 = bucket0(key, v.nb, h);
+  const u64 b1 = bucket1(h, b0, v.nb);
+  claimed_empty = false;
+  for (int attempt = 0; attempt < 256; ++attempt) {
+    u64 best_score = ~0ULL, best_word = 0;
+    i64 best_key = 0;
+    for (int which = 0; which < 2; ++which) {
+      u64 b = which ? b1 : b0;
+      i64 k = load_key_coherent(&v.keys[b * 16 + sub]);
+      u64 sc = __hip_atomic_load(&v.scores[b * 16 + sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool cand = sub < SLOTS && k != LOCKED_KEY;
+      if (k == EMPTY_KEY) sc = 0;  // an empty slot (erase since the first phase) beats any victim
+      u64 my = cand ? sc : ~0ULL;
+      // 16-lane min with the lane index as tie-break
+      u64 packed_lo = ((u64)sub);
+      for (int o = 8; o > 0; o >>= 1) {
+        u64 os = ((u64)(unsigned)__shfl_xor((int)(my >> 32), o) << 32) | (unsigned)__shfl_xor((int)my, o);
+        u64 ol = (u64)(unsigned)__shfl_xor((int)packed_lo, o);
+        if (os < my || (os == my && ol < packed_lo)) { my = os; packed_lo = ol; }
+      }
+      i64 kk = shfl_i64(k, gshift + (int)packed_lo);
+      if (my < best_score) { best_score = my; best_word = b * 16 + packed_lo; best_key = kk; }
+    }
+    if (best_score == ~0ULL) continue;  // everything locked by concurrent evictors: look again
+    if (best_key != EMPTY_KEY && !admit_always && in_score < best_score) return -1;
+    i64 old = 0;
+    if (sub == 0) old = (i64)atomicCAS((u64*)&v.keys[best_word], (u64)best_key, (u64)LOCKED_KEY);
+    old = shfl_i64(old, gshift);
+    if (old == best_key) {
+      claimed_empty = (best_key == EMPTY_KEY);
+      *victim_word = best_word;
+      return (i64)((best_word >> 4) * SLOTS + (best_word & 15));
+    }
+  }
+  return -3;
+}
+
+// rows/scores written by the 16 lanes must be visible before the key replaces LOCKED_KEY
+__device__ __forceinline__ void publish_key(const TableView& v, u64 word, i64 key, int sub) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (sub == 0) __hip_atomic_store(&v.keys[word], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void size_add(const TableView& v, u64 wave_id, long long delta) {

@@ -74,9 +74,10 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
           apply_one<KIND>(o, gg.y, p.y, s1.y, s2.y);
           apply_one<KIND>(o, gg.z, p.z, s1.z, s2.z);
           apply_one<KIND>(o, gg.w, p.w, s1.w, s2.w);
-          *reinterpret_cast<float4*>(pr + c) = p;
-          if (S >= 1) *reinterpret_cast<float4*>(pr + dim + c) = s1;
-          if (S >= 2) *reinterpret_cast<float4*>(pr + 2 * dim + c) = s2;
+          // write-through: the rows leave L2 during the kernel, not at the boundary to the next one
+          store_wt16(pr + c, *reinterpret_cast<uint4*>(&p));
+          if (S >= 1) store_wt16(pr + dim + c, *reinterpret_cast<uint4*>(&s1));
+          if (S >= 2) store_wt16(pr + 2 * dim + c, *reinterpret_cast<uint4*>(&s2));
         }
       } else {
         for (int c = sub; c < dim; c += 16) {

@@ -25,7 +25,7 @@ typedef tfra::AuxInitPod AuxInit;  // elem_bytes = sizeof(V); pattern[f] = aux_i
 // =============================== kernels ====================================================
 
 // ---- find (+ fused default fill, + exists) -------------------------------------------------
-template <int G, int U>
+template <int G, int U, bool WT = (G == 16)>
 __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const i64* __restrict__ keys,
                                                    unsigned char* __restrict__ out,
                                                    uint8_t* __restrict__ exists,
@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
     for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(src[u] + off);  // U rows in flight
     keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) *reinterpret_cast<T*>(dst[u] + off) = tmp[u];  // clamped tail: same bytes twice
+    for (int u = 0; u < U; ++u) {  // clamped tail: same bytes twice
+      if (G == 16 && WT) store_wt16(dst[u] + off, *reinterpret_cast<uint4*>(&tmp[u]));
+      else *reinterpret_cast<T*>(dst[u] + off) = tmp[u];
+    }
   }
 }
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t 
                                                             const unsigned char* __restrict__ vals,
                                                             const u64* __restrict__ scores,
                                                             unsigned field, AuxInit ai, int strategy,
-                                                            u64 epoch) {
+                                                            u64 epoch, int bounded, uint8_t* __restrict__ deferred) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   constexpr int KPW = 4 * U;
@@ -146,14 +149,15 @@ __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t 
     size_t i = base + j;
     if (i < n) {
       bool is_new;
-      i64 row = locate_or_claim_from(v, key[u], h[u], b0[u], k0[u], sub, gshift, is_new);
+      i64 row = locate_or_claim_from(v, key[u], h[u], b0[u], k0[u], sub, gshift, is_new, bounded != 0);
+      if (deferred && sub == 0) deferred[i] = row == NEED_EVICT;
       if (row >= 0) {
         copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes,
                         vals + i * (size_t)v.field_bytes, v.field_bytes, sub);
         if (is_new && v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
         update_score(v, row, is_new, strategy, scores ? scores[i] : 1, epoch, sub);
         fresh += (is_new && sub == 0);
-      } else {
+      } else if (row != NEED_EVICT) {
         failed += (sub == 0);
       }
     }
@@ -162,6 +166,44 @@ __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t 
   for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
   if (lane == 0) {
     if (fresh) size_add(v, wave, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// ---- phase 2 of a bounded-table upsert: keys that found neither themselves nor an empty slot
+// replace the minimum-score entry of their two home buckets (runs after phase 1 has completed, so
+// no row is being written by an assign while it is evicted).
+template <int G>
+__global__ __launch_bounds__(256) void insert_evict_kernel(TableView v, size_t n, const i64* __restrict__ keys,
+                                                           const unsigned char* __restrict__ vals,
+                                                           const u64* __restrict__ scores, unsigned field, AuxInit ai,
+                                                           int strategy, u64 epoch, const uint8_t* __restrict__ deferred) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const size_t i = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  int fresh = 0, failed = 0;
+  if (i < n && deferred[i]) {
+    const i64 key = keys[i];
+    const u64 in_score = scores ? scores[i] : 1;
+    const bool lru_like = strategy == TFRA_EVICT_LRU || strategy == TFRA_EVICT_EPOCHLRU;
+    u64 word = 0;
+    bool claimed_empty;
+    i64 row = evict_and_lock(v, key, strategy == TFRA_EVICT_EPOCHLFU ? ((epoch << 32) | in_score) : in_score, lru_like, sub,
+                             gshift, &word, claimed_empty);
+    if (row >= 0) {
+      copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes, vals + i * (size_t)v.field_bytes,
+                      v.field_bytes, sub);
+      if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
+      if (sub == 0) v.scores[word] = 0;  // the slot starts a new life: scores count from zero
+      update_score(v, row, true, strategy, in_score, epoch, sub);
+      publish_key(v, word, key, sub);
+      fresh = (claimed_empty && sub == 0);
+    } else if (row == -3) {
+      failed = (sub == 0);
+    }  // -1: not admitted (its score is below every resident score): silently dropped, like HKV
+  }
+  for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
+  if (lane == 0) {
+    if (fresh) size_add(v, i >> 2, fresh);
     if (failed) atomicAdd(v.err_count, (unsigned)failed);
   }
 }
@@ -671,7 +713,7 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
   const double soft = opts.max_load_factor * slots, hard = 0.92 * slots;
   if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
   // at max_capacity (eviction takes over) or after a failed growth there is nothing to decide
-  const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb < (opts.max_capacity + SLOTS - 1) / SLOTS);
+  const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb < std::max<u64>(2, opts.max_capacity / SLOTS));
   if (!can_grow) return TFRA_OK;
   if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
@@ -696,7 +738,7 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
   if (rc) return rc;
   size_pending = false;
   if ((double)(sz + n) > soft && can_grow) {
-    u64 max_nb = opts.max_capacity ? (opts.max_capacity + SLOTS - 1) / SLOTS : ~0ULL;
+    u64 max_nb = opts.max_capacity ? std::max<u64>(2, opts.max_capacity / SLOTS) : ~0ULL;
     u64 need = (u64)((double)(sz + n) / opts.max_load_factor / SLOTS) + 1;
     u64 tries[2] = {std::min(std::max(need, cur.nb * 2), max_nb), std::min(std::max(need, cur.nb + cur.nb / 4), max_nb)};
     rc = TFRA_ERR_OOM;
@@ -761,14 +803,38 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
   constexpr int U = 4;
   size_t waves = (n + 4 * U - 1) / (4 * U);
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  // Hkv flavour at max_capacity: the table cannot grow, full home buckets evict by score (2 phases)
+  const u64 max_nb_b = t->opts.max_capacity ? std::max<u64>(2, t->opts.max_capacity / SLOTS) : 0;
+  const bool bounded = t->opts.strategy >= 0 && max_nb_b && t->cur.nb >= max_nb_b && field == 0;
+  if (bounded && !(flags & TFRA_FLAG_UNIQUE_KEYS))
+    return set_error(TFRA_ERR_UNSUPPORTED, "insert: a bounded (Hkv) table at max_capacity needs TFRA_FLAG_UNIQUE_KEYS "
+                                           "(HKV's unique-keys contract) so that eviction is well defined");
   if (flags & TFRA_FLAG_UNIQUE_KEYS) {
+    uint8_t* deferred = nullptr;
+    if (bounded) {
+      rc = t->ensure_scratch(n, s);
+      if (rc) return rc;
+      t->apply_P = 0;
+      deferred = (uint8_t*)t->scratch;
+    }
     TableView v = t->view_of(t->cur);
+    const int bd = bounded ? 1 : 0;
     switch (g) {
-      case 16: insert_unique_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
-      case 8: insert_unique_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
-      case 4: insert_unique_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
-      case 2: insert_unique_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
-      default: insert_unique_kernel<1, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch); break;
+      case 16: insert_unique_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
+      case 8: insert_unique_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
+      case 4: insert_unique_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
+      case 2: insert_unique_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
+      default: insert_unique_kernel<1, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
+    }
+    if (bounded) {
+      dim3 grid2((unsigned)((n * 16 + 255) / 256));
+      switch (g) {
+        case 16: insert_evict_kernel<16><<<grid2, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, deferred); break;
+        case 8: insert_evict_kernel<8><<<grid2, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, deferred); break;
+        case 4: insert_evict_kernel<4><<<grid2, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, deferred); break;
+        case 2: insert_evict_kernel<2><<<grid2, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, deferred); break;
+        default: insert_evict_kernel<1><<<grid2, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, deferred); break;
+      }
     }
   } else {
     rc = t->ensure_winner(s);
@@ -867,7 +933,7 @@ int tfra_table_create(const tfra_table_opts* o, const tfra_allocator* alloc, tfr
   if (hipEventCreateWithFlags(&t->size_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
   t->h_size = t->h_scalar + 4;
   u64 nb = std::max<u64>(2, (u64)((double)t->opts.init_capacity / t->opts.max_load_factor / SLOTS) + 1);
-  if (t->opts.max_capacity) nb = std::min<u64>(nb, std::max<u64>(2, (t->opts.max_capacity + SLOTS - 1) / SLOTS));
+  if (t->opts.max_capacity) nb = std::min<u64>(nb, std::max<u64>(2, t->opts.max_capacity / SLOTS));  // slots <= max_capacity
   int rc = t->alloc_storage(nb, &t->cur, s);
   if (rc) return fail(rc);
   clear_kernel<<<2048, 256, 0, s>>>(t->view_of(t->cur), 1);
@@ -1027,7 +1093,7 @@ int tfra_table_capacity(tfra_table_t* tp, size_t* out) {
 int tfra_table_reserve(tfra_table_t* tp, size_t min_slots, tfra_stream_t stream) {
   TABLE_ENTER();
   u64 nb = (min_slots + SLOTS - 1) / SLOTS;
-  if (t->opts.max_capacity) nb = std::min<u64>(nb, (t->opts.max_capacity + SLOTS - 1) / SLOTS);
+  if (t->opts.max_capacity) nb = std::min<u64>(nb, std::max<u64>(2, t->opts.max_capacity / SLOTS));
   return t->grow(nb, s);
 }
 

@@ -1,9 +1,9 @@
 // Ablation entry point for kernel tuning (scripts/microbench.py).  Not part of the public ABI.
 #include <hip/hip_runtime.h>
 
-#include "../../include/tfra_mi355x.h"
-#include "tfra_device.h"
-#include "tfra_host.h"
+#include "../../../include/tfra_mi355x.h"
+#include "../tfra_device.h"
+#include "../tfra_host.h"
 
 using namespace tfra;
 

@@ -460,12 +460,14 @@ class HkvHashTable(_LookupInterfaceMirror):
   def insert(self, keys, values, name=None):
     """PY/hkv_hashtable_ops.py:339-367"""
     keys = self._table._keys(keys)
-    self._table.upsert(keys, values, scores=self._gen_scores(keys))
+    # HKV requires unique keys per call (PY/dynamic_embedding_variable.py:1377-1378); with that contract
+    # a full bounded table can evict by score
+    self._table.upsert(keys, values, scores=self._gen_scores(keys), unique_keys=True)
 
   def accum(self, keys, values_or_deltas, exists, name=None):
     """PY/hkv_hashtable_ops.py:369-402"""
     keys = self._table._keys(keys)
-    self._table.accum_or_assign(keys, values_or_deltas, exists, scores=self._gen_scores(keys))
+    self._table.accum_or_assign(keys, values_or_deltas, exists, scores=self._gen_scores(keys), unique_keys=True)
 
   def export_keys_and_scores(self, split_size, name=None):
     """PY/hkv_hashtable_ops.py:421-434"""

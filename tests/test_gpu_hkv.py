@@ -1,0 +1,132 @@
+"""GPU: HkvHashTable flavour — per-key scores and in-bucket min-score eviction of a bounded table.
+HierarchicalKV itself is third party and not on disk; these are the
+behavioural KATs the reference's own GPU tests hold at that boundary
+(K14 = T/hkv_hashtable_evict_test.py:241-573, K15 = T/hkv_hashtable_ops_test.py:572-625)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DIM = 8
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  return torch, de
+
+
+def make(de, torch, strategy, name, **cfg):
+  return de.get_variable(name, key_dtype=torch.int64, value_dtype=torch.int32, initializer=0, dim=DIM, init_size=1024,
+                         kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                             init_capacity=1024, max_capacity=1024, max_hbm_for_values=1024 * 64,
+                             evict_strategy=strategy, **cfg)))
+
+
+def up(torch, table, keys, val):
+  k = torch.from_numpy(np.asarray(keys, np.int64)).cuda()
+  v = torch.full((k.numel(), DIM), val, dtype=torch.int32, device="cuda")
+  table.upsert(k, v)
+
+
+def scores_of(table):
+  k, s = table.tables[0].export_keys_and_scores(1)
+  return k.cpu().numpy(), s.cpu().numpy()
+
+
+def test_k14_lfu(env):
+  """T/hkv_hashtable_evict_test.py:241-310"""
+  torch, de = env
+  t = make(de, torch, de.HkvEvictStrategy.LFU, "k14_lfu")
+  up(torch, t, [0, 1, 2, 3], 1)
+  np.testing.assert_array_equal(scores_of(t)[1], np.ones(4))
+  up(torch, t, [0, 1, 2, 3], 1)
+  np.testing.assert_array_equal(scores_of(t)[1], np.full(4, 2))
+  up(torch, t, [0, 1, 4, 5], 1)
+  np.testing.assert_array_equal(np.sort(scores_of(t)[1]), [1, 1, 2, 2, 3, 3])
+  up(torch, t, np.arange(4, 1034), 10)
+  k, s = scores_of(t)
+  assert len(k) < 1024 and len(k) == int(t.size().item())
+  np.testing.assert_array_equal(np.sort(k)[:6], np.arange(6))          # the frequent keys survive
+  np.testing.assert_array_equal(np.sort(s)[-6:], [2, 2, 2, 2, 3, 3])
+  assert len(np.unique(k)) == len(k)
+
+
+def test_k14_epoch_lfu(env):
+  """T/hkv_hashtable_evict_test.py:312-406: score = (epoch << 32) + count, epoch steps every 4 upserts."""
+  torch, de = env
+  t = make(de, torch, de.HkvEvictStrategy.EPOCHLFU, "k14_elfu", step_per_epoch=4)
+  for base in (1, 1 + (1 << 32), 1 + (2 << 32)):
+    up(torch, t, [0, 1, 2, 3], 1)
+    assert np.all(np.sort(scores_of(t)[1])[-4:] >= base)
+    up(torch, t, [0, 1, 2, 3], 1)
+    assert np.all(np.sort(scores_of(t)[1])[-4:] >= base + 1)
+    up(torch, t, [0, 1, 4, 5], 1)
+    assert np.all(np.sort(scores_of(t)[1])[-6:] >= np.array([base, base, base + 1, base + 1, base + 2, base + 2]))
+    up(torch, t, np.arange(4, 1024), 10)
+    k, s = scores_of(t)
+    assert len(k) < 1024
+    np.testing.assert_array_equal(np.sort(k)[:6], np.arange(6))
+    assert np.all(np.sort(s)[-6:] >= np.array([base + 1] * 4 + [base + 2] * 2))
+
+
+def test_k14_lru(env):
+  """T/hkv_hashtable_evict_test.py:408-479: later upsert => larger score; the oldest keys go first."""
+  torch, de = env
+  t = make(de, torch, de.HkvEvictStrategy.LRU, "k14_lru")
+  up(torch, t, [0, 1, 2, 3], 1)
+  assert np.all(np.isin([0, 1, 2, 3], scores_of(t)[0]))
+  up(torch, t, [2, 3, 6, 7], 1)
+  k, s = scores_of(t)
+  d = dict(zip(k.tolist(), s.tolist()))
+  assert max(d[0], d[1]) < min(d[2], d[3])
+  up(torch, t, np.arange(4, 1044), 10)
+  up(torch, t, np.arange(1024, 1400), 10)
+  k, s = scores_of(t)
+  assert len(k) <= 1024 and len(np.unique(k)) == len(k)
+  assert not np.any(np.isin([0, 1, 2, 3], k))
+
+
+def test_k14_customized(env):
+  """T/hkv_hashtable_evict_test.py:527-573: a batch with score 10000 survives a batch with score 1."""
+  torch, de = env
+
+  def gen(keys):
+    return torch.where(keys >= 2048, torch.full_like(keys, 10000), torch.ones_like(keys))
+
+  t = make(de, torch, de.HkvEvictStrategy.CUSTOMIZED, "k14_custom", gen_scores_fn=gen)
+  up(torch, t, np.arange(2048, 4096), 10)
+  up(torch, t, np.arange(0, 1024), 10)
+  k, s = scores_of(t)
+  assert len(k) > 900
+  assert np.all(s == 10000) and np.all(k >= 1024)
+  # evicting never corrupts rows: every resident key still maps to its row
+  out = t.lookup(torch.from_numpy(k).cuda()).cpu().numpy()
+  assert np.all(out == 10)
+
+
+def test_k15_repeat_insert_and_bounded_size(env):
+  """T/hkv_hashtable_ops_test.py:572-625: 50 000 keys into capacity 100 000, twice: size == 50 000 both
+  times (nothing may be evicted at load factor 0.5); :627-686: overflow keeps size in [N/2, N]."""
+  torch, de = env
+  for dim, dt in [(1, torch.int8), (8, torch.int32), (10, torch.int64), (64, torch.float32), (200, torch.float16)]:
+    t = de.get_variable("k15_%d" % dim, key_dtype=torch.int64, value_dtype=dt, initializer=-1, dim=dim,
+                        kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(init_capacity=100000,
+                                                                                       max_capacity=100000)))
+    keys = torch.arange(50000, dtype=torch.int64).cuda()
+    vals = (keys % 100)[:, None].repeat(1, dim).to(dt)
+    assert int(t.size().item()) == 0
+    for i in range(2):
+      t.upsert(keys, vals)
+      assert int(t.size().item()) == 50000
+    np.testing.assert_array_equal(t.lookup(keys).cpu().numpy(), vals.cpu().numpy())
+    t.clear()
+    assert int(t.size().item()) == 0
+  t = de.get_variable("k15_over", key_dtype=torch.int64, value_dtype=torch.float32, initializer=0.0, dim=4,
+                      kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(init_capacity=65536,
+                                                                                     max_capacity=65536)))
+  t.upsert(torch.arange(200000, dtype=torch.int64).cuda(), torch.ones((200000, 4)).cuda())
+  n2 = int(t.size().item())
+  assert 65536 // 2 <= n2 <= 65536
+  k, v = t.export()
+  assert len(np.unique(k.cpu().numpy())) == n2
