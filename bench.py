@@ -156,8 +156,13 @@ def main():
   if args.gpus > 1 or world > 1:
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    backend = os.environ.get("TFRA_BENCH_BACKEND", "nccl")  # "gloo": smoke-test the N>1 path on ONE GPU
+    if backend == "gloo":
+      local_rank = 0
+      dist.init_process_group("gloo")
+    else:
+      torch.cuda.set_device(local_rank)
+      dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
   dev = torch.device("cuda", local_rank)
   torch.cuda.set_device(dev)
   B, K, W = args.batch, args.steps, args.warmup
@@ -240,7 +245,7 @@ def main():
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
   if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 

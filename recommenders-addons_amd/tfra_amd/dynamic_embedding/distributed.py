@@ -49,10 +49,20 @@ class AllToAllEmbedding:
     self.ops = ops if ops is not None else _DeviceOps()
     self._route = None
 
+  def _a2a(self, out, inp, out_splits=None, in_splits=None):
+    """alltoall(v).  RCCL moves device buffers directly; the gloo backend (CPU tests, single-GPU
+    smoke runs of the N>1 code path) has no device alltoall, so buffers are staged through the host."""
+    if inp.is_cuda and dist.get_backend(self.group) == "gloo":
+      o = torch.empty(out.shape, dtype=out.dtype)
+      dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+      out.copy_(o)
+    else:
+      dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
   # -- id routing (PY/shadow_embedding_ops.py:397-422 __relocate_dense_feature__) ---------------
   def _exchange_counts(self, counts):
     recv = torch.empty_like(counts)
-    dist.all_to_all_single(recv, counts, group=self.group)
+    self._a2a(recv, counts)
     return recv
 
   def route_ids(self, ids):
@@ -67,7 +77,7 @@ class AllToAllEmbedding:
     both = torch.stack([counts, recv_counts]).tolist()
     send, recv = [int(x) for x in both[0]], [int(x) for x in both[1]]
     remote_ids = torch.empty(sum(recv), dtype=ids.dtype, device=ids.device)
-    dist.all_to_all_single(remote_ids, owner_major, recv, send, group=self.group)
+    self._a2a(remote_ids, owner_major, recv, send)
     self._route = (perm, send, recv, ids.numel())
     return remote_ids
 
@@ -77,7 +87,7 @@ class AllToAllEmbedding:
       return rows
     perm, send, recv, n = self._route
     back = torch.empty((sum(send), rows.shape[-1]), dtype=rows.dtype, device=rows.device)
-    dist.all_to_all_single(back, rows.contiguous(), send, recv, group=self.group)
+    self._a2a(back, rows.contiguous(), send, recv)
     return self.ops.scatter_rows(back, perm)
 
   def route_grads(self, grads):
@@ -87,7 +97,7 @@ class AllToAllEmbedding:
     perm, send, recv, n = self._route
     owner_major = self.ops.gather_rows(grads.reshape(n, -1), perm)
     remote = torch.empty((sum(recv), owner_major.shape[-1]), dtype=grads.dtype, device=grads.device)
-    dist.all_to_all_single(remote, owner_major, recv, send, group=self.group)
+    self._a2a(remote, owner_major, recv, send)
     return remote
 
   # -- the two halves of a training step ---------------------------------------------------------

@@ -1,0 +1,138 @@
+"""GPU, BASELINE.json's FULL sizes, through size-independent properties (no oracle can hold 10^8 keys
+in seconds): rows are a closed-form function of the key, so every lookup is checkable on the device.
+
+  C2  1xMI355X: 100M keys, dim=64 fp32, Zipf-1.2 batch=131072, lookup+insert+sparse-Adam
+  C3  1xMI355X: dim=128 fp16, 50 % unseen-key insert rate, bounded table (dynamic growth + eviction/export)
+  C5  26 tables, mixed dim {16,32,64,128}, combined lookup + FTRL apply  (tables scaled to fit quickly)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  return torch, de
+
+
+def row_of(torch, keys, dim, dtype=None):
+  """row[j] = ((key * 2654435761 + j * 40503) mod 65521) / 65521 - 0.5   (exact in fp32)"""
+  j = torch.arange(dim, device=keys.device, dtype=torch.int64)
+  v = ((keys[:, None] * 2654435761 + j[None, :] * 40503) % 65521).to(torch.float32) / 65521.0 - 0.5
+  return v if dtype is None else v.to(dtype)
+
+
+def test_c2_100m_keys_dim64(env):
+  torch, de = env
+  from bench import keys_of_ranks_torch, zipf_bounded, keys_of_ranks
+  N, dim, chunk = 100_000_000, 64, 5_000_000
+  t = de.CuckooHashTable(torch.int64, torch.float32, torch.zeros(dim), init_size=int(N * 1.02), device="cuda:0", dim=dim)
+  key_sum = 0
+  for lo in range(1, N + 1, chunk):
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(N, lo + chunk - 1) + 1, dtype=torch.int64, device="cuda"))
+    t._table.upsert(k, row_of(torch, k, dim), unique_keys=True)
+    key_sum = (key_sum + int(k.sum().item())) % (1 << 64)
+  assert int(t.size().item()) == N
+  # no growth happened: capacity was sized up front (load factor 0.75)
+  assert t._table.capacity() < int(N * 1.02 / 0.75) + 100
+  # Zipf lookups of resident keys + misses: every row is the closed form, misses get the default
+  rng = np.random.default_rng(1)
+  ids = torch.from_numpy(keys_of_ranks(zipf_bounded(rng, 131072, N))).cuda()
+  out, ex = t.lookup(ids, return_exists=True)
+  assert bool(ex.all())
+  assert torch.equal(out, row_of(torch, ids, dim))
+  miss = keys_of_ranks_torch(torch, torch.arange(N + 1, N + 100001, dtype=torch.int64, device="cuda"))
+  out, ex = t.lookup(miss, dynamic_default_values=torch.full((dim,), 7.0, device="cuda"), return_exists=True)
+  assert not bool(ex.any()) and bool((out == 7.0).all())
+  # erase -> find -> re-insert round trip on 2M keys; size is exact at every step
+  sub = keys_of_ranks_torch(torch, torch.arange(1, 2_000_001, dtype=torch.int64, device="cuda"))
+  t.remove(sub)
+  assert int(t.size().item()) == N - sub.numel()
+  assert not bool(t.lookup(sub[:50000], return_exists=True)[1].any())
+  t._table.upsert(sub, row_of(torch, sub, dim), unique_keys=True)
+  assert int(t.size().item()) == N
+  # idempotent upsert; checksum of all exported keys (order-free) and spot-check exported rows
+  t._table.upsert(sub, row_of(torch, sub, dim), unique_keys=True)
+  assert int(t.size().item()) == N
+  cap = t._table.capacity()
+  from tfra_amd import _capi
+  from tfra_amd.dynamic_embedding.table_ops import _ptr, _stream
+  win = 12_000_000
+  kbuf = torch.empty(win, dtype=torch.int64, device="cuda")
+  vbuf = torch.empty((win, dim), dtype=torch.float32, device="cuda")
+  total, ksum = 0, 0
+  for off in range(0, cap, win):
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _capi.call("tfra_table_export_batch", t._table._h, min(win, cap - off), off, _ptr(cnt), _ptr(kbuf), _ptr(vbuf), None,
+               _stream(t._table.device))
+    c = int(cnt.item())
+    total += c
+    ksum = (ksum + int(kbuf[:c].sum().item())) % (1 << 64)
+    assert torch.equal(vbuf[:1000], row_of(torch, kbuf[:1000], dim))
+  assert total == N and ksum == key_sum
+
+
+def test_c3_fp16_dim128_half_unseen_bounded(env):
+  """50 % of every batch are never-seen keys; the table is bounded (Hkv, LRU) so it fills up and
+  evicts.  Properties: size <= capacity always, and every key that IS resident returns its own row."""
+  torch, de = env
+  dim, cap, B = 128, 2_000_000, 131072
+  t = de.HkvHashTable(torch.int64, torch.float16, torch.zeros(dim, dtype=torch.float16), init_capacity=cap,
+                      max_capacity=cap, device="cuda:0", dim=dim, evict_strategy=de.HkvEvictStrategy.LRU)
+  gen = torch.Generator(device="cuda").manual_seed(3)
+  fresh = 1
+  seen = torch.arange(1, 500001, dtype=torch.int64, device="cuda") * 7919
+  t.insert(seen, row_of(torch, seen, dim, torch.float16))
+  for step in range(40):
+    old = seen[torch.randint(0, seen.numel(), (B // 2,), generator=gen, device="cuda")].unique()
+    new = (torch.arange(fresh, fresh + B // 2, dtype=torch.int64, device="cuda") << 24) + 1  # never seen before
+    fresh += B // 2
+    ids = torch.cat([old, new])
+    out, ex = t.lookup(ids, return_exists=True)
+    want = row_of(torch, ids, dim, torch.float16)
+    assert torch.equal(out[ex], want[ex])          # resident => its own row, bit exact (fp16 copy)
+    assert not bool(ex[old.numel():].any())         # new keys are misses before the write-back
+    t.insert(ids, want)
+    n = int(t.size().item())
+    assert n <= cap
+  assert int(t.size().item()) > cap * 0.95          # it did fill up => eviction was exercised
+  k, v = t.export()
+  assert k.numel() == int(t.size().item()) and k.unique().numel() == k.numel()
+  assert torch.equal(v[:20000], row_of(torch, k[:20000], dim, torch.float16))
+
+
+def test_c5_26_tables_mixed_dims_ftrl(env):
+  """Multi-slot DLRM shape: 26 tables, dims cycling {16,32,64,128}, one id per table per sample,
+  FTRL.  Small enough for the CPU oracle: fused HIP write-back vs (1+S) finds + dense FTRL + upserts."""
+  import oracle
+  from oracle import optimizers as oopt
+  torch, de = env
+  rng = np.random.default_rng(5)
+  hyper = dict(lr=0.05, l1=1e-3, l2=1e-3, init_acc=0.1)
+  dims = [16, 32, 64, 128]
+  B = 4096
+  for ti in range(26):
+    dim = dims[ti % 4]
+    n_keys = int(10 ** (2 + 2.5 * ti / 25))  # log-spaced table sizes
+    opt = de.optimizers.Ftrl(0.05, -0.5, 0.1, 1e-3, 1e-3)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    v = de.Variable(dim=dim, name="c5_%d" % ti, initializer=0.0, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    tabs = [oracle.CpuTable(dim) for _ in range(3)]
+    ora = oopt.SparseOptimizerOracle("ftrl", tabs[0], tabs[1:], hyper, 0.0)
+    for step in range(2):
+      ids = rng.zipf(1.2, size=B) % n_keys
+      g = (rng.standard_normal((B, dim)) * 0.1).astype(np.float32)
+      emb = v.lookup(torch.from_numpy(ids).cuda())
+      np.testing.assert_allclose(emb.cpu().numpy(), tabs[0].find(ids, np.zeros(dim, np.float32)), rtol=2e-6, atol=2e-6)
+      deo.apply_sparse(v, torch.from_numpy(ids).cuda(), torch.from_numpy(g).cuda())
+      uniq, inv = np.unique(ids, return_inverse=True)
+      gs = np.zeros((uniq.size, dim), np.float64); np.add.at(gs, inv, g.astype(np.float64))
+      ora.apply(uniq, gs.astype(np.float32))
+    k, val = v.export()
+    o = np.argsort(k.cpu().numpy())
+    ek, ev = tabs[0].export_sorted()
+    np.testing.assert_array_equal(k.cpu().numpy()[o], ek)
+    np.testing.assert_allclose(val.cpu().numpy()[o], ev, rtol=5e-6, atol=5e-6)
