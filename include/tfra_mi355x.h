@@ -219,6 +219,14 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
 int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out,
                      tfra_stream_t stream);
 
+/* embedding_lookup_sparse combiner (PY/dynamic_embedding_ops.py:224-291; SparseSegmentSum/Mean/SqrtN,
+ * K/segment_reduction_ops_gpu.cu.cc:30-60): out[r,:] = combine_{i : seg[i]==r} w[i] * rows[idx[i],:]
+ * with seg ASCENDING (SparseTensor row ids), weights NULL => 1.  combiner 0 sum, 1 mean (/ sum w),
+ * 2 sqrtn (/ sqrt(sum w^2)); empty rows -> 0.  rows/out fp32; members are added in input order. */
+int tfra_sparse_segment_combine(tfra_workspace_t* ws, size_t nnz, int dim, const float* rows,
+                                const int32_t* idx, const int64_t* seg, const float* weights, int combiner,
+                                size_t n_rows, float* out, tfra_stream_t stream);
+
 /* default_partition_fn (PY/dynamic_embedding_variable.py:165-197) + dynamic_partition in one
  * pass: owner[i] = mode 0: (key & 0x7fffffff) % num_shards (CUDA-build branch)
  *                  mode 1: floor_mod(key, num_shards)       (CPU-build branch)

@@ -264,6 +264,56 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(size_t nseg_cap, const i64
   }
 }
 
+// ------------------------------------ sparse segment combiner -----------------------------------
+__global__ void seg64_bounds_kernel(size_t n, const i64* __restrict__ seg, int* start_end, size_t n_rows) {
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  i64 s = seg[p];
+  if (s < 0 || (size_t)s >= n_rows) return;
+  if (p == 0 || seg[p - 1] != s) start_end[s] = (int)p;
+  if (p == n - 1 || seg[p + 1] != s) start_end[n_rows + s] = (int)p + 1;
+}
+
+// one 16-lane group per output row; members in input order, 4 row loads in flight
+template <bool VEC4>
+__global__ __launch_bounds__(256) void seg_combine_kernel(size_t n_rows, int dim, const float* __restrict__ rows,
+                                                          const int* __restrict__ idx, const float* __restrict__ w,
+                                                          const int* __restrict__ start_end, int combiner,
+                                                          float* __restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  const size_t r = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  if (r >= n_rows) return;
+  const int b = start_end[r], e = start_end[n_rows + r];
+  float wsum = 0.f;
+  for (int p = b; p < e; ++p) { float x = w ? w[p] : 1.f; wsum += combiner == 2 ? x * x : x; }
+  float scale = 1.f;
+  if (combiner == 1) scale = wsum;
+  if (combiner == 2) scale = sqrtf(wsum);
+  float* o = out + r * (size_t)dim;
+  if (VEC4) {
+    for (int c = sub * 4; c < dim; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = b; p < e; ++p) {
+        float x = w ? w[p] : 1.f;
+        float4 v = *reinterpret_cast<const float4*>(rows + (size_t)idx[p] * dim + c);
+        acc.x += v.x * x; acc.y += v.y * x; acc.z += v.z * x; acc.w += v.w * x;
+      }
+      if (combiner != 0) {
+        if (wsum != 0.f) { acc.x /= scale; acc.y /= scale; acc.z /= scale; acc.w /= scale; }
+        else acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(o + c) = acc;
+    }
+  } else {
+    for (int c = sub; c < dim; c += 16) {
+      float acc = 0.f;
+      for (int p = b; p < e; ++p) acc += rows[(size_t)idx[p] * dim + c] * (w ? w[p] : 1.f);
+      if (combiner != 0) acc = (wsum != 0.f) ? acc / scale : 0.f;
+      o[c] = acc;
+    }
+  }
+}
+
 // ------------------------------------ partition ------------------------------------------------
 __device__ __forceinline__ int owner_of(i64 key, int num, int mode) {
   if (mode == 0) return (int)(key & 0x7fffffff) % num;
@@ -437,6 +487,28 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
   bool vec4 = (dim % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
   if (vec4) seg_sum_kernel<true><<<grid, 256, 0, s>>>(max_segments, (const i64*)d_num_segments, dim, in, member, seg_start, out);
   else seg_sum_kernel<false><<<grid, 256, 0, s>>>(max_segments, (const i64*)d_num_segments, dim, in, member, seg_start, out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_sparse_segment_combine(tfra_workspace_t* ws, size_t nnz, int dim, const float* rows, const int32_t* idx,
+                                const int64_t* seg, const float* weights, int combiner, size_t n_rows, float* out,
+                                tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !out || dim <= 0 || combiner < 0 || combiner > 2) return set_error(TFRA_ERR_INVALID, "segment_combine: bad argument");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) HIP_TRY(hipSetDevice(ws->device)); }
+  if (n_rows == 0) return TFRA_OK;
+  if (nnz && (!rows || !idx || !seg)) return set_error(TFRA_ERR_INVALID, "segment_combine: null buffer");
+  if (nnz >= (1ULL << 31) || n_rows >= (1ULL << 30)) return set_error(TFRA_ERR_INVALID, "segment_combine: too large");
+  int rc = ws->ensure(align_up(2 * n_rows * sizeof(int)), s);
+  if (rc) return rc;
+  int* se = (int*)ws->buf;
+  HIP_TRY(hipMemsetAsync(se, 0, 2 * n_rows * sizeof(int), s));  // empty rows: start = end = 0
+  if (nnz) seg64_bounds_kernel<<<(unsigned)((nnz + 255) / 256), 256, 0, s>>>(nnz, (const i64*)seg, se, n_rows);
+  dim3 grid((unsigned)((n_rows * 16 + 255) / 256));
+  bool vec4 = dim % 4 == 0 && (((uintptr_t)rows | (uintptr_t)out) % 16 == 0);
+  if (vec4) seg_combine_kernel<true><<<grid, 256, 0, s>>>(n_rows, dim, rows, idx, weights, se, combiner, out);
+  else seg_combine_kernel<false><<<grid, 256, 0, s>>>(n_rows, dim, rows, idx, weights, se, combiner, out);
   HIP_TRY(hipGetLastError());
   return TFRA_OK;
 }

@@ -113,3 +113,19 @@ def partition_by_owner(owner, num_shards):
   _capi.call("tfra_partition_by_owner", _workspace(dev), n, _ptr(owner), num_shards, _ptr(perm), _ptr(counts),
              _stream(dev))
   return perm, counts
+
+
+COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
+
+
+def sparse_segment_combine(rows, idx, seg, weights, combiner, n_rows):
+  """out[r] = combine over {i: seg[i]==r} of weights[i]*rows[idx[i]]  (seg ascending; SparseSegment*)."""
+  rows = rows.to(torch.float32).contiguous()
+  idx = idx.to(torch.int32).contiguous()
+  seg = seg.to(torch.int64).contiguous()
+  w = None if weights is None else weights.to(torch.float32).contiguous()
+  dim = rows.shape[-1]
+  out = torch.empty((n_rows, dim), dtype=torch.float32, device=rows.device)
+  _capi.call("tfra_sparse_segment_combine", _workspace(rows.device), idx.numel(), dim, _ptr(rows), _ptr(idx), _ptr(seg),
+             _ptr(w), COMBINERS[combiner], n_rows, _ptr(out), _stream(rows.device))
+  return out

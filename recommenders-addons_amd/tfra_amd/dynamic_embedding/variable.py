@@ -348,18 +348,10 @@ def embedding_lookup_sparse(params, sp_ids, sp_weights=None, partition_strategy=
   uniq, idx, _ = device_ops.unique(ids)
   r = embedding_lookup(params, uniq, max_norm=max_norm, return_trainable=return_trainable)
   ue, tw = r if return_trainable else (r, None)
-  emb = device_ops.gather_rows(ue, idx).to(torch.float32)
   n = int(seg.max().item()) + 1 if num_rows is None else num_rows
-  w = torch.ones(ids.numel(), dtype=torch.float32, device=emb.device) if sp_weights is None else torch.as_tensor(
-      sp_weights, dtype=torch.float32, device=emb.device)
-  out = torch.zeros((n, params.dim), dtype=torch.float32, device=emb.device)
-  out.index_add_(0, seg, emb * w[:, None])
-  if combiner != "sum":
-    ws = torch.zeros(n, dtype=torch.float32, device=emb.device)
-    ws.index_add_(0, seg, w if combiner == "mean" else w * w)
-    if combiner == "sqrtn":
-      ws = ws.sqrt()
-    out = torch.where(ws[:, None] > 0, out / ws[:, None], torch.zeros_like(out))
+  # gather + weights + segment combine fused in one kernel (reads the unique rows through idx)
+  out = device_ops.sparse_segment_combine(ue, idx, seg, sp_weights if sp_weights is None else torch.as_tensor(
+      sp_weights, dtype=torch.float32, device=ue.device), combiner, n)
   return (out, tw) if return_trainable else out
 
 
