@@ -176,11 +176,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*[NTH/64]*/, int*
 //   is finished by the group that holds its head ("owner"): later chunks leave their share in
 //   s_left and the owner adds those in chunk order after one barrier.
 //   row_of(p)  -> const float* of position p's row        out_of(p_head) -> float* for the run sum
-template <int NCH, int NG, class RowOf, class OutOf>
+template <int NCH, int NG, int BATCH, class RowOf, class OutOf>
 __device__ __forceinline__ void ordered_run_sums(int n, int span, int dim, const unsigned char* s_flag,
                                                  float (*s_left)[64 * NCH], unsigned char* s_cont,
                                                  unsigned char* s_hashead, RowOf row_of, OutOf out_of) {
-  constexpr int BATCH = Batch<NCH>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, g = threadIdx.x >> 4;
   const int gs = g * span, ge = min(gs + span, n);
   const bool has_any = gs < n;
@@ -276,7 +275,10 @@ struct DescStore {
 
 // ---------------------------------------------------------------------------------------------
 // kernel A.  src < rows_base -> gradient row `src` of the caller's buffer, else scratch row
-// (src-rows_base).  Sort key (20 bits) = group slot(11) | position in tile(9).
+// (src-rows_base).  No sort: a key's FIRST position in the tile is its deterministic group id, so
+// unique ranks and the order of the multi-member groups come from block scans in position order
+// (= tf.unique order); the members of a multi-member group are ranked by popcounts over a
+// 512-bit position mask.
 template <int NCH>
 __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* __restrict__ ids,
                                                           const float* __restrict__ grads, int dim, unsigned P,
@@ -284,15 +286,19 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
                                                           float* __restrict__ scratch_rows, unsigned* overflow, int stop) {
   constexpr int NG = NTA / 16;
   constexpr unsigned GCAP = 2048;            // group table: 4x the tile => short probe chains
+  constexpr int W = TILE / 32;               // words of a position bitmask
+  constexpr int GM = GCAP / W;               // multi-member groups ranked per round (mask area = s_owner)
   __shared__ i64 s_key[TILE];                // ids of the tile, input order
-  __shared__ unsigned s_sort[TILE];          // packed sort keys, sorted
-  __shared__ unsigned s_owner[GCAP];
-  __shared__ unsigned s_rep[GCAP];           // smallest input position of the group (deterministic id)
-  __shared__ unsigned short s_u[TILE];       // unique rank (within the tile) of each head position
+  __shared__ unsigned s_owner[GCAP];         // group table; afterwards the position masks
+  __shared__ unsigned s_rep[GCAP];           // smallest input position of the group; later (m << 16 | base)
+  __shared__ unsigned s_cnt[GCAP];           // members per group
+  __shared__ unsigned short s_list[TILE + 1];  // positions of the multi-member groups, run after run
+  __shared__ unsigned short s_u[TILE];       // unique rank (within the tile) of the run starting at a list position
   __shared__ unsigned char s_flag[TILE + 1];
   __shared__ float s_left[NG][64 * NCH];
   __shared__ unsigned char s_cont[NG], s_hashead[NG];
   __shared__ int s_scan[NTA / 64];
+  unsigned* const s_mask = s_owner;
   const size_t tile = blockIdx.x, base = tile * TILE;
   const int nvalid = (int)min((size_t)TILE, n - base);
   static_assert(TILE == NTA && TILE == 512, "one id per thread; 9 position bits");
@@ -300,53 +306,72 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
   const bool ok = p < nvalid;
   const i64 key = ok ? ids[base + p] : 0;
   s_key[p] = key;
-  for (unsigned b = threadIdx.x; b < GCAP; b += NTA) { s_owner[b] = 0; s_rep[b] = 0xffffffffu; }
+  for (unsigned b = threadIdx.x; b < GCAP; b += NTA) { s_owner[b] = 0; s_rep[b] = 0xffffffffu; s_cnt[b] = 0; }
   __syncthreads();
   if (stop == 1) return;  // (tuning ablation, TFRA_DBG_STOP_A)
-  // Which hash slot a key lands in depends on the race between colliding keys, so the slot must not
-  // influence the order: groups are ordered by their first input position instead (also = the
-  // order tf.unique would emit them in).  Sort key (18 bits) = first position(9) | position(9).
+  // Which hash slot a key lands in depends on the race between colliding keys, so the slot never
+  // influences an order: a group is identified by its first input position.
   unsigned slot = 0;
-  if (ok) { slot = lds_group_slot(s_key, s_owner, GCAP, p, fmix64((u64)key)); atomicMin(&s_rep[slot], (unsigned)p); }
+  if (ok) {
+    slot = lds_group_slot(s_key, s_owner, GCAP, p, fmix64((u64)key));
+    atomicMin(&s_rep[slot], (unsigned)p);
+    atomicAdd(&s_cnt[slot], 1u);
+  }
   __syncthreads();
-  unsigned x[1] = {0xffffffffu};
-  if (ok) x[0] = (s_rep[slot] << 9) | (unsigned)p;
-  reg_bitonic<NTA, 1>(x, s_sort, TILE);
-  __syncthreads();
-  s_sort[p] = x[0];
-  __syncthreads();
+  const bool head = ok && s_rep[slot] == (unsigned)p;
+  const unsigned cnt = ok ? s_cnt[slot] : 0;
+  const bool single = head && cnt == 1, mhead = head && cnt > 1;
+  int n_unique, n_multi, L;
+  const int u = block_excl_scan<NTA>(head ? 1 : 0, s_scan, &n_unique);      // tf.unique rank
+  const int m = block_excl_scan<NTA>(mhead ? 1 : 0, s_scan, &n_multi);      // multi groups in position order
+  const int lbase = block_excl_scan<NTA>(mhead ? (int)cnt : 0, s_scan, &L);  // their runs in the member list
   if (stop == 2) return;
-  // heads / singles / unique ranks: one sorted position per thread
-  const unsigned me = x[0];
-  const bool head = p < nvalid && (p == 0 || (s_sort[p - 1] >> 9) != (me >> 9));
-  int ntile_unique;
-  const int u = block_excl_scan<NTA>(head ? 1 : 0, s_scan, &ntile_unique);
-  {
-    bool single = head && (p + 1 >= nvalid || (s_sort[p + 1] >> 9) != (me >> 9));
-    s_flag[p] = (head ? F_HEAD : 0) | (single ? F_SINGLE : 0);
-    if (head) {
-      s_u[p] = (unsigned short)u;
-      const i64 k = s_key[me & 511];
-      const unsigned src = single ? (unsigned)(base + (me & 511)) : rows_base + (unsigned)(base + u);
-      const unsigned b = (unsigned)__umul64hi(fmix64((u64)k), (u64)P);
-      unsigned pos = atomicAdd(&ds.cursor[(size_t)b * CSTRIDE], 1u);
-      if (pos < CMAX) {
-        size_t d = (size_t)b * CMAX + pos;
-        ds.key[d] = k; ds.src[d] = src; ds.ord[d] = ((unsigned)tile << 9) | (unsigned)u;
-      } else {
-        unsigned o = atomicAdd(ds.ovf_count, 1u);
-        if (o < ds.ovf_cap) { ds.ovf_key[o] = k; ds.ovf_src[o] = src; ds.ovf_ord[o] = ((unsigned)tile << 9) | (unsigned)u; ds.ovf_bucket[o] = b; }
-        else atomicAdd(overflow, 1u);
-      }
+  // descriptor append: the returning atomic is issued now, its result is consumed after the ranking
+  // rounds below so that its latency overlaps them
+  unsigned desc_pos = 0, desc_bucket = 0;
+  if (head) {
+    desc_bucket = (unsigned)__umul64hi(fmix64((u64)key), (u64)P);
+    desc_pos = atomicAdd(&ds.cursor[(size_t)desc_bucket * CSTRIDE], 1u);
+  }
+  s_flag[p] = 0;
+  if (mhead) { s_rep[slot] = ((unsigned)m << 16) | (unsigned)lbase; s_u[lbase] = (unsigned short)u; }
+  __syncthreads();  // s_rep now maps slot -> (m, base) for multi groups; s_owner is free
+  for (int c0 = 0; c0 < n_multi; c0 += GM) {
+    for (unsigned q = threadIdx.x; q < GCAP; q += NTA) s_mask[q] = 0;
+    __syncthreads();
+    const int mm = (ok && cnt > 1) ? (int)(s_rep[slot] >> 16) - c0 : -1;
+    if (mm >= 0 && mm < GM) atomicOr(&s_mask[mm * W + (p >> 5)], 1u << (p & 31));
+    __syncthreads();
+    if (mm >= 0 && mm < GM) {
+      int rank = __popc(s_mask[mm * W + (p >> 5)] & ((1u << (p & 31)) - 1u));
+      for (int wds = 0; wds < (p >> 5); ++wds) rank += __popc(s_mask[mm * W + wds]);
+      int pos = (int)(s_rep[slot] & 0xffffu) + rank;  // ascending input position inside the run
+      s_list[pos] = (unsigned short)p;
+      if (rank == 0) s_flag[pos] = F_HEAD;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_flag[L] = F_HEAD;
+  __syncthreads();
+  if (head) {
+    const unsigned src = single ? (unsigned)(base + p) : rows_base + (unsigned)(base + u);
+    const unsigned ordv = ((unsigned)tile << 9) | (unsigned)u;
+    if (desc_pos < CMAX) {
+      size_t d = (size_t)desc_bucket * CMAX + desc_pos;
+      ds.key[d] = key; ds.src[d] = src; ds.ord[d] = ordv;
+    } else {
+      unsigned o = atomicAdd(ds.ovf_count, 1u);
+      if (o < ds.ovf_cap) { ds.ovf_key[o] = key; ds.ovf_src[o] = src; ds.ovf_ord[o] = ordv; ds.ovf_bucket[o] = desc_bucket; }
+      else atomicAdd(overflow, 1u);
     }
   }
-  if (threadIdx.x == 0) s_flag[TILE] = F_HEAD;
-  __syncthreads();
   if (stop == 3) return;
-  ordered_run_sums<NCH, NG>(
-      nvalid, TILE / NG, dim, s_flag, s_left, s_cont, s_hashead,
-      [&](int q) { return grads + (base + (s_sort[q] & 511)) * (size_t)dim; },
-      [&](int ph) { return scratch_rows + (base + (size_t)s_u[ph]) * (size_t)dim; });
+  if (L > 0) {
+    ordered_run_sums<NCH, NG, 2 * Batch<NCH>::v>(  // one block per CU: registers for 16 rows in flight are free
+        L, (L + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
+        [&](int q) { return grads + (base + s_list[q]) * (size_t)dim; },
+        [&](int ph) { return scratch_rows + (base + (size_t)s_u[ph]) * (size_t)dim; });
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -357,7 +382,8 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
 // A bucket with more than CMAX descriptors is processed in 2^k passes, pass q taking the keys with
 // (hash & (2^k-1)) == q, reading its region plus its share of the overflow list.
 template <int NCH>
-__global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, unsigned rows_base, unsigned sum_base,
+__global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned ntiles, int dim, unsigned rows_base,
+                                                          unsigned sum_base,
                                                           const float* __restrict__ grads, DescStore ds,
                                                           float* __restrict__ scratch_rows, i64* __restrict__ u_keys,
                                                           unsigned* __restrict__ u_src, i64* __restrict__ d_total,
@@ -367,9 +393,10 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, u
   static_assert(CMAX == 1024, "10 entry bits");
   __shared__ i64 e_key[CMAX];
   __shared__ unsigned e_src[CMAX];
-  __shared__ unsigned e_ord[CMAX];      // descriptor ids; reused as s_skey once the sort keys are built
-  __shared__ unsigned s_sort[CMAX];     // group slot, then (sorted) entry index of each position
-  unsigned* const s_skey = e_ord;       // sorted: (group id << 11) | tile
+  __shared__ unsigned e_ord[CMAX];      // descriptor ids (tile << 9 | rank in tile)
+  __shared__ unsigned s_sort[CMAX];     // group slot of each gathered entry
+  __shared__ unsigned short s_list[CMAX + 1];  // entries of the multi-part groups, run after run, tile order
+  __shared__ unsigned s_skey_m[256];    // (group id << 11 | slot) of the multi-part groups
   __shared__ unsigned s_owner[GCAP];
   __shared__ unsigned s_rep[GCAP];      // smallest descriptor id of the group (deterministic)
   __shared__ unsigned char s_flag[CMAX + 1];
@@ -436,78 +463,117 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, int dim, u
     }
     if (n == 0) continue;
     if (stop == 1) continue;  // (tuning ablation, TFRA_DBG_STOP_C)
-    int n2 = 2;
-    while (n2 < n) n2 <<= 1;
-    for (unsigned q = threadIdx.x; q < GCAP; q += NT) { s_owner[q] = 0; s_rep[q] = 0xffffffffu; }
+    // ---- group by key: slot (arrival-order dependent, never used for ordering), deterministic
+    //      group id = smallest descriptor id of the group, member count -------------------------
+    unsigned* const s_cnt = reinterpret_cast<unsigned*>(&s_left[0][0]);  // [GCAP] until the run sums
+    unsigned* const s_mask = s_owner;                                    // [GCAP] once grouping is done
+    for (unsigned q = threadIdx.x; q < GCAP; q += NT) { s_owner[q] = 0; s_rep[q] = 0xffffffffu; s_cnt[q] = 0; }
     __syncthreads();
-    // group by key; a group's deterministic id = its smallest descriptor id (tile<<9|rank, 20 bits);
-    // the hash slot itself depends on arrival order and must not influence the order
     for (int q = threadIdx.x; q < n; q += NT) {
       unsigned slot = lds_group_slot(e_key, s_owner, GCAP, q, fmix64((u64)e_key[q]));
       atomicMin(&s_rep[slot], e_ord[q]);
+      atomicAdd(&s_cnt[slot], 1u);
       s_sort[q] = slot;
     }
     __syncthreads();
-    // sort key (31 bits) = group id(20) | tile(11), unique per entry; payload = entry index
-    auto key_of = [&](int q) { return q < n ? ((s_rep[s_sort[q]] << 11) | (e_ord[q] >> 9)) : 0xffffffffu; };
-    if (n2 <= NT) {
-      unsigned x[1] = {key_of(threadIdx.x)}, v[1] = {(unsigned)threadIdx.x};
-      __syncthreads();
-      reg_bitonic_kv<NT, 1>(x, v, s_skey, s_sort, n2);
-      __syncthreads();
-      s_skey[threadIdx.x] = x[0]; s_sort[threadIdx.x] = v[0];
-    } else if (n2 == 2 * NT) {
-      unsigned x[2], v[2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) { x[r] = key_of(threadIdx.x * 2 + r); v[r] = threadIdx.x * 2 + r; }
-      __syncthreads();
-      reg_bitonic_kv<NT, 2>(x, v, s_skey, s_sort, n2);
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 2; ++r) { s_skey[threadIdx.x * 2 + r] = x[r]; s_sort[threadIdx.x * 2 + r] = v[r]; }
-    } else {
-      unsigned x[4], v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { x[r] = key_of(threadIdx.x * 4 + r); v[r] = threadIdx.x * 4 + r; }
-      __syncthreads();
-      reg_bitonic_kv<NT, 4>(x, v, s_skey, s_sort, n2);
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s_skey[threadIdx.x * 4 + r] = x[r]; s_sort[threadIdx.x * 4 + r] = v[r]; }
-    }
-    __syncthreads();
-    if (stop == 2) continue;
-    // flags + unique ranks; pass-through runs (exactly one part) need no row traffic
-    int ccarry = 0;
+    // ---- the unique keys of this pass: singles first (gather order), then the multi-part groups
+    //      in ascending group id.  Which output slot a key gets does not affect any sum. ---------
+    const int W = (int)((ntiles + 31) >> 5);     // words of a tile bitmask
+    const int GM = min(128, (int)GCAP / W);      // multi-part groups that fit the mask area
+    int n_single = 0, n_multi = 0;
     for (int pb = 0; pb < n; pb += NT) {
       int q = pb + threadIdx.x;
-      unsigned me = q < n ? s_sort[q] : 0, mk = q < n ? s_skey[q] : 0;
-      bool hd = q < n && (q == 0 || (s_skey[q - 1] >> 11) != (mk >> 11));
-      bool single = hd && (q + 1 >= n || (s_skey[q + 1] >> 11) != (mk >> 11));
-      int tot;
-      int ex = block_excl_scan<NT>(hd ? 1 : 0, s_scan, &tot);
-      if (q < n) {
-        s_flag[q] = (hd ? F_HEAD : 0) | (single ? F_SINGLE : 0);
-        if (hd) {
-          long long o = off + out_used + ccarry + ex;
-          u_keys[o] = e_key[me];
-          u_src[o] = single ? e_src[me] : sum_base + (unsigned)o;
-          s_rank[q] = (unsigned short)(ccarry + ex);
-        }
+      unsigned slot = q < n ? s_sort[q] : 0;
+      bool hd = q < n && e_ord[q] == s_rep[slot];
+      bool single = hd && s_cnt[slot] == 1;
+      bool mhead = hd && !single;
+      int ts, tm;
+      int es = block_excl_scan<NT>(single ? 1 : 0, s_scan, &ts);
+      int em = block_excl_scan<NT>(mhead ? 1 : 0, s_scan, &tm);
+      if (single) {
+        long long o = off + out_used + n_single + es;
+        u_keys[o] = e_key[q];
+        u_src[o] = e_src[q];
       }
-      ccarry += tot;
+      if (mhead && n_multi + em < NT) s_skey_m[n_multi + em] = (s_rep[slot] << 11) | slot;  // (id, slot) to be ordered
+      n_single += ts;
+      n_multi += tm;
     }
-    if (threadIdx.x == 0) s_flag[n] = F_HEAD;
     __syncthreads();
-    const long long obase = off + out_used;
-    if (stop == 3) { out_used += ccarry; continue; }
-    ordered_run_sums<NCH, NG>(
-        n, (n + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
-        [&](int q) {
-          unsigned src = e_src[s_sort[q]];
-          return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
-        },
-        [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(obase + s_rank[ph])) * dim; });
+    if (n_multi > NT) {  // more multi-part keys than one per thread: split the bucket further by key hash
+      if (npass < 64) { npass <<= 1; pass = (unsigned)-1; out_used = 0; }
+      else if (threadIdx.x == 0) atomicAdd(overflow, 1u);
+      continue;
+    }
+    int L = 0;  // total members of multi-part groups
+    if (n_multi > 0) {
+      // order the (few) multi groups by id, give each its run [base, base+cnt) and mask row m
+      int m2 = 2;
+      while (m2 < n_multi) m2 <<= 1;
+      unsigned x[1] = {threadIdx.x < n_multi ? s_skey_m[threadIdx.x] : 0xffffffffu};
+      __syncthreads();
+      reg_bitonic<NT, 1>(x, s_skey_m, m2);
+      __syncthreads();
+      const bool live = threadIdx.x < n_multi;
+      const unsigned slot_m = x[0] & 2047u;
+      int tot;
+      int base = block_excl_scan<NT>(live ? (int)s_cnt[slot_m] : 0, s_scan, &tot);
+      L = tot;
+      if (live) {
+        s_rep[slot_m] = ((unsigned)threadIdx.x << 16) | (unsigned)base;  // slot -> (m, base)
+        long long o = off + out_used + n_single + threadIdx.x;
+        u_keys[o] = e_key[s_owner[slot_m] - 1];
+        u_src[o] = sum_base + (unsigned)o;
+        s_rank[base] = (unsigned short)threadIdx.x;
+      }
+      for (int q = threadIdx.x; q <= L; q += NT) s_flag[q] = 0;
+      __syncthreads();
+      // rank of a member inside its run = number of members from smaller tiles: a tile bitmask per
+      // group (a key has at most one part per tile) + popcounts; GM groups at a time
+      for (int c0 = 0; c0 < n_multi; c0 += GM) {
+        for (int q = threadIdx.x; q < GM * W; q += NT) s_mask[q] = 0;
+        __syncthreads();
+        for (int q = threadIdx.x; q < n; q += NT) {
+          unsigned slot = s_sort[q];
+          if (s_cnt[slot] >= 2) {
+            int m = (int)(s_rep[slot] >> 16) - c0;
+            unsigned tile = e_ord[q] >> 9;
+            if (m >= 0 && m < GM) atomicOr(&s_mask[m * W + (tile >> 5)], 1u << (tile & 31));
+          }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < n; q += NT) {
+          unsigned slot = s_sort[q];
+          if (s_cnt[slot] >= 2) {
+            unsigned mb = s_rep[slot];
+            int m = (int)(mb >> 16) - c0;
+            if (m >= 0 && m < GM) {
+              unsigned tile = e_ord[q] >> 9;
+              int rank = __popc(s_mask[m * W + (tile >> 5)] & ((1u << (tile & 31)) - 1u));
+              for (unsigned wds = 0; wds < (tile >> 5); ++wds) rank += __popc(s_mask[m * W + wds]);
+              int pos = (int)(mb & 0xffffu) + rank;   // tile order inside the run
+              s_list[pos] = (unsigned short)q;
+              if (rank == 0) s_flag[pos] = F_HEAD;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) s_flag[L] = F_HEAD;
+      __syncthreads();
+    }
+    const long long obase = off + out_used + n_single;
+    const int ccarry = n_single + n_multi;
+    if (stop == 2 || stop == 3) { out_used += ccarry; continue; }
+    if (L > 0) {
+      ordered_run_sums<NCH, NG, Batch<NCH>::v>(
+          L, (L + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
+          [&](int q) {
+            unsigned src = e_src[s_list[q]];
+            return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
+          },
+          [&](int ph) { return scratch_rows + (size_t)(sum_base - rows_base + (unsigned)(obase + s_rank[ph])) * dim; });
+    }
     out_used += ccarry;
     __syncthreads();
   }
@@ -586,10 +652,10 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
     default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   // the apply kernel runs after every merge block has read the cursors: it zeroes them for the next
