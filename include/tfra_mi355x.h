@@ -245,6 +245,13 @@ int tfra_partition_by_owner(tfra_workspace_t* ws, size_t n, const int32_t* owner
 int tfra_scatter_rows(size_t n, size_t row_bytes, const void* in, const int32_t* perm, void* out,
                       tfra_stream_t stream);
 
+/* Size restriction (PY/restrict_policies.py:205-230,332-358 do export -> top_k(-status)
+ * -> gather -> remove in Python): keys_out[0..k) = the k keys with the LOWEST status (timestamp or
+ * frequency), ties resolved in input order (stable).  status_dtype TFRA_I32 or TFRA_I64; k <= n.
+ * Feed keys_out to tfra_table_erase of the parameter table and of the status table.            */
+int tfra_select_lowest(tfra_workspace_t* ws, size_t n, const int64_t* keys, const void* status,
+                       int status_dtype, size_t k, int64_t* keys_out, tfra_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

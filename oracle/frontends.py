@@ -116,3 +116,47 @@ def alltoall_lookup_model(rank_tables, ids_per_rank, defaults, partition_fn=defa
         rows[sel] = rank_tables[owner].find(ids[sel], defaults)
     out.append(rows)
   return out
+
+
+# ---- size restriction (PY/restrict_policies.py) ---------------------------------------------------
+def restrict_select(keys, status, num_reserved):
+  """Keys a shard removes: `top_k(-status, n - reserved)` then gather (PY/restrict_policies.py:213-223,
+  341-351).  top_k(sorted=False) leaves the choice among EQUAL statuses unspecified; this restatement
+  (and the HIP path) resolves it by export order (stable)."""
+  keys = np.asarray(keys, dtype=np.int64).reshape(-1)
+  status = np.asarray(status).reshape(-1)
+  k = max(keys.size - int(num_reserved), 0)
+  order = np.argsort(status.astype(np.int64), kind="stable")
+  return keys[order[:k]]
+
+
+class RestrictPolicyOracle:
+  """Timestamp / Frequency policies over plain dicts (PY/restrict_policies.py:118-361): `apply_update`
+  and `apply_restriction(num_reserved, trigger)` for ONE shard; `table` is any dict-like key -> row."""
+
+  def __init__(self, kind):
+    assert kind in ("timestamp", "frequency")
+    self.kind = kind
+    self.status = {}
+
+  def apply_update(self, ids, now=None):
+    ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+    if self.kind == "timestamp":
+      for k in ids:
+        self.status[int(k)] = int(now)                # :168-177 every id gets the same fresh stamp
+    else:
+      old = {int(k): self.status.get(int(k), 0) for k in ids}   # :292-297 lookup (default 0) for the batch
+      for k in ids:
+        self.status[int(k)] = old[int(k)] + 1         # +1 once per call, duplicates included
+
+  def apply_restriction(self, table, num_reserved, trigger=None):
+    trigger = num_reserved if trigger is None else trigger
+    if len(table) <= trigger:                        # :202 cond(size > trigger)
+      return []
+    ks = np.fromiter(self.status.keys(), dtype=np.int64, count=len(self.status))
+    st = np.fromiter(self.status.values(), dtype=np.int64, count=len(self.status))
+    gone = restrict_select(ks, st, num_reserved)
+    for k in gone:
+      table.pop(int(k), None)
+      self.status.pop(int(k), None)
+    return [int(k) for k in gone]

@@ -221,6 +221,11 @@ __global__ void iota_kernel(int* p, size_t n) {
   if (i < n) p[i] = (int)i;
 }
 
+__global__ void widen_i32_kernel(const int* __restrict__ in, i64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
 // seg_sorted ascending (stable => member indices ascending inside a segment).  One 16-lane group
 // per segment walks its members in index order: out[seg,:] = sum_i in[i,:], ONE fp32 add per
 // element per member, i.e. exactly the order of a sequential CPU unsorted_segment_sum
@@ -552,6 +557,36 @@ int tfra_partition_by_owner(tfra_workspace_t* ws, size_t n, const int32_t* owner
   part_scatter_kernel<<<(unsigned)tiles, 256, 4 * num_shards * sizeof(int), s>>>(n, nullptr, owner, num_shards, 0, hist, nullptr,
                                                                                   perm_out);
   HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_select_lowest(tfra_workspace_t* ws, size_t n, const int64_t* keys, const void* status, int status_dtype,
+                       size_t k, int64_t* keys_out, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || (status_dtype != TFRA_I32 && status_dtype != TFRA_I64) || k > n)
+    return set_error(TFRA_ERR_INVALID, "select_lowest: bad argument (status int32/int64, k <= n)");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) HIP_TRY(hipSetDevice(ws->device)); }
+  if (k == 0) return TFRA_OK;
+  if (!keys || !status || !keys_out) return set_error(TFRA_ERR_INVALID, "select_lowest: null buffer");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "select_lowest: too many keys");
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, (const i64*)nullptr, (i64*)nullptr, (const i64*)nullptr,
+                                    (i64*)nullptr, n, 0u, 64u, s));
+  int rc = ws->ensure(3 * align_up(n * 8) + align_up(tmp_bytes), s);
+  if (rc) return rc;
+  Carver c{(unsigned char*)ws->buf};
+  i64* wide = c.take<i64>(n);
+  i64* st_sorted = c.take<i64>(n);
+  i64* k_sorted = c.take<i64>(n);
+  void* tmp = c.take<unsigned char>(tmp_bytes);
+  const i64* st = (const i64*)status;
+  if (status_dtype == TFRA_I32) {
+    widen_i32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const int*)status, wide, n);
+    st = wide;
+  }
+  // stable LSD radix sort, ascending, signed: equal statuses keep their input order
+  HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, st, st_sorted, (const i64*)keys, k_sorted, n, 0u, 64u, s));
+  HIP_TRY(hipMemcpyAsync(keys_out, k_sorted, k * sizeof(i64), hipMemcpyDeviceToDevice, s));
   return TFRA_OK;
 }
 

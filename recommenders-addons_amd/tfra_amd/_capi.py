@@ -87,6 +87,7 @@ _SIGS = {
     "tfra_partition": [_P, _SZ, _P, _I, _I, _P, _P, _P, _P],
     "tfra_partition_by_owner": [_P, _SZ, _P, _I, _P, _P, _P],
     "tfra_scatter_rows": [_SZ, _SZ, _P, _P, _P, _P],
+    "tfra_select_lowest": [_P, _SZ, _P, _P, _I, _SZ, _P, _P],
 }
 
 _lib = None

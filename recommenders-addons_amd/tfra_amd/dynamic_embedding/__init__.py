@@ -3,6 +3,7 @@
 from . import device_ops
 from . import optimizer as optimizers
 from .optimizer import CapturedTrainStep, DynamicEmbeddingOptimizer
+from .restrict_policies import FrequencyRestrictPolicy, RestrictPolicy, TimestampRestrictPolicy
 from .table_ops import (CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
                         KHkvHashTableMaxCapacity, KHkvHashTableMaxHbmForValuesByBytes)
 from .variable import (CuckooHashTableConfig, CuckooHashTableCreator, HkvHashTableConfig, HkvHashTableCreator,

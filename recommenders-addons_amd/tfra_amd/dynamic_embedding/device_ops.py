@@ -115,6 +115,21 @@ def partition_by_owner(owner, num_shards):
   return perm, counts
 
 
+def select_lowest(keys, status, k):
+  """The k keys with the lowest status (int32/int64), ties in input order (restrict policies)."""
+  keys = keys.reshape(-1).to(torch.int64).contiguous()
+  status = status.reshape(-1).contiguous()
+  if status.dtype not in (torch.int32, torch.int64):
+    raise TypeError("status must be int32 or int64")
+  n = keys.numel()
+  if status.numel() != n or k > n:
+    raise ValueError("select_lowest: need one status per key and k <= n")
+  out = torch.empty(k, dtype=torch.int64, device=keys.device)
+  _capi.call("tfra_select_lowest", _workspace(keys.device), n, _ptr(keys), _ptr(status),
+             4 if status.dtype == torch.int32 else 5, k, _ptr(out), _stream(keys.device))
+  return out
+
+
 COMBINERS = {"sum": 0, "mean": 1, "sqrtn": 2}
 
 

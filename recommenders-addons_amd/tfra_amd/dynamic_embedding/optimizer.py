@@ -169,6 +169,8 @@ class DynamicEmbeddingOptimizer:
     n = ids.numel()
     if n == 0:
       return
+    if getattr(var, "restrict_policy", None) is not None:  # PY/embedding_weights.py:441-442
+      var.restrict_policy.apply_update(ids)
     if (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and
         n <= (1 << 20) and not self.exact_order):
       # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic

@@ -112,6 +112,24 @@ class Variable:
                                  name=self._make_name(idx), checkpoint=checkpoint, init_size=self.init_size, device=dev,
                                  dim=self.dim, aux_fields=aux_fields, aux_init=aux_init))
     self._primary = _as_device(self.devices[0])
+    # PY/dynamic_embedding_variable.py:604-611: the policy CLASS is passed, instantiated on this variable
+    if restrict_policy is not None:
+      from .restrict_policies import RestrictPolicy
+      if not (isinstance(restrict_policy, type) and issubclass(restrict_policy, RestrictPolicy)):
+        raise TypeError("restrict_policy must be subclass of RestrictPolicy.")
+      self._restrict_policy = restrict_policy(self)
+    else:
+      self._restrict_policy = None
+
+  @property
+  def restrict_policy(self):
+    return self._restrict_policy
+
+  def restrict(self, num_reserved, **kwargs):
+    """PY/dynamic_embedding_variable.py:857-874: no-op without a policy."""
+    if self._restrict_policy is not None:
+      return self._restrict_policy.apply_restriction(num_reserved, **kwargs)
+    return None
 
   def _make_name(self, table_idx):
     """PY/dynamic_embedding_variable.py:768-770"""
@@ -311,6 +329,8 @@ class TrainableWrapper:
       self.params.accum(self.ids, old, new_values, self.exists)
     else:
       self.params.upsert(self.ids, new_values)
+    if self.params.restrict_policy is not None:  # PY/embedding_weights.py:441-442
+      self.params.restrict_policy.apply_update(self.ids)
     self._values = new_values
 
 

@@ -83,3 +83,41 @@ def test_port_replays_golden_vectors_from_reference_engine():
   assert len(files) >= 5
   for f in files:
     replay(f, lambda dim, dtype: oracle.CpuTable(dim, dtype, kind="port"))
+
+
+# ---- size restriction restatement (T/restrict_policies_test.py) -------------------------------------
+def test_restrict_oracle_timestamp_kat():
+  """T/restrict_policies_test.py:166-229: ids 0..5 then 4..8 a second later; keep 5 -> 4..8 survive."""
+  from oracle import frontends as ofe
+  orc, table = ofe.RestrictPolicyOracle("timestamp"), {}
+  for now, ids in ((100, np.arange(6)), (101, np.arange(4, 9))):
+    orc.apply_update(ids, now=now)
+    table.update({int(k): 1 for k in ids})
+  assert orc.apply_restriction(table, 5, trigger=100) == [] and len(table) == 9
+  orc.apply_restriction(table, 5, trigger=5)
+  assert sorted(table) == [4, 5, 6, 7, 8] and sorted(orc.status) == [4, 5, 6, 7, 8]
+
+
+def test_restrict_oracle_frequency_kat():
+  """T/restrict_policies_test.py:232-327: counts after 0..2 then 1..3 are [1,2,2,1]; keep 2 of 0..8."""
+  from oracle import frontends as ofe
+  orc = ofe.RestrictPolicyOracle("frequency")
+  orc.apply_update(np.arange(3)); orc.apply_update(np.arange(1, 4))
+  assert [orc.status[k] for k in range(4)] == [1, 2, 2, 1]
+  orc.apply_update(np.array([3, 3, 3]))
+  assert orc.status[3] == 2                       # lookup/+1/insert: a repeated id counts once per call
+  orc, table = ofe.RestrictPolicyOracle("frequency"), {}
+  for ids in (np.arange(6), np.arange(4, 9)):
+    orc.apply_update(ids)
+    table.update({int(k): 1 for k in ids})
+  orc.apply_restriction(table, 2, trigger=2)
+  assert sorted(table) == [4, 5]
+
+
+def test_restrict_select_is_stable_and_signed():
+  from oracle import frontends as ofe
+  keys = np.array([10, 11, 12, 13, 14], dtype=np.int64)
+  st = np.array([3, -1, 3, -1, 0], dtype=np.int32)
+  assert ofe.restrict_select(keys, st, 2).tolist() == [11, 13, 14]
+  assert ofe.restrict_select(keys, st, 9).tolist() == []
+  assert ofe.restrict_select(keys, st, 0).tolist() == [11, 13, 14, 10, 12]
