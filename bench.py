@@ -153,7 +153,7 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if args.gpus > 1 or world > 1:
+  if args.gpus > 1 or world > 1 or os.environ.get("TFRA_BENCH_FORCE_A2A") == "1":
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = os.environ.get("TFRA_BENCH_BACKEND", "nccl")  # "gloo": smoke-test the N>1 path on ONE GPU
@@ -174,7 +174,11 @@ def main():
   deo = de.DynamicEmbeddingOptimizer(opt)
   var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05),
                     **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
-  emb = AllToAllEmbedding(var, partition_mode=0) if world > 1 else None
+  # TFRA_BENCH_FORCE_A2A=1 (with WORLD_SIZE=1 under torch.distributed.run): keep the whole N>1 route,
+  # collectives included, on one rank — measures the routing overhead a multi-GPU step adds
+  force_a2a = os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist.is_initialized()
+  emb = (AllToAllEmbedding(var, partition_mode=0, dedup=os.environ.get("TFRA_BENCH_DEDUP", "1") == "1",
+                           force_collectives=force_a2a) if (world > 1 or force_a2a) else None)
   table = var.tables[0]
 
   # ---- pre-fill: every key this rank owns (ranks 1..n_total, owner = default_partition_fn) ------
@@ -346,7 +350,7 @@ def main():
     if not args.no_cpu_baseline:
       res["cpu_baseline"] = cpu_baseline(B)
     print(json.dumps(res))
-  if world > 1:
+  if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
 

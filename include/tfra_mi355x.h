@@ -215,6 +215,16 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
                      const int64_t* d_num_segments, size_t max_segments, float* out,
                      tfra_stream_t stream);
 
+/* tf.unique + unsorted_segment_sum in one call, parallel per key and order-fixed (the reduction half of
+ * tfra_table_apply_sparse: PY/dynamic_embedding_optimizer.py:177-190): keys_out[0..*d_count) = the
+ * distinct ids (a deterministic but unspecified order), rows_out[i,:] = sum of the rows of `in` whose
+ * id is keys_out[i] (fixed summation tree: bit-reproducible, not the sequential order).  keys_out [n],
+ * rows_out [n,dim]; fp32, dim % 4 == 0, dim <= 256, n <= 2^20.  *d_count = -1 if an internal limit
+ * overflowed (more than 1024 partial sums of one key; cannot happen for n <= 2^19).  Unlike
+ * tfra_segment_sum the cost does not grow with the multiplicity of the hottest id.            */
+int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int dim, const float* in,
+                       int64_t* keys_out, float* rows_out, int64_t* d_count, tfra_stream_t stream);
+
 /* out[i,:] = rows[idx[i],:] (tf.gather after unique). row_bytes = dim*sizeof(V). */
 int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out,
                      tfra_stream_t stream);
@@ -232,9 +242,11 @@ int tfra_sparse_segment_combine(tfra_workspace_t* ws, size_t nnz, int dim, const
  *                  mode 1: floor_mod(key, num_shards)       (CPU-build branch)
  *                  mode 2: fmix64(key) % num_shards         (opt-in, Zipf-balanced)
  * Produces owner-major keys_out, perm_out (original index of each output element, i.e. the
- * dynamic_partition of range(n)) and d_counts[num_shards] (device int64).                 */
-int tfra_partition(tfra_workspace_t* ws, size_t n, const int64_t* keys, int num_shards, int mode,
-                   int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream);
+ * dynamic_partition of range(n)) and d_counts[num_shards] (device int64).
+ * d_n: optional DEVICE int64 scalar; when non-NULL only the first min(n, *d_n) keys are partitioned
+ * (chains after tfra_unique without reading the unique count on the host).                  */
+int tfra_partition(tfra_workspace_t* ws, size_t n, const int64_t* d_n, const int64_t* keys, int num_shards,
+                   int mode, int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream);
 
 /* Same, for a caller-computed owner[i] in [0,num_shards) (custom `partitioner=` functions,
  * PY/dynamic_embedding_variable.py:484-500): only perm_out and d_counts are produced. */

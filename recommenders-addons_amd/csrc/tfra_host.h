@@ -72,3 +72,22 @@ struct Table {
 };
 
 }  // namespace tfra
+
+// Scratch of the front-end ops (tfra_workspace_create): one growing device buffer per caller stream.
+struct tfra_workspace {
+  int device = 0;
+  void* buf = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need, hipStream_t s) {
+    if (need <= bytes) return TFRA_OK;
+    if (buf) {
+      if (hipStreamSynchronize(s) != hipSuccess || hipFree(buf) != hipSuccess) return tfra::set_error(TFRA_ERR_HIP, "workspace: free failed");
+      buf = nullptr; bytes = 0;
+    }
+    size_t want = need > ((size_t)1 << 20) ? need : ((size_t)1 << 20);
+    hipError_t e = hipMalloc(&buf, want);
+    if (e != hipSuccess) { buf = nullptr; return tfra::set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "workspace: hipMalloc failed"); }
+    bytes = want;
+    return TFRA_OK;
+  }
+};

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
                                                           const float* __restrict__ grads, DescStore ds,
                                                           float* __restrict__ scratch_rows, i64* __restrict__ u_keys,
                                                           unsigned* __restrict__ u_src, i64* __restrict__ d_total,
-                                                          unsigned* overflow, int stop) {
+                                                          unsigned* overflow, int stop, uint2* __restrict__ bucket_out) {
   constexpr int NG = NT / 16;
   constexpr unsigned GCAP = CMAX;   // group table as large as the pass (LDS budget: 4 blocks per CU)
   static_assert(CMAX == 1024, "10 entry bits");
@@ -420,7 +420,10 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
   const unsigned n_ovf = n_b > CMAX ? min(*ds.ovf_count, ds.ovf_cap) : 0u;
   __syncthreads();
   if (threadIdx.x == 0 && b == P - 1) *d_total = off + n_b;
-  if (n_b == 0) return;
+  if (n_b == 0) {
+    if (bucket_out && threadIdx.x == 0) bucket_out[b] = make_uint2((unsigned)off, 0u);
+    return;
+  }
   unsigned npass = 1;
   if (n_b > CMAX) while ((unsigned)n_b > (unsigned)(CMAX / 2) * npass && npass < 64) npass <<= 1;
   const int n_reg = min(n_b, CMAX);
@@ -578,6 +581,49 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     __syncthreads();
   }
   for (int i = out_used + threadIdx.x; i < n_b; i += NT) u_src[off + i] = SKIP;
+  if (bucket_out && threadIdx.x == 0) bucket_out[b] = make_uint2((unsigned)off, (unsigned)out_used);
+}
+
+// tfra_reduce_by_key epilogue: bucket b's unique keys (u_keys/u_src[off_b .. off_b+cnt_b)) go to the
+// dense output at sum(cnt of the buckets before b); one 16-lane group per key copies the summed row.
+__global__ __launch_bounds__(256) void compact_gather_kernel(unsigned P, int dim, unsigned rows_base,
+                                                             const float* __restrict__ grads,
+                                                             const float* __restrict__ scratch_rows,
+                                                             const i64* __restrict__ u_keys,
+                                                             const unsigned* __restrict__ u_src,
+                                                             const uint2* __restrict__ bucket_out,
+                                                             const unsigned* __restrict__ err, i64* __restrict__ keys_out,
+                                                             float* __restrict__ rows_out, i64* __restrict__ d_count) {
+  __shared__ unsigned s_red[4];
+  const unsigned b = blockIdx.x;
+  unsigned acc = 0;
+  for (unsigned i = threadIdx.x; i < b; i += 256) acc += bucket_out[i].y;
+  for (int o2 = 32; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const unsigned before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const uint2 me = bucket_out[b];
+  if (b == P - 1 && threadIdx.x == 0) *d_count = *err ? (i64)-1 : (i64)(before + me.y);
+  // Inside the bucket the merge kernel leaves single-part keys in descriptor-arrival order (atomic
+  // cursors: differs from run to run).  Here the bucket's keys are written in ASCENDING KEY order, so
+  // the output order is a function of the id set alone: rank = number of smaller keys in the bucket.
+  constexpr unsigned LCAP = 2048;
+  __shared__ i64 s_k[LCAP];
+  const bool in_lds = me.y <= LCAP;
+  if (in_lds) for (unsigned i = threadIdx.x; i < me.y; i += 256) s_k[i] = u_keys[me.x + i];
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  for (unsigned i = threadIdx.x >> 4; i < me.y; i += 16) {
+    const i64 key = in_lds ? s_k[i] : u_keys[me.x + i];
+    unsigned r = 0;
+    for (unsigned j = sub; j < me.y; j += 16) r += (in_lds ? s_k[j] : u_keys[me.x + j]) < key;
+    for (int o2 = 8; o2 > 0; o2 >>= 1) r += __shfl_xor(r, o2);
+    const unsigned src = u_src[me.x + i];
+    const float* row = src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
+    float* out = rows_out + (size_t)(before + r) * dim;
+    for (int c = sub * 4; c < dim; c += 64) *reinterpret_cast<float4*>(out + c) = *reinterpret_cast<const float4*>(row + c);
+    if (sub == 0) keys_out[before + r] = key;
+  }
 }
 
 }  // namespace
@@ -652,14 +698,83 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
     default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c); break;
+    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
+    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
+    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
+    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   // the apply kernel runs after every merge block has read the cursors: it zeroes them for the next
   // call (no host-side state, so the three launches can be captured into a HIP graph and replayed)
   return launch_apply_indirect(t, s, p, npad, u_keys, u_src, grads, rows, rows_base, param_default_row, d_total, cursors,
                                P + 1, CSTRIDE);
+}
+
+// unique + unsorted_segment_sum in one call = kernels A and C above + a compaction.
+extern "C" int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int dim, const float* grads,
+                                  int64_t* keys_out, float* rows_out, int64_t* d_count, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_count) return set_error(TFRA_ERR_INVALID, "reduce_by_key: null argument");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) { if (hipSetDevice(ws->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: hipSetDevice"); } }
+  if (n == 0) {
+    if (hipMemsetAsync(d_count, 0, sizeof(int64_t), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: memset");
+    return TFRA_OK;
+  }
+  if (!ids || !grads || !keys_out || !rows_out) return set_error(TFRA_ERR_INVALID, "reduce_by_key: null buffer");
+  if (dim <= 0 || dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)rows_out) & 15))
+    return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
+                                           "(use tfra_unique + tfra_segment_sum otherwise)");
+  if (n > (1ULL << 20)) return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: at most 2^20 ids per call");
+  const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
+  unsigned P = 64;
+  while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t reg = (size_t)P * CMAX;
+  // cursors[P] | overflow count | error count (one 128-B line each) | bucket_out[P] | descriptor regions |
+  // overflow list | u_keys/u_src | d_total | rows [2*npad][dim]
+  const size_t head = al((size_t)(P + 2) * CSTRIDE * 4);
+  size_t bytes = head + al((size_t)P * 8) + al(reg * 8) + 2 * al(reg * 4) + al(npad * 8) + 3 * al(npad * 4) + al(npad * 8) +
+                 al(npad * 4) + 256 + 2 * al(npad * (size_t)dim * 4);
+  int rc = ws->ensure(bytes, s);
+  if (rc) return rc;
+  unsigned char* w = (unsigned char*)ws->buf;
+  unsigned* cursors = (unsigned*)w; w += head;
+  if (hipMemsetAsync(cursors, 0, head, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: memset");
+  uint2* bucket_out = (uint2*)w; w += al((size_t)P * 8);
+  DescStore ds;
+  ds.key = (i64*)w; w += al(reg * 8);
+  ds.src = (unsigned*)w; w += al(reg * 4);
+  ds.ord = (unsigned*)w; w += al(reg * 4);
+  ds.ovf_key = (i64*)w; w += al(npad * 8);
+  ds.ovf_src = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_ord = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_bucket = (unsigned*)w; w += al(npad * 4);
+  i64* u_keys = (i64*)w; w += al(npad * 8);
+  unsigned* u_src = (unsigned*)w; w += al(npad * 4);
+  i64* d_total = (i64*)w; w += 256;
+  float* rows = (float*)w;
+  ds.cursor = cursors;
+  ds.ovf_count = cursors + (size_t)P * CSTRIDE;
+  ds.ovf_cap = (unsigned)npad;
+  unsigned* err = cursors + (size_t)(P + 1) * CSTRIDE;
+  const unsigned rows_base = (unsigned)npad, sum_base = (unsigned)(2 * npad);
+  const int nch = (dim + 63) / 64;
+  const i64* k = (const i64*)ids;
+  dim3 ga((unsigned)ntiles), gc(P);
+  switch (nch) {
+    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
+    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
+    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
+    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
+  }
+  switch (nch) {
+    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
+    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
+    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
+    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
+  }
+  compact_gather_kernel<<<gc, 256, 0, s>>>(P, dim, rows_base, grads, rows, u_keys, u_src, bucket_out, err, (i64*)keys_out, rows_out,
+                                           (i64*)d_count);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: launch failed");
+  return TFRA_OK;
 }

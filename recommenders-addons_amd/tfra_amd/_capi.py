@@ -84,9 +84,10 @@ _SIGS = {
     "tfra_segment_sum": [_P, _SZ, _I, _P, _P, _P, _SZ, _P, _P],
     "tfra_gather_rows": [_SZ, _SZ, _P, _P, _P, _P],
     "tfra_sparse_segment_combine": [_P, _SZ, _I, _P, _P, _P, _P, _I, _SZ, _P, _P],
-    "tfra_partition": [_P, _SZ, _P, _I, _I, _P, _P, _P, _P],
+    "tfra_partition": [_P, _SZ, _P, _P, _I, _I, _P, _P, _P, _P],
     "tfra_partition_by_owner": [_P, _SZ, _P, _I, _P, _P, _P],
     "tfra_scatter_rows": [_SZ, _SZ, _P, _P, _P, _P],
+    "tfra_reduce_by_key": [_P, _SZ, _P, _I, _P, _P, _P, _P, _P],
     "tfra_select_lowest": [_P, _SZ, _P, _P, _I, _SZ, _P, _P],
 }
 

@@ -84,22 +84,40 @@ def segment_sum(grads, idx, num_segments_dev, max_segments):
   return out
 
 
+def reduce_by_key(ids, rows):
+  """unique + unsorted_segment_sum, parallel per key (hot ids do not serialise) and bit-reproducible.
+  Returns (keys[n] buffer, sums[n,dim] buffer, count device scalar): the first `count` entries are valid,
+  in a deterministic but unspecified key order."""
+  ids = ids.contiguous().reshape(-1)
+  rows = rows.to(torch.float32).contiguous()
+  n, dim = ids.numel(), rows.shape[-1]
+  dev = ids.device
+  keys = torch.empty(n, dtype=torch.int64, device=dev)
+  sums = torch.empty((n, dim), dtype=torch.float32, device=dev)
+  cnt = torch.zeros((), dtype=torch.int64, device=dev)
+  _capi.call("tfra_reduce_by_key", _workspace(dev), n, _ptr(ids), dim, _ptr(rows), _ptr(keys), _ptr(sums), _ptr(cnt),
+             _stream(dev))
+  return keys, sums, cnt
+
+
 PARTITION_MASK_MOD = 0  # int32(key & 0x7fffffff) % N   (CUDA-build branch of default_partition_fn)
 PARTITION_FLOOR_MOD = 1  # key % N                       (CPU-build branch)
 PARTITION_HASH = 2  # fmix64(key) % N               (opt-in, Zipf-balanced)
 
 
-def partition(keys, num_shards, mode=PARTITION_MASK_MOD):
+def partition(keys, num_shards, mode=PARTITION_MASK_MOD, n_dev=None):
   """default_partition_fn + dynamic_partition in one pass (PY/dynamic_embedding_variable.py:131-197).
-  Returns owner-major keys, perm (original index of each output element) and device counts[num_shards]."""
+  Returns owner-major keys, perm (original index of each output element) and device counts[num_shards].
+  n_dev: optional device int64 scalar — only the first min(n, n_dev) keys are partitioned (the buffers
+  keep length n; entries past sum(counts) are unspecified)."""
   flat = keys.contiguous().reshape(-1)
   n = flat.numel()
   dev = flat.device
   keys_out = torch.empty(n, dtype=torch.int64, device=dev)
   perm = torch.empty(n, dtype=torch.int32, device=dev)
   counts = torch.zeros(num_shards, dtype=torch.int64, device=dev)
-  _capi.call("tfra_partition", _workspace(dev), n, _ptr(flat), num_shards, mode, _ptr(keys_out), _ptr(perm),
-             _ptr(counts), _stream(dev))
+  _capi.call("tfra_partition", _workspace(dev), n, None if n_dev is None else _ptr(n_dev), _ptr(flat), num_shards, mode,
+             _ptr(keys_out), _ptr(perm), _ptr(counts), _stream(dev))
   return keys_out, perm, counts
 
 

@@ -3,9 +3,10 @@
 Mirror of `HvdAllToAllEmbedding` / `HvdVariable.__alltoall_embedding_lookup__`
 (DE/python/keras/layers/embedding.py:545-594, PY/shadow_embedding_ops.py:365-447):
 
-    forward : partition ids by owner rank -> alltoall(ids, splits) -> local table lookup
-              -> alltoall(rows, splits=remote_sizes) -> un-permute to input order
-    backward: permute grads owner-major -> alltoall(grads) -> local fused optimizer write-back
+    forward : unique ids -> partition by owner rank -> alltoall(ids, splits) -> local table lookup
+              -> alltoall(rows, splits=remote_sizes) -> un-permute -> expand to input order
+    backward: sum grads of repeated ids -> permute owner-major -> alltoall(grads)
+              -> local fused optimizer write-back (sums the <= world parts of a key)
 
 The reference does this with `hvd.alltoall` from Python; here it is `torch.distributed`
 (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests) with the partition / un-permute being
@@ -27,8 +28,20 @@ class _DeviceOps:
     from . import device_ops
     self._o = device_ops
 
-  def partition(self, ids, world, mode):
-    return self._o.partition(ids, world, mode)
+  def partition(self, ids, world, mode, n_dev=None):
+    return self._o.partition(ids, world, mode, n_dev=n_dev)
+
+  def unique_no_sync(self, ids):
+    return self._o.unique_no_sync(ids)
+
+  def segment_sum(self, grads, idx, cnt, max_segments):
+    return self._o.segment_sum(grads, idx, cnt, max_segments)
+
+  def can_reduce_by_key(self, n, dim):
+    return dim % 4 == 0 and dim <= 256 and n <= (1 << 19)
+
+  def reduce_by_key(self, ids, grads):
+    return self._o.reduce_by_key(ids, grads)
 
   def gather_rows(self, rows, idx):
     return self._o.gather_rows(rows, idx)
@@ -38,15 +51,27 @@ class _DeviceOps:
 
 
 class AllToAllEmbedding:
-  """One logical table sharded by key hash over the ranks of `group`."""
+  """One logical table sharded by key hash over the ranks of `group`.
 
-  def __init__(self, local, group=None, partition_mode=0, ops=None):
+  dedup=True (default): every rank sends each DISTINCT id of its batch once — `tf.unique` before the id
+  alltoall, as the reference does (PY/shadow_embedding_ops.py:316 `embedding_lookup_unique`) — and sums
+  the gradients of repeated ids locally before routing them back.  Under a Zipf head this bounds the
+  skew to <= world copies of a hot key at its owner and cuts the alltoall payload by the batch's
+  duplicate ratio (6x at Zipf-1.2, B = 131 072).  The unique count stays on the device; the ONLY host
+  read per lookup is the pair of split-size vectors that alltoallv needs (as `hvd.alltoall(ids, splits)`).
+  """
+
+  def __init__(self, local, group=None, partition_mode=0, ops=None, dedup=True, force_collectives=False):
     self.local = local
     self.group = group
     self.world = dist.get_world_size(group) if dist.is_initialized() else 1
     self.rank = dist.get_rank(group) if dist.is_initialized() else 0
     self.mode = partition_mode
     self.ops = ops if ops is not None else _DeviceOps()
+    self.dedup = dedup
+    # world == 1 normally short-circuits; `force_collectives` keeps the full route (used to exercise the
+    # RCCL calls on a single-GPU box)
+    self.passthrough = self.world == 1 and not (force_collectives and dist.is_initialized())
     self._route = None
 
   def _a2a(self, out, inp, out_splits=None, in_splits=None):
@@ -57,7 +82,7 @@ class AllToAllEmbedding:
       dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
       out.copy_(o)
     else:
-      dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+      dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
 
   # -- id routing (PY/shadow_embedding_ops.py:397-422 __relocate_dense_feature__) ---------------
   def _exchange_counts(self, counts):
@@ -68,37 +93,67 @@ class AllToAllEmbedding:
   def route_ids(self, ids):
     """Returns the ids this rank must serve and remembers the routing for the way back."""
     ids = ids.reshape(-1)
-    if self.world == 1:
+    if self.passthrough:
       self._route = None
       return ids
-    owner_major, perm, counts = self.ops.partition(ids, self.world, self.mode)
+    n = ids.numel()
+    idx = cnt = None
+    if self.dedup:
+      uniq, idx, cnt = self.ops.unique_no_sync(ids)   # uniq: length-n buffer, first `cnt` entries valid
+      owner_major, perm, counts = self.ops.partition(uniq, self.world, self.mode, n_dev=cnt)
+    else:
+      owner_major, perm, counts = self.ops.partition(ids, self.world, self.mode)
     recv_counts = self._exchange_counts(counts)
     # split sizes must be host-visible for alltoallv (as for hvd.alltoall(ids, splits))
     both = torch.stack([counts, recv_counts]).tolist()
     send, recv = [int(x) for x in both[0]], [int(x) for x in both[1]]
+    u = sum(send)                                      # = number of distinct ids when dedup, else n
     remote_ids = torch.empty(sum(recv), dtype=ids.dtype, device=ids.device)
-    self._a2a(remote_ids, owner_major, recv, send)
-    self._route = (perm, send, recv, ids.numel())
+    self._a2a(remote_ids, owner_major[:u], recv, send)
+    self._route = (perm[:u], send, recv, n, idx, cnt, u, ids)
     return remote_ids
 
   def return_rows(self, rows):
     """Rows for the ids served here -> rows in the asking ranks' input order."""
     if self._route is None:
       return rows
-    perm, send, recv, n = self._route
-    back = torch.empty((sum(send), rows.shape[-1]), dtype=rows.dtype, device=rows.device)
+    perm, send, recv, n, idx, cnt, u, _ = self._route
+    back = torch.empty((u, rows.shape[-1]), dtype=rows.dtype, device=rows.device)
     self._a2a(back, rows.contiguous(), send, recv)
-    return self.ops.scatter_rows(back, perm)
+    out = self.ops.scatter_rows(back, perm)            # owner-major -> order of the routed ids
+    if idx is not None:
+      out = self.ops.gather_rows(out, idx)             # distinct ids -> every position of the batch
+    return out
 
   def route_grads(self, grads):
-    """Gradients w.r.t. the rows of the last lookup -> owner ranks (order of `route_ids` output)."""
+    """Gradients w.r.t. the rows of the last lookup -> (keys, gradient rows) at the owner ranks.
+
+    dedup: the gradients of one id's repeats are summed here first.  The parallel reduction
+    (`reduce_by_key`, cost independent of how often the hottest id repeats) returns the distinct ids in
+    its own order, so the keys travel with the rows (8 B next to a dim*4-B row); the per-owner counts
+    are those of the forward pass — same id set, same partition function — so no new size exchange."""
     if self._route is None:
-      return grads
-    perm, send, recv, n = self._route
-    owner_major = self.ops.gather_rows(grads.reshape(n, -1), perm)
-    remote = torch.empty((sum(recv), owner_major.shape[-1]), dtype=grads.dtype, device=grads.device)
+      return self._served, grads
+    perm, send, recv, n, idx, cnt, u, ids = self._route
+    g = grads.reshape(n, -1)
+    if idx is None:
+      owner_major = self.ops.gather_rows(g, perm)
+      remote = torch.empty((sum(recv), g.shape[-1]), dtype=g.dtype, device=g.device)
+      self._a2a(remote, owner_major, recv, send)
+      return self._served, remote
+    if self.ops.can_reduce_by_key(n, g.shape[-1]):
+      keys_u, gsum, cnt2 = self.ops.reduce_by_key(ids, g)
+      owner_keys, perm2, _ = self.ops.partition(keys_u, self.world, self.mode, n_dev=cnt2)
+      owner_major = self.ops.gather_rows(gsum, perm2[:u])
+      remote_keys = torch.empty(sum(recv), dtype=ids.dtype, device=ids.device)
+      self._a2a(remote_keys, owner_keys[:u], recv, send)
+    else:  # sequential per-id sums in tf.unique order: same order as the forward route
+      gsum = self.ops.segment_sum(g, idx, cnt, max(u, 1))[:u]
+      owner_major = self.ops.gather_rows(gsum, perm)
+      remote_keys = self._served
+    remote = torch.empty((sum(recv), owner_major.shape[-1]), dtype=owner_major.dtype, device=grads.device)
     self._a2a(remote, owner_major, recv, send)
-    return remote
+    return remote_keys, remote
 
   # -- the two halves of a training step ---------------------------------------------------------
   def lookup(self, ids):
@@ -111,6 +166,7 @@ class AllToAllEmbedding:
     return out.reshape(shape + (out.shape[-1],))
 
   def apply_gradients(self, optimizer, grads):
-    """Backward of the alltoall (Horovod's registered gradient) + local sparse write-back."""
-    g = self.route_grads(grads)
-    optimizer.apply_sparse(self.local, self._served, g)
+    """Backward of the alltoall (Horovod's registered gradient) + local sparse write-back: the owner
+    sums what the ranks sent for one key (<= world parts when dedup) and applies one fused update."""
+    keys, g = self.route_grads(grads)
+    optimizer.apply_sparse(self.local, keys, g)

@@ -24,13 +24,48 @@ DIM = 6
 class _CpuOps:
   """numpy stand-ins with the signatures of tfra_amd.dynamic_embedding.device_ops."""
 
-  def partition(self, ids, world, mode):
+  def __init__(self, use_reduce=True):
+    self.use_reduce = use_reduce
+
+  def partition(self, ids, world, mode, n_dev=None):
     from oracle import frontends as ofe
     k = ids.numpy()
+    n_all = k.size
+    if n_dev is not None:
+      k = k[:int(n_dev)]
     owner = ofe.default_partition_fn(k, world, gpu_mode=(mode == 0))
     perm = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]).astype(np.int32)
     counts = np.array([(owner == r).sum() for r in range(world)], dtype=np.int64)
-    return torch.from_numpy(k[perm]), torch.from_numpy(perm), torch.from_numpy(counts)
+    pad = np.zeros(n_all - k.size, dtype=np.int64)     # the device op returns length-n buffers
+    return (torch.from_numpy(np.concatenate([k[perm], pad])), torch.from_numpy(np.concatenate([perm, pad.astype(np.int32)])),
+            torch.from_numpy(counts))
+
+  def unique_no_sync(self, ids):
+    from oracle import frontends as ofe
+    u, idx = ofe.unique(ids.numpy())
+    buf = np.zeros(ids.numel(), dtype=np.int64)
+    buf[:u.size] = u
+    return torch.from_numpy(buf), torch.from_numpy(idx.astype(np.int32)), torch.tensor(u.size, dtype=torch.int64)
+
+  def segment_sum(self, grads, idx, cnt, max_segments):
+    out = np.zeros((max_segments, grads.shape[-1]), dtype=np.float32)
+    g, ix = grads.numpy(), idx.numpy()
+    for i in range(ix.size):                           # input order, one fp32 add each
+      out[ix[i]] += g[i]
+    return torch.from_numpy(out)
+
+  def can_reduce_by_key(self, n, dim):
+    return self.use_reduce
+
+  def reduce_by_key(self, ids, grads):
+    """Distinct ids in DESCENDING key order (any fixed order is allowed), sums in input order."""
+    from oracle import optimizers as oopt
+    u, g, _ = oopt.segment_sum_by_key(ids.numpy().reshape(-1), grads.numpy())
+    order = np.argsort(-u, kind="stable")
+    n = ids.numel()
+    kb = np.zeros(n, dtype=np.int64); kb[:u.size] = u[order]
+    gb = np.zeros((n, grads.shape[-1]), dtype=np.float32); gb[:u.size] = g[order]
+    return torch.from_numpy(kb), torch.from_numpy(gb), torch.tensor(u.size, dtype=torch.int64)
 
   def gather_rows(self, rows, idx):
     return rows[idx.long()]
@@ -77,7 +112,7 @@ def _grads(rank, n):
   return np.random.default_rng(200 + rank).standard_normal((n, DIM)).astype(np.float32)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, dedup):
   os.environ["MASTER_ADDR"] = "127.0.0.1"
   os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -87,7 +122,7 @@ def _worker(rank, world, port, q):
   keys = _all_keys()
   mine = keys[ofe.default_partition_fn(keys, world) == rank]
   shard.t.insert(mine, np.tile(mine[:, None].astype(np.float32) * 0.5, (1, DIM)))
-  emb = AllToAllEmbedding(shard, partition_mode=0, ops=_CpuOps())
+  emb = AllToAllEmbedding(shard, partition_mode=0, ops=_CpuOps(use_reduce=(dedup != 'segsum')), dedup=bool(dedup))
   ids = torch.from_numpy(_ids(rank))
   out = emb.lookup(ids)
   g = _grads(rank, ids.numel())
@@ -99,11 +134,12 @@ def _worker(rank, world, port, q):
   dist.destroy_process_group()
 
 
-def test_alltoall_lookup_and_write_back_world2():
-  world, port = 2, 29511 + (os.getpid() % 200)
+@pytest.mark.parametrize("dedup", [True, "segsum", False])
+def test_alltoall_lookup_and_write_back_world2(dedup):
+  world, port = 2, 29511 + (os.getpid() % 200) + {True: 300, 'segsum': 600, False: 0}[dedup]
   ctx = mp.get_context("spawn")
   q = ctx.Queue()
-  procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, q, dedup)) for r in range(world)]
   for p in procs:
     p.start()
   res = {}
@@ -134,7 +170,10 @@ def test_alltoall_lookup_and_write_back_world2():
     for src in range(world):
       flat = ids[src].reshape(-1)
       sel = ofe.default_partition_fn(flat, world) == owner_rank
-      ks.append(flat[sel]); gs.append(_grads(src, flat.size)[sel])
+      k_src, g_src = flat[sel], _grads(src, flat.size)[sel]
+      if dedup:                                        # each source sums its repeats before routing
+        k_src, g_src, _ = oopt.segment_sum_by_key(k_src, g_src)
+      ks.append(k_src); gs.append(g_src)
     ks, gs = np.concatenate(ks), np.concatenate(gs)
     uniq, gsum, _ = oopt.segment_sum_by_key(ks, gs)
     p = tabs[owner_rank].find(uniq, np.full(DIM, -1.0, np.float32))

@@ -89,6 +89,99 @@ def test_partition_matches_default_partition_fn(env, shards, mode):
   np.testing.assert_array_equal(perm.cpu().numpy(), np.concatenate(idxs))
 
 
+@pytest.mark.parametrize("n_valid", [0, 1, 255, 256, 40000, 70001, 10**6])
+def test_partition_with_device_count(env, n_valid):
+  """d_n: only the first min(n, *d_n) keys are partitioned (chains after tfra_unique without a host read)."""
+  torch, de = env
+  n, shards = 70001, 8
+  keys = np.random.default_rng(3).integers(-2**62, 2**62, size=n).astype(np.int64)
+  ko, perm, counts = de.device_ops.partition(T(torch, keys), shards, 0, n_dev=torch.tensor(n_valid, device="cuda"))
+  m = min(n, n_valid)
+  owner = ofe.default_partition_fn(keys[:m], shards, gpu_mode=True)
+  parts, idxs = ofe.make_partition(keys[:m], owner, shards)
+  np.testing.assert_array_equal(counts.cpu().numpy(), [len(p) for p in parts])
+  np.testing.assert_array_equal(ko.cpu().numpy()[:m], np.concatenate(parts) if m else np.zeros(0, np.int64))
+  np.testing.assert_array_equal(perm.cpu().numpy()[:m], np.concatenate(idxs) if m else np.zeros(0, np.int32))
+
+
+@pytest.mark.parametrize("n,dim,hi,zipf", [(1, 4, 5, False), (511, 8, 40, False), (513, 64, 10**9, False),
+                                            (131072, 64, 10**8, True), (300000, 16, 2000, True),
+                                            (524288, 128, 50, False), (40000, 256, 3, False)])
+def test_reduce_by_key(env, n, dim, hi, zipf):
+  """unique + unsorted_segment_sum in one call: key set exact, sums vs an fp64 restatement, bit-reproducible."""
+  torch, de = env
+  rng = np.random.default_rng(n + dim)
+  ids = (rng.zipf(1.2, size=n) % hi if zipf else rng.integers(-hi, hi, size=n)).astype(np.int64) * 2654435761
+  ids[0] = np.iinfo(np.int64).min
+  g = rng.standard_normal((n, dim)).astype(np.float32)
+  keys, sums, cnt = de.device_ops.reduce_by_key(T(torch, ids), T(torch, g))
+  keys2, sums2, cnt2 = de.device_ops.reduce_by_key(T(torch, ids), T(torch, g))
+  u = int(cnt.item())
+  ku, inv, counts = np.unique(ids, return_inverse=True, return_counts=True)
+  assert u == ku.size == int(cnt2.item())
+  k = keys.cpu().numpy()[:u]
+  assert np.array_equal(k, keys2.cpu().numpy()[:u])                       # deterministic order
+  assert torch.equal(sums[:u], sums2[:u])                                 # and bit-reproducible sums
+  order = np.argsort(k)
+  np.testing.assert_array_equal(k[order], ku)
+  want = np.zeros((ku.size, dim), dtype=np.float64)
+  np.add.at(want, inv, g.astype(np.float64))
+  got = sums.cpu().numpy()[:u][order]
+  tol = 4e-7 * np.sqrt(counts.max()) * 4 + 1e-6
+  np.testing.assert_allclose(got, want, rtol=1e-5, atol=tol * np.abs(g).max())
+  single = counts == 1                                                  # ids seen once: the row itself
+  first = np.zeros(ku.size, dtype=np.int64); first[inv[::-1]] = np.arange(n)[::-1]
+  np.testing.assert_array_equal(got[single], g[first[single]])
+
+
+def test_reduce_by_key_rejects_unsupported(env):
+  torch, de = env
+  ids = torch.arange(8, device="cuda")
+  with pytest.raises(Exception, match="dim % 4"):
+    de.device_ops.reduce_by_key(ids, torch.zeros((8, 6), device="cuda"))
+  k, s_, c = de.device_ops.reduce_by_key(ids[:0], torch.zeros((0, 8), device="cuda"))
+  assert int(c.item()) == 0
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+@pytest.mark.parametrize("dedup", [True, False])
+def test_alltoall_route_single_rank(env, backend, dedup):
+  """The full id route (unique -> partition -> alltoall ids -> lookup -> alltoall rows -> un-permute ->
+  expand; backward mirror) on ONE rank with the collectives forced on: RCCL ("nccl") moves the device
+  buffers, "gloo" is the host-staged path.  Result must equal the direct single-table path."""
+  torch, de = env
+  import torch.distributed as dist
+  from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
+  port = 29900 + (1 if backend == "gloo" else 0) + (2 if dedup else 0)
+  dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                          **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+  try:
+    rng = np.random.default_rng(11)
+    opt = de.optimizers.SGD(0.01)   # linear in the gradient sum: a different (fixed) summation order stays ~1 ulp
+    kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
+    a = de.Variable(dim=8, name="a2a_a_%s_%d" % (backend, dedup), initializer=0.25, **kw)
+    b = de.Variable(dim=8, name="a2a_b_%s_%d" % (backend, dedup), initializer=0.25, **kw)
+    oa, ob = de.DynamicEmbeddingOptimizer(opt), de.DynamicEmbeddingOptimizer(de.optimizers.SGD(0.01))
+    emb = AllToAllEmbedding(a, partition_mode=0, dedup=dedup, force_collectives=True)
+    assert not emb.passthrough
+    for step in range(4):
+      ids = rng.zipf(1.3, size=(6, 500)).astype(np.int64) % 3000 * 7919
+      g = rng.standard_normal((ids.size, 8)).astype(np.float32)
+      out = emb.lookup(T(torch, ids))
+      ref = b.lookup(T(torch, ids))
+      assert out.shape == ref.shape
+      np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+      emb.apply_gradients(oa, T(torch, g))
+      ob.apply_sparse(b, T(torch, ids), T(torch, g))
+    ka, va = a.export(); kb, vb = b.export()
+    ia, ib = np.argsort(ka.cpu().numpy()), np.argsort(kb.cpu().numpy())
+    np.testing.assert_array_equal(ka.cpu().numpy()[ia], kb.cpu().numpy()[ib])
+    # gradient sums are formed in a different (still fixed) order when repeats are summed before routing
+    np.testing.assert_allclose(va.cpu().numpy()[ia], vb.cpu().numpy()[ib], rtol=1e-6, atol=1e-6)
+  finally:
+    dist.destroy_process_group()
+
+
 def test_k7_k8_sharding(env):
   """K7: default partitioner over 2 shards (T/dynamic_embedding_ops_test.py:324-349);
   K8: custom partitioner keys%2 over 3 shards (:382-408)."""
