@@ -243,6 +243,22 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
     if (sub == 0) old = (i64)atomicCAS((u64*)&v.keys[best_word], (u64)best_key, (u64)LOCKED_KEY);
     old = shfl_i64(old, gshift);
     if (old == best_key) {
+      if (best_key != EMPTY_KEY) {
+        // The key line and the score line were read by two unordered loads: a slot that a concurrent
+        // evictor published in between shows its NEW key with the OLD (minimum) score of the entry it
+        // replaced.  The slot is ours now, so its score is stable: re-read it and give the slot back
+        // if it is not the score the choice was based on.
+        unsigned lo = 0, hi = 0;
+        if (sub == 0) {
+          u64 now = __hip_atomic_load(&v.scores[best_word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          lo = (unsigned)now; hi = (unsigned)(now >> 32);
+        }
+        const u64 now = ((u64)(unsigned)__shfl((int)hi, gshift) << 32) | (unsigned)__shfl((int)lo, gshift);
+        if (now != best_score) {
+          if (sub == 0) __hip_atomic_store(&v.keys[best_word], best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          continue;
+        }
+      }
       claimed_empty = (best_key == EMPTY_KEY);
       *victim_word = best_word;
       return (i64)((best_word >> 4) * SLOTS + (best_word & 15));
@@ -255,6 +271,29 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
 __device__ __forceinline__ void publish_key(const TableView& v, u64 word, i64 key, int sub) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   if (sub == 0) __hip_atomic_store(&v.keys[word], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Per-key score of the Hkv strategies (what eviction compares): LRU = device clock, LFU += in_score,
+// EPOCH* = epoch << 32 | low word, CUSTOMIZED = caller's score (lookup_table_op_hkv.h:454-475).
+__device__ __forceinline__ void update_score(const TableView& v, i64 row, bool is_new, int strategy,
+                                             u64 in_score, u64 epoch, int sub) {
+  if (!v.scores || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
+  u64 b = (u64)row / SLOTS, s = (u64)row % SLOTS;
+  u64* p = &v.scores[b * 16 + s];
+  u64 old = is_new ? 0 : *p;
+  u64 ns;
+  switch (strategy) {
+    case TFRA_EVICT_LFU: atomicAdd(p, in_score); return;  // slots are zeroed on clear/erase
+    case TFRA_EVICT_EPOCHLRU: ns = (epoch << 32) | (wall_clock64() & 0xffffffffULL); break;
+    case TFRA_EVICT_EPOCHLFU: {
+      u64 cnt = (old & 0xffffffffULL) + in_score;
+      if (cnt > 0xffffffffULL) cnt = 0xffffffffULL;
+      ns = (epoch << 32) | cnt;
+    } break;
+    case TFRA_EVICT_CUSTOMIZED: ns = in_score; break;
+    default: ns = wall_clock64(); break;  // LRU: device-wide monotonic clock
+  }
+  *p = ns;
 }
 
 __device__ __forceinline__ void size_add(const TableView& v, u64 wave_id, long long delta) {

@@ -36,6 +36,8 @@ struct Table {
   unsigned* err_count = nullptr;
   i64* d_scalar = nullptr;
   i64* h_scalar = nullptr;  // pinned
+  uint8_t* evict_flags = nullptr;  // phase-2 flags of a fused write-back on a bounded table
+  size_t evict_flags_cap = 0;
   int* winner = nullptr;
   size_t winner_len = 0;
   void* scratch = nullptr;

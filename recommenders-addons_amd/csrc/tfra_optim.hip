@@ -10,6 +10,7 @@
 // (this file is compiled with -ffp-contract=off so no FMA contraction changes roundings).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
                                                     float aux0, float aux1, const i64* __restrict__ d_n,
                                                     const unsigned* __restrict__ src, const float* __restrict__ alt_rows,
                                                     unsigned alt_base, unsigned* __restrict__ rearm, unsigned rearm_count,
-                                                    unsigned rearm_stride) {
+                                                    unsigned rearm_stride, ScoreP sp, uint8_t* __restrict__ deferred) {
   constexpr int S = NSlots<KIND>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
@@ -50,9 +51,18 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
   if (active) {
     const i64 key = keys[g];
     bool is_new;
-    i64 row = locate_or_claim(v, key, sub, gshift, is_new);
+    i64 row;
+    if (deferred) {  // bounded (Hkv) table at max_capacity: keys without a free slot go to phase 2
+      u64 h;
+      const u64 b0 = bucket0(key, v.nb, h);
+      const i64 k0 = load_key_coherent(&v.keys[b0 * 16 + sub]);
+      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, true);
+      if (sub == 0) deferred[g] = row == NEED_EVICT;
+    } else {
+      row = locate_or_claim(v, key, sub, gshift, is_new);
+    }
     if (row < 0) {
-      failed = (sub == 0);
+      failed = (sub == 0 && row != NEED_EVICT);
     } else {
       fresh = (is_new && sub == 0);
       float* pr = reinterpret_cast<float*>(v.rows + (size_t)row * v.row_stride);
@@ -100,8 +110,66 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
         for (int f = S + 1; f < (int)v.n_fields; ++f)
           for (int c = sub; c < dim; c += 16) pr[f * dim + c] = (f == 1 ? aux0 : aux1);
       }
-      if (v.scores && sub == 0 && row < (i64)(v.nb * SLOTS)) v.scores[((u64)row / SLOTS) * 16 + (u64)row % SLOTS] = wall_clock64();
+      update_score(v, row, is_new, sp.strategy, 1, sp.epoch, sub);  // one write-back = one upsert
     }
+  } else if (deferred && g < n && sub == 0) {
+    deferred[g] = 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, g >> 2, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// Phase 2 on a bounded (Hkv) table at max_capacity, after phase 1 has finished every hit and free-slot
+// claim of the batch (so no row is being updated while it is evicted): each deferred key replaces the
+// minimum-score entry of its two home buckets and starts from the default row / initial slot values —
+// what find (miss -> default) + dense apply + upsert (evicting) give in the reference
+// (PY/dynamic_embedding_optimizer.py:165-204 on an HkvHashTable, lookup_table_op_hkv.h:522-537).
+template <int KIND, bool INDIRECT>
+__global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
+                                                          const float* __restrict__ grads,
+                                                          const float* __restrict__ defaults, int full, int dim,
+                                                          float aux0, float aux1, const i64* __restrict__ d_n,
+                                                          const unsigned* __restrict__ src,
+                                                          const float* __restrict__ alt_rows, unsigned alt_base,
+                                                          ScoreP sp, const uint8_t* __restrict__ deferred) {
+  constexpr int S = NSlots<KIND>::v;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  int fresh = 0, failed = 0;
+  if (o.d_lr) o.lr = *o.d_lr;
+  if (d_n) { size_t dn = (size_t)*d_n; if (dn < n) n = dn; }
+  if (g < n && deferred[g]) {
+    const i64 key = keys[g];
+    const unsigned sidx = INDIRECT ? src[g] : 0;
+    const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+    const u64 in_score = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | 1) : 1;
+    u64 word = 0;
+    bool claimed_empty;
+    i64 row = evict_and_lock(v, key, in_score, lru_like, sub, gshift, &word, claimed_empty);
+    if (row >= 0) {
+      float* pr = reinterpret_cast<float*>(v.rows + (size_t)row * v.row_stride);
+      const float* gr = INDIRECT ? (sidx < alt_base ? grads + (size_t)sidx * dim : alt_rows + (size_t)(sidx - alt_base) * dim)
+                                 : grads + g * (size_t)dim;
+      const float* df = defaults + (full ? g * (size_t)dim : 0);
+      for (int c = sub; c < dim; c += 16) {
+        float p = df[c], s1 = aux0, s2 = aux1;
+        apply_one<KIND>(o, gr[c], p, s1, s2);
+        pr[c] = p;
+        if (S >= 1) pr[dim + c] = s1;
+        if (S >= 2) pr[2 * dim + c] = s2;
+      }
+      for (int f = S + 1; f < (int)v.n_fields; ++f)
+        for (int c = sub; c < dim; c += 16) pr[f * dim + c] = (f == 1 ? aux0 : aux1);
+      if (sub == 0) v.scores[word] = 0;  // the slot starts a new life
+      update_score(v, row, true, sp.strategy, 1, sp.epoch, sub);
+      publish_key(v, word, key, sub);
+      fresh = (claimed_empty && sub == 0);
+    } else if (row == -3) {
+      failed = (sub == 0);
+    }  // -1: not admitted (LFU-type score below every resident score): dropped, like HKV
   }
   for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
   if (lane == 0) {
@@ -112,9 +180,46 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
 
 template <int KIND>
 void launch_apply(bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
-                  const float* d, int full, int dim, float a0, float a1, const i64* dn) {
-  if (vec4) apply_kernel<KIND, true, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0);
-  else apply_kernel<KIND, false, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0);
+                  const float* d, int full, int dim, float a0, float a1, const i64* dn, ScoreP sp, uint8_t* deferred) {
+  if (vec4) apply_kernel<KIND, true, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0, sp, deferred);
+  else apply_kernel<KIND, false, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0, sp, deferred);
+  if (deferred) apply_evict_kernel<KIND, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, sp, deferred);
+}
+
+template <int KIND>
+void launch_indirect(dim3 grid, hipStream_t s, TableView v, OptP o, size_t max_n, const i64* keys, const float* grads,
+                     const float* default_row, int dim, float a0, float a1, const i64* d_n, const unsigned* src,
+                     const float* alt_rows, unsigned alt_base, unsigned* rearm, unsigned rearm_count, unsigned rearm_stride,
+                     ScoreP sp, uint8_t* deferred) {
+  apply_kernel<KIND, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows,
+                                                      alt_base, rearm, rearm_count, rearm_stride, sp, deferred);
+  if (deferred)
+    apply_evict_kernel<KIND, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows,
+                                                        alt_base, sp, deferred);
+}
+
+// Hkv flavour at max_capacity (the table cannot grow): returns the phase-2 flag buffer, else nullptr
+int bounded_flags(Table* t, size_t n, hipStream_t s, uint8_t** out) {
+  *out = nullptr;
+  const u64 max_nb_b = t->opts.max_capacity ? std::max<u64>(2, t->opts.max_capacity / SLOTS) : 0;
+  if (!(t->opts.strategy >= 0 && max_nb_b && t->cur.nb >= max_nb_b)) return TFRA_OK;
+  if (t->evict_flags_cap < n) {
+    if (t->evict_flags) { if (hipStreamSynchronize(s) != hipSuccess) return set_error(TFRA_ERR_HIP, "apply: sync"); t->dfree(t->evict_flags, s); }
+    t->evict_flags = (uint8_t*)t->dalloc(n, s);
+    if (!t->evict_flags) { t->evict_flags_cap = 0; return set_error(TFRA_ERR_OOM, "apply: eviction flag buffer"); }
+    t->evict_flags_cap = n;
+  }
+  *out = t->evict_flags;
+  return TFRA_OK;
+}
+
+// one fused write-back counts as one upsert for the epoch strategies (lookup_table_op_hkv.h:528-536)
+void step_epoch(Table* t) {
+  const int strat = t->opts.strategy;
+  if (strat == TFRA_EVICT_EPOCHLRU || strat == TFRA_EVICT_EPOCHLFU) {
+    t->curr_step += 1;
+    if (t->opts.step_per_epoch > 0 && t->curr_step > t->opts.step_per_epoch) { t->global_epoch += 1; t->curr_step = 1; }
+  }
 }
 
 }  // namespace
@@ -130,12 +235,17 @@ int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, siz
   const int dim = t->opts.dim;
   const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
   dim3 grid((unsigned)((max_n * 16 + 255) / 256));
+  uint8_t* deferred;
+  int rc = bounded_flags(t, max_n, s, &deferred);
+  if (rc) return rc;
+  const ScoreP sp{t->opts.strategy, t->global_epoch};
   switch (p->kind) {
-    case TFRA_OPT_SGD: apply_kernel<TFRA_OPT_SGD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
-    case TFRA_OPT_ADAM: apply_kernel<TFRA_OPT_ADAM, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
-    case TFRA_OPT_ADAGRAD: apply_kernel<TFRA_OPT_ADAGRAD, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
-    default: apply_kernel<TFRA_OPT_FTRL, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride); break;
+    case TFRA_OPT_SGD: launch_indirect<TFRA_OPT_SGD>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
+    case TFRA_OPT_ADAM: launch_indirect<TFRA_OPT_ADAM>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
+    case TFRA_OPT_ADAGRAD: launch_indirect<TFRA_OPT_ADAGRAD>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
+    default: launch_indirect<TFRA_OPT_FTRL>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
   }
+  step_epoch(t);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   return TFRA_OK;
 }
@@ -168,12 +278,17 @@ extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_param
   const i64* k = (const i64*)keys;
   const float* d = (const float*)param_defaults;
   float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
+  uint8_t* deferred;
+  rc = bounded_flags(t, n, s, &deferred);
+  if (rc) return rc;
+  const ScoreP sp{t->opts.strategy, t->global_epoch};
   switch (p->kind) {
-    case TFRA_OPT_SGD: launch_apply<TFRA_OPT_SGD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
-    case TFRA_OPT_ADAM: launch_apply<TFRA_OPT_ADAM>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
-    case TFRA_OPT_ADAGRAD: launch_apply<TFRA_OPT_ADAGRAD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
-    default: launch_apply<TFRA_OPT_FTRL>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n); break;
+    case TFRA_OPT_SGD: launch_apply<TFRA_OPT_SGD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    case TFRA_OPT_ADAM: launch_apply<TFRA_OPT_ADAM>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    case TFRA_OPT_ADAGRAD: launch_apply<TFRA_OPT_ADAGRAD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    default: launch_apply<TFRA_OPT_FTRL>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
   }
+  step_epoch(t);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_optimizer: launch failed");
   return TFRA_OK;
 }

@@ -42,6 +42,9 @@ __device__ __forceinline__ void apply_one(const OptP& o, float g, float& p, floa
   }
 }
 
+// score strategy of the table + its current epoch (update_score)
+struct ScoreP { int strategy; u64 epoch; };
+
 template <int KIND> struct NSlots { static constexpr int v = KIND == TFRA_OPT_SGD ? 0 : (KIND == TFRA_OPT_ADAGRAD ? 1 : 2); };
 
 

@@ -97,27 +97,6 @@ __device__ __forceinline__ void init_aux_fields(const TableView& v, const AuxIni
   }
 }
 
-__device__ __forceinline__ void update_score(const TableView& v, i64 row, bool is_new, int strategy,
-                                             u64 in_score, u64 epoch, int sub) {
-  if (!v.scores || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
-  u64 b = (u64)row / SLOTS, s = (u64)row % SLOTS;
-  u64* p = &v.scores[b * 16 + s];
-  u64 old = is_new ? 0 : *p;
-  u64 ns;
-  switch (strategy) {
-    case TFRA_EVICT_LFU: atomicAdd(p, in_score); return;  // slots are zeroed on clear/erase
-    case TFRA_EVICT_EPOCHLRU: ns = (epoch << 32) | (wall_clock64() & 0xffffffffULL); break;
-    case TFRA_EVICT_EPOCHLFU: {
-      u64 cnt = (old & 0xffffffffULL) + in_score;
-      if (cnt > 0xffffffffULL) cnt = 0xffffffffULL;
-      ns = (epoch << 32) | cnt;
-    } break;
-    case TFRA_EVICT_CUSTOMIZED: ns = in_score; break;
-    default: ns = wall_clock64(); break;  // LRU: device-wide monotonic clock
-  }
-  *p = ns;
-}
-
 // ---- insert_or_assign, unique-keys fast path (single pass) ---------------------------------
 template <int G, int U>
 __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t n,
@@ -950,7 +929,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   hipStream_t s = nullptr;
   t->dfree(t->cur.keys, s); t->dfree(t->cur.rows, s); t->dfree(t->cur.scores, s);
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
-  t->dfree(t->winner, s); t->dfree(t->scratch, s);
+  t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s);
   if (t->h_scalar) (void)hipHostFree(t->h_scalar);
   if (t->chain_event) (void)hipEventDestroy(t->chain_event);
   if (t->size_event) (void)hipEventDestroy(t->size_event);

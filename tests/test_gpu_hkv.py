@@ -130,3 +130,99 @@ def test_k15_repeat_insert_and_bounded_size(env):
   assert 65536 // 2 <= n2 <= 65536
   k, v = t.export()
   assert len(np.unique(k.cpu().numpy())) == n2
+
+
+# ---- fused optimizer write-back on a bounded table that is full ------------------------------------
+def _opt_pair(de, kind):
+  o = de.optimizers
+  if kind == "sgd":
+    return o.SGD(0.1), dict(lr=0.1)
+  if kind == "adam":
+    return o.Adam(0.01, 0.9, 0.999, 1e-8), dict(lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8)
+  if kind == "adagrad":
+    return o.Adagrad(0.05, 0.1), dict(lr=0.05, init_acc=0.1)
+  return o.Ftrl(0.05, l1_regularization_strength=1e-3, l2_regularization_strength=1e-3), dict(lr=0.05, l1=1e-3, l2=1e-3)
+
+
+@pytest.mark.parametrize("dim", [8, 6])          # 8: tfra_table_apply_sparse; 6: unique + segment_sum + apply_optimizer
+@pytest.mark.parametrize("kind", ["sgd", "adam", "adagrad", "ftrl"])
+def test_fused_optimizer_evicts_on_full_bounded_table(env, kind, dim):
+  """The reference trains an HkvHashTable at capacity with find (miss -> default) + dense apply + upsert,
+  and the upsert evicts (PY/dynamic_embedding_optimizer.py:165-204, lookup_table_op_hkv.h:522-537).  The
+  fused write-back must do the same: new keys replace min-score entries instead of failing."""
+  torch, de = env
+  import oracle
+  from oracle import optimizers as oopt
+  rng = np.random.default_rng(dim * 10 + len(kind))
+  opt, hyper = _opt_pair(de, kind)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  var = de.get_variable("hkv_fused_%s_%d" % (kind, dim), key_dtype=torch.int64, value_dtype=torch.float32,
+                        initializer=0.25, dim=dim, init_size=1024,
+                        kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                            init_capacity=1024, max_capacity=1024, max_hbm_for_values=1 << 20,
+                            evict_strategy=de.HkvEvictStrategy.LRU)),
+                        **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  for lo in range(0, 3000, 500):   # fill beyond capacity: the table is now as full as it gets
+    k = np.arange(lo, lo + 500, dtype=np.int64)
+    var.upsert(torch.from_numpy(k).cuda(), torch.from_numpy(np.tile(k[:, None] * 1e-3, (1, dim)).astype(np.float32)).cuda())
+  n0 = int(var.size())
+  assert 900 < n0 <= 1024
+  rk, rv = var.export()
+  rk, rv = rk.cpu().numpy(), rv.cpu().numpy()
+  # CPU model of the reference sequence, seeded with what is resident
+  tabs = [oracle.CpuTable(dim) for _ in range(1 + len(opt.slots))]
+  tabs[0].insert(rk, rv)
+  ora = oopt.SparseOptimizerOracle(kind, tabs[0], tabs[1:], hyper, 0.25)
+  fresh_base = 10**6
+  for step in range(4):
+    resident = rng.choice(rk, size=100, replace=False)
+    fresh = np.arange(fresh_base, fresh_base + 150, dtype=np.int64)
+    fresh_base += 150
+    ids = np.concatenate([resident, resident[:40], fresh, fresh[:30]])
+    rng.shuffle(ids)
+    g = rng.standard_normal((ids.size, dim)).astype(np.float32)
+    # the oracle must not know keys the engine has evicted meanwhile: drop them from the model first
+    live, _ = var.export()
+    live = set(live.cpu().numpy().tolist())
+    for t in tabs:
+      ks, _ = t.export_sorted()
+      gone = np.array([x for x in ks.tolist() if x not in live], dtype=np.int64)
+      if gone.size:
+        t.remove(gone)
+    uniq = ora.apply(ids, g)
+    deo.apply_sparse(var, torch.from_numpy(ids).cuda(), torch.from_numpy(g).cuda())
+    size = int(var.size())                      # raises if any key could neither be placed nor evict
+    assert size <= 1024
+    got, ex = var.lookup(torch.from_numpy(uniq).cuda(), return_exists=True)
+    missing = uniq[~ex.cpu().numpy()]
+    assert missing.size == 0, "step %d: keys of the step not resident after its write-back: %s (fresh: %s)" % (
+        step, missing[:10], (missing >= 10**6)[:10])
+    want = tabs[0].find(uniq, np.full(dim, 0.25, np.float32))
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+    rk = var.export()[0].cpu().numpy()
+  # nothing was duplicated or lost track of
+  k, _ = var.export()
+  k = k.cpu().numpy()
+  assert len(np.unique(k)) == len(k) == int(var.size())
+
+
+def test_fused_optimizer_lfu_admission_on_full_table(env):
+  """LFU: a new key (count 1) only replaces an entry whose count is not higher; frequent keys survive."""
+  torch, de = env
+  opt = de.optimizers.SGD(0.1)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  var = de.get_variable("hkv_fused_lfu", key_dtype=torch.int64, value_dtype=torch.float32, initializer=0.0, dim=8,
+                        init_size=1024, kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                            init_capacity=1024, max_capacity=1024, max_hbm_for_values=1 << 20,
+                            evict_strategy=de.HkvEvictStrategy.LFU)))
+  hot = torch.arange(0, 64, device="cuda")
+  g1 = torch.ones((64, 8), device="cuda")
+  for _ in range(5):
+    deo.apply_sparse(var, hot, g1)               # count 5 each
+  for lo in range(1000, 6000, 500):             # 5000 one-shot keys through a 1020-slot table
+    ids = torch.arange(lo, lo + 500, device="cuda")
+    deo.apply_sparse(var, ids, torch.ones((500, 8), device="cuda"))
+    assert int(var.size()) <= 1024
+  v, ex = var.lookup(hot, return_exists=True)
+  assert bool(ex.all())
+  np.testing.assert_allclose(v.cpu().numpy(), np.full((64, 8), -0.5, np.float32), rtol=1e-6)
