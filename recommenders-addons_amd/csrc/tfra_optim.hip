@@ -198,21 +198,6 @@ void launch_indirect(dim3 grid, hipStream_t s, TableView v, OptP o, size_t max_n
                                                         alt_base, sp, deferred);
 }
 
-// Hkv flavour at max_capacity (the table cannot grow): returns the phase-2 flag buffer, else nullptr
-int bounded_flags(Table* t, size_t n, hipStream_t s, uint8_t** out) {
-  *out = nullptr;
-  const u64 max_nb_b = t->opts.max_capacity ? std::max<u64>(2, t->opts.max_capacity / SLOTS) : 0;
-  if (!(t->opts.strategy >= 0 && max_nb_b && t->cur.nb >= max_nb_b)) return TFRA_OK;
-  if (t->evict_flags_cap < n) {
-    if (t->evict_flags) { if (hipStreamSynchronize(s) != hipSuccess) return set_error(TFRA_ERR_HIP, "apply: sync"); t->dfree(t->evict_flags, s); }
-    t->evict_flags = (uint8_t*)t->dalloc(n, s);
-    if (!t->evict_flags) { t->evict_flags_cap = 0; return set_error(TFRA_ERR_OOM, "apply: eviction flag buffer"); }
-    t->evict_flags_cap = n;
-  }
-  *out = t->evict_flags;
-  return TFRA_OK;
-}
-
 // one fused write-back counts as one upsert for the epoch strategies (lookup_table_op_hkv.h:528-536)
 void step_epoch(Table* t) {
   const int strat = t->opts.strategy;
@@ -236,7 +221,7 @@ int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, siz
   const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
   dim3 grid((unsigned)((max_n * 16 + 255) / 256));
   uint8_t* deferred;
-  int rc = bounded_flags(t, max_n, s, &deferred);
+  int rc = t->bounded_flags(max_n, s, &deferred);
   if (rc) return rc;
   const ScoreP sp{t->opts.strategy, t->global_epoch};
   switch (p->kind) {
@@ -279,7 +264,7 @@ extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_param
   const float* d = (const float*)param_defaults;
   float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
   uint8_t* deferred;
-  rc = bounded_flags(t, n, s, &deferred);
+  rc = t->bounded_flags(n, s, &deferred);
   if (rc) return rc;
   const ScoreP sp{t->opts.strategy, t->global_epoch};
   switch (p->kind) {

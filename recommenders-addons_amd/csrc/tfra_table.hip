@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const
                                                     const uint8_t* __restrict__ exists,
                                                     const u64* __restrict__ scores, unsigned dim,
                                                     AuxInit ai, int strategy, u64 epoch,
-                                                    const int* __restrict__ order, size_t n_order) {
+                                                    const int* __restrict__ order, size_t n_order,
+                                                    uint8_t* __restrict__ deferred) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   const size_t wave = g >> 2;
@@ -311,8 +312,17 @@ __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const
     const unsigned char* src = vod + i * (size_t)v.field_bytes;
     if (!ex) {
       bool is_new;
-      i64 row = locate_or_claim(v, key, sub, gshift, is_new);
-      if (row < 0) failed = (sub == 0);
+      i64 row;
+      if (deferred) {  // bounded table at max_capacity: keys without a free slot evict in phase 2
+        u64 h;
+        const u64 b0 = bucket0(key, v.nb, h);
+        const i64 k0 = load_key_coherent(&v.keys[b0 * 16 + sub]);
+        row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, true);
+        if (sub == 0) deferred[i] = row == NEED_EVICT;
+      } else {
+        row = locate_or_claim(v, key, sub, gshift, is_new);
+      }
+      if (row < 0) failed = (sub == 0 && row != NEED_EVICT);
       else if (is_new) {
         copy_bytes16<G>(v.rows + (size_t)row * v.row_stride, src, v.field_bytes, sub);
         if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, 0);
@@ -325,6 +335,7 @@ __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const
         row_add<DT>(v.rows + (size_t)row * v.row_stride, src, dim, sub);
         update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
       }  // absent & exists: dropped
+      if (deferred && sub == 0) deferred[i] = 0;
     }
   }
   for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
@@ -643,6 +654,22 @@ int Table::ensure_winner(hipStream_t s) {
   return TFRA_OK;
 }
 
+// Hkv flavour at max_capacity (the table cannot grow): *out = the per-key phase-2 flag buffer of a
+// two-phase (place, then evict) write; nullptr while the table can still grow or is unbounded.
+int Table::bounded_flags(size_t n, hipStream_t s, uint8_t** out) {
+  *out = nullptr;
+  const u64 max_nb_b = opts.max_capacity ? std::max<u64>(2, opts.max_capacity / SLOTS) : 0;
+  if (!(opts.strategy >= 0 && max_nb_b && cur.nb >= max_nb_b)) return TFRA_OK;
+  if (evict_flags_cap < n) {
+    if (evict_flags) { HIP_TRY(hipStreamSynchronize(s)); dfree(evict_flags, s); }
+    evict_flags = (uint8_t*)dalloc(n, s);
+    if (!evict_flags) { evict_flags_cap = 0; return set_error(TFRA_ERR_OOM, "eviction flag buffer allocation failed"); }
+    evict_flags_cap = n;
+  }
+  *out = evict_flags;
+  return TFRA_OK;
+}
+
 int Table::ensure_scratch(size_t bytes, hipStream_t s) {
   if (scratch_bytes >= bytes) return TFRA_OK;
   apply_P = 0;  // the armed cursor area of tfra_table_apply_sparse does not survive a reallocation
@@ -845,28 +872,28 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
 template <int DT>
 static void launch_accum(int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k, const unsigned char* vod,
                          const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai, int strat, u64 epoch,
-                         const int* order, size_t n_order) {
+                         const int* order, size_t n_order, uint8_t* deferred) {
   dim3 block(256);
   switch (g) {
-    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
   }
 }
 
 static void launch_accum_dt(int dt, int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k,
                             const unsigned char* vod, const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai,
-                            int strat, u64 epoch, const int* order, size_t n_order) {
+                            int strat, u64 epoch, const int* order, size_t n_order, uint8_t* deferred) {
   switch (dt) {
-    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
-    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order); break;
+    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
   }
 }
 
@@ -981,10 +1008,35 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
   const i64* k = (const i64*)keys;
   if (flags & TFRA_FLAG_UNIQUE_KEYS) {
     dim3 grid((unsigned)((n * 16 + 255) / 256));
+    uint8_t* deferred;
+    rc = t->bounded_flags(n, s, &deferred);
+    if (rc) return rc;
     launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
-                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, 0);
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, 0, deferred);
+    if (deferred) {  // phase 2: the absent keys that found no free slot replace a minimum-score entry
+      const unsigned char* vals = (const unsigned char*)vod;
+      const u64* sc = (const u64*)scores;
+      const int strat = t->opts.strategy;
+      const u64 epoch = t->global_epoch;
+      dim3 block(256);
+      switch (g) {
+        case 16: insert_evict_kernel<16><<<grid, block, 0, s>>>(v, n, k, vals, sc, 0, t->aux, strat, epoch, deferred); break;
+        case 8: insert_evict_kernel<8><<<grid, block, 0, s>>>(v, n, k, vals, sc, 0, t->aux, strat, epoch, deferred); break;
+        case 4: insert_evict_kernel<4><<<grid, block, 0, s>>>(v, n, k, vals, sc, 0, t->aux, strat, epoch, deferred); break;
+        case 2: insert_evict_kernel<2><<<grid, block, 0, s>>>(v, n, k, vals, sc, 0, t->aux, strat, epoch, deferred); break;
+        default: insert_evict_kernel<1><<<grid, block, 0, s>>>(v, n, k, vals, sc, 0, t->aux, strat, epoch, deferred); break;
+      }
+    }
     HIP_TRY(hipGetLastError());
     return TFRA_OK;
+  }
+  {
+    uint8_t* bounded_now;
+    rc = t->bounded_flags(1, s, &bounded_now);
+    if (rc) return rc;
+    if (bounded_now)
+      return set_error(TFRA_ERR_UNSUPPORTED, "accum: a bounded (Hkv) table at max_capacity needs TFRA_FLAG_UNIQUE_KEYS "
+                                             "(HKV's unique-keys contract) so that eviction is well defined");
   }
   // Duplicate-safe mode: the reference applies duplicates sequentially in index order
   // (LaunchTensorsAccum on one thread).  Group occurrences by key on the host and run one
@@ -1018,7 +1070,7 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
   for (auto& r : rounds) {
     dim3 grid((unsigned)((r.size() * 16 + 255) / 256));
     launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
-                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, d_order + off, r.size());
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, d_order + off, r.size(), nullptr);
     off += r.size();
   }
   HIP_TRY(hipGetLastError());

@@ -226,3 +226,51 @@ def test_fused_optimizer_lfu_admission_on_full_table(env):
   v, ex = var.lookup(hot, return_exists=True)
   assert bool(ex.all())
   np.testing.assert_allclose(v.cpu().numpy(), np.full((64, 8), -0.5, np.float32), rtol=1e-6)
+
+
+def test_accum_evicts_on_full_bounded_table(env):
+  """accum_or_assign on a full bounded table (the bp_v2 write-back, PY/dynamic_embedding_variable.py:806-855):
+  (absent, exists=False) inserts by evicting a minimum-score entry; (present, exists=True) adds in place;
+  mismatching flags stay no-ops (K/lookup_impl/lookup_table_op_cpu.h accumrase semantics)."""
+  torch, de = env
+  rng = np.random.default_rng(9)
+  t = de.get_variable("hkv_accum_full", key_dtype=torch.int64, value_dtype=torch.float32, initializer=0.0, dim=DIM,
+                      init_size=1024, kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                          init_capacity=1024, max_capacity=1024, max_hbm_for_values=1 << 20,
+                          evict_strategy=de.HkvEvictStrategy.LRU)))
+  for lo in range(0, 3000, 500):
+    k = np.arange(lo, lo + 500, dtype=np.int64)
+    t.upsert(torch.from_numpy(k).cuda(), torch.from_numpy(np.tile(k[:, None] * 1.0, (1, DIM)).astype(np.float32)).cuda())
+  assert int(t.size()) >= 1000
+  for step in range(4):
+    rk, rv = t.export()
+    rk, rv = rk.cpu().numpy(), rv.cpu().numpy()
+    pick = rng.choice(rk.size, size=120, replace=False)
+    present_add, present_noop = rk[pick[:80]], rk[pick[80:]]
+    fresh_ins = np.arange(10**7 + step * 300, 10**7 + step * 300 + 200, dtype=np.int64)
+    absent_noop = np.arange(2 * 10**7 + step * 50, 2 * 10**7 + step * 50 + 50, dtype=np.int64)
+    keys = np.concatenate([present_add, present_noop, fresh_ins, absent_noop])
+    exists = np.concatenate([np.ones(80, bool), np.zeros(40, bool), np.zeros(200, bool), np.ones(50, bool)])
+    order = rng.permutation(keys.size)
+    keys, exists = keys[order], exists[order]
+    delta = rng.integers(-8, 8, size=(keys.size, DIM)).astype(np.float32)
+    old = np.zeros_like(delta)
+    # Variable.accum computes where(exists, new - old, new): feed (old=0, new=delta)
+    t.accum(torch.from_numpy(keys).cuda(), torch.from_numpy(old).cuda(), torch.from_numpy(delta).cuda(),
+            torch.from_numpy(exists).cuda())
+    assert int(t.size()) <= 1024               # raises if a key could neither be placed nor evict
+    got, ex = t.lookup(torch.from_numpy(keys).cuda(), return_exists=True)
+    got, ex = got.cpu().numpy(), ex.cpu().numpy()
+    row_of = dict(zip(rk.tolist(), rv))
+    fresh_set, noop_set = set(fresh_ins.tolist()), set(absent_noop.tolist())
+    for i, (k, e) in enumerate(zip(keys.tolist(), exists.tolist())):
+      if k in noop_set:                         # absent & exists: dropped
+        assert not ex[i]
+      elif k in fresh_set:                      # absent & !exists: inserted (evicting), row = the delta
+        assert ex[i], "fresh key %d of step %d not resident" % (k, step)
+        np.testing.assert_array_equal(got[i], delta[i])
+      elif ex[i]:                               # still resident (LRU keeps what this step touched)
+        want = row_of[k] + delta[i] if e else row_of[k]
+        np.testing.assert_array_equal(got[i], want)
+      else:                                     # only an untouched (no-op) resident may have been evicted
+        assert not e
