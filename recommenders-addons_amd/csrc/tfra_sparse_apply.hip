@@ -8,17 +8,23 @@
 // repeats ~24 000 times, so the reduction must be parallel per key yet order-fixed:
 //
 //   A  tile_reduce   one block per TILE=512 ids (one id per thread): equal ids are grouped with an
-//      LDS hash, a packed (group, position) u32 is bitonic-sorted in REGISTERS (shuffles inside a
-//      wave, LDS only across waves).  One descriptor (key, src, tile) per unique key per tile is
-//      appended to the key's merge bucket (bucket = mulhi(fmix64(key), P), one returning atomic
-//      per descriptor on a per-bucket cursor): ids occurring once in the tile point straight at
-//      their gradient row (nothing is copied); runs of >= 2 are summed by 16-lane groups into a
-//      scratch row, ascending input position.
+//      LDS hash; a group's deterministic id is its FIRST POSITION in the tile, so the unique ranks
+//      and the order of the multi-member groups come out of block scans, and the members of a group
+//      are ranked by popcounts over a 512-bit position mask — no sort.  One descriptor
+//      (key, src, tile<<9|rank) per unique key per tile is appended to the key's merge bucket
+//      (bucket = mulhi(fmix64(key), P), one returning atomic per descriptor on a per-bucket cursor
+//      that lives on its own 128-B line): ids occurring once in the tile point straight at their
+//      gradient row (nothing is copied); runs of >= 2 are summed by 16-lane groups into a scratch
+//      row, ascending input position.
 //   C  bucket_merge  one block per bucket: loads its descriptors (one coalesced read), groups by key
-//      (LDS hash), sorts (group, tile), sums each key's parts in TILE ORDER -> ONE (key, src) per
-//      unique key of the batch (pass-through again when there is a single part).
+//      (LDS hash; group id = smallest descriptor id), passes single-part keys through, orders the
+//      few multi-part groups (register bitonic of <= 256 ids), ranks their members by tile with a
+//      tile bitmask + popcounts and sums each key's parts in TILE ORDER -> ONE (key, src) per
+//      unique key of the batch.
 //   apply_kernel<INDIRECT> (tfra_optim.hip) one 16-lane group per unique key: locate-or-insert
-//      the row, read [p|m|v], apply, write back.
+//      the row, read [p|m|v], apply, write back; re-arms the cursors for the next call.
+//   tfra_reduce_by_key = A + C + compact_gather_kernel (dense (key, sum) output in a deterministic
+//      order) for callers that route the sums elsewhere (multi-GPU gradient alltoall).
 //
 // Row reads are issued in batches of independent loads before the order-dependent adds, so the
 // kernels are bound by memory-level parallelism, not by one latency per row.
