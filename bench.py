@@ -141,6 +141,11 @@ def main():
   ap.add_argument("--keys", type=int, default=100_000_000, help="resident keys PER GPU")
   ap.add_argument("--batch", type=int, default=131072, help="ids per GPU per step")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--plan", choices=["off", "lookup", "prefetch"], default="off",
+                  help="where the id-only half of the write-back (which ids repeat, summation order, unique keys) is built: "
+                       "off = inside the write-back call; lookup = on a second HIP stream next to the lookup of the same "
+                       "batch; prefetch = on a second stream for batch i+1 while step i runs (ids known ahead, as an input "
+                       "pipeline provides them).  Every step builds exactly one plan inside the timed region.")
   ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (same kernels; "
                   "measured equal to eager launches: the step is bound by kernel boundaries, not by the host)")
   args = ap.parse_args()
@@ -208,13 +213,48 @@ def main():
 
   use_graph = world == 1 and args.graph
   captured = None
-  if use_graph:
+  prefetch_graph = use_graph and args.plan == "prefetch"
+  if prefetch_graph:
+    captured = de.CapturedPrefetchStep(var, deo, B)
+    captured.grads.copy_(grads)
+    captured.capture(ids_all[0])
+  elif use_graph:
     captured = de.CapturedTrainStep(var, deo, B)
     captured.grads.copy_(grads)
     captured.capture(warmup_ids=ids_all[0])
 
+  plan_mode = args.plan if world == 1 and not use_graph else "off"
+  side = torch.cuda.Stream(device=dev) if plan_mode != "off" else None
+  plans = [None, None]
+  main_stream = torch.cuda.current_stream(dev)
+
+  def build_plan(slot, ids):
+    side.wait_stream(main_stream)
+    with torch.cuda.stream(side):
+      plans[slot] = deo.plan(var, ids, plans[slot])
+
+  if plan_mode == "prefetch":
+    build_plan(0, ids_all[0])
+
   def step(i, timed_idx=None):
     ids = ids_all[i]
+    if plan_mode != "off":
+      if timed_idx is not None:
+        ev_a[timed_idx].record()
+      if plan_mode == "lookup":
+        build_plan(i & 1, ids)
+      else:  # the plan of THIS batch was built during the previous step; build the next one now
+        build_plan((i + 1) & 1, ids_all[(i + 1) % (K + W)])
+      out = var.lookup(ids)
+      if timed_idx is not None:
+        ev_b[timed_idx].record()
+      deo.apply_sparse(var, ids, grads, plan=plans[i & 1])
+      if timed_idx is not None:
+        ev_c[timed_idx].record()
+      return out
+    if prefetch_graph:
+      # one replay = [main: lookup + run sums + fused Adam of batch i] || [second stream: plan of batch i+1]
+      return captured.step(ids_all[(i + 1) % (K + W)])
     if captured is not None:
       # one HIP-graph replay = lookup + tile-reduce + bucket-merge + fused Adam (+ the batch copy)
       return captured.step(ids)
@@ -321,7 +361,11 @@ def main():
             "global_batch": B * world, "keys_per_gpu": resident, "unique_ratio": round(uniq_ratio, 4),
             "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
             "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
-            "launch": "hipGraph replay" if use_graph else "eager",
+            "launch": ("hipGraph replay (two streams)" if prefetch_graph else "hipGraph replay") if use_graph else "eager",
+            "write_back_plan": {"off": "built inside the write-back call",
+                                "lookup": "id-only half built on a second HIP stream next to the lookup of the same batch",
+                                "prefetch": "id-only half of batch i+1 built on a second HIP stream while step i runs "
+                                            "(one plan per step inside the timed region)"}["prefetch" if prefetch_graph else plan_mode],
         },
         "roofline": {
             "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",

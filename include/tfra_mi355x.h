@@ -192,9 +192,25 @@ int tfra_table_apply_optimizer(tfra_table_t* t, const tfra_opt_params* p, size_t
  * gradients of equal ids are summed in a fixed order (deterministic), then one fused update per
  * unique key as above.  = _resource_apply_sparse_duplicate_indices + the write-back sequence
  * (PY/dynamic_embedding_optimizer.py:165-204).  param_default_row: [dim] fp32, used for unseen keys.
- * Requires float32 values, dim % 4 == 0, dim <= 256. */
+ * Requires float32 values, dim % 4 == 0, dim <= 256, n <= 2^18 (262 144) ids per call. */
 int tfra_table_apply_sparse(tfra_table_t* t, const tfra_opt_params* p, size_t n, const int64_t* ids,
                             const float* grads, const float* param_default_row, tfra_stream_t stream);
+
+/* tfra_table_apply_sparse split at the point where gradients are needed.  Which ids repeat, in which
+ * order their gradients are summed and which unique keys the step updates depends on the ids alone,
+ * and the ids of a step are known at lookup time (PY/embedding_weights.py keeps them in the
+ * TrainableWrapper) or earlier (input pipeline).  tfra_sparse_plan_build does that id-only half on ANY
+ * stream — concurrently with the lookup of the same ids, or while the previous step still runs —
+ * and tfra_table_apply_planned does the gradient half (run sums + fused update) when the gradients
+ * exist.  Results are bit-identical to tfra_table_apply_sparse(ids, grads).  The caller orders the two
+ * calls (event / same stream) and keeps `plan` untouched until apply_planned's work has finished; a plan
+ * can be rebuilt for the next batch afterwards (it owns its device buffers: ~ (650 + 8*dim) B per id). */
+typedef struct tfra_sparse_plan tfra_sparse_plan_t;
+int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out);
+int tfra_sparse_plan_destroy(tfra_sparse_plan_t* plan);
+int tfra_sparse_plan_build(tfra_sparse_plan_t* plan, size_t n, const int64_t* ids, int dim, tfra_stream_t stream);
+int tfra_table_apply_planned(tfra_table_t* t, const tfra_opt_params* p, const tfra_sparse_plan_t* plan,
+                             const float* grads, const float* param_default_row, tfra_stream_t stream);
 
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 
@@ -219,8 +235,8 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
  * tfra_table_apply_sparse: PY/dynamic_embedding_optimizer.py:177-190): keys_out[0..*d_count) = the
  * distinct ids (a deterministic but unspecified order), rows_out[i,:] = sum of the rows of `in` whose
  * id is keys_out[i] (fixed summation tree: bit-reproducible, not the sequential order).  keys_out [n],
- * rows_out [n,dim]; fp32, dim % 4 == 0, dim <= 256, n <= 2^20.  *d_count = -1 if an internal limit
- * overflowed (more than 1024 partial sums of one key; cannot happen for n <= 2^19).  Unlike
+ * rows_out [n,dim]; fp32, dim % 4 == 0, dim <= 256, n <= 2^18.  *d_count = -1 if an internal limit
+ * overflowed (thousands of multi-part keys hashing into one merge bucket).  Unlike
  * tfra_segment_sum the cost does not grow with the multiplicity of the hottest id.            */
 int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int dim, const float* in,
                        int64_t* keys_out, float* rows_out, int64_t* d_count, tfra_stream_t stream);

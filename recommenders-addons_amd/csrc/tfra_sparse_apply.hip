@@ -59,6 +59,8 @@ constexpr int NTA = 512;     // kernel-A threads (32 groups of 16 lanes)
 constexpr int NT = 256;      // kernel-C threads (16 groups)
 constexpr int CMAX = 1024;   // descriptors one kernel-C pass holds in LDS = capacity of a bucket region
 constexpr int MAXCH = 4;     // D <= 256 (one float4 per lane per 64-column chunk)
+constexpr size_t MAX_IDS = (size_t)CMAX * TILE / 2;  // ids per call: a key present in every tile has n/TILE parts and
+                                                     // must fit one merge pass together with the keys sharing the pass
 constexpr unsigned SKIP = 0xffffffffu;
 constexpr unsigned char F_HEAD = 1, F_SINGLE = 2;
 constexpr unsigned CSTRIDE = 32;  // u32 words between bucket cursors: one 128-B line each (atomics on
@@ -285,11 +287,15 @@ struct DescStore {
 // unique ranks and the order of the multi-member groups come from block scans in position order
 // (= tf.unique order); the members of a multi-member group are ranked by popcounts over a
 // 512-bit position mask.
-template <int NCH>
+// PLAN: the id-only half (tfra_sparse_plan_build) — everything but the run sums; the run structure
+// (member position | head flag | unique rank, one u32 per list entry) is stored for tile_sums_kernel.
+template <int NCH, bool PLAN>
 __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* __restrict__ ids,
                                                           const float* __restrict__ grads, int dim, unsigned P,
                                                           unsigned rows_base, DescStore ds,
-                                                          float* __restrict__ scratch_rows, unsigned* overflow, int stop) {
+                                                          float* __restrict__ scratch_rows, unsigned* overflow, int stop,
+                                                          unsigned* __restrict__ plan_entries,
+                                                          unsigned* __restrict__ plan_len) {
   constexpr int NG = NTA / 16;
   constexpr unsigned GCAP = 2048;            // group table: 4x the tile => short probe chains
   constexpr int W = TILE / 32;               // words of a position bitmask
@@ -372,12 +378,48 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
     }
   }
   if (stop == 3) return;
+  if (PLAN) {
+    if (threadIdx.x == 0) plan_len[tile] = (unsigned)L;
+    for (int q = threadIdx.x; q < L; q += NTA)
+      plan_entries[base + q] = (unsigned)s_list[q] | ((unsigned)(s_flag[q] & F_HEAD) << 9) | ((unsigned)s_u[q] << 16);
+    return;
+  }
   if (L > 0) {
     ordered_run_sums<NCH, NG, 2 * Batch<NCH>::v>(  // one block per CU: registers for 16 rows in flight are free
         L, (L + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
         [&](int q) { return grads + (base + s_list[q]) * (size_t)dim; },
         [&](int ph) { return scratch_rows + (base + (size_t)s_u[ph]) * (size_t)dim; });
   }
+}
+
+// gradient half of kernel A for a planned batch: the run sums of one tile, following the stored run
+// structure (same chunking as the fused kernel => the same summation tree, bit for bit).
+template <int NCH>
+__global__ __launch_bounds__(NTA) void tile_sums_kernel(const float* __restrict__ grads, int dim,
+                                                        const unsigned* __restrict__ plan_entries,
+                                                        const unsigned* __restrict__ plan_len,
+                                                        float* __restrict__ scratch_rows) {
+  constexpr int NG = NTA / 16;
+  __shared__ unsigned short s_list[TILE + 1];
+  __shared__ unsigned short s_u[TILE];
+  __shared__ unsigned char s_flag[TILE + 1];
+  __shared__ float s_left[NG][64 * NCH];
+  __shared__ unsigned char s_cont[NG], s_hashead[NG];
+  const size_t tile = blockIdx.x, base = tile * TILE;
+  const int L = (int)plan_len[tile];
+  if (L == 0) return;
+  for (int q = threadIdx.x; q < L; q += NTA) {
+    const unsigned e = plan_entries[base + q];
+    s_list[q] = (unsigned short)(e & 511u);
+    s_flag[q] = (unsigned char)((e >> 9) & 1u);
+    s_u[q] = (unsigned short)(e >> 16);
+  }
+  if (threadIdx.x == 0) s_flag[L] = F_HEAD;
+  __syncthreads();
+  ordered_run_sums<NCH, NG, 2 * Batch<NCH>::v>(
+      L, (L + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
+      [&](int q) { return grads + (base + s_list[q]) * (size_t)dim; },
+      [&](int ph) { return scratch_rows + (base + (size_t)s_u[ph]) * (size_t)dim; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,13 +429,25 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
 // publishes the total entry count.
 // A bucket with more than CMAX descriptors is processed in 2^k passes, pass q taking the keys with
 // (hash & (2^k-1)) == q, reading its region plus its share of the overflow list.
-template <int NCH>
+// PLAN: the id-only half — (key, src) outputs as usual, no sums; per pass with multi-part keys the member
+// list is stored as (src of the member, head flag | scratch row of the run's sum) for bucket_sums_kernel.
+struct BucketPlan {
+  unsigned* src;      // [d_total slots] src of list entry (off_b + position)
+  unsigned* outf;     // [d_total slots] bit 31 = run head, low bits = scratch row receiving the run's sum
+  uint2* pass;        // [P * MAXPASS] (start inside the bucket's slot range, L) of every pass with L > 0
+  unsigned* npass;    // [P]
+  unsigned* off;      // [P] first slot of the bucket
+};
+constexpr int MAXPASS = 64;
+
+template <int NCH, bool PLAN>
 __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned ntiles, int dim, unsigned rows_base,
                                                           unsigned sum_base,
                                                           const float* __restrict__ grads, DescStore ds,
                                                           float* __restrict__ scratch_rows, i64* __restrict__ u_keys,
                                                           unsigned* __restrict__ u_src, i64* __restrict__ d_total,
-                                                          unsigned* overflow, int stop, uint2* __restrict__ bucket_out) {
+                                                          unsigned* overflow, int stop, uint2* __restrict__ bucket_out,
+                                                          BucketPlan bp) {
   constexpr int NG = NT / 16;
   constexpr unsigned GCAP = CMAX;   // group table as large as the pass (LDS budget: 4 blocks per CU)
   static_assert(CMAX == 1024, "10 entry bits");
@@ -426,10 +480,12 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
   const unsigned n_ovf = n_b > CMAX ? min(*ds.ovf_count, ds.ovf_cap) : 0u;
   __syncthreads();
   if (threadIdx.x == 0 && b == P - 1) *d_total = off + n_b;
+  if (PLAN && threadIdx.x == 0) { bp.off[b] = (unsigned)off; bp.npass[b] = 0; }
   if (n_b == 0) {
     if (bucket_out && threadIdx.x == 0) bucket_out[b] = make_uint2((unsigned)off, 0u);
     return;
   }
+  int plan_used = 0, plan_np = 0;  // PLAN: list slots and passes stored so far
   unsigned npass = 1;
   if (n_b > CMAX) while ((unsigned)n_b > (unsigned)(CMAX / 2) * npass && npass < 64) npass <<= 1;
   const int n_reg = min(n_b, CMAX);
@@ -510,7 +566,7 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     }
     __syncthreads();
     if (n_multi > NT) {  // more multi-part keys than one per thread: split the bucket further by key hash
-      if (npass < 64) { npass <<= 1; pass = (unsigned)-1; out_used = 0; }
+      if (npass < 64) { npass <<= 1; pass = (unsigned)-1; out_used = 0; plan_used = 0; plan_np = 0; }
       else if (threadIdx.x == 0) atomicAdd(overflow, 1u);
       continue;
     }
@@ -574,6 +630,21 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
     const long long obase = off + out_used + n_single;
     const int ccarry = n_single + n_multi;
     if (stop == 2 || stop == 3) { out_used += ccarry; continue; }
+    if (PLAN) {
+      if (L > 0) {
+        for (int q = threadIdx.x; q < L; q += NT) {
+          bp.src[off + plan_used + q] = e_src[s_list[q]];
+          bp.outf[off + plan_used + q] =
+              (s_flag[q] & F_HEAD) ? (0x80000000u | (sum_base - rows_base + (unsigned)(obase + s_rank[q]))) : 0u;
+        }
+        if (threadIdx.x == 0) bp.pass[(size_t)b * MAXPASS + plan_np] = make_uint2((unsigned)plan_used, (unsigned)L);
+        plan_used += L;
+        plan_np += 1;
+      }
+      out_used += ccarry;
+      __syncthreads();
+      continue;
+    }
     if (L > 0) {
       ordered_run_sums<NCH, NG, Batch<NCH>::v>(
           L, (L + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
@@ -588,6 +659,46 @@ __global__ __launch_bounds__(NT) void bucket_merge_kernel(unsigned P, unsigned n
   }
   for (int i = out_used + threadIdx.x; i < n_b; i += NT) u_src[off + i] = SKIP;
   if (bucket_out && threadIdx.x == 0) bucket_out[b] = make_uint2((unsigned)off, (unsigned)out_used);
+  if (PLAN && threadIdx.x == 0) bp.npass[b] = (unsigned)plan_np;
+}
+
+// gradient half of kernel C for a planned batch: per pass the ordered sums of the multi-part keys'
+// parts (same chunking as the fused kernel => the same summation tree).
+template <int NCH>
+__global__ __launch_bounds__(NT) void bucket_sums_kernel(int dim, unsigned rows_base, const float* __restrict__ grads,
+                                                         float* __restrict__ scratch_rows, BucketPlan bp,
+                                                         const unsigned* __restrict__ plan_err, unsigned* table_err) {
+  constexpr int NG = NT / 16;
+  __shared__ unsigned e_src[CMAX];
+  __shared__ unsigned s_out[CMAX];
+  __shared__ unsigned char s_flag[CMAX + 1];
+  __shared__ float s_left[NG][64 * NCH];
+  __shared__ unsigned char s_cont[NG], s_hashead[NG];
+  const unsigned b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && *plan_err) atomicAdd(table_err, *plan_err);
+  const unsigned np = bp.npass[b];
+  if (np == 0) return;
+  const size_t off = bp.off[b];
+  for (unsigned ps = 0; ps < np; ++ps) {
+    const uint2 pl = bp.pass[(size_t)b * MAXPASS + ps];
+    const int L = (int)pl.y;
+    for (int q = threadIdx.x; q < L; q += NT) {
+      e_src[q] = bp.src[off + pl.x + q];
+      const unsigned of = bp.outf[off + pl.x + q];
+      s_out[q] = of & 0x7fffffffu;
+      s_flag[q] = (of >> 31) ? F_HEAD : 0;
+    }
+    if (threadIdx.x == 0) s_flag[L] = F_HEAD;
+    __syncthreads();
+    ordered_run_sums<NCH, NG, Batch<NCH>::v>(
+        L, (L + NG - 1) / NG, dim, s_flag, s_left, s_cont, s_hashead,
+        [&](int q) {
+          unsigned src = e_src[q];
+          return src < rows_base ? grads + (size_t)src * dim : scratch_rows + (size_t)(src - rows_base) * dim;
+        },
+        [&](int ph) { return scratch_rows + (size_t)s_out[ph] * dim; });
+    __syncthreads();
+  }
 }
 
 // tfra_reduce_by_key epilogue: bucket b's unique keys (u_keys/u_src[off_b .. off_b+cnt_b)) go to the
@@ -652,9 +763,10 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   if (dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)param_default_row) & 15))
     return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
                                            "(use tfra_unique + tfra_segment_sum + tfra_table_apply_optimizer otherwise)");
-  if (n > (1ULL << 20))
-    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^20 ids per call (tile index has 11 bits and one key "
-                                           "may hold ntiles <= CMAX parts); split the batch or use the unique + "
+  if (n > MAX_IDS)
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^18 ids per call (one partial sum per key and 512-id "
+                                           "tile; a merge pass holds 1024 partial sums, so a key in every tile must leave "
+                                           "room for the keys sharing its pass); split the batch or use the unique + "
                                            "segment_sum path");
   rc = t->prepare_insert(n, s);
   if (rc) return rc;
@@ -698,16 +810,16 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   static const int stop_a = getenv("TFRA_DBG_STOP_A") ? atoi(getenv("TFRA_DBG_STOP_A")) : 0;
   static const int stop_c = getenv("TFRA_DBG_STOP_C") ? atoi(getenv("TFRA_DBG_STOP_C")) : 0;
   switch (nch) {
-    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
-    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
-    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
-    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a); break;
+    case 1: tile_reduce_kernel<1, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a, nullptr, nullptr); break;
+    case 2: tile_reduce_kernel<2, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a, nullptr, nullptr); break;
+    case 3: tile_reduce_kernel<3, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a, nullptr, nullptr); break;
+    default: tile_reduce_kernel<4, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a, nullptr, nullptr); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr); break;
+    case 1: bucket_merge_kernel<1, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr, BucketPlan{}); break;
+    case 2: bucket_merge_kernel<2, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr, BucketPlan{}); break;
+    case 3: bucket_merge_kernel<3, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr, BucketPlan{}); break;
+    default: bucket_merge_kernel<4, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, t->err_count, stop_c, nullptr, BucketPlan{}); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
   // the apply kernel runs after every merge block has read the cursors: it zeroes them for the next
@@ -730,7 +842,7 @@ extern "C" int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t*
   if (dim <= 0 || dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)rows_out) & 15))
     return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
                                            "(use tfra_unique + tfra_segment_sum otherwise)");
-  if (n > (1ULL << 20)) return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: at most 2^20 ids per call");
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: at most 2^18 ids per call");
   const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
   unsigned P = 64;
   while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
@@ -768,19 +880,163 @@ extern "C" int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t*
   const i64* k = (const i64*)ids;
   dim3 ga((unsigned)ntiles), gc(P);
   switch (nch) {
-    case 1: tile_reduce_kernel<1><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
-    case 2: tile_reduce_kernel<2><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
-    case 3: tile_reduce_kernel<3><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
-    default: tile_reduce_kernel<4><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0); break;
+    case 1: tile_reduce_kernel<1, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0, nullptr, nullptr); break;
+    case 2: tile_reduce_kernel<2, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0, nullptr, nullptr); break;
+    case 3: tile_reduce_kernel<3, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0, nullptr, nullptr); break;
+    default: tile_reduce_kernel<4, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, err, 0, nullptr, nullptr); break;
   }
   switch (nch) {
-    case 1: bucket_merge_kernel<1><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
-    case 2: bucket_merge_kernel<2><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
-    case 3: bucket_merge_kernel<3><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
-    default: bucket_merge_kernel<4><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out); break;
+    case 1: bucket_merge_kernel<1, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out, BucketPlan{}); break;
+    case 2: bucket_merge_kernel<2, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out, BucketPlan{}); break;
+    case 3: bucket_merge_kernel<3, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out, BucketPlan{}); break;
+    default: bucket_merge_kernel<4, false><<<gc, NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, grads, ds, rows, u_keys, u_src, d_total, err, 0, bucket_out, BucketPlan{}); break;
   }
   compact_gather_kernel<<<gc, 256, 0, s>>>(P, dim, rows_base, grads, rows, u_keys, u_src, bucket_out, err, (i64*)keys_out, rows_out,
                                            (i64*)d_count);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: launch failed");
   return TFRA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Planned write-back: the id-only half of tfra_table_apply_sparse (grouping, ranks, descriptors,
+// (key, src) outputs, run structure) is built ahead — on any stream, typically concurrently with the
+// lookup of the same ids or while the previous step is still running — and the gradient half
+// (run sums of tiles, run sums of buckets, fused apply) follows it when the gradients exist.
+struct tfra_sparse_plan {
+  int device = 0;
+  void* buf = nullptr;
+  size_t bytes = 0;
+  // filled by build
+  size_t n = 0, npad = 0, ntiles = 0;
+  unsigned P = 0;
+  int dim = 0;
+  unsigned* cursors = nullptr;
+  unsigned* err = nullptr;
+  unsigned* tile_entries = nullptr;
+  unsigned* tile_len = nullptr;
+  BucketPlan bp{};
+  i64* u_keys = nullptr;
+  unsigned* u_src = nullptr;
+  i64* d_total = nullptr;
+  float* rows = nullptr;
+};
+
+extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
+  if (!out) return set_error(TFRA_ERR_INVALID, "sparse_plan_create: null out");
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_create: no device");
+  tfra_sparse_plan* pl = new tfra_sparse_plan();
+  pl->device = device;
+  *out = pl;
+  return TFRA_OK;
+}
+
+extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
+  if (!pl) return TFRA_OK;
+  if (pl->buf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->buf); }
+  delete pl;
+  return TFRA_OK;
+}
+
+extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const int64_t* ids, int dim, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pl) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null plan");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != pl->device) { if (hipSetDevice(pl->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: hipSetDevice"); } }
+  pl->n = 0;
+  if (n == 0) return TFRA_OK;
+  if (!ids) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null ids");
+  if (dim <= 0 || dim % 4 != 0 || dim > 64 * MAXCH)
+    return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: needs dim % 4 == 0 and dim <= 256");
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
+  const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
+  unsigned P = 64;
+  while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t reg = (size_t)P * CMAX;
+  const size_t head = al((size_t)(P + 2) * CSTRIDE * 4);
+  size_t bytes = head + al(reg * 8) + 2 * al(reg * 4) + al(npad * 8) + 3 * al(npad * 4)   // descriptors + overflow list
+                 + al(npad * 8) + al(npad * 4) + 256                                       // u_keys, u_src, d_total
+                 + al(npad * 4) + al(ntiles * 4)                                           // tile run structure
+                 + 2 * al(npad * 4) + al((size_t)P * MAXPASS * 8) + 2 * al((size_t)P * 4)  // bucket run structure
+                 + 2 * al(npad * (size_t)dim * 4);                                         // partial-sum rows
+  if (pl->bytes < bytes) {
+    if (pl->buf) {
+      if (hipDeviceSynchronize() != hipSuccess || hipFree(pl->buf) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: free");
+      pl->buf = nullptr; pl->bytes = 0;
+    }
+    hipError_t e = hipMalloc(&pl->buf, bytes);
+    if (e != hipSuccess) { pl->buf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
+    pl->bytes = bytes;
+  }
+  unsigned char* w = (unsigned char*)pl->buf;
+  pl->cursors = (unsigned*)w; w += head;
+  if (hipMemsetAsync(pl->cursors, 0, head, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+  DescStore ds;
+  ds.key = (i64*)w; w += al(reg * 8);
+  ds.src = (unsigned*)w; w += al(reg * 4);
+  ds.ord = (unsigned*)w; w += al(reg * 4);
+  ds.ovf_key = (i64*)w; w += al(npad * 8);
+  ds.ovf_src = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_ord = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_bucket = (unsigned*)w; w += al(npad * 4);
+  pl->u_keys = (i64*)w; w += al(npad * 8);
+  pl->u_src = (unsigned*)w; w += al(npad * 4);
+  pl->d_total = (i64*)w; w += 256;
+  pl->tile_entries = (unsigned*)w; w += al(npad * 4);
+  pl->tile_len = (unsigned*)w; w += al(ntiles * 4);
+  pl->bp.src = (unsigned*)w; w += al(npad * 4);
+  pl->bp.outf = (unsigned*)w; w += al(npad * 4);
+  pl->bp.pass = (uint2*)w; w += al((size_t)P * MAXPASS * 8);
+  pl->bp.npass = (unsigned*)w; w += al((size_t)P * 4);
+  pl->bp.off = (unsigned*)w; w += al((size_t)P * 4);
+  pl->rows = (float*)w;
+  ds.cursor = pl->cursors;
+  ds.ovf_count = pl->cursors + (size_t)P * CSTRIDE;
+  ds.ovf_cap = (unsigned)npad;
+  pl->err = pl->cursors + (size_t)(P + 1) * CSTRIDE;
+  const unsigned rows_base = (unsigned)npad, sum_base = (unsigned)(2 * npad);
+  tile_reduce_kernel<1, true><<<dim3((unsigned)ntiles), NTA, 0, s>>>(n, (const i64*)ids, nullptr, dim, P, rows_base, ds, nullptr,
+                                                                     pl->err, 0, pl->tile_entries, pl->tile_len);
+  bucket_merge_kernel<1, true><<<dim3(P), NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, nullptr, ds, nullptr,
+                                                       pl->u_keys, pl->u_src, pl->d_total, pl->err, 0, nullptr, pl->bp);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
+  pl->n = n; pl->npad = npad; pl->ntiles = ntiles; pl->P = P; pl->dim = dim;
+  return TFRA_OK;
+}
+
+extern "C" int tfra_table_apply_planned(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl,
+                                        const float* grads, const float* param_default_row, tfra_stream_t stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !p || !pl) return set_error(TFRA_ERR_INVALID, "apply_planned: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(t->mu);
+  int rc = t->enter(s);
+  if (rc) return rc;
+  if (pl->n == 0) return TFRA_OK;
+  if (!grads || !param_default_row) return set_error(TFRA_ERR_INVALID, "apply_planned: null buffer");
+  if (t->opts.value_dtype != TFRA_F32) return set_error(TFRA_ERR_UNSUPPORTED, "apply_planned: value_dtype must be float32");
+  if (p->kind < 0 || p->kind > TFRA_OPT_FTRL) return set_error(TFRA_ERR_INVALID, "apply_planned: unknown kind");
+  int need = p->kind == TFRA_OPT_SGD ? 0 : (p->kind == TFRA_OPT_ADAGRAD ? 1 : 2);
+  if (t->opts.aux_fields < need) return set_error(TFRA_ERR_INVALID, "apply_planned: table lacks optimizer slot fields");
+  if (t->opts.dim != pl->dim) return set_error(TFRA_ERR_INVALID, "apply_planned: the plan was built for another dim");
+  if (t->opts.device != pl->device && t->opts.device >= 0) return set_error(TFRA_ERR_INVALID, "apply_planned: plan and table live on different devices");
+  if ((((uintptr_t)grads | (uintptr_t)param_default_row) & 15))
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_planned: gradient / default buffers must be 16-B aligned");
+  rc = t->prepare_insert(pl->n, s);
+  if (rc) return rc;
+  const int dim = pl->dim;
+  const unsigned rows_base = (unsigned)pl->npad;
+  dim3 ga((unsigned)pl->ntiles), gc(pl->P);
+  switch ((dim + 63) / 64) {
+    case 1: tile_sums_kernel<1><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows);
+            bucket_sums_kernel<1><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
+    case 2: tile_sums_kernel<2><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows);
+            bucket_sums_kernel<2><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
+    case 3: tile_sums_kernel<3><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows);
+            bucket_sums_kernel<3><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
+    default: tile_sums_kernel<4><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows);
+             bucket_sums_kernel<4><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
+  }
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_planned: launch failed");
+  return launch_apply_indirect(t, s, p, pl->npad, pl->u_keys, pl->u_src, grads, pl->rows, rows_base, param_default_row,
+                               pl->d_total, nullptr, 0, 0);
 }

@@ -78,6 +78,10 @@ _SIGS = {
     "tfra_table_load": [_P, ctypes.c_char_p, _SZ, _P, ctypes.POINTER(_SZ)],
     "tfra_table_apply_optimizer": [_P, ctypes.POINTER(OptParams), _SZ, _P, _P, _P, _I, _P, _P],
     "tfra_table_apply_sparse": [_P, ctypes.POINTER(OptParams), _SZ, _P, _P, _P, _P],
+    "tfra_sparse_plan_create": [_I, _P],
+    "tfra_sparse_plan_destroy": [_P],
+    "tfra_sparse_plan_build": [_P, _SZ, _P, _I, _P],
+    "tfra_table_apply_planned": [_P, ctypes.POINTER(OptParams), _P, _P, _P, _P],
     "tfra_workspace_create": [_I, ctypes.POINTER(_P)],
     "tfra_workspace_destroy": [_P],
     "tfra_unique": [_P, _SZ, _P, _P, _P, _P, _P],

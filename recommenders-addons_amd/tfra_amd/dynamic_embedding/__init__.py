@@ -2,9 +2,9 @@
 (`/root/reference/tensorflow_recommenders_addons/dynamic_embedding/__init__.py`) for the hot path."""
 from . import device_ops
 from . import optimizer as optimizers
-from .optimizer import CapturedTrainStep, DynamicEmbeddingOptimizer
+from .optimizer import CapturedPrefetchStep, CapturedTrainStep, DynamicEmbeddingOptimizer
 from .restrict_policies import FrequencyRestrictPolicy, RestrictPolicy, TimestampRestrictPolicy
-from .table_ops import (CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
+from .table_ops import (SparsePlan, CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
                         KHkvHashTableMaxCapacity, KHkvHashTableMaxHbmForValuesByBytes)
 from .variable import (CuckooHashTableConfig, CuckooHashTableCreator, HkvHashTableConfig, HkvHashTableCreator,
                        KVCreator, TrainableWrapper, Variable, default_partition_fn, embedding_lookup,

@@ -38,7 +38,7 @@ class _DeviceOps:
     return self._o.segment_sum(grads, idx, cnt, max_segments)
 
   def can_reduce_by_key(self, n, dim):
-    return dim % 4 == 0 and dim <= 256 and n <= (1 << 19)
+    return dim % 4 == 0 and dim <= 256 and n <= (1 << 18)
 
   def reduce_by_key(self, ids, grads):
     return self._o.reduce_by_key(ids, grads)

@@ -158,12 +158,36 @@ class DynamicEmbeddingOptimizer:
         raise TypeError("expected the TrainableWrapper returned by embedding_lookup(..., return_trainable=True)")
       self.apply_sparse(tw.params, tw.ids, grad, p)
 
-  def apply_sparse(self, var, ids, grad, p=None):
+  @staticmethod
+  def can_plan(var, n):
+    """The planned / two-kernel write-back covers one shard, fp32 rows with dim % 4 == 0, dim <= 256."""
+    return (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and
+            n <= (1 << 18) and var.value_dtype == torch.float32)
+
+  def plan(self, var, ids, plan=None):
+    """Build (or rebuild) the id-only half of `apply_sparse(var, ids, ...)` on the current stream; pass the
+    result as `apply_sparse(..., plan=plan)`.  Call it under `torch.cuda.stream(side_stream)` to overlap it
+    with the lookup of the same ids or with the previous step."""
+    from .table_ops import SparsePlan
+    ids = torch.as_tensor(ids, device=var._primary).reshape(-1)
+    if not self.can_plan(var, ids.numel()) or self.exact_order:
+      raise ValueError("this variable / batch takes the unique + segment_sum write-back, which has no plan")
+    if plan is None:
+      plan = SparsePlan(var._tables[0]._device, var.dim)
+    return plan.build(ids)
+
+  def apply_sparse(self, var, ids, grad, p=None, plan=None):
     """Sum gradients of duplicate ids, then one fused update per unique key and shard."""
     if p is None:
       self.iterations += 1
       p = self.opt.params(self.iterations)
     self._check(var)
+    if plan is not None:
+      if getattr(var, "restrict_policy", None) is not None:
+        var.restrict_policy.apply_update(plan.ids)
+      t = var._tables[0]
+      t._table.apply_planned(p, plan, grad.reshape(-1, var.dim), t._default_value.to(torch.float32))
+      return
     ids = torch.as_tensor(ids, device=var._primary).reshape(-1)
     grad = grad.reshape(-1, var.dim).to(torch.float32)
     n = ids.numel()
@@ -172,7 +196,7 @@ class DynamicEmbeddingOptimizer:
     if getattr(var, "restrict_policy", None) is not None:  # PY/embedding_weights.py:441-442
       var.restrict_policy.apply_update(ids)
     if (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and
-        n <= (1 << 20) and not self.exact_order):
+        n <= (1 << 18) and not self.exact_order):
       # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic
       t = var._tables[0]
       t._table.apply_sparse(p, ids, grad, t._default_value.to(torch.float32))
@@ -259,6 +283,93 @@ class CapturedTrainStep:
     self._params()  # advances the global step and refreshes the device-side lr_t
     self.graph.replay()
     return self.out
+
+  def close(self):
+    self.table.set_capture_safe(False)
+
+
+class CapturedPrefetchStep:
+  """Two-stream training step captured into HIP graphs: while the main stream runs batch i
+  (lookup -> run sums following plan i -> fused update), a second stream builds the plan of batch i+1
+  (its ids are known ahead, as an input pipeline provides them).  The id-only half of the write-back
+  (which ids repeat, in which order their gradients are summed, the unique keys) is ~40 % of a step and
+  leaves the critical path; launched eagerly the extra launches would make the step host-bound, so the
+  fork/join lives inside the graph.  Two graphs alternate (the two plans and id buffers swap roles).
+
+      cs = CapturedPrefetchStep(var, deo, batch).capture(first_ids)
+      for batch in stream:  out = cs.step(next_ids, grads)     # runs the batch staged by the previous call
+  """
+
+  def __init__(self, var, optimizer, batch, reserve_slots=None):
+    from .table_ops import SparsePlan
+    if var.shard_num != 1 or not DynamicEmbeddingOptimizer.can_plan(var, batch):
+      raise ValueError("CapturedPrefetchStep needs a single-shard fp32 Variable with dim % 4 == 0, dim <= 256")
+    self.var, self.deo, self.batch = var, optimizer, int(batch)
+    self.t = var.tables[0]
+    self.table = self.t._table
+    dev = self.table.device
+    self.dev = dev
+    self.ids = [torch.zeros(self.batch, dtype=torch.int64, device=dev) for _ in range(2)]
+    self.grads = torch.zeros((self.batch, var.dim), dtype=torch.float32, device=dev)
+    self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
+    self.plans = [SparsePlan(dev, var.dim) for _ in range(2)]
+    self.default = self.t._default_value.to(torch.float32)
+    self.side = torch.cuda.Stream(device=dev)
+    self.graphs = [None, None]
+    self.out = [None, None]
+    self.cur = 0
+    if reserve_slots:
+      self.table.reserve(reserve_slots)
+
+  def _params(self):
+    self.deo.iterations += 1
+    p = self.deo.opt.params(self.deo.iterations)
+    self.lr.fill_(p.lr)
+    p.d_lr = self.lr.data_ptr()
+    return p
+
+  def _body(self, cur, p):
+    main = torch.cuda.current_stream(self.dev)
+    self.side.wait_stream(main)                                  # fork
+    with torch.cuda.stream(self.side):
+      self.plans[1 - cur].build(self.ids[1 - cur], sync=False)   # plan of the NEXT batch
+    self.out[cur] = self.var.lookup(self.ids[cur])
+    self.table.apply_planned(p, self.plans[cur], self.grads, self.default, sync=False)
+    main.wait_stream(self.side)                                  # join
+
+  def capture(self, first_ids):
+    """Stages `first_ids` as the first batch, sizes every buffer with two eager warm-up steps on that
+    batch (they are real steps: the table sees them), then captures the two graphs."""
+    self.table.set_capture_safe(True)
+    for b in self.ids:
+      b.copy_(first_ids.reshape(-1))
+    warm = torch.cuda.Stream(device=self.dev)
+    warm.wait_stream(torch.cuda.current_stream(self.dev))
+    with torch.cuda.stream(warm):
+      self.plans[0].build(self.ids[0], sync=False)
+      for cur in (0, 1):
+        self._body(cur, self._params())
+    torch.cuda.current_stream(self.dev).wait_stream(warm)
+    torch.cuda.synchronize(self.dev)
+    for cur in (0, 1):
+      p = self._params()
+      self.graphs[cur] = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graphs[cur]):
+        self._body(cur, p)
+    self.deo.iterations -= 2                                     # captures do not execute
+    self.cur = 0                                                 # plans[0] is built for ids[0] (= first_ids)
+    return self
+
+  def step(self, next_ids, grads=None):
+    """Runs the staged batch, stages `next_ids` (its plan is built meanwhile); returns the staged batch's rows."""
+    cur = self.cur
+    self.ids[1 - cur].copy_(next_ids.reshape(-1))
+    if grads is not None:
+      self.grads.copy_(grads.reshape(self.batch, -1))
+    self._params()
+    self.graphs[cur].replay()
+    self.cur = 1 - cur
+    return self.out[cur]
 
   def close(self):
     self.table.set_capture_safe(False)

@@ -309,6 +309,68 @@ def _apply_sparse(self, params, ids, grads, default_row):
 _DeviceTable.apply_sparse = _apply_sparse
 
 
+class SparsePlan:
+  """The id-only half of `apply_sparse` for one batch (tfra_sparse_plan_*): which ids repeat, the order
+  their gradients are summed in, the unique keys of the step.  Build it as soon as the ids are known —
+  on a side stream next to the lookup of the same ids, or while the previous step is still running —
+  and hand it to `_DeviceTable.apply_planned` with the gradients.  Stream ordering is handled here:
+  `apply_planned` waits for the build, a rebuild waits for the last `apply_planned` that used the plan."""
+
+  def __init__(self, device, dim):
+    self._device = _as_device(device)
+    self._dim = int(dim)
+    self._h = ctypes.c_void_p()
+    _capi.call("tfra_sparse_plan_create", self._device.index, ctypes.byref(self._h))
+    self._built = torch.cuda.Event()
+    self._used = None
+    self.ids = None
+    self.n = 0
+
+  def build(self, ids, sync=True):
+    """Enqueue the build on the CURRENT stream of the plan's device.  sync=False leaves the ordering
+    against `apply_planned` to the caller (a captured HIP graph orders them by its edges)."""
+    ids = ids.to(self._device, torch.int64).contiguous().reshape(-1)
+    stream = torch.cuda.current_stream(self._device)
+    if sync:
+      if self._used is not None:
+        stream.wait_event(self._used)     # the previous batch's sums/apply still read the plan buffers
+      ids.record_stream(stream)
+    self.ids, self.n = ids, ids.numel()   # keeps the ids alive until the next build
+    _capi.call("tfra_sparse_plan_build", self._h, self.n, _ptr(ids), self._dim, _stream(self._device))
+    if sync:
+      self._built.record(stream)
+    return self
+
+  def __del__(self):
+    try:
+      if self._h:
+        _capi.call("tfra_sparse_plan_destroy", self._h)
+        self._h = None
+    except Exception:
+      pass
+
+
+def _apply_planned(self, params, plan, grads, default_row, sync=True):
+  """Gradient half of apply_sparse for a batch whose id-only half was built ahead (`SparsePlan`)."""
+  if plan._dim != self._dim or plan._device != self._device:
+    raise ValueError("the plan was built for dim %d on %s" % (plan._dim, plan._device))
+  grads = grads.to(self._device, torch.float32).contiguous()
+  if grads.numel() != plan.n * self._dim:
+    raise ValueError("Expected shape %s for grads, got %s" % ([plan.n, self._dim], list(grads.shape)))
+  d = default_row.to(self._device, torch.float32).contiguous()
+  stream = torch.cuda.current_stream(self._device)
+  if sync:
+    stream.wait_event(plan._built)
+  _capi.call("tfra_table_apply_planned", self._h, ctypes.byref(params), plan._h, _ptr(grads), _ptr(d), _stream(self._device))
+  if sync:
+    if plan._used is None:
+      plan._used = torch.cuda.Event()
+    plan._used.record(stream)
+
+
+_DeviceTable.apply_planned = _apply_planned
+
+
 class _LookupInterfaceMirror:
   """Shared method surface of CuckooHashTable / HkvHashTable (tf LookupInterface subclasses)."""
 

@@ -105,8 +105,8 @@ def test_partition_with_device_count(env, n_valid):
 
 
 @pytest.mark.parametrize("n,dim,hi,zipf", [(1, 4, 5, False), (511, 8, 40, False), (513, 64, 10**9, False),
-                                            (131072, 64, 10**8, True), (300000, 16, 2000, True),
-                                            (524288, 128, 50, False), (40000, 256, 3, False)])
+                                            (131072, 64, 10**8, True), (250000, 16, 2000, True),
+                                            (262144, 128, 50, False), (40000, 256, 3, False)])
 def test_reduce_by_key(env, n, dim, hi, zipf):
   """unique + unsorted_segment_sum in one call: key set exact, sums vs an fp64 restatement, bit-reproducible."""
   torch, de = env
@@ -426,6 +426,89 @@ def test_apply_sparse_hot_bucket_multipass(env):
   np.testing.assert_allclose(val.cpu().numpy()[o], ev, rtol=2e-6, atol=2e-6)
 
 
+def _hot_bucket_ids(rng, n):
+  from bench import fmix64_np
+  P = 64
+  while P < 2048 and P * 128 < n:
+    P *= 2
+  cand = rng.integers(1, 2**62, size=200000).astype(np.int64)
+  h = fmix64_np(cand.astype(np.uint64))
+  bucket = ((h >> np.uint64(32)).astype(np.uint64) * np.uint64(P)) >> np.uint64(32)
+  hot = cand[bucket == 7][:100]
+  ids = np.concatenate([np.tile(hot, n // 100), hot[: n % 100]])
+  rng.shuffle(ids)
+  return ids
+
+
+@pytest.mark.parametrize("kind,dim,n,shape", [("adam", 64, 131072, "zipf"), ("ftrl", 8, 3001, "zipf"),
+                                               ("adagrad", 128, 20000, "uniform"), ("sgd", 256, 5000, "zipf"),
+                                               ("adagrad", 8, 40064, "hot_bucket"), ("adam", 16, 1, "uniform"),
+                                               ("adam", 32, 262144, "zipf")])
+def test_planned_write_back_is_bit_identical(env, kind, dim, n, shape):
+  """tfra_sparse_plan_build (on a side stream) + tfra_table_apply_planned == tfra_table_apply_sparse, bit
+  for bit, over several steps with the plan object reused — same keys, same rows, same slots."""
+  torch, de = env
+  from bench import zipf_bounded, keys_of_ranks
+  rng = np.random.default_rng(n + dim)
+  mk = {"sgd": lambda: de.optimizers.SGD(0.1), "adam": lambda: de.optimizers.Adam(0.01),
+        "adagrad": lambda: de.optimizers.Adagrad(0.05, 0.1),
+        "ftrl": lambda: de.optimizers.Ftrl(0.05, l1_regularization_strength=1e-3, l2_regularization_strength=1e-3)}[kind]
+  opt_a, opt_b = mk(), mk()
+  kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt_a)
+  name = "plan_%s_%d_%d_%s" % (kind, dim, n, shape)
+  a = de.Variable(dim=dim, name=name + "_a", initializer=0.3, **kw)
+  b = de.Variable(dim=dim, name=name + "_b", initializer=0.3, **kw)
+  da, db = de.DynamicEmbeddingOptimizer(opt_a), de.DynamicEmbeddingOptimizer(opt_b)
+  side = torch.cuda.Stream()
+  plan = None
+  for step in range(3):
+    if shape == "zipf":
+      ids = keys_of_ranks(zipf_bounded(rng, n, 10**7))
+    elif shape == "hot_bucket":
+      ids = _hot_bucket_ids(rng, n)
+    else:
+      ids = rng.integers(-10**6, 10**6, size=n).astype(np.int64)
+    g = (rng.standard_normal((n, dim)) * 0.05).astype(np.float32)
+    ids_t, g_t = T(torch, ids), T(torch, g)
+    da.apply_sparse(a, ids_t, g_t)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      plan = db.plan(b, ids_t, plan)
+    out = b.lookup(ids_t[: min(n, 1000)])            # the lookup of the step runs next to the plan build
+    db.apply_sparse(b, ids_t, g_t, plan=plan)
+    assert out.shape[-1] == dim
+  assert int(a.size()) == int(b.size())
+  ka, va = a.export()
+  kb, vb = b.export()
+  ia, ib = np.argsort(ka.cpu().numpy()), np.argsort(kb.cpu().numpy())
+  np.testing.assert_array_equal(ka.cpu().numpy()[ia], kb.cpu().numpy()[ib])
+  np.testing.assert_array_equal(va.cpu().numpy()[ia], vb.cpu().numpy()[ib])
+  for slot in opt_a.slots:                            # optimizer state vectors too
+    sa = da.get_slot(a, slot).lookup(ka[ia])
+    sb = db.get_slot(b, slot).lookup(ka[ia])
+    assert torch.equal(sa, sb)
+
+
+def test_plan_rejects_mismatches(env):
+  torch, de = env
+  opt = de.optimizers.SGD(0.1)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  v8 = de.Variable(dim=8, name="plan_rej8", initializer=0.0)
+  v6 = de.Variable(dim=6, name="plan_rej6", initializer=0.0)
+  v16 = de.Variable(dim=16, name="plan_rej16", initializer=0.0)
+  ids = torch.arange(10, device="cuda")
+  with pytest.raises(ValueError):
+    deo.plan(v6, ids)                                 # dim % 4 != 0 takes the unique + segment_sum path
+  plan = deo.plan(v8, ids)
+  with pytest.raises(ValueError):
+    deo.apply_sparse(v16, ids, torch.zeros((10, 16), device="cuda"), plan=plan)
+  with pytest.raises(ValueError):
+    deo.apply_sparse(v8, ids, torch.zeros((9, 8), device="cuda"), plan=plan)
+  empty = deo.plan(v8, ids[:0])
+  deo.apply_sparse(v8, ids[:0], torch.zeros((0, 8), device="cuda"), plan=empty)
+  assert int(v8.size()) == 0
+
+
 def test_captured_train_step_matches_eager(env):
   """HIP-graph replay of lookup + sparse Adam == the same steps launched eagerly (bit for bit),
   including Adam's per-step lr_t fed through device memory."""
@@ -456,6 +539,44 @@ def test_captured_train_step_matches_eager(env):
       for b in batches:
         looks.append(cap.step(T(torch, b)).cpu().numpy().copy())
       cap.close()
+    k, val = v.export()
+    o = np.argsort(k.cpu().numpy())
+    outs.append((k.cpu().numpy()[o], val.cpu().numpy()[o], looks))
+  np.testing.assert_array_equal(outs[0][0], outs[1][0])
+  np.testing.assert_array_equal(outs[0][1], outs[1][1])
+  for a, b in zip(outs[0][2], outs[1][2]):
+    np.testing.assert_array_equal(a, b)
+
+
+def test_captured_prefetch_step_matches_eager(env):
+  """Two-stream HIP-graph step (plan of batch i+1 built next to step i) == eager steps, bit for bit."""
+  torch, de = env
+  from bench import zipf_bounded, keys_of_ranks
+  dim, B, n_keys = 64, 8192, 30000
+  rng = np.random.default_rng(22)
+  batches = [keys_of_ranks(zipf_bounded(rng, B, n_keys)) for _ in range(6)]
+  g = (rng.standard_normal((B, dim)) * 0.01).astype(np.float32)
+  outs = []
+  for mode in ("eager", "graph"):
+    opt = de.optimizers.Adam(1e-2)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    v = de.Variable(dim=dim, name="capf_" + mode, initializer=0.05, init_size=200000,
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    looks = []
+    if mode == "eager":
+      for _ in range(2):  # the captured variant runs 2 eager warm-up steps on batch 0
+        deo.apply_sparse(v, T(torch, batches[0]), T(torch, g))
+      for b in batches[:-1]:
+        looks.append(v.lookup(T(torch, b)).cpu().numpy())
+        deo.apply_sparse(v, T(torch, b), T(torch, g))
+    else:
+      cap = de.CapturedPrefetchStep(v, deo, B)
+      cap.grads.copy_(T(torch, g))
+      cap.capture(T(torch, batches[0]))
+      for i in range(len(batches) - 1):       # step i runs batch i and stages batch i+1
+        looks.append(cap.step(T(torch, batches[i + 1])).cpu().numpy().copy())
+      cap.close()
+    assert deo.iterations == 2 + len(batches) - 1
     k, val = v.export()
     o = np.argsort(k.cpu().numpy())
     outs.append((k.cpu().numpy()[o], val.cpu().numpy()[o], looks))
