@@ -141,11 +141,11 @@ def main():
   ap.add_argument("--keys", type=int, default=100_000_000, help="resident keys PER GPU")
   ap.add_argument("--batch", type=int, default=131072, help="ids per GPU per step")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--plan", choices=["off", "lookup", "prefetch"], default="off",
+  ap.add_argument("--plan", choices=["off", "prefetch"], default="prefetch",
                   help="where the id-only half of the write-back (which ids repeat, summation order, unique keys) is built: "
-                       "off = inside the write-back call; lookup = on a second HIP stream next to the lookup of the same "
-                       "batch; prefetch = on a second stream for batch i+1 while step i runs (ids known ahead, as an input "
-                       "pipeline provides them).  Every step builds exactly one plan inside the timed region.")
+                       "prefetch = on a second HIP stream for batch i+1 while step i runs (ids known one batch ahead, as an "
+                       "input pipeline provides them; one C call per step; every step builds exactly one plan inside the "
+                       "timed region); off = inside the write-back call (tfra_table_apply_sparse).  Single GPU only.")
   ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (same kernels; "
                   "measured equal to eager launches: the step is bound by kernel boundaries, not by the host)")
   args = ap.parse_args()
@@ -213,48 +213,21 @@ def main():
 
   use_graph = world == 1 and args.graph
   captured = None
-  prefetch_graph = use_graph and args.plan == "prefetch"
-  if prefetch_graph:
-    captured = de.CapturedPrefetchStep(var, deo, B)
-    captured.grads.copy_(grads)
-    captured.capture(ids_all[0])
-  elif use_graph:
+  if use_graph:
     captured = de.CapturedTrainStep(var, deo, B)
     captured.grads.copy_(grads)
     captured.capture(warmup_ids=ids_all[0])
 
   plan_mode = args.plan if world == 1 and not use_graph else "off"
-  side = torch.cuda.Stream(device=dev) if plan_mode != "off" else None
-  plans = [None, None]
-  main_stream = torch.cuda.current_stream(dev)
-
-  def build_plan(slot, ids):
-    side.wait_stream(main_stream)
-    with torch.cuda.stream(side):
-      plans[slot] = deo.plan(var, ids, plans[slot])
-
+  prefetch = None
   if plan_mode == "prefetch":
-    build_plan(0, ids_all[0])
+    prefetch = de.PrefetchStep(var, deo).prime(ids_all[0])
 
-  def step(i, timed_idx=None):
+  def step(i, timed_idx=None, fused_call=False):
     ids = ids_all[i]
-    if plan_mode != "off":
-      if timed_idx is not None:
-        ev_a[timed_idx].record()
-      if plan_mode == "lookup":
-        build_plan(i & 1, ids)
-      else:  # the plan of THIS batch was built during the previous step; build the next one now
-        build_plan((i + 1) & 1, ids_all[(i + 1) % (K + W)])
-      out = var.lookup(ids)
-      if timed_idx is not None:
-        ev_b[timed_idx].record()
-      deo.apply_sparse(var, ids, grads, plan=plans[i & 1])
-      if timed_idx is not None:
-        ev_c[timed_idx].record()
-      return out
-    if prefetch_graph:
-      # one replay = [main: lookup + run sums + fused Adam of batch i] || [second stream: plan of batch i+1]
-      return captured.step(ids_all[(i + 1) % (K + W)])
+    if prefetch is not None and not fused_call:
+      # ONE C call: [main: lookup + run sums + fused Adam of batch i] + [second stream: plan of batch i+1]
+      return prefetch.step(grads, ids_all[(i + 1) % (K + W)])
     if captured is not None:
       # one HIP-graph replay = lookup + tile-reduce + bucket-merge + fused Adam (+ the batch copy)
       return captured.step(ids)
@@ -283,6 +256,7 @@ def main():
   t0 = time.perf_counter()
   for i in range(K):
     step(W + i, i)
+  host_enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (== elapsed when host-bound)
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
@@ -293,6 +267,16 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+  fused_call_ms = None
+  if prefetch is not None:
+    # secondary timed loop with the write-back as ONE fused call on one stream (--plan off): gives the
+    # per-launch event timings of the roofline block and the unprefetched step time for comparison
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(K):
+      step((W + i) % (K + W), i, fused_call=True)
+    torch.cuda.synchronize()
+    fused_call_ms = 1e3 * (time.perf_counter() - t1) / K
   if use_graph:
     fwd_ms = bwd_ms = None  # phases are inside one graph launch
   else:
@@ -361,11 +345,12 @@ def main():
             "global_batch": B * world, "keys_per_gpu": resident, "unique_ratio": round(uniq_ratio, 4),
             "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
             "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
-            "launch": ("hipGraph replay (two streams)" if prefetch_graph else "hipGraph replay") if use_graph else "eager",
-            "write_back_plan": {"off": "built inside the write-back call",
-                                "lookup": "id-only half built on a second HIP stream next to the lookup of the same batch",
+            "host_enqueue_ms_per_step": round(1e3 * host_enqueue_s / K, 4),
+            "launch": "hipGraph replay" if use_graph else ("one C call per step, two streams" if prefetch is not None else "eager"),
+            "write_back_plan": {"off": "built inside the write-back call (tfra_table_apply_sparse)",
                                 "prefetch": "id-only half of batch i+1 built on a second HIP stream while step i runs "
-                                            "(one plan per step inside the timed region)"}["prefetch" if prefetch_graph else plan_mode],
+                                            "(tfra_table_step_prefetch; one plan per step inside the timed region)"}[plan_mode],
+            "ms_per_step_fused_call": fused_call_ms,
         },
         "roofline": {
             "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",
@@ -373,7 +358,7 @@ def main():
             "frac": find_bytes / (find_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("find_kernel"),
             "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
             "avg_launch_us_back_to_back": find_b2b_us,
-            "timing": "HIP events around the launch inside the timed region" if fwd_ms is not None else "back-to-back",
+            "timing": ("HIP events around the launch inside the timed region" if prefetch is None else "HIP events around the launch in the fused-call timed loop (the prefetch step is one C call)") if fwd_ms is not None else "back-to-back",
         },
         "roofline_write_back": {
             "bound": "hbm", "kernel": "tile_reduce_kernel + bucket_merge_kernel + apply_kernel<INDIRECT> "

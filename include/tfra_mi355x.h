@@ -212,6 +212,20 @@ int tfra_sparse_plan_build(tfra_sparse_plan_t* plan, size_t n, const int64_t* id
 int tfra_table_apply_planned(tfra_table_t* t, const tfra_opt_params* p, const tfra_sparse_plan_t* plan,
                              const float* grads, const float* param_default_row, tfra_stream_t stream);
 
+/* One whole training step of a single table on two streams, driven from C (what a TF executor does
+ * between the ops of one session.run, without the host framework in the loop):
+ *   main : rows_out = find(ids_cur) [n = plan_cur's id count; skipped when rows_out is NULL]
+ *          -> tfra_table_apply_planned(plan_cur, grads)
+ *   side : tfra_sparse_plan_build(plan_next, ids_next) — started when the lookup has drained, i.e. next to
+ *          the gradient half; plan_next may be NULL (last step).
+ * plan_cur must have been built from ids_cur (by the previous call as its plan_next, or by
+ * tfra_sparse_plan_build on main_stream).  Ordering between the two streams is handled inside.      */
+int tfra_table_step_prefetch(tfra_table_t* t, const tfra_opt_params* p, tfra_sparse_plan_t* plan_cur,
+                             const int64_t* ids_cur, void* rows_out, const void* find_default,
+                             const float* grads, const float* param_default_row,
+                             tfra_sparse_plan_t* plan_next, const int64_t* ids_next, size_t n_next,
+                             tfra_stream_t main_stream, tfra_stream_t side_stream);
+
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 
 /* Scratch for unique/partition; grows on demand, reusable across calls on one stream. */

@@ -2,7 +2,7 @@
 (`/root/reference/tensorflow_recommenders_addons/dynamic_embedding/__init__.py`) for the hot path."""
 from . import device_ops
 from . import optimizer as optimizers
-from .optimizer import CapturedPrefetchStep, CapturedTrainStep, DynamicEmbeddingOptimizer
+from .optimizer import CapturedTrainStep, DynamicEmbeddingOptimizer, PrefetchStep
 from .restrict_policies import FrequencyRestrictPolicy, RestrictPolicy, TimestampRestrictPolicy
 from .table_ops import (SparsePlan, CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
                         KHkvHashTableMaxCapacity, KHkvHashTableMaxHbmForValuesByBytes)

@@ -12,6 +12,7 @@ ResourceApply{GradientDescent,Adam,Adagrad[V2],Ftrl}.  Slots of unseen keys star
 slot initial value (zeros / `initial_accumulator_value`), state is per key (lazy), the step
 counter for Adam's bias correction is global (PY/...optimizer.py:870-931).
 """
+import ctypes
 import math
 
 import torch
@@ -288,88 +289,57 @@ class CapturedTrainStep:
     self.table.set_capture_safe(False)
 
 
-class CapturedPrefetchStep:
-  """Two-stream training step captured into HIP graphs: while the main stream runs batch i
-  (lookup -> run sums following plan i -> fused update), a second stream builds the plan of batch i+1
-  (its ids are known ahead, as an input pipeline provides them).  The id-only half of the write-back
-  (which ids repeat, in which order their gradients are summed, the unique keys) is ~40 % of a step and
-  leaves the critical path; launched eagerly the extra launches would make the step host-bound, so the
-  fork/join lives inside the graph.  Two graphs alternate (the two plans and id buffers swap roles).
+class PrefetchStep:
+  """The two-stream training step driven by ONE C call per step (`tfra_table_step_prefetch`): main stream =
+  lookup of batch i -> run sums following plan i -> fused update; second stream = plan of batch i+1, started
+  when the lookup has drained.  No graph, no Python between the launches.
 
-      cs = CapturedPrefetchStep(var, deo, batch).capture(first_ids)
-      for batch in stream:  out = cs.step(next_ids, grads)     # runs the batch staged by the previous call
+      ps = PrefetchStep(var, deo); ps.prime(first_ids)
+      for ...: rows = ps.step(grads, next_ids)      # runs the staged batch, stages next_ids (None at the end)
   """
 
-  def __init__(self, var, optimizer, batch, reserve_slots=None):
+  def __init__(self, var, optimizer):
     from .table_ops import SparsePlan
-    if var.shard_num != 1 or not DynamicEmbeddingOptimizer.can_plan(var, batch):
-      raise ValueError("CapturedPrefetchStep needs a single-shard fp32 Variable with dim % 4 == 0, dim <= 256")
-    self.var, self.deo, self.batch = var, optimizer, int(batch)
+    if var.shard_num != 1 or not DynamicEmbeddingOptimizer.can_plan(var, 1):
+      raise ValueError("PrefetchStep needs a single-shard fp32 Variable with dim % 4 == 0, dim <= 256")
+    optimizer._check(var)
+    self.var, self.deo = var, optimizer
     self.t = var.tables[0]
     self.table = self.t._table
-    dev = self.table.device
-    self.dev = dev
-    self.ids = [torch.zeros(self.batch, dtype=torch.int64, device=dev) for _ in range(2)]
-    self.grads = torch.zeros((self.batch, var.dim), dtype=torch.float32, device=dev)
-    self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
-    self.plans = [SparsePlan(dev, var.dim) for _ in range(2)]
-    self.default = self.t._default_value.to(torch.float32)
-    self.side = torch.cuda.Stream(device=dev)
-    self.graphs = [None, None]
-    self.out = [None, None]
+    self.dev = self.table.device
+    self.plans = [SparsePlan(self.dev, var.dim) for _ in range(2)]
+    self.ids = [None, None]
+    self.default = self.t._default_value.to(device=self.dev, dtype=torch.float32).contiguous()
+    self.side = torch.cuda.Stream(device=self.dev)
     self.cur = 0
-    if reserve_slots:
-      self.table.reserve(reserve_slots)
 
-  def _params(self):
-    self.deo.iterations += 1
-    p = self.deo.opt.params(self.deo.iterations)
-    self.lr.fill_(p.lr)
-    p.d_lr = self.lr.data_ptr()
-    return p
-
-  def _body(self, cur, p):
-    main = torch.cuda.current_stream(self.dev)
-    self.side.wait_stream(main)                                  # fork
-    with torch.cuda.stream(self.side):
-      self.plans[1 - cur].build(self.ids[1 - cur], sync=False)   # plan of the NEXT batch
-    self.out[cur] = self.var.lookup(self.ids[cur])
-    self.table.apply_planned(p, self.plans[cur], self.grads, self.default, sync=False)
-    main.wait_stream(self.side)                                  # join
-
-  def capture(self, first_ids):
-    """Stages `first_ids` as the first batch, sizes every buffer with two eager warm-up steps on that
-    batch (they are real steps: the table sees them), then captures the two graphs."""
-    self.table.set_capture_safe(True)
-    for b in self.ids:
-      b.copy_(first_ids.reshape(-1))
-    warm = torch.cuda.Stream(device=self.dev)
-    warm.wait_stream(torch.cuda.current_stream(self.dev))
-    with torch.cuda.stream(warm):
-      self.plans[0].build(self.ids[0], sync=False)
-      for cur in (0, 1):
-        self._body(cur, self._params())
-    torch.cuda.current_stream(self.dev).wait_stream(warm)
-    torch.cuda.synchronize(self.dev)
-    for cur in (0, 1):
-      p = self._params()
-      self.graphs[cur] = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(self.graphs[cur]):
-        self._body(cur, p)
-    self.deo.iterations -= 2                                     # captures do not execute
-    self.cur = 0                                                 # plans[0] is built for ids[0] (= first_ids)
+  def prime(self, ids):
+    """Stage the first batch: its plan is built on the current stream."""
+    ids = torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+    self.plans[self.cur].build(ids, sync=False)
+    self.ids[self.cur] = ids
     return self
 
-  def step(self, next_ids, grads=None):
-    """Runs the staged batch, stages `next_ids` (its plan is built meanwhile); returns the staged batch's rows."""
+  def step(self, grads, next_ids=None):
+    from .table_ops import _ptr
     cur = self.cur
-    self.ids[1 - cur].copy_(next_ids.reshape(-1))
-    if grads is not None:
-      self.grads.copy_(grads.reshape(self.batch, -1))
-    self._params()
-    self.graphs[cur].replay()
+    ids = self.ids[cur]
+    n = ids.numel()
+    self.deo.iterations += 1
+    p = self.deo.opt.params(self.deo.iterations)
+    grads = grads.reshape(n, self.var.dim)
+    if grads.dtype != torch.float32 or not grads.is_contiguous():
+      grads = grads.to(torch.float32).contiguous()
+    out = torch.empty((n, self.var.dim), dtype=torch.float32, device=self.dev)
+    nxt = None
+    if next_ids is not None:
+      nxt = torch.as_tensor(next_ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+      nxt.record_stream(self.side)
+      self.ids[1 - cur] = nxt                       # kept alive until its step has run
+    main = torch.cuda.current_stream(self.dev)
+    _capi.call("tfra_table_step_prefetch", self.table._h, ctypes.byref(p), self.plans[cur]._h, _ptr(ids), _ptr(out),
+               _ptr(self.default), _ptr(grads), _ptr(self.default), self.plans[1 - cur]._h if nxt is not None else None,
+               _ptr(nxt), 0 if nxt is None else nxt.numel(), ctypes.c_void_p(main.cuda_stream),
+               ctypes.c_void_p(self.side.cuda_stream))
     self.cur = 1 - cur
-    return self.out[cur]
-
-  def close(self):
-    self.table.set_capture_safe(False)
+    return out

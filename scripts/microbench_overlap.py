@@ -43,3 +43,35 @@ for name, f, p in (("find only", 1, 0), ("plan only", 0, 1), ("both (2 streams)"
   run(f, p)
   g, w = run(f, p)
   print("%-18s gpu %7.1f us/iter   wall %7.1f us/iter" % (name, g, w))
+
+# ---- gradient half (tile_sums -> bucket_sums -> apply) on the main stream vs plan build on the side stream
+g = torch.randn((B, DIM), device="cuda") * 0.01
+planX = deo.plan(var, ids[0])
+planY = deo.plan(var, ids[1])
+p = opt.params(1)
+tab = var.tables[0]._table
+dflt = var.tables[0]._default_value.to(torch.float32)
+torch.cuda.synchronize()
+
+
+def run2(do_apply, do_plan):
+  torch.cuda.synchronize()
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  a.record()
+  for i in range(R):
+    if do_plan:
+      with torch.cuda.stream(side):
+        planY.build(ids[1 + (i & 1)], sync=False)
+    if do_apply:
+      tab.apply_planned(p, planX, g, dflt, sync=False)
+  main.wait_stream(side)
+  b.record()
+  torch.cuda.synchronize()
+  return a.elapsed_time(b) * 1e3 / R, (time.perf_counter() - t0) * 1e6 / R
+
+
+for name, f, q in (("apply_planned only", 1, 0), ("plan only", 0, 1), ("both (2 streams)", 1, 1)):
+  run2(f, q)
+  gq, w = run2(f, q)
+  print("%-18s gpu %7.1f us/iter   wall %7.1f us/iter" % (name, gq, w))

@@ -548,35 +548,31 @@ def test_captured_train_step_matches_eager(env):
     np.testing.assert_array_equal(a, b)
 
 
-def test_captured_prefetch_step_matches_eager(env):
-  """Two-stream HIP-graph step (plan of batch i+1 built next to step i) == eager steps, bit for bit."""
+def test_prefetch_step_driver_matches_eager(env):
+  """tfra_table_step_prefetch (lookup + gradient half on the main stream, plan of the next batch on a second
+  stream, one C call per step) == eager lookup + apply_sparse, bit for bit."""
   torch, de = env
   from bench import zipf_bounded, keys_of_ranks
-  dim, B, n_keys = 64, 8192, 30000
-  rng = np.random.default_rng(22)
-  batches = [keys_of_ranks(zipf_bounded(rng, B, n_keys)) for _ in range(6)]
-  g = (rng.standard_normal((B, dim)) * 0.01).astype(np.float32)
+  dim, B, n_keys = 64, 20000, 50000
+  rng = np.random.default_rng(23)
+  batches = [keys_of_ranks(zipf_bounded(rng, B, n_keys)) for _ in range(7)]
+  grads = [(rng.standard_normal((B, dim)) * 0.01).astype(np.float32) for _ in range(7)]
   outs = []
-  for mode in ("eager", "graph"):
+  for mode in ("eager", "driver"):
     opt = de.optimizers.Adam(1e-2)
     deo = de.DynamicEmbeddingOptimizer(opt)
-    v = de.Variable(dim=dim, name="capf_" + mode, initializer=0.05, init_size=200000,
-                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    v = de.Variable(dim=dim, name="pfd_" + mode, initializer=0.05, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
     looks = []
     if mode == "eager":
-      for _ in range(2):  # the captured variant runs 2 eager warm-up steps on batch 0
-        deo.apply_sparse(v, T(torch, batches[0]), T(torch, g))
-      for b in batches[:-1]:
+      for b, g in zip(batches, grads):
         looks.append(v.lookup(T(torch, b)).cpu().numpy())
         deo.apply_sparse(v, T(torch, b), T(torch, g))
     else:
-      cap = de.CapturedPrefetchStep(v, deo, B)
-      cap.grads.copy_(T(torch, g))
-      cap.capture(T(torch, batches[0]))
-      for i in range(len(batches) - 1):       # step i runs batch i and stages batch i+1
-        looks.append(cap.step(T(torch, batches[i + 1])).cpu().numpy().copy())
-      cap.close()
-    assert deo.iterations == 2 + len(batches) - 1
+      ps = de.PrefetchStep(v, deo).prime(T(torch, batches[0]))
+      for i, g in enumerate(grads):
+        nxt = T(torch, batches[i + 1]) if i + 1 < len(batches) else None
+        looks.append(ps.step(T(torch, g), nxt).cpu().numpy())
+    assert deo.iterations == len(batches)
     k, val = v.export()
     o = np.argsort(k.cpu().numpy())
     outs.append((k.cpu().numpy()[o], val.cpu().numpy()[o], looks))
