@@ -14,12 +14,18 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["insert_unique_kernel", "bucket_merge_kernel", "tile_reduce_kernel", "find_kernel", "apply_kernel"]
+KERNELS = ["insert_unique_kernel", "bucket_merge_kernel", "tile_reduce_kernel", "find_kernel", "apply_kernel",
+           "tile_reduce_kernel<plan>", "bucket_merge_kernel<plan>", "tile_sums_kernel", "bucket_sums_kernel"]
 
 
 def short(name):
-  m = re.search(r"(\w+_kernel)", name)
-  return m.group(1) if m else None
+  m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
+  if not m:
+    return None
+  k = m.group(1)
+  if k in ("tile_reduce_kernel", "bucket_merge_kernel") and m.group(2) and "true" in m.group(2):
+    k += "<plan>"   # id-only half (tfra_sparse_plan_build)
+  return k
 
 
 def main():
@@ -71,7 +77,9 @@ def main():
       d["l2_hit_rate"] = round(t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"]), 3)
   summary = {
       "round": int(re.sub(r"\D", "", tag) or 0),
-      "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline  (+ separate "
+      "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline  [default "
+                 "--plan prefetch: tile_sums/bucket_sums/apply on the main stream, <plan> kernels on the second stream; its "
+                 "secondary fused-call loop contributes tile_reduce/bucket_merge]  (+ separate "
                  "--pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum passes, --steps 20)  [scripts/profile_round.sh, "
                  "scripts/summarize_profile.py]",
       "workload": "BASELINE configs[1]: 100M keys, dim 64 fp32 [p|m|v], Zipf-1.2 batch 131072",
