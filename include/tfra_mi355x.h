@@ -216,10 +216,11 @@ int tfra_table_apply_planned(tfra_table_t* t, const tfra_opt_params* p, const tf
  * between the ops of one session.run, without the host framework in the loop):
  *   main : rows_out = find(ids_cur) [n = plan_cur's id count; skipped when rows_out is NULL]
  *          -> tfra_table_apply_planned(plan_cur, grads)
- *   side : tfra_sparse_plan_build(plan_next, ids_next) — started when the lookup has drained, i.e. next to
- *          the gradient half; plan_next may be NULL (last step).
- * plan_cur must have been built from ids_cur (by the previous call as its plan_next, or by
- * tfra_sparse_plan_build on main_stream).  Ordering between the two streams is handled inside.      */
+ *   side : tfra_sparse_plan_build(plan_next, ids_next), free-running; plan_next may be NULL (last step).
+ * plan_cur must have been built from ids_cur (by an earlier call as its plan_next, or by
+ * tfra_sparse_plan_build on main_stream).  The streams are ordered inside, normally without any
+ * cross-queue event: rotate >= 3 plans (4 recommended) so that plan_next's buffers — last read by the
+ * step that used it as plan_cur — are idle when it is rebuilt; with fewer the call waits on the host.  */
 int tfra_table_step_prefetch(tfra_table_t* t, const tfra_opt_params* p, tfra_sparse_plan_t* plan_cur,
                              const int64_t* ids_cur, void* rows_out, const void* find_default,
                              const float* grads, const float* param_default_row,

@@ -36,7 +36,9 @@ struct Table {
   unsigned* err_count = nullptr;
   i64* d_scalar = nullptr;
   i64* h_scalar = nullptr;  // pinned
-  hipEvent_t step_event = nullptr;  // tfra_table_step_prefetch fork point
+  unsigned* progress_host = nullptr;  // tfra_table_step_prefetch: pinned progress counter of the main stream
+  unsigned step_gen = 0;
+  std::mutex step_mu;
   uint8_t* evict_flags = nullptr;  // phase-2 flags of a fused write-back on a bounded table
   size_t evict_flags_cap = 0;
   int* winner = nullptr;

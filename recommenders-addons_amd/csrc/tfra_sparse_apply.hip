@@ -393,16 +393,32 @@ __global__ __launch_bounds__(NTA) void tile_reduce_kernel(size_t n, const i64* _
   }
 }
 
+// Last kernel of a plan build (behind the two plan kernels on the same stream): re-arms the bucket cursors and
+// the overflow counter for the NEXT build of this plan (saves a memset launch per build), latches the error
+// count for the gradient half, and publishes the build's generation to the host (pinned memory).
+__global__ __launch_bounds__(256) void plan_finish_kernel(unsigned* cursors, unsigned P, unsigned* err_latched,
+                                                          unsigned* built_host, unsigned gen) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i == P + 1) { *err_latched = cursors[(size_t)i * CSTRIDE]; cursors[(size_t)i * CSTRIDE] = 0; }  // error word
+  else if (i <= P) cursors[(size_t)i * CSTRIDE] = 0;                                             // cursors + overflow count
+  if (i == 0 && built_host) __hip_atomic_store(built_host, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // gradient half of kernel A for a planned batch: the run sums of one tile, following the stored run
 // structure (same chunking as the fused kernel => the same summation tree, bit for bit).
 template <int NCH>
 __global__ __launch_bounds__(NTA) void tile_sums_kernel(const float* __restrict__ grads, int dim,
                                                         const unsigned* __restrict__ plan_entries,
                                                         const unsigned* __restrict__ plan_len,
-                                                        float* __restrict__ scratch_rows) {
+                                                        float* __restrict__ scratch_rows, unsigned* progress,
+                                                        unsigned progress_val) {
   constexpr int NG = NTA / 16;
   __shared__ unsigned short s_list[TILE + 1];
   __shared__ unsigned short s_u[TILE];
+  // tfra_table_step_prefetch: host-visible progress counter (pinned memory) — this kernel running means the
+  // lookup of step `progress_val` and every earlier step of the main stream are complete
+  if (progress && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ unsigned char s_flag[TILE + 1];
   __shared__ float s_left[NG][64 * NCH];
   __shared__ unsigned char s_cont[NG], s_hashead[NG];
@@ -920,8 +936,13 @@ struct tfra_sparse_plan {
   unsigned* u_src = nullptr;
   i64* d_total = nullptr;
   float* rows = nullptr;
-  hipEvent_t ev_built = nullptr;   // tfra_table_step_prefetch: recorded after a build on the side stream
-  bool ev_pending = false;
+  // tfra_table_step_prefetch
+  bool armed = false;              // cursors are zero (re-armed by plan_finish_kernel of the previous build)
+  unsigned* err_latched = nullptr;
+  unsigned* built_host = nullptr;  // pinned, device-visible: generation of the last build whose kernels have finished
+  unsigned gen = 0;                // generation of the last enqueued build
+  bool ev_recorded = false;        // the last build ran on a side stream (tfra_table_step_prefetch)
+  unsigned last_used_step = 0;     // last step whose gradient half read this plan
 };
 
 extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
@@ -936,7 +957,7 @@ extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
 extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
   if (!pl) return TFRA_OK;
   if (pl->buf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->buf); }
-  if (pl->ev_built) (void)hipEventDestroy(pl->ev_built);
+  if (pl->built_host) (void)hipHostFree(pl->built_host);
   delete pl;
   return TFRA_OK;
 }
@@ -970,10 +991,12 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
     hipError_t e = hipMalloc(&pl->buf, bytes);
     if (e != hipSuccess) { pl->buf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
     pl->bytes = bytes;
+    pl->armed = false;
   }
   unsigned char* w = (unsigned char*)pl->buf;
   pl->cursors = (unsigned*)w; w += head;
-  if (hipMemsetAsync(pl->cursors, 0, head, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+  const bool same_layout = pl->armed && pl->P == P;
+  if (!same_layout && hipMemsetAsync(pl->cursors, 0, head, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
   DescStore ds;
   ds.key = (i64*)w; w += al(reg * 8);
   ds.src = (unsigned*)w; w += al(reg * 4);
@@ -1002,22 +1025,25 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
                                                                      pl->err, 0, pl->tile_entries, pl->tile_len);
   bucket_merge_kernel<1, true><<<dim3(P), NT, 0, s>>>(P, (unsigned)ntiles, dim, rows_base, sum_base, nullptr, ds, nullptr,
                                                        pl->u_keys, pl->u_src, pl->d_total, pl->err, 0, nullptr, pl->bp);
+  pl->gen += 1;
+  pl->err_latched = pl->cursors + (size_t)(P + 1) * CSTRIDE + 1;   // same line as the error word, not re-armed
+  plan_finish_kernel<<<dim3((P + 2 + 255) / 256), 256, 0, s>>>(pl->cursors, P, pl->err_latched, pl->built_host, pl->gen);
+  pl->armed = true;
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
   pl->n = n; pl->npad = npad; pl->ntiles = ntiles; pl->P = P; pl->dim = dim;
   return TFRA_OK;
 }
 
 static int apply_planned_impl(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl, const float* grads,
-                              const float* param_default_row, tfra_stream_t stream, const std::function<int()>* mid);
+                              const float* param_default_row, tfra_stream_t stream, unsigned* progress, unsigned progress_val);
 
 extern "C" int tfra_table_apply_planned(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl,
                                         const float* grads, const float* param_default_row, tfra_stream_t stream) {
-  return apply_planned_impl(tp, p, pl, grads, param_default_row, stream, nullptr);
+  return apply_planned_impl(tp, p, pl, grads, param_default_row, stream, nullptr, 0);
 }
 
-// mid: optional hook run between the tile sums and the bucket sums (tfra_table_step_prefetch forks there)
 static int apply_planned_impl(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl, const float* grads,
-                              const float* param_default_row, tfra_stream_t stream, const std::function<int()>* mid) {
+                              const float* param_default_row, tfra_stream_t stream, unsigned* progress, unsigned progress_val) {
   Table* t = reinterpret_cast<Table*>(tp);
   if (!t || !p || !pl) return set_error(TFRA_ERR_INVALID, "apply_planned: null argument");
   hipStream_t s = (hipStream_t)stream;
@@ -1041,27 +1067,36 @@ static int apply_planned_impl(tfra_table_t* tp, const tfra_opt_params* p, const 
   dim3 ga((unsigned)pl->ntiles), gc(pl->P);
   const int nch = (dim + 63) / 64;
   switch (nch) {
-    case 1: tile_sums_kernel<1><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows); break;
-    case 2: tile_sums_kernel<2><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows); break;
-    case 3: tile_sums_kernel<3><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows); break;
-    default: tile_sums_kernel<4><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows); break;
+    case 1: tile_sums_kernel<1><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows, progress, progress_val); break;
+    case 2: tile_sums_kernel<2><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows, progress, progress_val); break;
+    case 3: tile_sums_kernel<3><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows, progress, progress_val); break;
+    default: tile_sums_kernel<4><<<ga, NTA, 0, s>>>(grads, dim, pl->tile_entries, pl->tile_len, pl->rows, progress, progress_val); break;
   }
-  if (mid) { rc = (*mid)(); if (rc) return rc; }
   switch (nch) {
-    case 1: bucket_sums_kernel<1><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
-    case 2: bucket_sums_kernel<2><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
-    case 3: bucket_sums_kernel<3><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
-    default: bucket_sums_kernel<4><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err, t->err_count); break;
+    case 1: bucket_sums_kernel<1><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err_latched, t->err_count); break;
+    case 2: bucket_sums_kernel<2><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err_latched, t->err_count); break;
+    case 3: bucket_sums_kernel<3><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err_latched, t->err_count); break;
+    default: bucket_sums_kernel<4><<<gc, NT, 0, s>>>(dim, rows_base, grads, pl->rows, pl->bp, pl->err_latched, t->err_count); break;
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_planned: launch failed");
   return launch_apply_indirect(t, s, p, pl->npad, pl->u_keys, pl->u_src, grads, pl->rows, rows_base, param_default_row,
                                pl->d_total, nullptr, 0, 0);
 }
 
-// One training step driven from C on two streams (no Python between the launches, no graph):
-//   main : [wait: plan_cur built] lookup(ids_cur) -> run sums following plan_cur -> fused update
-//   side : after the lookup has drained (it fills every wave slot of the chip, nothing overlaps with it)
-//          build plan_next from ids_next — next to the gradient half, whose kernels leave slots free.
+// One training step driven from C on two streams (no Python between the launches, no graph).
+//   main : lookup(ids_cur) -> tile sums -> bucket sums -> fused update           (plan_cur)
+//   side : build plan_next from ids_next, free-running
+// Cross-queue events cost ~5 us (stream wait) / ~7 us (record) each between two kernels of the main stream,
+// so the two streams are ordered through two host-visible counters in pinned memory instead, and the host
+// only falls back to an event / a sync when a counter lags:
+//   * table progress: written by the first block of the tile sums of step s  =>  every earlier step is done.
+//     plan_next's buffers were last read by step plan_next->last_used_step; the build is enqueued once the
+//     progress has passed it (with >= 3 plans in rotation that is always the case unless the host is far
+//     ahead of the GPU, in which case it waits here instead of in a queue);
+//   * plan built: written by a 1-thread kernel behind the build.  If it already shows plan_cur's generation
+//     the gradient half is enqueued without any wait packet (the build's kernels have completed, so their
+//     writes are in memory and the main-stream kernels start with a fresh cache view); otherwise — the host
+//     got ahead of the side stream — the host waits for the side stream.
 extern "C" int tfra_table_step_prefetch(tfra_table_t* tp, const tfra_opt_params* p, tfra_sparse_plan_t* plan_cur,
                                         const int64_t* ids_cur, void* rows_out, const void* find_default,
                                         const float* grads, const float* param_default_row,
@@ -1071,34 +1106,42 @@ extern "C" int tfra_table_step_prefetch(tfra_table_t* tp, const tfra_opt_params*
   if (!t || !p || !plan_cur) return set_error(TFRA_ERR_INVALID, "step_prefetch: null argument");
   hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
   if (ms == ss && plan_next) return set_error(TFRA_ERR_INVALID, "step_prefetch: needs two different streams");
+  if (plan_next == plan_cur) return set_error(TFRA_ERR_INVALID, "step_prefetch: plan_next must differ from plan_cur");
+  std::lock_guard<std::mutex> step_lock(t->step_mu);   // one driver call at a time per table
   int rc = TFRA_OK;
+  if (!t->progress_host) {
+    if (hipHostMalloc((void**)&t->progress_host, 64, hipHostMallocDefault) != hipSuccess) { t->progress_host = nullptr; return set_error(TFRA_ERR_OOM, "step_prefetch: hipHostMalloc"); }
+    *t->progress_host = 0;
+  }
+  const unsigned step = ++t->step_gen;
+  if (plan_next) {
+    if (!plan_next->built_host) {
+      if (hipHostMalloc((void**)&plan_next->built_host, 64, hipHostMallocDefault) != hipSuccess) { plan_next->built_host = nullptr; return set_error(TFRA_ERR_OOM, "step_prefetch: hipHostMalloc"); }
+      *plan_next->built_host = 0;
+    }
+    if (plan_next->last_used_step) {  // the gradient half that read plan_next's buffers must be over
+      const unsigned need = plan_next->last_used_step + 1;
+      volatile unsigned* prog = t->progress_host;
+      bool ok = false;
+      for (int it = 0; it < 200000 && !ok; ++it) ok = (int)(*prog - need) >= 0;   // ~ a few ms at most
+      if (!ok && hipStreamSynchronize(ms) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: sync");
+    }
+  }
   if (plan_cur->n && rows_out) {
     rc = tfra_table_find(tp, plan_cur->n, ids_cur, rows_out, nullptr, find_default, 0, main_stream);
     if (rc) return rc;
   }
-  // fork point: right after the lookup.  (Forking after the tile sums instead — so that the plan kernels
-  // only ever meet the bucket sums and the apply — measured worse: 75.9 vs 68 us per step.)
-  constexpr int fork_at = 0;
-  std::function<int()> fork = [&]() -> int {
-    if (!plan_next) return TFRA_OK;
-    if (!t->step_event && hipEventCreateWithFlags(&t->step_event, hipEventDisableTiming) != hipSuccess)
-      return set_error(TFRA_ERR_HIP, "step_prefetch: event");
-    if (!plan_next->ev_built && hipEventCreateWithFlags(&plan_next->ev_built, hipEventDisableTiming) != hipSuccess)
-      return set_error(TFRA_ERR_HIP, "step_prefetch: event");
-    // plan_next's buffers were last read by the gradient half of the previous step on the main stream: whatever
-    // is enqueued now is behind it, so one event orders both
-    if (hipEventRecord(t->step_event, ms) != hipSuccess || hipStreamWaitEvent(ss, t->step_event, 0) != hipSuccess)
-      return set_error(TFRA_ERR_HIP, "step_prefetch: fork");
-    int r = tfra_sparse_plan_build(plan_next, n_next, ids_next, t->opts.dim, side_stream);
-    if (r) return r;
-    if (hipEventRecord(plan_next->ev_built, ss) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: record");
-    plan_next->ev_pending = true;
-    return TFRA_OK;
-  };
-  if (plan_cur->ev_pending) {
-    if (hipStreamWaitEvent(ms, plan_cur->ev_built, 0) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: join");
-    plan_cur->ev_pending = false;
+  if (plan_next) {
+    rc = tfra_sparse_plan_build(plan_next, n_next, ids_next, t->opts.dim, side_stream);
+    if (rc) return rc;
+    plan_next->ev_recorded = true;   // built on the side stream: the join below applies
   }
-  if (fork_at == 0) { rc = fork(); if (rc) return rc; }
-  return apply_planned_impl(tp, p, plan_cur, grads, param_default_row, main_stream, fork_at == 1 ? &fork : nullptr);
+  if (plan_cur->ev_recorded) {  // built on the side stream by an earlier call
+    const bool built = plan_cur->built_host && (int)(*(volatile unsigned*)plan_cur->built_host - plan_cur->gen) >= 0;
+    if (!built && hipStreamSynchronize(ss) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: join");   // rare
+    plan_cur->ev_recorded = false;
+  }
+  plan_cur->last_used_step = step;
+  if (plan_cur->n == 0) return TFRA_OK;   // no kernel publishes this step: a later slot check falls back to a sync
+  return apply_planned_impl(tp, p, plan_cur, grads, param_default_row, main_stream, t->progress_host, step);
 }

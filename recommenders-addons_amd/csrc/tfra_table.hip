@@ -957,7 +957,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   t->dfree(t->cur.keys, s); t->dfree(t->cur.rows, s); t->dfree(t->cur.scores, s);
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
   t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s);
-  if (t->step_event) (void)hipEventDestroy(t->step_event);
+  if (t->progress_host) (void)hipHostFree(t->progress_host);
   if (t->h_scalar) (void)hipHostFree(t->h_scalar);
   if (t->chain_event) (void)hipEventDestroy(t->chain_event);
   if (t->size_event) (void)hipEventDestroy(t->size_event);

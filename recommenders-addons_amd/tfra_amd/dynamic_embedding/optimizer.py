@@ -55,15 +55,28 @@ class Adam(_Opt):
   def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
     self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
 
-  def params(self, step):
+  _CHUNK = 1024
+
+  def _lr_t(self, step):
+    """lr_t = lr*sqrt(1-b2^t)/(1-b1^t), evaluated in fp32 like TF's kernel prologue.  Computed for 1024 steps
+    at a time (the same fp32 ufuncs element by element) so that the per-step host cost is a list lookup."""
     import numpy as np
-    f32 = np.float32
-    # lr_t = lr*sqrt(1-b2^t)/(1-b1^t), evaluated in fp32 like TF's kernel prologue
-    b1p = f32(np.power(f32(self.b1), f32(step)))
-    b2p = f32(np.power(f32(self.b2), f32(step)))
-    lr_t = f32(f32(self.lr) * np.sqrt(f32(1) - b2p) / (f32(1) - b1p))
+    base = (step // self._CHUNK) * self._CHUNK
+    cache = getattr(self, "_lr_cache", None)
+    if cache is None or cache[0] != (base, self.lr, self.b1, self.b2):
+      f32 = np.float32
+      t = np.arange(base, base + self._CHUNK, dtype=np.float32)
+      b1p = np.power(f32(self.b1), t).astype(np.float32)
+      b2p = np.power(f32(self.b2), t).astype(np.float32)
+      with np.errstate(divide="ignore", invalid="ignore"):
+        lr_t = (f32(self.lr) * np.sqrt(f32(1) - b2p) / (f32(1) - b1p)).astype(np.float32)
+      cache = ((base, self.lr, self.b1, self.b2), lr_t.tolist())
+      self._lr_cache = cache
+    return cache[1][step - base]
+
+  def params(self, step):
     p = _capi.OptParams()
-    p.kind, p.lr, p.beta1, p.beta2, p.eps = self.kind, float(lr_t), self.b1, self.b2, self.eps
+    p.kind, p.lr, p.beta1, p.beta2, p.eps = self.kind, self._lr_t(step), self.b1, self.b2, self.eps
     return p
 
 
@@ -291,12 +304,15 @@ class CapturedTrainStep:
 
 class PrefetchStep:
   """The two-stream training step driven by ONE C call per step (`tfra_table_step_prefetch`): main stream =
-  lookup of batch i -> run sums following plan i -> fused update; second stream = plan of batch i+1, started
-  when the lookup has drained.  No graph, no Python between the launches.
+  lookup of batch i -> run sums following plan i -> fused update; second stream = plan of batch i+1.
+  No graph, no Python between the launches, and normally no cross-queue event either (the C driver orders
+  the streams through host-visible progress counters; NPLANS plans rotate so that a plan's buffers are
+  idle long before they are rebuilt).
 
       ps = PrefetchStep(var, deo); ps.prime(first_ids)
       for ...: rows = ps.step(grads, next_ids)      # runs the staged batch, stages next_ids (None at the end)
   """
+  NPLANS = 4
 
   def __init__(self, var, optimizer):
     from .table_ops import SparsePlan
@@ -307,8 +323,8 @@ class PrefetchStep:
     self.t = var.tables[0]
     self.table = self.t._table
     self.dev = self.table.device
-    self.plans = [SparsePlan(self.dev, var.dim) for _ in range(2)]
-    self.ids = [None, None]
+    self.plans = [SparsePlan(self.dev, var.dim) for _ in range(self.NPLANS)]
+    self.ids = [None] * self.NPLANS
     self.default = self.t._default_value.to(device=self.dev, dtype=torch.float32).contiguous()
     self.side = torch.cuda.Stream(device=self.dev)
     self.cur = 0
@@ -323,6 +339,7 @@ class PrefetchStep:
   def step(self, grads, next_ids=None):
     from .table_ops import _ptr
     cur = self.cur
+    nxt_slot = (cur + 1) % self.NPLANS
     ids = self.ids[cur]
     n = ids.numel()
     self.deo.iterations += 1
@@ -333,13 +350,16 @@ class PrefetchStep:
     out = torch.empty((n, self.var.dim), dtype=torch.float32, device=self.dev)
     nxt = None
     if next_ids is not None:
-      nxt = torch.as_tensor(next_ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+      nxt = next_ids
+      if not (torch.is_tensor(nxt) and nxt.dtype == torch.int64 and nxt.dim() == 1 and nxt.is_contiguous() and
+              nxt.device == self.dev):
+        nxt = torch.as_tensor(next_ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
       nxt.record_stream(self.side)
-      self.ids[1 - cur] = nxt                       # kept alive until its step has run
+      self.ids[nxt_slot] = nxt                      # kept alive until its step has run
     main = torch.cuda.current_stream(self.dev)
     _capi.call("tfra_table_step_prefetch", self.table._h, ctypes.byref(p), self.plans[cur]._h, _ptr(ids), _ptr(out),
-               _ptr(self.default), _ptr(grads), _ptr(self.default), self.plans[1 - cur]._h if nxt is not None else None,
+               _ptr(self.default), _ptr(grads), _ptr(self.default), self.plans[nxt_slot]._h if nxt is not None else None,
                _ptr(nxt), 0 if nxt is None else nxt.numel(), ctypes.c_void_p(main.cuda_stream),
                ctypes.c_void_p(self.side.cuda_stream))
-    self.cur = 1 - cur
+    self.cur = nxt_slot
     return out

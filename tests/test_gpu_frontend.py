@@ -580,3 +580,49 @@ def test_prefetch_step_driver_matches_eager(env):
   np.testing.assert_array_equal(outs[0][1], outs[1][1])
   for a, b in zip(outs[0][2], outs[1][2]):
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("nplans", [2, 3, 4])
+def test_prefetch_step_driver_ragged_and_few_plans(env, nplans):
+  """Batch sizes change from step to step (incl. an empty batch), only `nplans` plans rotate (2 forces the
+  host-side fallback waits of the driver), other table ops run between the steps: still bit-identical."""
+  torch, de = env
+  from bench import zipf_bounded, keys_of_ranks
+  dim, n_keys = 32, 20000
+  rng = np.random.default_rng(100 + nplans)
+  sizes = [5000, 1, 70000, 0, 513, 131072, 12, 30000, 30000, 7]
+  batches = [keys_of_ranks(zipf_bounded(rng, max(n, 1), n_keys))[:n] for n in sizes]
+  grads = [(rng.standard_normal((n, dim)) * 0.01).astype(np.float32) for n in sizes]
+  outs = []
+  for mode in ("eager", "driver"):
+    opt = de.optimizers.Adagrad(0.05, 0.1)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    v = de.Variable(dim=dim, name="pfr_%s_%d" % (mode, nplans), initializer=0.05,
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    looks = []
+    if mode == "eager":
+      for b, g in zip(batches, grads):
+        looks.append(v.lookup(T(torch, b)).cpu().numpy())
+        if b.size:
+          deo.apply_sparse(v, T(torch, b), T(torch, g))
+        else:
+          deo.iterations += 1
+        looks.append(v.lookup(T(torch, batches[0][:100])).cpu().numpy())   # an unrelated op between the steps
+    else:
+      ps = de.PrefetchStep(v, deo)
+      ps.NPLANS = nplans
+      ps.plans = ps.plans[:nplans] if nplans <= len(ps.plans) else ps.plans
+      ps.ids = [None] * nplans
+      ps.prime(T(torch, batches[0]))
+      for i, g in enumerate(grads):
+        nxt = T(torch, batches[i + 1]) if i + 1 < len(batches) else None
+        looks.append(ps.step(T(torch, g), nxt).cpu().numpy())
+        looks.append(v.lookup(T(torch, batches[0][:100])).cpu().numpy())
+    assert deo.iterations == len(batches)
+    k, val = v.export()
+    o = np.argsort(k.cpu().numpy())
+    outs.append((k.cpu().numpy()[o], val.cpu().numpy()[o], looks))
+  np.testing.assert_array_equal(outs[0][0], outs[1][0])
+  np.testing.assert_array_equal(outs[0][1], outs[1][1])
+  for a, b in zip(outs[0][2], outs[1][2]):
+    np.testing.assert_array_equal(a, b)
