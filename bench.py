@@ -302,8 +302,19 @@ def main():
     return e0.elapsed_time(e1) * 1e3 / reps
 
   find_b2b_us = timed(lambda: table.lookup(ids0))
+  # the same launch over a DIFFERENT batch each time (as in a step: rows not warm from the previous launch);
+  # 50 launches between two events => the events' own cost (~4 us around a single launch) is amortised.
+  # This is the duration rocprofv3 reports for find_kernel inside the steps (profiles/).
+  rot = [0]
+
+  def find_rotating():
+    rot[0] = (rot[0] + 1) % (K + W)
+    table.lookup(ids_all[rot[0]])
+
+  find_rot_us = timed(find_rotating)
   find_bytes = B * (8 + 2 * DIM * 4)
-  find_us = fwd_ms * 1e3 if (fwd_ms is not None and world == 1) else find_b2b_us
+  find_evt_us = fwd_ms * 1e3 if (fwd_ms is not None and world == 1) else None
+  find_us = find_rot_us
   # (2) write-back pipeline tile_reduce -> bucket_merge -> apply_kernel<INDIRECT> (one C-ABI call):
   #     algorithmic bytes = B*(8 + Rb) (ids + gradient rows read once) + U*(8 + 7*Rb) (fused Adam on
   #     the unique keys) — the dedup itself has no algorithmic traffic.
@@ -312,6 +323,15 @@ def main():
   p = opt.params(1)
   wb_us = timed(lambda: table._table.apply_sparse(p, ids0, grads, table._default_value))
   wb_bytes = B * (8 + DIM * 4) + U * (8 + 7 * DIM * 4)
+  # (2b) the same write-back split as the default step runs it: gradient half (tile_sums -> bucket_sums ->
+  #      apply_kernel<INDIRECT>, main stream) and id-only half (plan build, second stream), each alone
+  grad_half_us = plan_us = None
+  if world == 1 and de.DynamicEmbeddingOptimizer.can_plan(var, B):
+    plan0 = deo.plan(var, ids0)
+    torch.cuda.synchronize()
+    dflt = table._default_value.to(torch.float32)
+    grad_half_us = timed(lambda: table._table.apply_planned(p, plan0, grads, dflt, sync=False))
+    plan_us = timed(lambda: plan0.build(ids0, sync=False))
   # (3) the fused optimizer kernel alone on pre-summed unique keys
   gsum = torch.randn((U, DIM), generator=gen, device=dev) * 0.01
   apply_us = timed(lambda: table._table.apply_optimizer(p, uniq, gsum, table._default_value))
@@ -357,12 +377,18 @@ def main():
             "achieved": find_bytes / (find_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": find_bytes / (find_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("find_kernel"),
             "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
-            "avg_launch_us_back_to_back": find_b2b_us,
-            "timing": ("HIP events around the launch inside the timed region" if prefetch is None else "HIP events around the launch in the fused-call timed loop (the prefetch step is one C call)") if fwd_ms is not None else "back-to-back",
+            "avg_launch_us_same_batch_back_to_back": find_b2b_us,
+            "avg_launch_us_single_launch_between_events_in_step": find_evt_us,
+            "timing": "HIP events around 50 launches, a different resident-table batch each (avg_launch_us); also one launch between two events inside the steps of the fused-call loop (includes ~4 us of event cost)",
         },
         "roofline_write_back": {
             "bound": "hbm", "kernel": "tile_reduce_kernel + bucket_merge_kernel + apply_kernel<INDIRECT> "
-                                      "(duplicate-gradient reduction + fused sparse Adam, one C-ABI call)",
+                                      "(duplicate-gradient reduction + fused sparse Adam as ONE C-ABI call, --plan off)",
+            "split_for_the_default_step": {
+                "gradient_half_us_alone": grad_half_us, "gradient_half_kernels": "tile_sums_kernel + bucket_sums_kernel + "
+                "apply_kernel<INDIRECT> (main stream)", "plan_build_us_alone": plan_us,
+                "plan_build_kernels": "tile_reduce_kernel<plan> + bucket_merge_kernel<plan> + plan_finish_kernel (second stream)",
+                "achieved_GBps_gradient_half": (wb_bytes / (grad_half_us * 1e-6) / 1e9) if grad_half_us else None},
             "achieved": wb_bytes / (wb_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": wb_bytes / (wb_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "traffic": (sum(traffic_of(k) for k in ("tile_reduce_kernel", "bucket_merge_kernel", "apply_kernel"))
