@@ -218,7 +218,7 @@ def main():
     captured.grads.copy_(grads)
     captured.capture(warmup_ids=ids_all[0])
 
-  plan_mode = args.plan if world == 1 and not use_graph else "off"
+  plan_mode = args.plan if (world == 1 and emb is None and not use_graph) else "off"
   prefetch = None
   if plan_mode == "prefetch":
     prefetch = de.PrefetchStep(var, deo).prime(ids_all[0])
