@@ -626,3 +626,48 @@ def test_prefetch_step_driver_ragged_and_few_plans(env, nplans):
   np.testing.assert_array_equal(outs[0][1], outs[1][1])
   for a, b in zip(outs[0][2], outs[1][2]):
     np.testing.assert_array_equal(a, b)
+
+
+def test_prefetch_step_driver_with_growth_and_bounded_table(env):
+  """The step driver on (a) a table that rehashes several times while steps are in flight and (b) a bounded
+  Hkv table at capacity (the gradient half evicts): same results as the plain calls / capacity respected."""
+  torch, de = env
+  dim = 16
+  rng = np.random.default_rng(31)
+  # (a) growth: 12 steps of 40 000 mostly-new keys into a table that starts with 64 slots
+  batches = [np.concatenate([rng.integers(0, 10**9, size=39000), rng.integers(0, 500, size=1000)]).astype(np.int64) for _ in range(12)]
+  grads = [(rng.standard_normal((40000, dim)) * 0.1).astype(np.float32) for _ in range(12)]
+  outs = []
+  for mode in ("eager", "driver"):
+    opt = de.optimizers.Adam(1e-2)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    v = de.Variable(dim=dim, name="pfg_" + mode, initializer=0.1, init_size=64, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    if mode == "eager":
+      for b, g in zip(batches, grads):
+        v.lookup(T(torch, b))
+        deo.apply_sparse(v, T(torch, b), T(torch, g))
+    else:
+      ps = de.PrefetchStep(v, deo).prime(T(torch, batches[0]))
+      for i, g in enumerate(grads):
+        ps.step(T(torch, g), T(torch, batches[i + 1]) if i + 1 < len(batches) else None)
+    k, val = v.export()
+    o = np.argsort(k.cpu().numpy())
+    outs.append((k.cpu().numpy()[o], val.cpu().numpy()[o]))
+  assert outs[0][0].size > 400000
+  np.testing.assert_array_equal(outs[0][0], outs[1][0])
+  np.testing.assert_array_equal(outs[0][1], outs[1][1])
+  # (b) bounded table, LRU: every step's keys are resident afterwards, size never exceeds the capacity
+  opt = de.optimizers.SGD(0.5)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  v = de.get_variable("pfb_hkv", key_dtype=torch.int64, value_dtype=torch.float32, initializer=1.0, dim=dim, init_size=4096,
+                      kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                          init_capacity=4096, max_capacity=4096, max_hbm_for_values=1 << 22,
+                          evict_strategy=de.HkvEvictStrategy.LRU)))
+  steps = [np.arange(i * 1500, i * 1500 + 1500, dtype=np.int64) * 7 + 1 for i in range(8)]
+  ps = de.PrefetchStep(v, deo).prime(T(torch, steps[0]))
+  for i in range(len(steps)):
+    ps.step(torch.ones((1500, dim), device="cuda"), T(torch, steps[i + 1]) if i + 1 < len(steps) else None)
+    assert int(v.size()) <= 4096
+    got, ex = v.lookup(T(torch, steps[i]), return_exists=True)
+    assert bool(ex.all())
+    np.testing.assert_array_equal(got.cpu().numpy(), np.full((1500, dim), 0.5, np.float32))
