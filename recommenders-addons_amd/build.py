@@ -31,7 +31,8 @@ def _compile(src, force, newest_hdr):
   if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
       and os.path.getmtime(obj) > newest_hdr):
     return obj, False
-  cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+  extra = ["-DTFRA_WITH_TUNING"] if os.environ.get("TFRA_WITH_TUNING") else []
+  cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
   subprocess.check_call(cmd)
   return obj, True
 

@@ -824,8 +824,12 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   const int nch = (dim + 63) / 64;
   const i64* k = (const i64*)ids;
   dim3 ga((unsigned)ntiles), gc(P);
+#ifdef TFRA_WITH_TUNING  // phase ablation for scripts/ablate_apply.sh (build with TFRA_WITH_TUNING=1); never in the product build
   static const int stop_a = getenv("TFRA_DBG_STOP_A") ? atoi(getenv("TFRA_DBG_STOP_A")) : 0;
   static const int stop_c = getenv("TFRA_DBG_STOP_C") ? atoi(getenv("TFRA_DBG_STOP_C")) : 0;
+#else
+  constexpr int stop_a = 0, stop_c = 0;
+#endif
   switch (nch) {
     case 1: tile_reduce_kernel<1, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a, nullptr, nullptr); break;
     case 2: tile_reduce_kernel<2, false><<<ga, NTA, 0, s>>>(n, k, grads, dim, P, rows_base, ds, rows, t->err_count, stop_a, nullptr, nullptr); break;
