@@ -17,9 +17,15 @@ def default_partition_fn(keys, shard_num, gpu_mode=True):
 
 
 def dynamic_partition(data, partitions, num):
-  """tf.dynamic_partition: stable split of rows by partition id."""
+  """tf.dynamic_partition: `partitions` indexes the leading dims of `data`; stable split.  Partition ids
+  outside [0, num) are DISCARDED — the behaviour of the reference's GPU kernel
+  (K/dynamic_partition_op_gpu.cu.cc, T/dynamic_partition_op_test.py:221-283); its CPU kernel raises."""
   data = np.asarray(data)
-  return [data[partitions == p] for p in range(num)]
+  partitions = np.asarray(partitions)
+  tail = data.shape[partitions.ndim:]
+  flat = data.reshape((partitions.size,) + tail)
+  p = partitions.reshape(-1)
+  return [flat[p == q] for q in range(num)]
 
 
 def make_partition(data, partition_index, shard_num):
@@ -32,12 +38,15 @@ def make_partition(data, partition_index, shard_num):
 
 
 def dynamic_stitch(indices, values):
-  """tf.dynamic_stitch: out[indices[p][i]] = values[p][i]  (PY/..._variable.py:157-162)."""
-  n = sum(len(i) for i in indices)
-  tail = values[0].shape[1:]
+  """tf.dynamic_stitch: merged[indices[m][i, ...]] = values[m][i, ...]; first dim = max(index) + 1
+  (PY/dynamic_embedding_variable.py:157-162, T/dynamic_stitch_op_test.py)."""
+  indices = [np.asarray(i) for i in indices]
+  values = [np.asarray(v) for v in values]
+  tail = values[0].shape[indices[0].ndim:]
+  n = max([int(i.max()) + 1 for i in indices if i.size] + [0])
   out = np.zeros((n,) + tail, dtype=values[0].dtype)
   for i, v in zip(indices, values):
-    out[i] = v
+    out[i.reshape(-1)] = v.reshape((-1,) + tail)
   return out
 
 

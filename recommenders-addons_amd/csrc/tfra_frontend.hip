@@ -353,7 +353,12 @@ __global__ __launch_bounds__(256) void part_hist_kernel(size_t n, const i64* __r
   for (int s = threadIdx.x; s < num; s += 256) cnt[s] = 0;
   __syncthreads();
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) atomicAdd(&cnt[owner ? min(max(owner[i], 0), num - 1) : owner_of(keys[i], num, mode)], 1);
+  if (i < n) {
+    // caller-computed partitions outside [0, num) are DISCARDED, like the reference's GPU DynamicPartition
+    // (T/dynamic_partition_op_test.py:221-283; its CPU kernel raises instead)
+    const int o = owner ? owner[i] : owner_of(keys[i], num, mode);
+    if ((unsigned)o < (unsigned)num) atomicAdd(&cnt[o], 1);
+  }
   __syncthreads();
   for (int s = threadIdx.x; s < num; s += 256) hist[(size_t)blockIdx.x * num + s] = cnt[s];
 }
@@ -402,7 +407,9 @@ __global__ __launch_bounds__(256) void part_scatter_kernel(size_t n, const i64* 
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   bool ok = i < n;
   i64 key = (ok && keys) ? keys[i] : 0;
-  int own = ok ? (owner ? min(max(owner[i], 0), num - 1) : owner_of(key, num, mode)) : -1;
+  int own = ok ? (owner ? owner[i] : owner_of(key, num, mode)) : -1;
+  if ((unsigned)own >= (unsigned)num) own = -1;  // out of range: discarded
+  ok = own >= 0;
   int rank = 0;
   u64 todo = __ballot(ok);
   while (todo) {

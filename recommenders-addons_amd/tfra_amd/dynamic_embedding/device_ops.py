@@ -133,6 +133,55 @@ def partition_by_owner(owner, num_shards):
   return perm, counts
 
 
+def dynamic_partition(data, partitions, num_partitions):
+  """tf.dynamic_partition on the device (K/dynamic_partition_op_gpu.cu.cc): `partitions` indexes the leading
+  dims of `data`; returns `num_partitions` tensors, rows in input order.  Like the reference's GPU kernel,
+  partition ids outside [0, num_partitions) are discarded (the CPU kernel raises).  The output shapes are
+  data dependent: one host read of the counts, as for the TF op."""
+  partitions = torch.as_tensor(partitions, device=data.device)
+  if tuple(data.shape[:partitions.dim()]) != tuple(partitions.shape):
+    raise ValueError("data.shape must start with partitions.shape: %s vs %s" % (list(data.shape), list(partitions.shape)))
+  tail = tuple(data.shape[partitions.dim():])
+  n = partitions.numel()
+  width = 1
+  for t in tail:
+    width *= t
+  if n == 0 or width == 0:
+    counts = [0] * num_partitions if n == 0 else torch.bincount(
+        partitions.reshape(-1).clamp(0, num_partitions).to(torch.int64), minlength=num_partitions + 1)[:num_partitions].tolist()
+    return [torch.empty((c,) + tail, dtype=data.dtype, device=data.device) for c in counts]
+  perm, counts = partition_by_owner(partitions.reshape(-1), num_partitions)
+  counts = counts.tolist()
+  rows = gather_rows(data.reshape(n, width), perm[:sum(counts)])
+  return [r.reshape((-1,) + tail) for r in torch.split(rows, counts)]
+
+
+def dynamic_stitch(indices, data):
+  """tf.dynamic_stitch on the device (K/dynamic_stitch_op_gpu.cu.cc): merged[indices[m][i, ...]] =
+  data[m][i, ...], first dim = max(index) + 1 (one host read).  Indices are expected to be distinct (what
+  dynamic_partition of range(n) produces); rows no index names stay zero."""
+  indices = [torch.as_tensor(i) for i in indices]
+  data = [torch.as_tensor(d) for d in data]
+  dev = data[0].device
+  tail = tuple(data[0].shape[indices[0].dim():])
+  for i, d in zip(indices, data):
+    if tuple(d.shape[:i.dim()]) != tuple(i.shape) or tuple(d.shape[i.dim():]) != tail:
+      raise ValueError("data[m].shape must be indices[m].shape + a common suffix")
+  width = 1
+  for t in tail:
+    width *= t
+  flat_idx = torch.cat([i.reshape(-1).to(device=dev, dtype=torch.int32) for i in indices]) if indices else None
+  n_in = 0 if flat_idx is None else flat_idx.numel()
+  n_out = int(flat_idx.max().item()) + 1 if n_in else 0
+  out = torch.zeros((n_out,) + tail, dtype=data[0].dtype, device=dev)
+  if n_in == 0 or width == 0:
+    return out
+  rows = torch.cat([d.reshape(-1, width) for d in data]).contiguous()
+  _capi.call("tfra_scatter_rows", n_in, width * rows.element_size(), _ptr(rows), _ptr(flat_idx.contiguous()), _ptr(out),
+             _stream(dev))
+  return out
+
+
 def select_lowest(keys, status, k):
   """The k keys with the lowest status (int32/int64), ties in input order (restrict policies)."""
   keys = keys.reshape(-1).to(torch.int64).contiguous()

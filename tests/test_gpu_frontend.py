@@ -671,3 +671,41 @@ def test_prefetch_step_driver_with_growth_and_bounded_table(env):
     got, ex = v.lookup(T(torch, steps[i]), return_exists=True)
     assert bool(ex.all())
     np.testing.assert_array_equal(got.cpu().numpy(), np.full((1500, dim), 0.5, np.float32))
+
+
+def test_dynamic_partition_reference_kats(env):
+  """The reference's own DynamicPartition cases (T/dynamic_partition_op_test.py) on the device ops, incl. the
+  GPU kernel's discard-out-of-range behaviour."""
+  torch, de = env
+  from tests import kats_partition
+  for name, data, parts, num, want in kats_partition.partition_cases():
+    got = de.device_ops.dynamic_partition(T(torch, data), T(torch, parts), num)
+    assert len(got) == num, name
+    for g, w in zip(got, want):
+      g = g.cpu().numpy()
+      w = np.asarray(w, dtype=np.float32).reshape(g.shape) if np.asarray(w).size == 0 else np.asarray(w)
+      np.testing.assert_array_equal(g, w, err_msg=name)
+  with pytest.raises(ValueError):      # testErrorWrongDimsIndices :324-329
+    de.device_ops.dynamic_partition(T(torch, np.zeros((3, 1), np.float32)), T(torch, np.zeros((2, 1), np.int32)), 4)
+
+
+def test_dynamic_stitch_reference_kats(env):
+  """The reference's own DynamicStitch cases (T/dynamic_stitch_op_test.py) + partition/stitch round trip."""
+  torch, de = env
+  from tests import kats_partition
+  for name, idx, data, want in kats_partition.stitch_cases():
+    got = de.device_ops.dynamic_stitch([torch.from_numpy(np.asarray(i)) for i in idx],
+                                       [T(torch, np.asarray(d)) for d in data]).cpu().numpy()
+    np.testing.assert_array_equal(got, np.asarray(want).reshape(got.shape), err_msg=name)
+  with pytest.raises(ValueError):      # testErrorDataDimSizeMismatch :197-208
+    de.device_ops.dynamic_stitch([torch.tensor([0, 4, 5]), torch.tensor([1, 6, 2, 3])],
+                                 [T(torch, np.zeros((3, 2), np.float32)), T(torch, np.zeros((4, 3), np.float32))])
+  # dynamic_stitch(dynamic_partition(range(n)), dynamic_partition(data)) == data  (PY/..._variable.py:131-162)
+  rng = np.random.default_rng(4)
+  n, shards = 50001, 7
+  data = rng.standard_normal((n, 5)).astype(np.float32)
+  owner = rng.integers(0, shards, size=n).astype(np.int32)
+  parts = de.device_ops.dynamic_partition(T(torch, data), T(torch, owner), shards)
+  idxs = de.device_ops.dynamic_partition(torch.arange(n, dtype=torch.int32, device="cuda"), T(torch, owner), shards)
+  back = de.device_ops.dynamic_stitch(idxs, parts)
+  np.testing.assert_array_equal(back.cpu().numpy(), data)

@@ -121,3 +121,23 @@ def test_restrict_select_is_stable_and_signed():
   assert ofe.restrict_select(keys, st, 2).tolist() == [11, 13, 14]
   assert ofe.restrict_select(keys, st, 9).tolist() == []
   assert ofe.restrict_select(keys, st, 0).tolist() == [11, 13, 14, 10, 12]
+
+
+# ---- DynamicPartition / DynamicStitch restatements vs the reference's own known answers ------------
+def test_dynamic_partition_kats_oracle():
+  from oracle import frontends as ofe
+  from tests import kats_partition
+  for name, data, parts, num, want in kats_partition.partition_cases():
+    got = ofe.dynamic_partition(data, parts, num)
+    assert len(got) == num, name
+    for g, w in zip(got, want):
+      w = np.asarray(w, dtype=np.float64).reshape(g.shape) if np.asarray(w).size == 0 else np.asarray(w)
+      np.testing.assert_array_equal(g, w, err_msg=name)
+
+
+def test_dynamic_stitch_kats_oracle():
+  from oracle import frontends as ofe
+  from tests import kats_partition
+  for name, idx, data, want in kats_partition.stitch_cases():
+    got = ofe.dynamic_stitch(idx, data)
+    np.testing.assert_array_equal(got, np.asarray(want).reshape(got.shape), err_msg=name)
