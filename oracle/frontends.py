@@ -96,6 +96,32 @@ def embedding_lookup_sparse(table, sp_indices_row, sp_values, defaults, combiner
   return res
 
 
+def safe_embedding_lookup_sparse(table, indices, ids, dense_shape, defaults, weights=None, combiner="mean",
+                                 default_id=None):
+  """PY/dynamic_embedding_ops.py:296-430 (TFRA's variant: ids are never pruned): flatten the leading dims,
+  drop entries with weight <= 0 unless combiner == "sum", combine per row, empty rows -> zeros or the
+  embedding of `default_id`, restore the leading dims."""
+  indices = np.asarray(indices, dtype=np.int64).reshape(len(ids), -1)
+  ids = np.asarray(ids, dtype=np.int64)
+  lead = [int(x) for x in dense_shape[:-1]]
+  rows = np.ravel_multi_index(tuple(indices[:, d] for d in range(len(lead))), lead) if len(ids) else np.zeros(0, np.int64)
+  n = int(np.prod(lead))
+  w = None if weights is None else np.asarray(weights, np.float32)
+  if w is not None and combiner != "sum":
+    keep = w > 0
+    rows, ids, w = rows[keep], ids[keep], w[keep]
+  dim = np.asarray(defaults).reshape(-1).size
+  if len(ids):
+    res = embedding_lookup_sparse(table, rows, ids, defaults, combiner=combiner, sp_weights=w, num_rows=n)
+  else:
+    res = np.zeros((n, dim), np.float32)
+  if default_id is not None:
+    empty = np.ones(n, bool)
+    empty[rows] = False
+    res[empty] = table.find(np.array([default_id], np.int64), defaults).astype(np.float32)[0]
+  return res.reshape(tuple(lead) + (res.shape[-1],))
+
+
 def sharded_lookup(tables, ids, defaults_fn, partition_fn=default_partition_fn):
   """Variable.lookup over N shards: partition -> per-shard find -> stitch
   (PY/dynamic_embedding_variable.py:933-986)."""

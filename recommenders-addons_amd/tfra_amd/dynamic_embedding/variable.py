@@ -378,24 +378,59 @@ def embedding_lookup_sparse(params, sp_ids, sp_weights=None, partition_strategy=
 def safe_embedding_lookup_sparse(params, sp_ids, sparse_weights=None, combiner="mean", default_id=None,
                                  name="safe_embedding_lookup_sparse", partition_strategy=None, max_norm=None,
                                  return_trainable=False, num_rows=None):
-  """PY/dynamic_embedding_ops.py:296-430: drop ids < 0 and non-positive weights; empty rows yield
-  zeros (or the `default_id` embedding)."""
-  indices, ids = sp_ids
+  """PY/dynamic_embedding_ops.py:296-430.  `sp_ids` = (indices[nnz, R], values[nnz][, dense_shape[R]]) — a
+  SparseTensor of rank R >= 2 (or row ids [nnz] for rank 2).  Semantics of the reference, NOT of
+  `tf.nn.safe_embedding_lookup_sparse`: ids are never pruned (any int64 is a legal key, negative ones too,
+  T/dynamic_embedding_ops_test.py:1007-1050); entries with weight <= 0 are dropped unless combiner == "sum"
+  (`_prune_invalid_weights`, :374-376); rows left without entries yield zeros, or the embedding of
+  `default_id` (`sparse_fill_empty_rows`, :379-408); leading dims are flattened for the lookup and restored
+  on the result (:356-367, 411-424)."""
+  if combiner not in ("mean", "sqrtn", "sum"):
+    raise ValueError("combiner must be one of 'mean', 'sqrtn' or 'sum'")
+  dense_shape = None
+  if len(sp_ids) == 3:
+    indices, ids, dense_shape = sp_ids
+    dense_shape = [int(x) for x in dense_shape]
+  else:
+    indices, ids = sp_ids
   indices = torch.as_tensor(indices, device=params._primary)
   ids = torch.as_tensor(ids, device=params._primary)
-  keep = ids >= 0
+  lead = None
+  if indices.dim() == 2 and indices.shape[1] > 2:
+    if dense_shape is None:
+      raise ValueError("sparse ids of rank > 2 need their dense_shape: sp_ids = (indices, values, dense_shape)")
+    lead = dense_shape[:-1]
+    rows = torch.zeros(indices.shape[0], dtype=torch.int64, device=indices.device)
+    for d in range(len(lead)):                       # row-major flattening of the leading dims
+      rows = rows * lead[d] + indices[:, d].to(torch.int64)
+    n = 1
+    for d in lead:
+      n *= d
+  else:
+    rows = (indices[:, 0] if indices.dim() == 2 else indices).to(torch.int64)
+    if dense_shape is not None:
+      n = dense_shape[0]
+    elif num_rows is not None:
+      n = num_rows
+    else:
+      n = int(rows.max().item()) + 1 if rows.numel() else 0
   w = None
+  keep = None
   if sparse_weights is not None:
     w = torch.as_tensor(sparse_weights, dtype=torch.float32, device=params._primary)
-    keep &= w > 0
-  rows = indices[:, 0] if indices.dim() == 2 else indices
-  n = int(rows.max().item()) + 1 if num_rows is None else num_rows
-  out = embedding_lookup_sparse(params, (rows[keep], ids[keep]), None if w is None else w[keep], combiner=combiner,
-                                max_norm=max_norm, return_trainable=return_trainable, num_rows=n)
+    if combiner != "sum":
+      keep = w > 0
+  if keep is not None:
+    rows, ids, w = rows[keep], ids[keep], w[keep]
+  out = embedding_lookup_sparse(params, (rows, ids), w, combiner=combiner, max_norm=max_norm,
+                                return_trainable=return_trainable, num_rows=n)
   res, tw = out if return_trainable else (out, None)
-  if default_id is not None:
+  if default_id is not None and n:
     empty = torch.ones(n, dtype=torch.bool, device=res.device)
-    empty[rows[keep].to(torch.int64)] = False
-    d = params.lookup(torch.tensor([default_id], dtype=torch.int64, device=params._primary)).to(torch.float32)
+    empty[rows] = False
+    d = embedding_lookup(params, torch.tensor([default_id], dtype=torch.int64, device=params._primary),
+                         max_norm=max_norm).to(torch.float32)
     res = torch.where(empty[:, None], d, res)
+  if lead is not None:
+    res = res.reshape(tuple(lead) + (res.shape[-1],))
   return (res, tw) if return_trainable else res

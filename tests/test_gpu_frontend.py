@@ -709,3 +709,28 @@ def test_dynamic_stitch_reference_kats(env):
   idxs = de.device_ops.dynamic_partition(torch.arange(n, dtype=torch.int32, device="cuda"), T(torch, owner), shards)
   back = de.device_ops.dynamic_stitch(idxs, parts)
   np.testing.assert_array_equal(back.cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_safe_embedding_lookup_sparse_reference_kats(env, shards):
+  """T/dynamic_embedding_ops_test.py:1007-1165 (2-D, incl. `partitioned`) and :1205-1324 (3-D): ids are never
+  pruned (-100 is a key), weights <= 0 are, empty rows -> zeros / `default_id`."""
+  torch, de = env
+  from tests import kats_sparse
+  E = kats_sparse.embeddings(np.random.default_rng(shards))
+  v = de.Variable(dim=kats_sparse.DIM, devices=["cuda:0"] * shards, name="safe_kat_%d" % shards, initializer=0.0)
+  ks = np.array(sorted(E), dtype=np.int64)
+  v.upsert(T(torch, ks), T(torch, np.stack([E[int(k)] for k in ks])))
+
+  def lookup(idx, ids, shape, w, default_id):
+    return de.safe_embedding_lookup_sparse(v, (np.asarray(idx), np.asarray(ids, np.int64), shape),
+                                           None if w is None else np.asarray(w, np.float32),
+                                           default_id=default_id).cpu().numpy()
+
+  kats_sparse.run(lookup, E)
+  # combiner "sum" keeps non-positive weights (`_prune_invalid_weights` is skipped, :374-376)
+  got = de.safe_embedding_lookup_sparse(v, (np.asarray(kats_sparse.IDX_2D), np.asarray(kats_sparse.IDS, np.int64),
+                                            kats_sparse.SHAPE_2D), np.asarray(kats_sparse.WEIGHTS, np.float32),
+                                        combiner="sum").cpu().numpy()
+  np.testing.assert_allclose(got[4], 0.0 * E[0] - 0.5 * E[1], rtol=1e-6, atol=1e-6)
+  np.testing.assert_allclose(got[0], E[0] + 2 * E[1] + E[-100], rtol=1e-6, atol=1e-6)

@@ -141,3 +141,15 @@ def test_dynamic_stitch_kats_oracle():
   for name, idx, data, want in kats_partition.stitch_cases():
     got = ofe.dynamic_stitch(idx, data)
     np.testing.assert_array_equal(got, np.asarray(want).reshape(got.shape), err_msg=name)
+
+
+def test_safe_embedding_lookup_sparse_kats_oracle():
+  """T/dynamic_embedding_ops_test.py:1007-1324 on the NumPy restatement (negative ids are legal keys)."""
+  from oracle import frontends as ofe
+  from tests import kats_sparse
+  E = kats_sparse.embeddings(np.random.default_rng(0))
+  t = oracle.CpuTable(kats_sparse.DIM)
+  ks = np.array(sorted(E), dtype=np.int64)
+  t.insert(ks, np.stack([E[int(k)] for k in ks]))
+  zeros = np.zeros(kats_sparse.DIM, np.float32)
+  kats_sparse.run(lambda idx, ids, shape, w, d: ofe.safe_embedding_lookup_sparse(t, idx, ids, shape, zeros, w, "mean", d), E)
