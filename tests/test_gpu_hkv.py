@@ -274,3 +274,42 @@ def test_accum_evicts_on_full_bounded_table(env):
         np.testing.assert_array_equal(got[i], want)
       else:                                     # only an untouched (no-op) resident may have been evicted
         assert not e
+
+
+# ---- the reference's per-strategy smoke cases (T/hkv_hashtable_evict_test.py:110-239) ----------------
+def _gen_scores_plus_one(keys):
+  return keys + 1          # gen_scores_fn of the reference tests (:88-91)
+
+
+@pytest.mark.parametrize("strategy_name", ["LRU", "LFU", "EPOCHLRU", "EPOCHLFU", "CUSTOMIZED"])
+def test_evict_strategy_basic_and_score_exports(env, strategy_name):
+  """test_evict_strategy (:110-153), test_export_keys_and_scores (:155-196), test_export_with_scores (:198-239):
+  for every strategy upsert 4 keys, read them back, export (keys, scores) and (keys, values, scores)."""
+  torch, de = env
+  strategy = getattr(de.HkvEvictStrategy, strategy_name)
+  t = de.get_variable("evs_" + strategy_name, key_dtype=torch.int64, value_dtype=torch.int32, initializer=0, dim=DIM,
+                      init_size=1024, kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                          init_capacity=1024, max_capacity=1024, max_hbm_for_values=1024 * 64,
+                          evict_strategy=strategy, gen_scores_fn=_gen_scores_plus_one)))
+  assert int(t.size()) == 0
+  keys = torch.tensor([0, 1, 2, 3], device="cuda")
+  values = torch.tensor([[0] * DIM, [1] * DIM, [2] * DIM, [3] * DIM], dtype=torch.int32, device="cuda")
+  t.upsert(keys, values)
+  assert torch.equal(t.lookup(keys), values)
+  ek, es = t.tables[0].export_keys_and_scores(1)
+  ek, es = ek.cpu().numpy(), es.cpu().numpy()
+  np.testing.assert_array_equal(np.sort(ek), [0, 1, 2, 3])
+  k2, v2, s2 = t.tables[0].export_with_scores(1)
+  k2, v2, s2 = k2.cpu().numpy(), v2.cpu().numpy(), s2.cpu().numpy()
+  o = np.argsort(k2)
+  np.testing.assert_array_equal(k2[o], [0, 1, 2, 3])
+  np.testing.assert_array_equal(v2[o], values.cpu().numpy())          # export order is unspecified: compare by key
+  for keys_x, scores_x in ((ek, es), (k2, s2)):
+    if strategy_name == "CUSTOMIZED":
+      np.testing.assert_array_equal(scores_x[np.argsort(keys_x)], [1, 2, 3, 4])
+    elif strategy_name in ("LFU", "EPOCHLFU"):
+      np.testing.assert_array_equal(scores_x, np.ones(4))
+    else:
+      assert (scores_x > 0).all()                                     # a clock value
+  with pytest.raises(ValueError):
+    t.tables[0].export_keys_and_scores(0)                             # split_size must be a positive integer
