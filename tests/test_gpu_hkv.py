@@ -313,3 +313,27 @@ def test_evict_strategy_basic_and_score_exports(env, strategy_name):
       assert (scores_x > 0).all()                                     # a clock value
   with pytest.raises(ValueError):
     t.tables[0].export_keys_and_scores(0)                             # split_size must be a positive integer
+
+
+def test_reach_max_hbm(env):
+  """T/hkv_hashtable_ops_test.py:627-693: 2 Mi-slot table, int64 values dim 32; the first half of the keys all
+  fit (size == n/2 exactly: nothing is evicted at load factor 0.5), the second half fills/evicts within bounds."""
+  torch, de = env
+  n, dim = 1024 * 1024 * 2, 32
+  t = de.get_variable("reach_max_hbm", key_dtype=torch.int64, value_dtype=torch.int64,
+                      initializer=np.array([-1], dtype=np.int64), dim=dim,
+                      kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(
+                          init_capacity=n, max_capacity=n, max_hbm_for_values=8 * (dim + 1) * 1024 * 1024 * 4)))
+  t.clear()
+  assert int(t.size()) == 0
+  k = torch.arange(0, n // 2, device="cuda")
+  t.upsert(k, k[:, None].repeat(1, dim))
+  assert int(t.size()) == n // 2
+  k2 = torch.arange(n // 2, n, device="cuda")
+  t.upsert(k2, k2[:, None].repeat(1, dim))
+  assert n // 2 <= int(t.size()) <= n
+  probe = torch.arange(n - 1000, n, device="cuda")          # the newest keys are resident (LRU) with their rows
+  got, ex = t.lookup(probe, return_exists=True)
+  assert bool(ex.all()) and torch.equal(got, probe[:, None].repeat(1, dim))
+  t.clear()
+  assert int(t.size()) == 0
