@@ -337,3 +337,42 @@ def test_reach_max_hbm(env):
   assert bool(ex.all()) and torch.equal(got, probe[:, None].repeat(1, dim))
   t.clear()
   assert int(t.size()) == 0
+
+
+def test_basic_odd_capacity_and_reserved_bit(env):
+  """T/hkv_hashtable_ops_test.py:76-100: a capacity that is no power of two, reserved_key_start_bit set."""
+  torch, de = env
+  t = de.get_variable("hkv_basic", key_dtype=torch.int64, value_dtype=torch.int32, initializer=0, dim=8, init_size=1024,
+                      kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(max_capacity=99999,
+                                                                                     reserved_key_start_bit=1)))
+  assert int(t.size()) == 0
+  t.clear()
+  k = torch.tensor([-1, -2, -3, 0, 2**63 - 1, -2**63], device="cuda")   # incl. HKV's reserved key patterns
+  t.upsert(k, torch.arange(6, dtype=torch.int32, device="cuda")[:, None].repeat(1, 8))
+  assert int(t.size()) == 6
+  got, ex = t.lookup(k, return_exists=True)
+  assert bool(ex.all()) and got[:, 0].tolist() == [0, 1, 2, 3, 4, 5]
+
+
+@pytest.mark.parametrize("vdtype", ["float32", "int32", "int64", "int8"])
+def test_insert_sizes_all_dims(env, vdtype):
+  """T/hkv_hashtable_ops_test.py:248-290: 18 upserts of 85 new keys each, size == (i+1)*85, for every dim."""
+  torch, de = env
+  dt = getattr(torch, vdtype)
+  for dim in [1, 2, 4, 8, 10, 16, 32, 64, 100, 200]:
+    t = de.get_variable("hkv_insert_%s_%d" % (vdtype, dim), key_dtype=torch.int64, value_dtype=dt,
+                        initializer=np.array([-1]), dim=dim, init_size=102400,
+                        kv_creator=de.HkvHashTableCreator(config=de.HkvHashTableConfig(init_capacity=102400,
+                                                                                       max_capacity=102400)))
+    for i in range(18):
+      k = torch.arange(85 * i, 85 * (i + 1), device="cuda")
+      v = (k % 100)[:, None].repeat(1, dim).to(dt)
+      t.upsert(k, v)
+      assert int(t.size()) == (i + 1) * 85
+    k = torch.arange(0, 85 * 18 + 5, device="cuda")
+    got, ex = t.lookup(k, return_exists=True)
+    assert ex.tolist() == [True] * (85 * 18) + [False] * 5
+    assert torch.equal(got[:85 * 18], (k[:85 * 18] % 100)[:, None].repeat(1, dim).to(dt))
+    assert bool((got[85 * 18:] == -1).all())
+    t.clear()
+    assert int(t.size()) == 0
