@@ -91,6 +91,24 @@ def ftrl(p, a, z, g, lr, l1, l2, lr_power=-0.5):
   return p, a_new, z
 
 
+def momentum(p, accum, g, lr, momentum_, use_nesterov=False):
+  """ResourceApplyMomentum (TF core training_ops.cc): accum = accum*momentum + g; var -= lr*accum, or with
+  use_nesterov var -= g*lr + accum*momentum*lr."""
+  accum = (accum * f32(momentum_) + g).astype(f32)
+  if use_nesterov:
+    p = (p - (g * f32(lr) + accum * f32(f32(momentum_) * f32(lr)))).astype(f32)
+  else:
+    p = (p - accum * f32(lr)).astype(f32)
+  return p, accum
+
+
+def rmsprop(p, ms, mom, g, lr, rho, momentum_, eps):
+  """ResourceApplyRMSProp: ms += (g*g - ms)*(1-rho); mom = mom*momentum + lr*g/sqrt(ms+eps); var -= mom."""
+  ms = (ms + (g * g - ms) * f32(1.0 - rho)).astype(f32)
+  mom = (mom * f32(momentum_) + (g * f32(lr)) / np.sqrt(ms + f32(eps))).astype(f32)
+  return (p - mom).astype(f32), ms, mom
+
+
 class SparseOptimizerOracle:
   """The reference's write-back sequence over CPU tables (one table per slot, like
   ``create_slots``): (1+S) finds -> dense apply on [U,dim] -> (1+S) upserts.
@@ -127,6 +145,15 @@ class SparseOptimizerOracle:
       z = self.slots[1].find(uniq, np.zeros(dim, f32))
       p, a, z = ftrl(p, a, z, g, h["lr"], h["l1"], h["l2"], h.get("lr_power", -0.5))
       new_slots = [a, z]
+    elif self.kind == "momentum":
+      a = self.slots[0].find(uniq, np.zeros(dim, f32))
+      p, a = momentum(p, a, g, h["lr"], h["momentum"], h.get("nesterov", False))
+      new_slots = [a]
+    elif self.kind == "rmsprop":
+      ms = self.slots[0].find(uniq, np.full(dim, h.get("initial_rms", 1.0), f32))
+      mom = self.slots[1].find(uniq, np.zeros(dim, f32))
+      p, ms, mom = rmsprop(p, ms, mom, g, h["lr"], h["rho"], h["momentum"], h["eps"])
+      new_slots = [ms, mom]
     else:
       raise ValueError(self.kind)
     self.param.insert(uniq, p)

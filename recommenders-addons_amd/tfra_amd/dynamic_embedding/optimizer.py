@@ -116,6 +116,63 @@ class Ftrl(_Opt):
     return p
 
 
+class Generic(_Opt):
+  """Any dense update rule, run as the reference runs EVERY optimizer (PY/dynamic_embedding_optimizer.py:165-204):
+  sum the gradients of repeated ids, (1+S) table finds, the rule on the dense [U, dim] tensors — host-framework
+  math, as TF's ResourceApply* kernels are for the reference — and (1+S) table upserts.  Subclass and implement
+  `update(step, p, g, *slots) -> (p_new, *slots_new)` (fp32 torch tensors), or pass `update=`.  The four rules
+  with a fused HIP kernel (SGD, Adam, Adagrad, Ftrl) do not take this path."""
+  kind = None
+
+  def __init__(self, slots=(), slot_init=(), update=None):
+    self.slots = tuple(slots)
+    self._slot_init = tuple(float(x) for x in slot_init) + (0.0,) * (4 - len(slot_init))
+    if len(self.slots) > 4:
+      raise ValueError("at most 4 slot vectors per row")
+    if update is not None:
+      self.update = update
+
+  def aux_init(self):
+    return self._slot_init[:4]
+
+  def params(self, step):
+    return None      # no fused kernel: DynamicEmbeddingOptimizer runs `update` on dense tensors
+
+  def update(self, step, p, g, *slots):
+    raise NotImplementedError
+
+
+class Momentum(Generic):
+  """tf.train.MomentumOptimizer (ResourceApplyMomentum / Keras SGD with momentum): accum = momentum*accum + g;
+  p -= lr*accum, or with use_nesterov: p -= lr*g + lr*momentum*accum."""
+
+  def __init__(self, learning_rate=0.01, momentum=0.9, use_nesterov=False):
+    super().__init__(slots=("momentum",), slot_init=(0.0,))
+    self.lr, self.momentum, self.nesterov = learning_rate, momentum, use_nesterov
+
+  def update(self, step, p, g, accum):
+    accum = accum * self.momentum + g
+    if self.nesterov:
+      p = p - (g * self.lr + accum * (self.momentum * self.lr))
+    else:
+      p = p - accum * self.lr
+    return p, accum
+
+
+class RMSProp(Generic):
+  """tf.train.RMSPropOptimizer (ResourceApplyRMSProp, non-centered): ms = rho*ms + (1-rho)*g^2;
+  mom = momentum*mom + lr*g/sqrt(ms + eps); p -= mom.  `rms` starts at 1 (TF1) — pass initial_rms=0 for Keras."""
+
+  def __init__(self, learning_rate=0.001, decay=0.9, momentum=0.0, epsilon=1e-10, initial_rms=1.0):
+    super().__init__(slots=("rms", "momentum"), slot_init=(initial_rms, 0.0))
+    self.lr, self.rho, self.momentum, self.eps = learning_rate, decay, momentum, epsilon
+
+  def update(self, step, p, g, ms, mom):
+    ms = ms + (g * g - ms) * (1.0 - self.rho)
+    mom = mom * self.momentum + (g * self.lr) / torch.sqrt(ms + self.eps)
+    return p - mom, ms, mom
+
+
 class SlotView:
   """`optimizer.get_slot(var, name)`: a read view on one co-located state vector; plays the role of
   the `<param>/<opt>/<slot>` de.Variable of create_slots (PY/...optimizer.py:870-904)."""
@@ -133,6 +190,15 @@ class SlotView:
     v = outs[0] if perm is None else device_ops.scatter_rows(torch.cat(outs, 0), perm)
     return v.reshape(tuple(keys.shape) + (self.var.dim,))
 
+  def upsert(self, keys, values):
+    """Write the state vector of `keys` (rows are created with the parameter's default if missing)."""
+    keys = torch.as_tensor(keys, device=self.var._primary)
+    kp, perm, counts = self.var._partition(keys)
+    vp = self.var._split_rows(values.reshape(-1, self.var.dim), perm, counts)
+    for i, t in enumerate(self.var._tables):
+      if kp[i].numel():
+        t._table.upsert(kp[i].to(t._device), vp[i].to(t._device), field=self.field)
+
 
 class DynamicEmbeddingOptimizer:
   """`de.DynamicEmbeddingOptimizer(opt)` (PY/dynamic_embedding_optimizer.py:807-867)."""
@@ -142,7 +208,8 @@ class DynamicEmbeddingOptimizer:
     CPU unsorted_segment_sum) through unique + segment_sum + apply; the default uses the fused
     two-kernel path whose fixed summation tree is deterministic but not the sequential order."""
     if not isinstance(opt, _Opt):
-      raise TypeError("optimizer must be one of tfra_amd.dynamic_embedding.optimizers.{SGD,Adam,Adagrad,Ftrl}")
+      raise TypeError("optimizer must be one of tfra_amd.dynamic_embedding.optimizers.{SGD,Adam,Adagrad,Ftrl} or a "
+                      "subclass of optimizers.Generic")
     self.opt = opt
     self.iterations = 0
     self.exact_order = exact_order
@@ -172,6 +239,30 @@ class DynamicEmbeddingOptimizer:
         raise TypeError("expected the TrainableWrapper returned by embedding_lookup(..., return_trainable=True)")
       self.apply_sparse(tw.params, tw.ids, grad, p)
 
+  def _apply_generic(self, var, ids, grad):
+    """The reference's write-back sequence for an arbitrary rule (`Generic`)."""
+    ids = torch.as_tensor(ids, device=var._primary).reshape(-1)
+    grad = grad.reshape(-1, var.dim).to(torch.float32)
+    n = ids.numel()
+    if n == 0:
+      return
+    if getattr(var, "restrict_policy", None) is not None:
+      var.restrict_policy.apply_update(ids)
+    if var.dim % 4 == 0 and var.dim <= 256 and n <= (1 << 18) and not self.exact_order:
+      uniq_buf, gsum, cnt = device_ops.reduce_by_key(ids, grad)
+    else:
+      uniq_buf, idx, cnt = device_ops.unique_no_sync(ids)
+      gsum = device_ops.segment_sum(grad, idx, cnt, n)
+    u = int(cnt.item())
+    uniq, g = uniq_buf[:u], gsum[:u]
+    views = [self.get_slot(var, name) for name in self.opt.slots]
+    p = var.lookup(uniq).to(torch.float32)
+    slots = [v.lookup(uniq).to(torch.float32) for v in views]
+    new = self.opt.update(self.iterations, p, g, *slots)
+    var.upsert(uniq, new[0].to(var.value_dtype))
+    for v, s_new in zip(views, new[1:]):
+      v.upsert(uniq, s_new.to(var.value_dtype))
+
   @staticmethod
   def can_plan(var, n):
     """The planned / two-kernel write-back covers one shard, fp32 rows with dim % 4 == 0, dim <= 256."""
@@ -184,8 +275,8 @@ class DynamicEmbeddingOptimizer:
     with the lookup of the same ids or with the previous step."""
     from .table_ops import SparsePlan
     ids = torch.as_tensor(ids, device=var._primary).reshape(-1)
-    if not self.can_plan(var, ids.numel()) or self.exact_order:
-      raise ValueError("this variable / batch takes the unique + segment_sum write-back, which has no plan")
+    if not self.can_plan(var, ids.numel()) or self.exact_order or self.opt.kind is None:
+      raise ValueError("this variable / batch / optimizer takes the unique + segment_sum write-back, which has no plan")
     if plan is None:
       plan = SparsePlan(var._tables[0]._device, var.dim)
     return plan.build(ids)
@@ -196,6 +287,8 @@ class DynamicEmbeddingOptimizer:
       self.iterations += 1
       p = self.opt.params(self.iterations)
     self._check(var)
+    if self.opt.kind is None:
+      return self._apply_generic(var, ids, grad)
     if plan is not None:
       if getattr(var, "restrict_policy", None) is not None:
         var.restrict_policy.apply_update(plan.ids)

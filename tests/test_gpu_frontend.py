@@ -260,6 +260,10 @@ OPTS = {
     "adagrad_v2": (lambda de: de.optimizers.Adagrad(0.05, 0.1, 1e-7), dict(lr=0.05, init_acc=0.1, eps=1e-7)),
     "ftrl": (lambda de: de.optimizers.Ftrl(0.05, -0.5, 0.1, 1e-3, 1e-3), dict(lr=0.05, l1=1e-3, l2=1e-3, init_acc=0.1)),
     "ftrl_pow": (lambda de: de.optimizers.Ftrl(0.05, -0.3, 0.1, 0.0, 1e-3), dict(lr=0.05, l1=0.0, l2=1e-3, init_acc=0.1, lr_power=-0.3)),
+    # rules without a fused kernel: the reference's own find / dense-apply / upsert sequence (optimizers.Generic)
+    "momentum": (lambda de: de.optimizers.Momentum(0.05, 0.9), dict(lr=0.05, momentum=0.9)),
+    "momentum_nesterov": (lambda de: de.optimizers.Momentum(0.05, 0.9, use_nesterov=True), dict(lr=0.05, momentum=0.9, nesterov=True)),
+    "rmsprop": (lambda de: de.optimizers.RMSProp(0.01, 0.9, 0.5, 1e-10), dict(lr=0.01, rho=0.9, momentum=0.5, eps=1e-10)),
 }
 
 
@@ -304,6 +308,43 @@ def test_k13_fused_optimizer_matches_reference_sequence(env, name, dim, shards):
     got = deo.get_slot(v, sname).lookup(T(torch, ek)).cpu().numpy()
     exp = tabs[1 + si].find(ek, np.zeros(dim, np.float32))
     np.testing.assert_allclose(got, exp, rtol=tol, atol=tol)
+
+
+def test_generic_optimizer_custom_rule_and_errors(env):
+  """optimizers.Generic with a user rule (here Adamax, T/dynamic_embedding_optimizer_test.py:313-319 lists it):
+  same write-back sequence; a plan cannot be built for it; slot count is limited by the row layout."""
+  torch, de = env
+
+  def adamax(step, p, g, m, v, lr=0.01, b1=0.9, b2=0.999, eps=1e-7):
+    m = m * b1 + g * (1 - b1)
+    v = torch.maximum(v * b2, g.abs())
+    return p - (lr / (1 - b1 ** step)) * m / (v + eps), m, v
+
+  opt = de.optimizers.Generic(slots=("m", "v"), slot_init=(0.0, 0.0), update=adamax)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  var = de.Variable(dim=8, name="generic_adamax", initializer=0.5, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  rng = np.random.default_rng(2)
+  ref = {}
+  for step in range(1, 6):
+    ids = rng.integers(0, 30, size=64).astype(np.int64)
+    g = rng.standard_normal((64, 8)).astype(np.float32)
+    deo.apply_sparse(var, T(torch, ids), T(torch, g))
+    uniq, inv = np.unique(ids, return_inverse=True)
+    gs = np.zeros((uniq.size, 8), np.float64); np.add.at(gs, inv, g.astype(np.float64))
+    for k, gk in zip(uniq.tolist(), gs.astype(np.float32)):
+      p, m, v = ref.get(k, (np.full(8, 0.5, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32)))
+      m = m * 0.9 + gk * 0.1
+      v = np.maximum(v * 0.999, np.abs(gk))
+      ref[k] = ((p - (0.01 / (1 - 0.9 ** step)) * m / (v + 1e-7)).astype(np.float32), m.astype(np.float32), v.astype(np.float32))
+  ks = np.array(sorted(ref), dtype=np.int64)
+  got = var.lookup(T(torch, ks)).cpu().numpy()
+  np.testing.assert_allclose(got, np.stack([ref[int(k)][0] for k in ks]), rtol=2e-5, atol=2e-6)
+  np.testing.assert_allclose(deo.get_slot(var, "v").lookup(T(torch, ks)).cpu().numpy(),
+                             np.stack([ref[int(k)][2] for k in ks]), rtol=2e-5, atol=2e-6)
+  with pytest.raises(ValueError):
+    deo.plan(var, T(torch, ks))
+  with pytest.raises(ValueError):
+    de.optimizers.Generic(slots=("a", "b", "c", "d", "e"))
 
 
 def test_optimizer_requires_slots(env):
