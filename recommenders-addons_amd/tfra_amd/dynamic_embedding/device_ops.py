@@ -205,6 +205,10 @@ def sparse_segment_combine(rows, idx, seg, weights, combiner, n_rows):
   rows = rows.to(torch.float32).contiguous()
   idx = idx.to(torch.int32).contiguous()
   seg = seg.to(torch.int64).contiguous()
+  if idx.numel() != seg.numel():       # T/math_ops_test.py:60-69
+    raise ValueError("indices and segment_ids must have the same number of elements: %d vs %d" % (idx.numel(), seg.numel()))
+  if weights is not None and torch.as_tensor(weights).numel() != idx.numel():
+    raise ValueError("weights must have one element per index")
   w = None if weights is None else weights.to(torch.float32).contiguous()
   dim = rows.shape[-1]
   out = torch.empty((n_rows, dim), dtype=torch.float32, device=rows.device)

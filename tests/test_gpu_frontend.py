@@ -775,3 +775,20 @@ def test_safe_embedding_lookup_sparse_reference_kats(env, shards):
                                         combiner="sum").cpu().numpy()
   np.testing.assert_allclose(got[4], 0.0 * E[0] - 0.5 * E[1], rtol=1e-6, atol=1e-6)
   np.testing.assert_allclose(got[0], E[0] + 2 * E[1] + E[-100], rtol=1e-6, atol=1e-6)
+
+
+def test_sparse_segment_sum_reference_kats(env):
+  """T/math_ops_test.py:60-131 (de.math.sparse_segment_sum with / without num_segments)."""
+  torch, de = env
+  data = T(torch, np.array([[1, 2, 3, 4], [-1, -2, -3, -4], [5, 6, 7, 8]], np.float32))
+  idx = torch.tensor([0, 1], dtype=torch.int32, device="cuda")
+  seg = torch.tensor([0, 5], dtype=torch.int64, device="cuda")
+  for n in (6, 100):
+    got = de.device_ops.sparse_segment_combine(data, idx, seg, None, "sum", n).cpu().numpy()
+    want = np.zeros((n, 4), np.float32)
+    want[0], want[5] = [1, 2, 3, 4], [-1, -2, -3, -4]
+    np.testing.assert_array_equal(got, want)
+  with pytest.raises(ValueError):      # 6 indices vs 7 segment ids
+    de.device_ops.sparse_segment_combine(T(torch, np.arange(20, dtype=np.float32).reshape(10, 2)),
+                                         torch.arange(6, dtype=torch.int32, device="cuda"),
+                                         torch.arange(7, dtype=torch.int64, device="cuda"), None, "sum", 100)
