@@ -177,8 +177,13 @@ class SlotView:
   """`optimizer.get_slot(var, name)`: a read view on one co-located state vector; plays the role of
   the `<param>/<opt>/<slot>` de.Variable of create_slots (PY/...optimizer.py:870-904)."""
 
-  def __init__(self, var, field, init):
+  def __init__(self, var, field, init, name=None):
     self.var, self.field, self.init = var, field, init
+    self.name = name if name is not None else "%s/slot%d" % (var.name, field)
+
+  def size(self, index=None):
+    """A slot vector lives in the row of its key: it has exactly the keys of the parameter."""
+    return self.var.size(index)
 
   def lookup(self, keys):
     keys = torch.as_tensor(keys, device=self.var._primary)
@@ -221,7 +226,10 @@ class DynamicEmbeddingOptimizer:
 
   def get_slot(self, var, name):
     f = self.opt.slots.index(name) + 1
-    return SlotView(var, f, self.opt.aux_init()[f - 1])
+    return SlotView(var, f, self.opt.aux_init()[f - 1], "%s/%s/%s" % (var.name, type(self.opt).__name__, name))
+
+  def get_slot_names(self):
+    return list(self.opt.slots)
 
   def _check(self, var):
     if var.aux_fields < len(self.opt.slots):

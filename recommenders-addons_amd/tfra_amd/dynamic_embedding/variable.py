@@ -125,6 +125,11 @@ class Variable:
   def restrict_policy(self):
     return self._restrict_policy
 
+  def get_slot_variables(self, optimizer):
+    """PY/dynamic_embedding_variable.py:1157-1200: the optimizer's state variables of this parameter, sorted by
+    name (here: views on the co-located state vectors of the rows)."""
+    return sorted((optimizer.get_slot(self, n) for n in optimizer.get_slot_names()), key=lambda v: v.name)
+
   def restrict(self, num_reserved, **kwargs):
     """PY/dynamic_embedding_variable.py:857-874: no-op without a policy."""
     if self._restrict_policy is not None:

@@ -172,3 +172,40 @@ def test_policy_matches_oracle_on_random_stream(de, kind):
           table = {k: table.get(k, 0) for k in live}
   finally:
     time.time = real_time
+
+
+def test_variable_with_restrict_and_slot_variables(de):
+  """test_dynamic_embedding_variable_with_restrict_v1 (T/dynamic_embedding_variable_test.py:1831-1893) and
+  test_get_slot_variables (:1959-1996): train until both variables exceed the trigger, restrict to
+  num_reserved; the variables, their optimizer slots and the policy status all end at num_reserved keys."""
+  data_len, maxval, num_reserved, trigger, dim = 32, 256, 100, 150, 8
+  rng = np.random.default_rng(0)
+  opt = de.optimizers.Adam(0.1)
+  optmz = de.DynamicEmbeddingOptimizer(opt)
+  kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
+  vs = [de.get_variable("tstp_guard", key_dtype=torch.int64, value_dtype=torch.float32, initializer=-1.0, dim=dim,
+                        init_size=256, restrict_policy=de.TimestampRestrictPolicy, **kw),
+        de.get_variable("freq_guard", key_dtype=torch.int64, value_dtype=torch.float32, initializer=-1.0, dim=dim,
+                        init_size=256, restrict_policy=de.FrequencyRestrictPolicy, **kw)]
+  sizes = [0, 0]
+  while not all(s > trigger for s in sizes):
+    for v in vs:
+      for _ in range(3):
+        ids = torch.from_numpy(rng.integers(0, maxval, size=(data_len, 1))).cuda()
+        emb, tw = de.embedding_lookup(v, ids, return_trainable=True)
+        optmz.apply_gradients([(torch.ones_like(emb), tw)])
+    sizes = [int(v.size()) for v in vs]
+  assert all(s >= trigger for s in sizes)
+  for v in vs:
+    v.restrict(num_reserved, trigger=trigger)
+  assert [int(v.size()) for v in vs] == [num_reserved, num_reserved]
+  for v in vs:
+    slots = v.get_slot_variables(optmz)
+    assert [s.name for s in slots] == sorted("%s/Adam/%s" % (v.name, n) for n in ("m", "v"))
+    for sp in slots:
+      assert int(sp.size()) == num_reserved
+    assert int(v.restrict_policy.status.size()) == num_reserved
+    # survivors still carry their optimizer state
+    keys, _ = v.export()
+    m = slots[0].lookup(keys)
+    assert bool((m != 0).any())
