@@ -204,7 +204,9 @@ int tfra_table_apply_sparse(tfra_table_t* t, const tfra_opt_params* p, size_t n,
  * and tfra_table_apply_planned does the gradient half (run sums + fused update) when the gradients
  * exist.  Results are bit-identical to tfra_table_apply_sparse(ids, grads).  The caller orders the two
  * calls (event / same stream) and keeps `plan` untouched until apply_planned's work has finished; a plan
- * can be rebuilt for the next batch afterwards (it owns its device buffers: ~ (650 + 8*dim) B per id). */
+ * can be rebuilt for the next batch afterwards (it owns its device buffers: ~ (650 + 8*dim) B per id).
+ * A plan object is not internally locked: one thread builds / consumes it at a time (different plans and
+ * different tables are independent).                                                                  */
 typedef struct tfra_sparse_plan tfra_sparse_plan_t;
 int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out);
 int tfra_sparse_plan_destroy(tfra_sparse_plan_t* plan);
