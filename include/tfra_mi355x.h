@@ -188,23 +188,31 @@ int tfra_table_apply_optimizer(tfra_table_t* t, const tfra_opt_params* p, size_t
                                const int64_t* keys, const float* grads, const void* param_defaults,
                                int default_is_full, const int64_t* d_n, tfra_stream_t stream);
 
-/* The whole backward half of a training step in two kernels: ids [n] MAY repeat (a raw Zipf batch);
- * gradients of equal ids are summed in a fixed order (deterministic), then one fused update per
- * unique key as above.  = _resource_apply_sparse_duplicate_indices + the write-back sequence
- * (PY/dynamic_embedding_optimizer.py:165-204).  param_default_row: [dim] fp32, used for unseen keys.
+/* The whole backward half of a training step: ids [n] MAY repeat (a raw Zipf batch); gradients of equal
+ * ids are summed in a fixed order (deterministic; ids occurring <= 8 times in the batch: strictly in batch order),
+ * then one fused update per unique key as above.  = _resource_apply_sparse_duplicate_indices + the write-back
+ * sequence (PY/dynamic_embedding_optimizer.py:165-204).  param_default_row: [dim] fp32, used for unseen keys.
  * Requires float32 values, dim % 4 == 0, dim <= 256, n <= 2^18 (262 144) ids per call. */
 int tfra_table_apply_sparse(tfra_table_t* t, const tfra_opt_params* p, size_t n, const int64_t* ids,
                             const float* grads, const float* param_default_row, tfra_stream_t stream);
 
-/* tfra_table_apply_sparse split at the point where gradients are needed.  Which ids repeat, in which
- * order their gradients are summed and which unique keys the step updates depends on the ids alone,
- * and the ids of a step are known at lookup time (PY/embedding_weights.py keeps them in the
- * TrainableWrapper) or earlier (input pipeline).  tfra_sparse_plan_build does that id-only half on ANY
- * stream — concurrently with the lookup of the same ids, or while the previous step still runs —
- * and tfra_table_apply_planned does the gradient half (run sums + fused update) when the gradients
- * exist.  Results are bit-identical to tfra_table_apply_sparse(ids, grads).  The caller orders the two
- * calls (event / same stream) and keeps `plan` untouched until apply_planned's work has finished; a plan
- * can be rebuilt for the next batch afterwards (it owns its device buffers: ~ (650 + 8*dim) B per id).
+/* insert_or_assign of a batch whose keys MAY repeat — the LAST occurrence wins, like the reference's sequential
+ * LaunchTensorsInsert (K/cuckoo_hashtable_op.cc:104-140) — de-duplicated on the device, also on a bounded (Hkv)
+ * table running at max_capacity (eviction needs one writer per key).  values [n,dim] of the table's dtype;
+ * scores [n] or NULL (the last occurrence's score; LFU without scores counts the occurrences).  n <= 2^18. */
+int tfra_table_upsert_sparse(tfra_table_t* t, size_t n, const int64_t* ids, const void* values,
+                             const uint64_t* scores, tfra_stream_t stream);
+
+/* The two calls above split at the point where gradients / values are needed.  Which ids repeat, in which order
+ * their gradients are summed and which unique keys the step writes depends on the ids alone, and the ids of a step
+ * are known at lookup time (PY/embedding_weights.py keeps them in the TrainableWrapper) or earlier (input
+ * pipeline).  tfra_sparse_plan_build does that id-only half on ANY stream — next to the lookup of the same ids, or
+ * while the previous step still runs: the batch as CSR-by-key (unique keys, and per key its batch positions in
+ * ascending order; keys with many occurrences pre-split into runs of <= 512) — and tfra_table_apply_planned /
+ * tfra_table_upsert_planned do the rest when the gradients / values exist.  Results are bit-identical to the
+ * one-call forms.  The caller orders build and use (event / same stream) and keeps `plan` untouched until the
+ * work using it has finished; a plan can be rebuilt for the next batch afterwards (it owns its device buffers:
+ * ~ (90 + dim/2) B per id + 12 MB).  dim: the table's dim (0 for a plan only used by upsert_planned).
  * A plan object is not internally locked: one thread builds / consumes it at a time (different plans and
  * different tables are independent).                                                                  */
 typedef struct tfra_sparse_plan tfra_sparse_plan_t;
@@ -213,14 +221,24 @@ int tfra_sparse_plan_destroy(tfra_sparse_plan_t* plan);
 int tfra_sparse_plan_build(tfra_sparse_plan_t* plan, size_t n, const int64_t* ids, int dim, tfra_stream_t stream);
 int tfra_table_apply_planned(tfra_table_t* t, const tfra_opt_params* p, const tfra_sparse_plan_t* plan,
                              const float* grads, const float* param_default_row, tfra_stream_t stream);
+int tfra_table_upsert_planned(tfra_table_t* t, const tfra_sparse_plan_t* plan, const void* values,
+                              const uint64_t* scores, tfra_stream_t stream);
+/* Introspection (tests, tools): counts[6] = {keys with > 8 occurrences, other keys, partial sums, 512-entry bins,
+ * entries of the other keys, build errors}; when keys != NULL also the CSR itself, keys with > 8 occurrences first:
+ * keys[i], cnt[i], and positions[] = the batch positions of key 0, of key 1, ... each ascending (cap = length of
+ * keys/cnt, positions holds n).  Host buffers; synchronises `stream`. */
+int tfra_sparse_plan_read(const tfra_sparse_plan_t* plan, uint32_t* counts, int64_t* keys, uint32_t* cnt,
+                          uint32_t* positions, size_t cap, tfra_stream_t stream);
 
 /* One whole training step of a single table on two streams, driven from C (what a TF executor does
  * between the ops of one session.run, without the host framework in the loop):
  *   main : rows_out = find(ids_cur) [n = plan_cur's id count; skipped when rows_out is NULL]
- *          -> tfra_table_apply_planned(plan_cur, grads)
+ *          -> tfra_table_apply_planned(plan_cur, grads)            (tfra_table_step_prefetch)
+ *          or tfra_table_upsert_planned(plan_cur, values, scores)  (tfra_table_step_prefetch_assign)
  *   side : tfra_sparse_plan_build(plan_next, ids_next), free-running; plan_next may be NULL (last step).
  * plan_cur must have been built from ids_cur (by an earlier call as its plan_next, or by
- * tfra_sparse_plan_build on main_stream).  The streams are ordered inside, normally without any
+ * tfra_sparse_plan_build on main_stream).  ids_next must be complete in memory when the call is made (the side
+ * stream does not wait for the main stream).  The streams are ordered inside, normally without any
  * cross-queue event: rotate >= 3 plans (4 recommended) so that plan_next's buffers — last read by the
  * step that used it as plan_cur — are idle when it is rebuilt; with fewer the call waits on the host.  */
 int tfra_table_step_prefetch(tfra_table_t* t, const tfra_opt_params* p, tfra_sparse_plan_t* plan_cur,
@@ -228,6 +246,11 @@ int tfra_table_step_prefetch(tfra_table_t* t, const tfra_opt_params* p, tfra_spa
                              const float* grads, const float* param_default_row,
                              tfra_sparse_plan_t* plan_next, const int64_t* ids_next, size_t n_next,
                              tfra_stream_t main_stream, tfra_stream_t side_stream);
+int tfra_table_step_prefetch_assign(tfra_table_t* t, tfra_sparse_plan_t* plan_cur, const int64_t* ids_cur,
+                                    void* rows_out, const void* find_default, const void* values,
+                                    const uint64_t* scores, tfra_sparse_plan_t* plan_next,
+                                    const int64_t* ids_next, size_t n_next, tfra_stream_t main_stream,
+                                    tfra_stream_t side_stream);
 
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 
@@ -249,12 +272,11 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
                      tfra_stream_t stream);
 
 /* tf.unique + unsorted_segment_sum in one call, parallel per key and order-fixed (the reduction half of
- * tfra_table_apply_sparse: PY/dynamic_embedding_optimizer.py:177-190): keys_out[0..*d_count) = the
- * distinct ids (a deterministic but unspecified order), rows_out[i,:] = sum of the rows of `in` whose
- * id is keys_out[i] (fixed summation tree: bit-reproducible, not the sequential order).  keys_out [n],
- * rows_out [n,dim]; fp32, dim % 4 == 0, dim <= 256, n <= 2^18.  *d_count = -1 if an internal limit
- * overflowed (thousands of multi-part keys hashing into one merge bucket).  Unlike
- * tfra_segment_sum the cost does not grow with the multiplicity of the hottest id.            */
+ * tfra_table_apply_sparse, same summation tree: PY/dynamic_embedding_optimizer.py:177-190): keys_out[0..*d_count) =
+ * the distinct ids (unspecified order, may differ between calls), rows_out[i,:] = sum of the rows of `in` whose
+ * id is keys_out[i] (bit-reproducible per key; ids occurring <= 8 times: strictly in input order).  keys_out [n],
+ * rows_out [n,dim]; fp32, dim % 4 == 0, dim <= 256, n <= 2^18.  *d_count = -1 if an internal capacity overflowed
+ * (pathological hash skew).  Unlike tfra_segment_sum the cost does not grow with the multiplicity of the hottest id. */
 int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int dim, const float* in,
                        int64_t* keys_out, float* rows_out, int64_t* d_count, tfra_stream_t stream);
 

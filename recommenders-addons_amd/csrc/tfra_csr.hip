@@ -1,0 +1,1351 @@
+// Write-back of a batch whose ids MAY repeat, organised as CSR-by-key.
+//
+// Reference: the gradients of duplicate ids are summed, then ONE update per key
+// (`_resource_apply_sparse_duplicate_indices` = unique + unsorted_segment_sum,
+// PY/dynamic_embedding_optimizer.py:177-190) followed by (1+S) finds + dense apply + (1+S) upserts
+// (:165-204); a plain upsert of a batch with repeats keeps the LAST occurrence
+// (LaunchTensorsInsert on one thread, K/cuckoo_hashtable_op.cc:104-140).
+//
+// A Zipf-1.2 batch of 131 072 ids is extremely bimodal: ~790 keys occur more than 8 times and hold
+// ~100 000 of the positions (the hottest ~24 000), the other ~21 000 keys share the remaining ~30 000.
+//
+//   PLAN (id-only, tfra_sparse_plan_build; any stream, typically one batch ahead on a second stream)
+//     csr_tile_kernel    one block per 512 ids: equal ids grouped with an LDS hash; one descriptor
+//                        (key, tile, count, where the tile keeps the positions) per distinct key of the tile,
+//                        appended to the key's merge bucket (hash of the key).
+//     csr_bucket_kernel  one block per bucket: groups its descriptors by key, orders a key's descriptors by tile
+//                        (per-key tile table + wave scans), and emits
+//                          cold keys (<= 8 occurrences): (key, first, count) + their batch positions, ascending;
+//                          hot keys: their positions laid out in BINS of 512 entries — every 512 consecutive
+//                            occurrences of a key fill one bin, the remainder (< 512, padded to 16) shares a bin
+//                            with other remainders, never straddling — and (key, first partial, #partials).
+//     csr_finish_kernel  publishes the counts, re-arms the cursors for the next build.
+//   GRADIENT HALF (tfra_table_apply_planned)
+//     hot_sums_kernel    one block per bin: 32 groups x 16 rows in flight, ordered add -> one partial row per run
+//     apply_csr_kernel   one 16-lane group per unique key (hot keys first): gathers its <= 8 gradient rows or
+//                        its partial rows IN ORDER, sums, locates/claims the table row, applies the optimizer.
+//   ASSIGN (tfra_table_upsert_planned): upsert_csr_kernel — one group per unique key copies the row of the
+//     key's LAST occurrence (no sums, any value dtype).
+//
+// Summation tree of a key = f(its occurrence count) only: [16 consecutive occurrences, ascending batch position,
+// sequential] -> [the 32 groups of a bin, sequential] -> [the key's partials, sequential]; keys with <= 8
+// occurrences are summed strictly in batch order (bit-identical to the reference's sequential sum).  WHERE a
+// key's records land (atomic cursors) differs from run to run, the values do not: results are bit-reproducible.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tfra_mi355x.h"
+#include "tfra_device.h"
+#include "tfra_host.h"
+#include "tfra_optim_device.h"
+#include "tfra_reduce_device.h"
+
+using namespace tfra;
+using namespace tfra::red;
+
+namespace {
+
+constexpr int DIRECT = 8;                 // occurrences the update kernel gathers by itself
+constexpr int SEG = 512;                  // entries of a hot bin = rows one hot_sums block reduces
+constexpr unsigned E_SKIP = 1u << 31, E_HEAD = 1u << 30, E_POS = (1u << 18) - 1;
+constexpr unsigned TABW = 4096;           // u32 entries of the per-pass tile table (16 KB)
+constexpr unsigned CTR_STRIDE = 16;       // u64 words between two counters (one 128-B line each)
+constexpr int MAXPASS_SPLIT = 64;
+// Output space is handed out by ATOMIC counters, and same-line atomics of different workgroups serialise at ~25 ns
+// each on this chip (1024 bucket blocks on ONE counter line: 25 us, measured).  So the outputs are split into NSH
+// shards with private counters and private ranges: bucket b allocates in shard b % NSH (P/NSH = 16 atomics per line),
+// and the last plan kernel publishes dense maps (keymap / binmap) over the shards for the kernels of the other half.
+constexpr unsigned NSH = 64;
+constexpr unsigned REC_WORDS = 16;        // a key record = 64 B: [0,1] key [2] count; few occurrences: [4..11] its batch
+                                          // positions, ascending; many: [3] first partial row [4] #partials [5] entry
+                                          // address of its last occurrence
+constexpr unsigned KM_MANY = 1u << 31;    // keymap: the record lives in `hrec`
+
+// global descriptor store: bucket b owns [b*CMAX, b*CMAX + cm); overflow list behind it
+struct CsrDesc {
+  i64* key;
+  unsigned* ord;        // tile << 18 | (count == 1: position in tile, else: run index in the tile) << 9 | (count - 1)
+  unsigned* cursor;     // [P] one per 128-B line
+  i64* ovf_key;
+  unsigned* ovf_ord;
+  unsigned* ovf_bucket;
+  unsigned* ovf_count;
+  unsigned ovf_cap;
+};
+
+struct CsrOut {
+  u64* counters;        // [NSH] one per line: few-keys | many-keys << 16 | partials << 32 | bins << 48; [NSH]: deferred keys
+  unsigned* crec;       // [NSH*cr] records of the keys with <= DIRECT occurrences
+  unsigned* hrec;       // [NSH*hr] records of the others
+  unsigned* hent;       // [NSH*br] bins of SEG entries: batch position | E_HEAD | E_SKIP
+  unsigned* hout;       // [NSH*br*32] per 16-entry item: partial row of the run starting there
+  unsigned cr, hr, pr, br;   // per-shard capacities: records, records, partial rows, bins
+};
+
+// ---------------------------------------------------------------------------------------------
+// plan kernel 1: per tile of 512 ids.
+__global__ __launch_bounds__(NTA) void csr_tile_kernel(size_t n, const i64* __restrict__ ids, unsigned P, unsigned cm,
+                                                       CsrDesc ds, unsigned* err,
+                                                       unsigned* __restrict__ tile_entries,
+                                                       unsigned short* __restrict__ run_start,
+                                                       unsigned* __restrict__ tile_len, u64* counters) {
+  // the allocation counters of this build start at zero (the bucket kernel, next on the stream, uses them)
+  if (blockIdx.x == 0 && threadIdx.x <= NSH) counters[(size_t)threadIdx.x * CTR_STRIDE] = 0;
+  constexpr unsigned GCAP = 2048;            // group table: 4x the tile => short probe chains
+  constexpr int W = TILE / 32;               // words of a position bitmask
+  constexpr int GM = GCAP / W;               // multi-member groups ranked per round (mask area = s_owner)
+  __shared__ i64 s_key[TILE];
+  __shared__ unsigned s_owner[GCAP];         // group table; afterwards the position masks
+  __shared__ unsigned s_rep[GCAP];           // smallest input position of the group; later (m << 16 | base)
+  __shared__ unsigned s_cnt[GCAP];
+  __shared__ unsigned short s_list[TILE];    // positions of the multi-member groups, run after run, ascending
+  __shared__ unsigned short s_run[TILE];     // ... and the run (multi-member group) each list entry belongs to
+  __shared__ int s_scan[NTA / 64];
+  unsigned* const s_mask = s_owner;
+  const size_t tile = blockIdx.x, base = tile * TILE;
+  const int nvalid = (int)min((size_t)TILE, n - base);
+  const int p = threadIdx.x;
+  const bool ok = p < nvalid;
+  const i64 key = ok ? ids[base + p] : 0;
+  s_key[p] = key;
+  for (unsigned b = threadIdx.x; b < GCAP; b += NTA) { s_owner[b] = 0; s_rep[b] = 0xffffffffu; s_cnt[b] = 0; }
+  __syncthreads();
+  unsigned slot = 0;
+  if (ok) {
+    slot = lds_group_slot(s_key, s_owner, GCAP, p, fmix64((u64)key));
+    atomicMin(&s_rep[slot], (unsigned)p);
+    atomicAdd(&s_cnt[slot], 1u);
+  }
+  __syncthreads();
+  const bool head = ok && s_rep[slot] == (unsigned)p;
+  const unsigned cnt = ok ? s_cnt[slot] : 0;
+  const bool mhead = head && cnt > 1;
+  int n_multi, L;
+  const int m = block_excl_scan<NTA>(mhead ? 1 : 0, s_scan, &n_multi);
+  const int lbase = block_excl_scan<NTA>(mhead ? (int)cnt : 0, s_scan, &L);
+  // descriptor append: the returning atomic is issued now and consumed after the ranking rounds
+  unsigned desc_pos = 0, desc_bucket = 0;
+  if (head) {
+    desc_bucket = (unsigned)__umul64hi(fmix64((u64)key), (u64)P);
+    desc_pos = atomicAdd(&ds.cursor[(size_t)desc_bucket * CSTRIDE], 1u);
+  }
+  if (mhead) s_rep[slot] = ((unsigned)m << 16) | (unsigned)lbase;
+  __syncthreads();  // s_rep maps slot -> (m, base) for multi groups; s_owner is free
+  for (int c0 = 0; c0 < n_multi; c0 += GM) {
+    for (unsigned q = threadIdx.x; q < GCAP; q += NTA) s_mask[q] = 0;
+    __syncthreads();
+    const int mm = (ok && cnt > 1) ? (int)(s_rep[slot] >> 16) - c0 : -1;
+    if (mm >= 0 && mm < GM) atomicOr(&s_mask[mm * W + (p >> 5)], 1u << (p & 31));
+    __syncthreads();
+    if (mm >= 0 && mm < GM) {
+      int rank = __popc(s_mask[mm * W + (p >> 5)] & ((1u << (p & 31)) - 1u));
+      for (int wds = 0; wds < (p >> 5); ++wds) rank += __popc(s_mask[mm * W + wds]);
+      s_list[(int)(s_rep[slot] & 0xffffu) + rank] = (unsigned short)p;  // ascending input position inside the run
+      s_run[(int)(s_rep[slot] & 0xffffu) + rank] = (unsigned short)(s_rep[slot] >> 16);
+    }
+    __syncthreads();
+  }
+  if (head) {
+    const unsigned where = cnt == 1 ? (unsigned)p : (unsigned)m;
+    if (cnt > 1) run_start[base + m] = (unsigned short)lbase;
+    const unsigned ordv = ((unsigned)tile << 18) | (where << 9) | (cnt - 1);
+    if (desc_pos < cm) {
+      size_t d = (size_t)desc_bucket * CMAX + desc_pos;
+      ds.key[d] = key; ds.ord[d] = ordv;
+    } else {
+      unsigned o = atomicAdd(ds.ovf_count, 1u);
+      if (o < ds.ovf_cap) { ds.ovf_key[o] = key; ds.ovf_ord[o] = ordv; ds.ovf_bucket[o] = desc_bucket; }
+      else atomicAdd(err, 1u);
+    }
+  }
+  // the tile keeps its own member lists: csr_scatter_kernel moves them once the bucket kernel has said where to
+  for (int q = threadIdx.x; q < L; q += NTA) tile_entries[base + q] = (unsigned)s_list[q] | ((unsigned)s_run[q] << 9);
+  if (threadIdx.x == 0) tile_len[tile] = (unsigned)L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan kernel 2: per merge bucket.  Dynamic LDS: cm*36 + TABW*4 bytes.
+__global__ __launch_bounds__(NT) void csr_bucket_kernel(unsigned P, unsigned ntiles, unsigned cm, CsrDesc ds,
+                                                        uint4* __restrict__ drec, CsrOut out, unsigned* err) {
+  extern __shared__ unsigned char smem[];
+  i64* const e_key = reinterpret_cast<i64*>(smem);            // [cm] descriptors of the pass
+  unsigned* const e_ord = reinterpret_cast<unsigned*>(e_key + cm);
+  unsigned* const s_owner = e_ord + cm;                         // [cm] group table (1 + claiming descriptor)
+  unsigned* const s_ct = s_owner + cm;                          // [cm] per group: #descriptors | entries << 11
+  unsigned* const s_pref = s_ct + cm;                           // [cm] per descriptor: entries of its key in earlier tiles
+  unsigned* const s_a = s_pref + cm;                            // [cm] per group: allocation, see below
+  unsigned* const s_b = s_a + cm;
+  unsigned* const s_tab = s_b + cm;                             // [TABW] tile table of the multi-descriptor keys
+  unsigned short* const s_slot = reinterpret_cast<unsigned short*>(s_tab + TABW);  // [cm] group of each descriptor
+  unsigned short* const s_hot = s_slot + cm;                    // [cm] head descriptors of the hot keys
+  __shared__ int s_scan[NT / 64];
+  __shared__ unsigned s_nhot, s_nshared, s_hot_ok;
+  __shared__ unsigned s_cold_ok;
+  __shared__ unsigned sh_ckbase, sh_hkbase, sh_pbase, sh_bbase;
+  const unsigned b = blockIdx.x;
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = threadIdx.x >> 4, wv = threadIdx.x >> 6;
+  const int n_b = (int)ds.cursor[(size_t)b * CSTRIDE];
+  if (n_b == 0) return;
+  const unsigned n_ovf = n_b > (int)cm ? min(*ds.ovf_count, ds.ovf_cap) : 0u;
+  const int n_reg = min(n_b, (int)cm);
+  // A bucket with more descriptors than one pass holds (several very hot keys hashing together) is processed in
+  // npass = 2^k passes, pass q taking the keys with (hash >> 40) & (npass-1) == q.  Emission goes through atomic
+  // cursors and cannot be redone, so npass is fixed up front from a histogram of the 64 finest classes.
+  unsigned npass = 1;
+  if (n_b > (int)cm) {
+    __shared__ unsigned s_hist[MAXPASS_SPLIT];
+    __shared__ unsigned s_np;
+    if (threadIdx.x < MAXPASS_SPLIT) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_reg + (int)n_ovf; q += NT) {
+      i64 k = 0; bool take = false;
+      if (q < n_reg) { k = ds.key[(size_t)b * CMAX + q]; take = true; }
+      else if (ds.ovf_bucket[q - n_reg] == b) { k = ds.ovf_key[q - n_reg]; take = true; }
+      if (take) atomicAdd(&s_hist[(unsigned)(fmix64((u64)k) >> 40) & (MAXPASS_SPLIT - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned np = 2;
+      for (; np < MAXPASS_SPLIT; np <<= 1) {
+        unsigned worst = 0;
+        for (unsigned c = 0; c < np; ++c) {
+          unsigned sum = 0;
+          for (unsigned j = c; j < MAXPASS_SPLIT; j += np) sum += s_hist[j];
+          worst = max(worst, sum);
+        }
+        if (worst <= cm) break;
+      }
+      s_np = np;
+    }
+    __syncthreads();
+    npass = s_np;
+  }
+  const unsigned ntile_pad = (ntiles + 63) & ~63u;         // table row length (<= 512)
+  const int rows_per_round = (int)(TABW / ntile_pad);
+  for (unsigned pass = 0; pass < npass; ++pass) {
+    int n = 0;
+    if (npass == 1) {
+      for (int q = threadIdx.x; q < n_reg; q += NT) {
+        size_t d = (size_t)b * CMAX + q;
+        e_key[q] = ds.key[d]; e_ord[q] = ds.ord[d];
+      }
+      n = n_reg;
+      __syncthreads();
+    } else {  // filtered gather from the region and from the overflow list
+      int carry = 0;
+      bool too_many = false;
+      for (int q0 = 0; q0 < n_reg + (int)n_ovf; q0 += NT) {
+        int q = q0 + threadIdx.x;
+        i64 k = 0; unsigned od = 0; bool take = false;
+        if (q < n_reg) {
+          size_t d = (size_t)b * CMAX + q;
+          k = ds.key[d]; od = ds.ord[d]; take = true;
+        } else if (q < n_reg + (int)n_ovf) {
+          unsigned o = q - n_reg;
+          if (ds.ovf_bucket[o] == b) { k = ds.ovf_key[o]; od = ds.ovf_ord[o]; take = true; }
+        }
+        take = take && (((unsigned)(fmix64((u64)k) >> 40) & (npass - 1)) == pass);
+        int tot;
+        int ex = block_excl_scan<NT>(take ? 1 : 0, s_scan, &tot);
+        if (carry + tot > (int)cm) too_many = true;
+        if (take && !too_many) { e_key[carry + ex] = k; e_ord[carry + ex] = od; }
+        carry += tot;
+      }
+      __syncthreads();
+      if (too_many) {  // even 64 classes are not enough (one key with > cm parts cannot happen: cm >= #tiles)
+        if (threadIdx.x == 0) atomicAdd(err, 1u);
+        continue;
+      }
+      n = carry;
+    }
+    if (n == 0) continue;
+    // ---- group by key --------------------------------------------------------------------------
+    for (unsigned q = threadIdx.x; q < cm; q += NT) { s_owner[q] = 0; s_ct[q] = 0; }
+    if (threadIdx.x == 0) { s_nhot = 0; s_nshared = 0; s_hot_ok = 1; }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n; q += NT) {
+      unsigned slot = lds_group_slot(e_key, s_owner, cm, q, fmix64((u64)e_key[q]));
+      atomicAdd(&s_ct[slot], 1u | (((e_ord[q] & 511u) + 1u) << 11));
+      s_slot[q] = (unsigned short)slot;
+      s_pref[q] = 0;
+    }
+    __syncthreads();
+    // ---- entries of the same key in EARLIER tiles, for the keys with more than one descriptor: a row of
+    //      per-tile counts per key, exclusive wave scan along the row -------------------------------
+    int n_multi = 0;
+    for (int pb = 0; pb < n; pb += NT) {
+      int q = pb + threadIdx.x;
+      unsigned slot = q < n ? s_slot[q] : 0;
+      bool mh = q < n && s_owner[slot] - 1 == (unsigned)q && (s_ct[slot] & 2047u) > 1;
+      int tm;
+      int em = block_excl_scan<NT>(mh ? 1 : 0, s_scan, &tm);
+      if (mh) s_a[slot] = (unsigned)(n_multi + em);
+      n_multi += tm;
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < n_multi; c0 += rows_per_round) {
+      const int nrows = min(rows_per_round, n_multi - c0);
+      for (unsigned q = threadIdx.x; q < (unsigned)nrows * ntile_pad; q += NT) s_tab[q] = 0;
+      __syncthreads();
+      for (int q = threadIdx.x; q < n; q += NT) {
+        unsigned slot = s_slot[q];
+        if ((s_ct[slot] & 2047u) > 1) {
+          int mrow = (int)s_a[slot] - c0;
+          if (mrow >= 0 && mrow < nrows) s_tab[mrow * ntile_pad + (e_ord[q] >> 18)] = (e_ord[q] & 511u) + 1u;
+        }
+      }
+      __syncthreads();
+      const unsigned epl = ntile_pad / 64;   // elements per lane (<= 8)
+      for (int mrow = wv; mrow < nrows; mrow += NT / 64) {
+        unsigned* row = s_tab + mrow * ntile_pad + lane * epl;
+        unsigned loc = 0;
+        for (unsigned e = 0; e < epl; ++e) loc += row[e];
+        unsigned incl = loc;
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+          unsigned t2 = (unsigned)__shfl_up((int)incl, o2);
+          if (lane >= o2) incl += t2;
+        }
+        unsigned run = incl - loc;
+        for (unsigned e = 0; e < epl; ++e) { unsigned c = row[e]; row[e] = run; run += c; }
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < n; q += NT) {
+        unsigned slot = s_slot[q];
+        if ((s_ct[slot] & 2047u) > 1) {
+          int mrow = (int)s_a[slot] - c0;
+          if (mrow >= 0 && mrow < nrows) s_pref[q] = s_tab[mrow * ntile_pad + (e_ord[q] >> 18)];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- allocation.  keys with few occurrences: a block scan; the others (few keys): thread 0 ------------
+    //   few : s_a = rank among the pass's such keys
+    //   many: s_a = first partial (relative) | first full bin (relative) << 16, s_b = first 16-entry item of the remainder
+    int nck = 0;
+    for (int pb = 0; pb < n; pb += NT) {
+      int q = pb + threadIdx.x;
+      unsigned slot = q < n ? s_slot[q] : 0;
+      bool hd = q < n && s_owner[slot] - 1 == (unsigned)q;
+      unsigned tot = hd ? (s_ct[slot] >> 11) : 0;
+      bool cold = hd && tot <= (unsigned)DIRECT;
+      int tt;
+      int ex = block_excl_scan<NT>(cold ? 1 : 0, s_scan, &tt);
+      if (cold) s_a[slot] = (unsigned)(nck + ex);
+      if (hd && !cold) { unsigned i = atomicAdd(&s_nhot, 1u); s_hot[i] = (unsigned short)q; }
+      nck += tt;
+    }
+    __syncthreads();
+    const unsigned shard = b & (NSH - 1);
+    if (threadIdx.x == 0) {
+      const unsigned nh = s_nhot;
+      unsigned nshared = 0, used = 32, nfulltot = 0, npart = 0;
+      for (unsigned i = 0; i < nh; ++i) {
+        const unsigned slot = s_slot[s_hot[i]];
+        const unsigned tot = s_ct[slot] >> 11, nfull = tot >> 9, rem = tot & 511u, it = (rem + 15) >> 4;
+        unsigned remitem = 0;
+        if (rem) {
+          if (used + it > 32) { nshared++; used = 0; }
+          remitem = (nshared - 1) * 32 + used;
+          used += it;
+        }
+        s_a[slot] = npart | (nfulltot << 16);
+        s_b[slot] = remitem;
+        nfulltot += nfull;
+        npart += nfull + (rem ? 1 : 0);
+      }
+      const unsigned nbins = nshared + nfulltot;
+      const u64 c = atomicAdd(&out.counters[(size_t)shard * CTR_STRIDE],
+                              (u64)nck | ((u64)nh << 16) | ((u64)npart << 32) | ((u64)nbins << 48));
+      sh_ckbase = (unsigned)(c & 0xffffu); sh_hkbase = (unsigned)((c >> 16) & 0xffffu);
+      sh_pbase = (unsigned)((c >> 32) & 0xffffu); sh_bbase = (unsigned)(c >> 48);
+      s_nshared = nshared;
+      // a shard's range is sized for twice its fair share (+ the single-key worst case for bins / partials): only a
+      // pathological hash skew gets here; the keys are skipped and the build reports the error
+      s_cold_ok = sh_ckbase + nck <= out.cr;
+      s_hot_ok = sh_hkbase + nh <= out.hr && sh_pbase + npart <= out.pr && sh_bbase + nbins <= out.br;
+      if (!s_cold_ok || (nh && !s_hot_ok)) atomicAdd(err, 1u);
+    }
+    __syncthreads();
+    const unsigned nh = s_nhot, nshared = s_nshared;
+    const bool hot_ok = s_hot_ok != 0, cold_ok = s_cold_ok != 0;
+    const unsigned ckbase = shard * out.cr + sh_ckbase, hkbase = shard * out.hr + sh_hkbase,
+                   pbase = shard * out.pr + sh_pbase, bbase = shard * out.br + sh_bbase;
+    // shared bins start as "nothing here": every 16-entry item is its own empty run
+    if (hot_ok)
+      for (unsigned q = threadIdx.x; q < nshared * SEG; q += NT)
+        out.hent[(size_t)bbase * SEG + q] = E_SKIP | ((q & 15u) == 0 ? E_HEAD : 0u);
+    // key records
+    if (cold_ok) {
+      for (int q = threadIdx.x; q < n; q += NT) {
+        unsigned slot = s_slot[q];
+        if (s_owner[slot] - 1 != (unsigned)q) continue;
+        unsigned tot = s_ct[slot] >> 11;
+        if (tot <= (unsigned)DIRECT) {
+          unsigned* rec = out.crec + (size_t)(ckbase + s_a[slot]) * REC_WORDS;
+          rec[0] = (unsigned)(u64)e_key[q]; rec[1] = (unsigned)((u64)e_key[q] >> 32); rec[2] = tot;
+        }
+      }
+    }
+    if (hot_ok) {
+      for (unsigned i = threadIdx.x; i < nh; i += NT) {
+        const int q = s_hot[i];
+        const unsigned slot = s_slot[q];
+        const unsigned tot = s_ct[slot] >> 11, nfull = tot >> 9, rem = tot & 511u;
+        const unsigned partrel = s_a[slot] & 0xffffu, fullrel = s_a[slot] >> 16, remitem = s_b[slot];
+        const unsigned fullbin0 = bbase + nshared + fullrel;
+        const unsigned last_addr = rem ? (bbase * SEG + remitem * 16 + rem - 1) : ((fullbin0 + nfull - 1) * SEG + SEG - 1);
+        unsigned* rec = out.hrec + (size_t)(hkbase + i) * REC_WORDS;
+        rec[0] = (unsigned)(u64)e_key[q]; rec[1] = (unsigned)((u64)e_key[q] >> 32); rec[2] = tot;
+        rec[3] = pbase + partrel; rec[4] = nfull + (rem ? 1 : 0); rec[5] = last_addr;
+        for (unsigned j = 0; j < nfull; ++j) out.hout[(size_t)(fullbin0 + j) * 32] = pbase + partrel + j;
+        if (rem) out.hout[(size_t)bbase * 32 + remitem] = pbase + partrel + nfull;
+      }
+    }
+    __syncthreads();   // the SKIP fill above is ordered before the entries below
+    // ---- entries: descriptor (tile, where, c) owns entries [pref, pref + c) of its key ----------------
+    auto write_entry = [&](unsigned slot, unsigned e, unsigned position) {
+      const unsigned tot = s_ct[slot] >> 11;
+      if (tot <= (unsigned)DIRECT) {
+        if (cold_ok) out.crec[(size_t)(ckbase + s_a[slot]) * REC_WORDS + 4 + e] = position;
+      } else if (hot_ok) {
+        const unsigned nfull = tot >> 9, fullrel = s_a[slot] >> 16;
+        size_t addr;
+        bool hd;
+        if (e < nfull * SEG) { addr = (size_t)(bbase + nshared + fullrel) * SEG + e; hd = (e & (SEG - 1)) == 0; }
+        else { addr = (size_t)bbase * SEG + s_b[slot] * 16 + (e - nfull * SEG); hd = e == nfull * SEG; }
+        out.hent[addr] = position | (hd ? E_HEAD : 0u);
+      }
+    };
+    for (int q = threadIdx.x; q < n; q += NT) {
+      const unsigned od = e_ord[q];
+      if ((od & 511u) == 0) write_entry(s_slot[q], s_pref[q], ((od >> 18) << 9) | ((od >> 9) & 511u));
+    }
+    // descriptors with count >= 2: where their member list goes (csr_scatter_kernel does the moving, one thread per
+    // member, all tiles at once — the block of the hottest bucket alone would take ~100 dependent round trips)
+    for (int q = threadIdx.x; q < n; q += NT) {
+      const unsigned od = e_ord[q];
+      if ((od & 511u) == 0) continue;
+      const unsigned slot = s_slot[q], tot = s_ct[slot] >> 11, e0 = s_pref[q];
+      uint4 r;
+      if (tot <= (unsigned)DIRECT) r = cold_ok ? make_uint4((ckbase + s_a[slot]) * REC_WORDS + 4 + e0, 0u, 0u, 0xffffffffu)
+                                               : make_uint4(0u, 0u, 0u, 0xfffffffeu);
+      else if (hot_ok) r = make_uint4(e0, (bbase + nshared + (s_a[slot] >> 16)) * SEG, bbase * SEG + s_b[slot] * 16, tot >> 9);
+      else r = make_uint4(0u, 0u, 0u, 0xfffffffeu);   // dropped (capacity error reported)
+      drec[(size_t)(od >> 18) * TILE + ((od >> 9) & 511u)] = r;
+    }
+    __syncthreads();
+  }
+}
+
+// plan kernel 3 (the last one): per tile again.
+//  (a) every member of a multi-member run goes to the place csr_bucket_kernel chose for its descriptor:
+//      entry e = e0 + (rank inside the run) of its key;
+//  (b) dense maps over the allocation shards: keymap[g] = record of the g-th unique key (keys with many occurrences
+//      first), binmap[i] = i-th bin;
+//  (c) block 0: publishes the counts (device copy for the kernels of the other half, pinned host copy for the
+//      driver), re-arms the bucket cursors for the next build, latches the errors.
+//   d_counts: [0] keys with many occurrences [1] other keys [2] - [3] bins [4] - [5] errors of the build
+__global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __restrict__ tile_entries,
+                                                          const unsigned short* __restrict__ run_start,
+                                                          const unsigned* __restrict__ tile_len,
+                                                          const uint4* __restrict__ drec, CsrOut out,
+                                                          unsigned* __restrict__ keymap, unsigned* __restrict__ binmap,
+                                                          unsigned* cursors, unsigned P,
+                                                          unsigned* d_counts, unsigned* host_counts, unsigned gen) {
+  __shared__ unsigned s_hpre[NSH + 1], s_cpre[NSH + 1], s_bpre[NSH + 1];
+  if (threadIdx.x < 64) {   // wave 0: prefix sums of the shards' counts (clamped to the shard capacities)
+    const unsigned sh = threadIdx.x;
+    const u64 c = out.counters[(size_t)sh * CTR_STRIDE];
+    const unsigned nc = min((unsigned)(c & 0xffffu), out.cr), nh = min((unsigned)((c >> 16) & 0xffffu), out.hr),
+                   nb = min((unsigned)(c >> 48), out.br);
+    unsigned ic = nc, ih = nh, ib = nb;
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+      unsigned tc = (unsigned)__shfl_up((int)ic, o2), th = (unsigned)__shfl_up((int)ih, o2), tb = (unsigned)__shfl_up((int)ib, o2);
+      if ((int)sh >= o2) { ic += tc; ih += th; ib += tb; }
+    }
+    s_cpre[sh + 1] = ic; s_hpre[sh + 1] = ih; s_bpre[sh + 1] = ib;
+    if (sh == 0) { s_cpre[0] = 0; s_hpre[0] = 0; s_bpre[0] = 0; }
+  }
+  __syncthreads();
+  const unsigned nhot = s_hpre[NSH], ncold = s_cpre[NSH], nbins = s_bpre[NSH];
+  auto shard_of = [](const unsigned* pre, unsigned x) {   // largest s with pre[s] <= x
+    unsigned lo = 0;
+    for (unsigned step = NSH / 2; step > 0; step >>= 1) if (pre[lo + step] <= x) lo += step;
+    return lo;
+  };
+  const unsigned gid = blockIdx.x * NTA + threadIdx.x;
+  if (gid < nhot) {
+    const unsigned sh = shard_of(s_hpre, gid);
+    keymap[gid] = KM_MANY | (sh * out.hr + (gid - s_hpre[sh]));
+  } else if (gid < nhot + ncold) {
+    const unsigned x = gid - nhot, sh = shard_of(s_cpre, x);
+    keymap[gid] = sh * out.cr + (x - s_cpre[sh]);
+  }
+  if (gid < nbins) {
+    const unsigned sh = shard_of(s_bpre, gid);
+    binmap[gid] = sh * out.br + (gid - s_bpre[sh]);
+  }
+  if (blockIdx.x == 0) {
+    for (unsigned i = threadIdx.x; i <= P; i += NTA) cursors[(size_t)i * CSTRIDE] = 0;   // bucket cursors + overflow count
+    if (threadIdx.x == 0) {
+      const unsigned e = cursors[(size_t)(P + 1) * CSTRIDE];
+      cursors[(size_t)(P + 1) * CSTRIDE] = 0;
+      const unsigned v[6] = {nhot, ncold, 0u, nbins, 0u, e};
+      for (int k = 0; k < 6; ++k) d_counts[k] = v[k];
+      if (host_counts) {
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  // (a)
+  const size_t base = (size_t)blockIdx.x * TILE;
+  const int L = (int)tile_len[blockIdx.x];
+  const int q = threadIdx.x;
+  if (q >= L) return;
+  const unsigned te = tile_entries[base + q];
+  const unsigned m = te >> 9, position = (unsigned)base + (te & 511u);
+  const unsigned rank = (unsigned)q - run_start[base + m];
+  const uint4 r = drec[base + m];
+  if (r.w == 0xffffffffu) { out.crec[(size_t)r.x + rank] = position; return; }
+  if (r.w == 0xfffffffeu) return;
+  const unsigned e = r.x + rank, nfull = r.w;
+  if (e < nfull * SEG) out.hent[(size_t)r.y + e] = position | ((e & (SEG - 1)) == 0 ? E_HEAD : 0u);
+  else out.hent[(size_t)r.z + (e - nfull * SEG)] = position | (e == nfull * SEG ? E_HEAD : 0u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient half, kernel 1: one block per hot bin.
+template <int NCH>
+__global__ __launch_bounds__(NTA) void hot_sums_kernel(const float* __restrict__ grads, int dim,
+                                                       const unsigned* __restrict__ hent, const unsigned* __restrict__ hout,
+                                                       const unsigned* __restrict__ binmap,
+                                                       const unsigned* __restrict__ d_counts, float* __restrict__ partial,
+                                                       unsigned* progress, unsigned progress_val) {
+  constexpr int NG = NTA / 16;
+  __shared__ unsigned s_pos[SEG];
+  __shared__ unsigned s_out[SEG];
+  __shared__ unsigned char s_flag[SEG + 1];
+  __shared__ float s_left[NG][64 * NCH];
+  __shared__ unsigned char s_cont[NG], s_hashead[NG];
+  // tfra_table_step_prefetch: host-visible progress counter (pinned memory) — this kernel running means the
+  // lookup of step `progress_val` and every earlier step of the main stream are complete
+  if (progress && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned nbins = d_counts[3];
+  for (unsigned ib = blockIdx.x; ib < nbins; ib += gridDim.x) {
+    const unsigned bin = binmap[ib];
+    const unsigned e = hent[(size_t)bin * SEG + threadIdx.x];
+    s_pos[threadIdx.x] = e & E_POS;
+    s_flag[threadIdx.x] = (unsigned char)(((e & E_HEAD) ? F_HEAD : 0) | ((e & E_SKIP) ? F_SINGLE : 0));
+    if ((e & E_HEAD) && !(e & E_SKIP)) s_out[threadIdx.x] = hout[(size_t)bin * 32 + (threadIdx.x >> 4)];
+    if (threadIdx.x == 0) s_flag[SEG] = F_HEAD;
+    __syncthreads();
+    ordered_run_sums<NCH, NG, Batch<NCH>::v>(
+        SEG, 16, dim, s_flag, s_left, s_cont, s_hashead,
+        [&](int q) { return grads + (size_t)s_pos[q] * dim; },
+        [&](int ph) { return partial + (size_t)s_out[ph] * dim; });
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct CsrKeys {
+  const unsigned* keymap;
+  const unsigned* crec; const unsigned* hrec;
+  const unsigned* hent;
+  const unsigned* d_counts;
+};
+
+// one coalesced 64-B load per key group: lane i holds word i of the key's record
+__device__ __forceinline__ unsigned load_record(const CsrKeys& ks, unsigned g, int sub, bool& many) {
+  const unsigned km = ks.keymap[g];
+  many = (km & KM_MANY) != 0;
+  return (many ? ks.hrec : ks.crec)[(size_t)(km & ~KM_MANY) * REC_WORDS + sub];
+}
+
+// the <= 8 source rows of one batch of a key's sum: loads issued together, adds in order
+template <int NB>
+__device__ __forceinline__ void add_rows(float4& acc, const float* (&src)[8], int nsrc, int c) {
+  float4 x[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) x[j] = *reinterpret_cast<const float4*>(src[j] + c);
+  if (NB == 8) { keep_live(x[0], x[1], x[2], x[3]); keep_live(x[NB - 4], x[NB - 3], x[NB - 2], x[NB - 1]); }
+  else if (NB == 4) keep_live(x[0], x[1], x[2], x[3]);
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (j < nsrc) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+}
+
+// gradient half, kernel 2: one 16-lane group per unique key, hot keys first (their partial lists are the longest
+// chains of the kernel: started first, they finish inside the kernel's duration).
+// PHASE2: bounded (Hkv) table at max_capacity — the keys of `dlist` (no free slot in phase 1) replace the minimum-score
+// entry of their two home buckets and start from the default row / initial slot values, exactly like
+// apply_evict_kernel (tfra_optim.hip).
+template <int KIND, bool PHASE2>
+__global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int dim, const float* __restrict__ grads,
+                                                        const float* __restrict__ partial, CsrKeys ks,
+                                                        const float* __restrict__ default_row, float aux0, float aux1,
+                                                        ScoreP sp, unsigned* __restrict__ dlist, u64* dcount) {
+  constexpr int S = NSlots<KIND>::v;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned total = PHASE2 ? (unsigned)*dcount : ks.d_counts[0] + ks.d_counts[1];
+  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  int fresh = 0, failed = 0;
+  if (o.d_lr) o.lr = *o.d_lr;
+  if (!PHASE2 && blockIdx.x == 0 && threadIdx.x == 0 && ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);  // plan overflow
+  // trips are uniform per wave (the batch width below is a wave-wide maximum): a group past the end re-reads the
+  // last key's records and does nothing else
+  for (unsigned wbase = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 2; wbase < total; wbase += ngroups) {
+    const unsigned it_raw = wbase + (unsigned)(lane >> 4);
+    const bool active = it_raw < total;
+    const unsigned it = active ? it_raw : total - 1;
+    const unsigned g = PHASE2 ? dlist[it] : it;
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const i64 key = (i64)(((u64)(unsigned)__shfl((int)w, gshift + 1) << 32) | (unsigned)__shfl((int)w, gshift));
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    const unsigned first = (unsigned)__shfl((int)w, gshift + 3);             // keys with many occurrences: first partial row
+    const unsigned nsrc = hot ? (unsigned)__shfl((int)w, gshift + 4) : cnt;
+    // first probe in flight while the sources are resolved
+    u64 h;
+    const u64 b0 = bucket0(key, v.nb, h);
+    i64 k0 = 0;
+    if (!PHASE2) k0 = load_key_coherent(key_line(v, b0) + sub);
+    const float* src[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned jj = min((unsigned)j, nsrc - 1);
+      const unsigned position = (unsigned)__shfl((int)w, gshift + 4 + (int)min(jj, 7u));   // (few occurrences) word 4+j
+      src[j] = hot ? partial + (size_t)(first + jj) * dim : grads + (size_t)position * dim;
+    }
+    // wave-uniform batch width: 1 / 2 / 4 / 8 rows in flight (most keys of a Zipf batch occur once)
+    unsigned wmax = min(nsrc, 8u);
+    for (int o2 = 32; o2 >= 16; o2 >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o2));
+    wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wmax);
+    if (!active) continue;
+    i64 row;
+    bool is_new = false;
+    u64 word = 0;
+    bool claimed_empty = false;
+    if (PHASE2) {
+      const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+      const u64 in_score = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | 1) : 1;
+      row = evict_and_lock(v, key, in_score, lru_like, sub, gshift, &word, claimed_empty);
+      is_new = true;
+    } else {
+      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded);
+      if (row == NEED_EVICT && sub == 0) dlist[atomicAdd(dcount, 1ULL)] = g;
+    }
+    if (row < 0) {
+      failed += (sub == 0 && (PHASE2 ? row == -3 : row != NEED_EVICT));
+      continue;
+    }
+    fresh += ((PHASE2 ? claimed_empty : is_new) && sub == 0);
+    float* pr = reinterpret_cast<float*>(row_ptr(v, row));
+    for (int c = sub * 4; c < dim; c += 64) {
+      float4 p = *reinterpret_cast<const float4*>((is_new ? default_row : pr) + c);
+      float4 s1 = *reinterpret_cast<const float4*>(pr + (S >= 1 ? dim : 0) + c);
+      float4 s2 = *reinterpret_cast<const float4*>(pr + (S >= 2 ? 2 * dim : 0) + c);
+      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wmax <= 1) add_rows<1>(gg, src, (int)nsrc, c);
+      else if (wmax <= 2) add_rows<2>(gg, src, (int)nsrc, c);
+      else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
+      else add_rows<8>(gg, src, (int)nsrc, c);
+      for (unsigned j0 = 8; j0 < nsrc; j0 += 8) {   // hot keys with more than 8 partials
+        const float* s2r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s2r[j] = partial + (size_t)(first + min(j0 + j, nsrc - 1)) * dim;
+        add_rows<8>(gg, s2r, (int)(nsrc - j0), c);
+      }
+      float4 dummy = p;
+      keep_live(dummy, p, s1, s2);
+      if (is_new || S < 1) s1 = make_float4(aux0, aux0, aux0, aux0);
+      if (is_new || S < 2) s2 = make_float4(aux1, aux1, aux1, aux1);
+      apply_one<KIND>(o, gg.x, p.x, s1.x, s2.x);
+      apply_one<KIND>(o, gg.y, p.y, s1.y, s2.y);
+      apply_one<KIND>(o, gg.z, p.z, s1.z, s2.z);
+      apply_one<KIND>(o, gg.w, p.w, s1.w, s2.w);
+      // write-through: the rows leave L2 during the kernel, not at the boundary to the next one
+      store_wt16(pr + c, *reinterpret_cast<uint4*>(&p));
+      if (S >= 1) store_wt16(pr + dim + c, *reinterpret_cast<uint4*>(&s1));
+      if (S >= 2) store_wt16(pr + 2 * dim + c, *reinterpret_cast<uint4*>(&s2));
+    }
+    // aux fields the optimizer does not own (table created with more slots than it uses)
+    if (is_new && (int)v.n_fields - 1 > S) {
+      for (int f = S + 1; f < (int)v.n_fields; ++f)
+        for (int c = sub; c < dim; c += 16)
+          __hip_atomic_store(pr + f * dim + c, (f == 1 ? aux0 : aux1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (PHASE2) {
+      if (sub == 0) store_wt8(score_word(v, word), 0);  // the slot starts a new life
+      update_score<true>(v, row, true, sp.strategy, 1, sp.epoch, sub);
+      publish_key(v, word, key, sub);
+    } else {
+      update_score(v, row, is_new, sp.strategy, 1, sp.epoch, sub);  // one write-back = one upsert
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tfra_reduce_by_key epilogue: the same per-key sums as apply_csr_kernel, written out instead of applied.
+__global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* __restrict__ grads,
+                                                         const float* __restrict__ partial, CsrKeys ks,
+                                                         i64* __restrict__ keys_out, float* __restrict__ rows_out,
+                                                         i64* __restrict__ d_count) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
+  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d_count = ks.d_counts[5] ? (i64)-1 : (i64)total;
+  for (unsigned wbase = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 2; wbase < total; wbase += ngroups) {
+    const unsigned it_raw = wbase + (unsigned)(lane >> 4);
+    const bool active = it_raw < total;
+    const unsigned g = active ? it_raw : total - 1;
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const i64 key = (i64)(((u64)(unsigned)__shfl((int)w, gshift + 1) << 32) | (unsigned)__shfl((int)w, gshift));
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    const unsigned first = (unsigned)__shfl((int)w, gshift + 3);
+    const unsigned nsrc = hot ? (unsigned)__shfl((int)w, gshift + 4) : cnt;
+    const float* src[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned jj = min((unsigned)j, nsrc - 1);
+      const unsigned position = (unsigned)__shfl((int)w, gshift + 4 + (int)min(jj, 7u));
+      src[j] = hot ? partial + (size_t)(first + jj) * dim : grads + (size_t)position * dim;
+    }
+    unsigned wmax = min(nsrc, 8u);
+    for (int o2 = 32; o2 >= 16; o2 >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o2));
+    wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wmax);
+    if (!active) continue;
+    for (int c = sub * 4; c < dim; c += 64) {
+      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wmax <= 1) add_rows<1>(gg, src, (int)nsrc, c);
+      else if (wmax <= 2) add_rows<2>(gg, src, (int)nsrc, c);
+      else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
+      else add_rows<8>(gg, src, (int)nsrc, c);
+      for (unsigned j0 = 8; j0 < nsrc; j0 += 8) {
+        const float* s2r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s2r[j] = partial + (size_t)(first + min(j0 + j, nsrc - 1)) * dim;
+        add_rows<8>(gg, s2r, (int)(nsrc - j0), c);
+      }
+      *reinterpret_cast<float4*>(rows_out + (size_t)g * dim + c) = gg;
+    }
+    if (sub == 0) keys_out[g] = key;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ASSIGN write-back: row of the key's LAST occurrence in the batch -> the table (insert_or_assign with repeats,
+// "last one wins").  scores: optional per-position in_score (the last occurrence's is used; LFU adds count).
+template <int G, bool PHASE2>
+__global__ __launch_bounds__(256) void upsert_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
+                                                         const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
+                                                         ScoreP sp, unsigned* __restrict__ dlist, u64* dcount,
+                                                         unsigned* progress, unsigned progress_val) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned total = PHASE2 ? (unsigned)*dcount : ks.d_counts[0] + ks.d_counts[1];
+  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  int fresh = 0, failed = 0;
+  if (!PHASE2 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
+    if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
+  }
+  for (unsigned it = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); it < total; it += ngroups) {
+    const unsigned g = PHASE2 ? dlist[it] : it;
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const i64 key = (i64)(((u64)(unsigned)__shfl((int)w, gshift + 1) << 32) | (unsigned)__shfl((int)w, gshift));
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3 + (int)min(cnt, 8u)));   // few: the last position itself
+    if (hot) last = ks.hent[last] & E_POS;                                                   // many: where it is stored
+    u64 h;
+    const u64 b0 = bucket0(key, v.nb, h);
+    i64 row;
+    bool is_new = false, claimed_empty = false;
+    u64 word = 0;
+    const u64 in_one = scores ? scores[last] : 1;
+    const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+    if (PHASE2) {
+      const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+      row = evict_and_lock(v, key, sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score, lru_like, sub,
+                           gshift, &word, claimed_empty);
+      is_new = true;
+    } else {
+      const bool pf1 = sp.bounded > 1;
+      const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+      const i64 k1 = load_key_coherent(key_line(v, pf1 ? bucket1(h, b0, v.nb) : b0) + sub);
+      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded, pf1 ? &k1 : nullptr);
+      if (row == NEED_EVICT && sub == 0) dlist[atomicAdd(dcount, 1ULL)] = g;
+    }
+    if (row < 0) {
+      failed += (sub == 0 && (PHASE2 ? row == -3 : row != NEED_EVICT));
+      continue;
+    }
+    fresh += ((PHASE2 ? claimed_empty : is_new) && sub == 0);
+    unsigned char* pr = row_ptr(v, row);
+    const unsigned char* sr = vals + (size_t)last * v.field_bytes;
+    if (PHASE2) copy_bytes16_wt<G>(pr, sr, v.field_bytes, sub);
+    else copy_bytes16<G>(pr, sr, v.field_bytes, sub);
+    if (is_new && v.n_fields > 1) {   // slot fields of a brand-new row start at aux_init
+      for (unsigned f = 1; f < v.n_fields; ++f) {
+        const unsigned pat = ai.pattern[(f - 1) & 3];
+        unsigned char* q = pr + f * v.field_bytes;
+        if ((v.field_bytes & 3) == 0)
+          for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          for (unsigned off = sub; off < v.field_bytes; off += 16)
+            __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (PHASE2) {
+      if (sub == 0) store_wt8(score_word(v, word), 0);
+      update_score<true>(v, row, true, sp.strategy, in_score, sp.epoch, sub);
+      publish_key(v, word, key, sub);
+    } else {
+      update_score(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+struct tfra_sparse_plan {
+  int device = 0;
+  void* buf = nullptr;
+  size_t bytes = 0;
+  // layout of the last build
+  size_t n = 0, npad = 0, ntiles = 0;
+  unsigned P = 0, cm = 0;
+  int dim = 0;
+  unsigned* cursors = nullptr;
+  CsrDesc ds{};
+  CsrOut out{};
+  unsigned* tile_entries = nullptr;
+  unsigned short* run_start = nullptr;
+  unsigned* tile_len = nullptr;
+  uint4* drec = nullptr;
+  unsigned* keymap = nullptr;
+  unsigned* binmap = nullptr;
+  unsigned* d_counts = nullptr;
+  unsigned* dlist = nullptr;
+  float* partial = nullptr;
+  bool armed = false;              // cursors/counters are zero (re-armed by the last kernel of the previous build)
+  unsigned* host_counts = nullptr; // pinned: [0] generation of the last COMPLETED build, [1..6] its counts
+  unsigned gen = 0;                // generation of the last enqueued build
+  bool ev_recorded = false;        // the last build ran on a side stream (tfra_table_step_prefetch)
+  unsigned last_used_step = 0;     // last step whose write-back read this plan
+};
+
+extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
+  if (!out) return set_error(TFRA_ERR_INVALID, "sparse_plan_create: null out");
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_create: no device");
+  tfra_sparse_plan* pl = new tfra_sparse_plan();
+  pl->device = device;
+  *out = pl;
+  return TFRA_OK;
+}
+
+extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
+  if (!pl) return TFRA_OK;
+  if (pl->buf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->buf); }
+  if (pl->host_counts) (void)hipHostFree(pl->host_counts);
+  delete pl;
+  return TFRA_OK;
+}
+
+static size_t plan_smem_bytes(unsigned cm) { return (size_t)cm * 36 + (size_t)TABW * 4; }
+
+extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const int64_t* ids, int dim, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pl) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null plan");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != pl->device) { if (hipSetDevice(pl->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: hipSetDevice"); } }
+  pl->n = 0;
+  if (n == 0) return TFRA_OK;
+  if (!ids) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null ids");
+  if (dim < 0 || dim % 4 != 0 || dim > 64 * MAXCH)
+    return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: needs dim % 4 == 0 and dim <= 256 (dim 0: assign-only plan)");
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
+  const size_t ntiles = (n + TILE - 1) / TILE, npad = ntiles * TILE;
+  unsigned P = 64;
+  while (P < 2048 && (size_t)P * 128 < n) P <<= 1;
+  const unsigned cm = ntiles <= 256 ? 512u : 1024u;   // a key present in every tile must fit one pass with room to spare
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t reg = (size_t)P * CMAX;
+  const size_t head = al((size_t)(P + 2) * CSTRIDE * 4);
+  const size_t ctr = al((size_t)(NSH + 1) * CTR_STRIDE * 8);
+  // per-shard capacities: twice the fair share + slack; bins / partial rows also cover ONE key holding every id
+  CsrOut& o = pl->out;
+  o.cr = (unsigned)(2 * npad / NSH + 64);
+  o.hr = (unsigned)(2 * (npad / 9) / NSH + 64);
+  o.pr = (unsigned)(npad / SEG + 2 * (npad / 9) / NSH + 64);
+  o.br = (unsigned)(npad / SEG + (npad / 16 + npad / 9) / NSH / 16 + 2 * (P / NSH + 1) + 32);
+  const size_t nrec_c = (size_t)NSH * o.cr, nrec_h = (size_t)NSH * o.hr, nbin = (size_t)NSH * o.br, npart = (size_t)NSH * o.pr;
+  size_t bytes = head + ctr + 256                                               // cursors, counters, d_counts
+                 + al(reg * 8) + al(reg * 4) + al(npad * 8) + 2 * al(npad * 4)  // descriptors + overflow list
+                 + al(npad * 4) + al(npad * 2) + al(ntiles * 4) + al(npad * 16) // tile lists, run starts, lengths, destinations
+                 + al(nrec_c * REC_WORDS * 4) + al(nrec_h * REC_WORDS * 4)      // key records
+                 + al(nbin * SEG * 4) + al(nbin * 32 * 4)                       // bins + run outputs
+                 + al(npad * 4) + al(nbin * 4)                                  // keymap, binmap
+                 + al(npad * 4)                                                 // deferred list
+                 + al(npart * (size_t)dim * 4);                                 // partial rows
+  if (pl->bytes < bytes) {
+    if (pl->buf) {
+      if (hipDeviceSynchronize() != hipSuccess || hipFree(pl->buf) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: free");
+      pl->buf = nullptr; pl->bytes = 0;
+    }
+    hipError_t e = hipMalloc(&pl->buf, bytes);
+    if (e != hipSuccess) { pl->buf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
+    pl->bytes = bytes;
+    pl->armed = false;
+  }
+  unsigned char* w = (unsigned char*)pl->buf;
+  pl->cursors = (unsigned*)w; w += head;
+  o.counters = (u64*)w; w += ctr;
+  pl->d_counts = (unsigned*)w; w += 256;
+  const bool same_layout = pl->armed && pl->P == P;
+  if (!same_layout && hipMemsetAsync(pl->buf, 0, head + ctr, s) != hipSuccess)
+    return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+  CsrDesc& ds = pl->ds;
+  ds.key = (i64*)w; w += al(reg * 8);
+  ds.ord = (unsigned*)w; w += al(reg * 4);
+  ds.ovf_key = (i64*)w; w += al(npad * 8);
+  ds.ovf_ord = (unsigned*)w; w += al(npad * 4);
+  ds.ovf_bucket = (unsigned*)w; w += al(npad * 4);
+  pl->tile_entries = (unsigned*)w; w += al(npad * 4);
+  pl->run_start = (unsigned short*)w; w += al(npad * 2);
+  pl->tile_len = (unsigned*)w; w += al(ntiles * 4);
+  pl->drec = (uint4*)w; w += al(npad * 16);
+  o.crec = (unsigned*)w; w += al(nrec_c * REC_WORDS * 4);
+  o.hrec = (unsigned*)w; w += al(nrec_h * REC_WORDS * 4);
+  o.hent = (unsigned*)w; w += al(nbin * SEG * 4);
+  o.hout = (unsigned*)w; w += al(nbin * 32 * 4);
+  pl->keymap = (unsigned*)w; w += al(npad * 4);
+  pl->binmap = (unsigned*)w; w += al(nbin * 4);
+  pl->dlist = (unsigned*)w; w += al(npad * 4);
+  pl->partial = (float*)w;
+  pl->gen += 1;
+  ds.cursor = pl->cursors;
+  ds.ovf_count = pl->cursors + (size_t)P * CSTRIDE;
+  ds.ovf_cap = (unsigned)npad;
+  unsigned* err = pl->cursors + (size_t)(P + 1) * CSTRIDE;
+  csr_tile_kernel<<<dim3((unsigned)ntiles), NTA, 0, s>>>(n, (const i64*)ids, P, cm, ds, err, pl->tile_entries, pl->run_start, pl->tile_len, o.counters);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(csr_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)plan_smem_bytes(1024));
+    attr_set = true;
+  }
+  csr_bucket_kernel<<<dim3(P), NT, plan_smem_bytes(cm), s>>>(P, (unsigned)ntiles, cm, ds, pl->drec, o, err);
+  csr_scatter_kernel<<<dim3((unsigned)ntiles), NTA, 0, s>>>(pl->tile_entries, pl->run_start, pl->tile_len, pl->drec, o, pl->keymap,
+                                                           pl->binmap, pl->cursors, P, pl->d_counts, pl->host_counts, pl->gen);
+  pl->armed = true;
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
+  pl->n = n; pl->npad = npad; pl->ntiles = ntiles; pl->P = P; pl->cm = cm; pl->dim = dim;
+  return TFRA_OK;
+}
+
+// the plan's counts as the host knows them: exact when the build has completed and published them
+// (step driver), otherwise the worst case (grid-stride kernels read the real counts from device memory)
+static void plan_grids(const tfra_sparse_plan* pl, unsigned* key_blocks, unsigned* bin_blocks) {
+  size_t keys = pl->n, bins = (size_t)NSH * pl->out.br;
+  if (pl->host_counts && (int)(*(volatile unsigned*)pl->host_counts - pl->gen) >= 0) {
+    keys = (size_t)pl->host_counts[1] + pl->host_counts[2];
+    bins = pl->host_counts[4];
+  } else {
+    keys = std::min<size_t>(keys, 32768);   // grid-stride beyond 2048 blocks
+    bins = std::min<size_t>(bins, 1024);
+  }
+  *key_blocks = (unsigned)std::max<size_t>(1, (keys * 16 + 255) / 256);
+  *bin_blocks = (unsigned)std::max<size_t>(1, bins);
+}
+
+static CsrKeys keys_of(const tfra_sparse_plan* pl) {
+  return CsrKeys{pl->keymap, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts};
+}
+
+static u64* dcount_of(const tfra_sparse_plan* pl) { return pl->out.counters + (size_t)NSH * CTR_STRIDE; }
+
+template <int KIND>
+static void launch_apply_csr(Table* t, hipStream_t s, const tfra_sparse_plan* pl, const OptP& o, const float* grads,
+                             const float* default_row, unsigned key_blocks, const ScoreP& sp) {
+  TableView v = t->view_of(t->cur);
+  const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
+  u64* dcount = dcount_of(pl);
+  if (sp.bounded) (void)hipMemsetAsync(dcount, 0, sizeof(u64), s);   // deferred list of this use of the plan
+  apply_csr_kernel<KIND, false><<<key_blocks, 256, 0, s>>>(v, o, pl->dim, grads, pl->partial, keys_of(pl), default_row, a0, a1, sp,
+                                                           pl->dlist, dcount);
+  if (sp.bounded)
+    apply_csr_kernel<KIND, true><<<key_blocks, 256, 0, s>>>(v, o, pl->dim, grads, pl->partial, keys_of(pl), default_row, a0, a1, sp,
+                                                            pl->dlist, dcount);
+}
+
+static int apply_planned_impl(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl, const float* grads,
+                              const float* param_default_row, tfra_stream_t stream, unsigned* progress, unsigned progress_val) {
+  // caller holds t->mu
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !p || !pl) return set_error(TFRA_ERR_INVALID, "apply_planned: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = t->enter(s);
+  if (rc) return rc;
+  if (pl->n == 0) return TFRA_OK;
+  if (!grads || !param_default_row) return set_error(TFRA_ERR_INVALID, "apply_planned: null buffer");
+  if (t->opts.value_dtype != TFRA_F32) return set_error(TFRA_ERR_UNSUPPORTED, "apply_planned: value_dtype must be float32");
+  if (p->kind < 0 || p->kind > TFRA_OPT_FTRL) return set_error(TFRA_ERR_INVALID, "apply_planned: unknown kind");
+  int need = p->kind == TFRA_OPT_SGD ? 0 : (p->kind == TFRA_OPT_ADAGRAD ? 1 : 2);
+  if (t->opts.aux_fields < need) return set_error(TFRA_ERR_INVALID, "apply_planned: table lacks optimizer slot fields");
+  if (t->opts.dim != pl->dim) return set_error(TFRA_ERR_INVALID, "apply_planned: the plan was built for another dim");
+  if (t->opts.device != pl->device && t->opts.device >= 0) return set_error(TFRA_ERR_INVALID, "apply_planned: plan and table live on different devices");
+  if ((((uintptr_t)grads | (uintptr_t)param_default_row) & 15))
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_planned: gradient / default buffers must be 16-B aligned");
+  rc = t->prepare_insert(pl->n, s);
+  if (rc) return rc;
+  const int dim = pl->dim;
+  unsigned key_blocks, bin_blocks;
+  plan_grids(pl, &key_blocks, &bin_blocks);
+  const int nch = (dim + 63) / 64;
+  switch (nch) {
+    case 1: hot_sums_kernel<1><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, progress, progress_val); break;
+    case 2: hot_sums_kernel<2><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, progress, progress_val); break;
+    case 3: hot_sums_kernel<3><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, progress, progress_val); break;
+    default: hot_sums_kernel<4><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, progress, progress_val); break;
+  }
+  uint8_t* bounded_now;
+  rc = t->bounded_flags(1, s, &bounded_now);
+  if (rc) return rc;
+  const ScoreP sp{t->opts.strategy, t->global_epoch, bounded_now ? (t->dense ? 2 : 1) : 0};
+  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power, p->d_lr};
+  switch (p->kind) {
+    case TFRA_OPT_SGD: launch_apply_csr<TFRA_OPT_SGD>(t, s, pl, o, grads, param_default_row, key_blocks, sp); break;
+    case TFRA_OPT_ADAM: launch_apply_csr<TFRA_OPT_ADAM>(t, s, pl, o, grads, param_default_row, key_blocks, sp); break;
+    case TFRA_OPT_ADAGRAD: launch_apply_csr<TFRA_OPT_ADAGRAD>(t, s, pl, o, grads, param_default_row, key_blocks, sp); break;
+    default: launch_apply_csr<TFRA_OPT_FTRL>(t, s, pl, o, grads, param_default_row, key_blocks, sp); break;
+  }
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_planned: launch failed");
+  step_epoch_public(t);
+  return TFRA_OK;
+}
+
+extern "C" int tfra_table_apply_planned(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl,
+                                        const float* grads, const float* param_default_row, tfra_stream_t stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t) return set_error(TFRA_ERR_INVALID, "apply_planned: null table");
+  std::lock_guard<std::mutex> lock(t->mu);
+  return apply_planned_impl(tp, p, pl, grads, param_default_row, stream, nullptr, 0);
+}
+
+static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, const void* values, const uint64_t* scores,
+                               tfra_stream_t stream, unsigned* progress, unsigned progress_val) {
+  // caller holds t->mu
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !pl) return set_error(TFRA_ERR_INVALID, "upsert_planned: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = t->enter(s);
+  if (rc) return rc;
+  if (pl->n == 0) return TFRA_OK;
+  if (!values) return set_error(TFRA_ERR_INVALID, "upsert_planned: null values");
+  if (t->opts.device != pl->device && t->opts.device >= 0) return set_error(TFRA_ERR_INVALID, "upsert_planned: plan and table live on different devices");
+  rc = t->prepare_insert(pl->n, s);
+  if (rc) return rc;
+  unsigned key_blocks, bin_blocks;
+  plan_grids(pl, &key_blocks, &bin_blocks);
+  uint8_t* bounded_now;
+  rc = t->bounded_flags(1, s, &bounded_now);
+  if (rc) return rc;
+  const ScoreP sp{t->opts.strategy, t->global_epoch, bounded_now ? (t->dense ? 2 : 1) : 0};
+  TableView v = t->view_of(t->cur);
+  size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)values | 16;
+  int g = (int)(x & (~x + 1));
+  if (g > 16) g = 16;
+  u64* dcount = dcount_of(pl);
+  const unsigned char* vals = (const unsigned char*)values;
+  const u64* sc = (const u64*)scores;
+  if (sp.bounded && hipMemsetAsync(dcount, 0, sizeof(u64), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: memset");
+  switch (g) {
+    case 16: upsert_csr_kernel<16, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
+    case 8: upsert_csr_kernel<8, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
+    case 4: upsert_csr_kernel<4, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
+    case 2: upsert_csr_kernel<2, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
+    default: upsert_csr_kernel<1, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
+  }
+  if (sp.bounded) {
+    switch (g) {
+      case 16: upsert_csr_kernel<16, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
+      case 8: upsert_csr_kernel<8, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
+      case 4: upsert_csr_kernel<4, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
+      case 2: upsert_csr_kernel<2, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
+      default: upsert_csr_kernel<1, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
+    }
+  }
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");
+  step_epoch_public(t);
+  return TFRA_OK;
+}
+
+extern "C" int tfra_table_upsert_planned(tfra_table_t* tp, const tfra_sparse_plan_t* pl, const void* values,
+                                         const uint64_t* scores, tfra_stream_t stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t) return set_error(TFRA_ERR_INVALID, "upsert_planned: null table");
+  std::lock_guard<std::mutex> lock(t->mu);
+  return upsert_planned_impl(tp, pl, values, scores, stream, nullptr, 0);
+}
+
+// Introspection for tests and tools: the plan's CSR as flat arrays (copies; synchronises the stream).
+//   counts[6]; keys[nkeys] (keys with many occurrences first); cnt[nkeys]; positions[n]: key 0's, key 1's, ... each ascending
+extern "C" int tfra_sparse_plan_read(const tfra_sparse_plan_t* pl, uint32_t* counts, int64_t* keys, uint32_t* cnt,
+                                     uint32_t* positions, size_t cap, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pl || !counts) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: null argument");
+  if (pl->n == 0) { for (int i = 0; i < 6; ++i) counts[i] = 0; return TFRA_OK; }
+  if (hipMemcpyAsync(counts, pl->d_counts, 6 * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
+  const unsigned nhot = counts[0], ncold = counts[1], nbins = counts[3];
+  if (!keys) return TFRA_OK;
+  if ((size_t)nhot + ncold > cap) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: buffers too small");
+  const CsrOut& o = pl->out;
+  const size_t nrec_c = (size_t)NSH * o.cr, nrec_h = (size_t)NSH * o.hr, nbin = (size_t)NSH * o.br;
+  std::vector<unsigned> km((size_t)nhot + ncold), bm(nbins), crec(nrec_c * REC_WORDS), hrec(nrec_h * REC_WORDS), hent(nbin * SEG), hout(nbin * 32);
+  auto cp = [&](void* d, const void* sdev, size_t b) { return b == 0 || hipMemcpyAsync(d, sdev, b, hipMemcpyDeviceToHost, s) == hipSuccess; };
+  bool ok = cp(km.data(), pl->keymap, km.size() * 4) && cp(bm.data(), pl->binmap, bm.size() * 4) && cp(crec.data(), o.crec, crec.size() * 4) &&
+            cp(hrec.data(), o.hrec, hrec.size() * 4) && cp(hent.data(), o.hent, hent.size() * 4) && cp(hout.data(), o.hout, hout.size() * 4);
+  if (!ok || hipStreamSynchronize(s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
+  // partial row -> entry address of the head of its run (only the bins of this build)
+  std::vector<std::pair<unsigned, size_t>> heads;
+  for (unsigned i = 0; i < nbins; ++i) {
+    const size_t bin = bm[i];
+    for (unsigned it = 0; it < 32; ++it) {
+      const unsigned e = hent[bin * SEG + it * 16];
+      if ((e & E_HEAD) && !(e & E_SKIP)) heads.push_back({hout[bin * 32 + it], bin * SEG + it * 16});
+    }
+  }
+  std::sort(heads.begin(), heads.end());
+  size_t w = 0;
+  for (size_t i = 0; i < km.size(); ++i) {
+    const bool many = (km[i] & KM_MANY) != 0;
+    const unsigned* rec = (many ? hrec.data() : crec.data()) + (size_t)(km[i] & ~KM_MANY) * REC_WORDS;
+    keys[i] = (int64_t)(((uint64_t)rec[1] << 32) | rec[0]);
+    cnt[i] = rec[2];
+    if (!many) {
+      for (unsigned j = 0; j < rec[2]; ++j) { if (w >= pl->n) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: too many entries"); positions[w++] = rec[4 + j]; }
+      continue;
+    }
+    for (unsigned pth = 0; pth < rec[4]; ++pth) {
+      auto itp = std::lower_bound(heads.begin(), heads.end(), std::make_pair(rec[3] + pth, (size_t)0));
+      if (itp == heads.end() || itp->first != rec[3] + pth) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: a partial has no run");
+      size_t a = itp->second;
+      bool first = true;
+      for (; (a % SEG != 0 || first) && (first || !(hent[a] & E_HEAD)); ++a) {
+        first = false;
+        if (!(hent[a] & E_SKIP)) { if (w >= pl->n) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: too many entries"); positions[w++] = hent[a] & E_POS; }
+      }
+    }
+  }
+  return TFRA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-call forms: the plan is built on the caller's stream into a plan object owned by the table.
+static int own_plan(Table* t, tfra_sparse_plan** out) {
+  if (!t->own_plan) {
+    tfra_sparse_plan* pl = nullptr;
+    int rc = tfra_sparse_plan_create(t->device, &pl);
+    if (rc) return rc;
+    t->own_plan = pl;
+  }
+  *out = reinterpret_cast<tfra_sparse_plan*>(t->own_plan);
+  return TFRA_OK;
+}
+
+namespace tfra {
+void destroy_own_plan(Table* t) {
+  if (t->own_plan) { tfra_sparse_plan_destroy(reinterpret_cast<tfra_sparse_plan*>(t->own_plan)); t->own_plan = nullptr; }
+}
+}  // namespace tfra
+
+extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* p, size_t n, const int64_t* ids,
+                                       const float* grads, const float* param_default_row, tfra_stream_t stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !p) return set_error(TFRA_ERR_INVALID, "apply_sparse: null argument");
+  if (n == 0) return TFRA_OK;
+  if (!ids || !grads || !param_default_row) return set_error(TFRA_ERR_INVALID, "apply_sparse: null buffer");
+  if (t->opts.value_dtype != TFRA_F32) return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: value_dtype must be float32");
+  const int dim = t->opts.dim;
+  if (dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)param_default_row) & 15))
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
+                                           "(use tfra_unique + tfra_segment_sum + tfra_table_apply_optimizer otherwise)");
+  if (n > MAX_IDS)
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^18 ids per call; split the batch or use the unique + "
+                                           "segment_sum path");
+  tfra_sparse_plan* pl;
+  std::lock_guard<std::mutex> lock(t->mu);
+  int rc = t->enter((hipStream_t)stream);   // orders the rebuild of the table's own plan behind its previous use
+  if (rc) return rc;
+  rc = own_plan(t, &pl);
+  if (rc) return rc;
+  rc = tfra_sparse_plan_build(pl, n, ids, dim, stream);
+  if (rc) return rc;
+  return apply_planned_impl(tp, p, pl, grads, param_default_row, stream, nullptr, 0);
+}
+
+// insert_or_assign of a batch whose keys may repeat, last occurrence wins, dedup on the device
+extern "C" int tfra_table_upsert_sparse(tfra_table_t* tp, size_t n, const int64_t* ids, const void* values,
+                                        const uint64_t* scores, tfra_stream_t stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t) return set_error(TFRA_ERR_INVALID, "upsert_sparse: null table");
+  if (n == 0) return TFRA_OK;
+  if (!ids || !values) return set_error(TFRA_ERR_INVALID, "upsert_sparse: null buffer");
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "upsert_sparse: at most 2^18 ids per call");
+  tfra_sparse_plan* pl;
+  std::lock_guard<std::mutex> lock(t->mu);
+  int rc = t->enter((hipStream_t)stream);
+  if (rc) return rc;
+  rc = own_plan(t, &pl);
+  if (rc) return rc;
+  rc = tfra_sparse_plan_build(pl, n, ids, 0, stream);
+  if (rc) return rc;
+  return upsert_planned_impl(tp, pl, values, scores, stream, nullptr, 0);
+}
+
+// unique + unsorted_segment_sum in one call = the plan + the hot sums + a gather (the reduction half of
+// tfra_table_apply_sparse with the same summation tree, so routing the sums elsewhere — multi-GPU gradient
+// alltoall — and applying them there gives the same bits as applying them here).
+extern "C" int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int dim, const float* grads,
+                                  int64_t* keys_out, float* rows_out, int64_t* d_count, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_count) return set_error(TFRA_ERR_INVALID, "reduce_by_key: null argument");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) { if (hipSetDevice(ws->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: hipSetDevice"); } }
+  if (n == 0) {
+    if (hipMemsetAsync(d_count, 0, sizeof(int64_t), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: memset");
+    return TFRA_OK;
+  }
+  if (!ids || !grads || !keys_out || !rows_out) return set_error(TFRA_ERR_INVALID, "reduce_by_key: null buffer");
+  if (dim <= 0 || dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)rows_out) & 15))
+    return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
+                                           "(use tfra_unique + tfra_segment_sum otherwise)");
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "reduce_by_key: at most 2^18 ids per call");
+  if (!ws->plan) {
+    tfra_sparse_plan* np_ = nullptr;
+    int rc = tfra_sparse_plan_create(ws->device, &np_);
+    if (rc) return rc;
+    ws->plan = np_;
+  }
+  tfra_sparse_plan* pl = reinterpret_cast<tfra_sparse_plan*>(ws->plan);
+  int rc = tfra_sparse_plan_build(pl, n, ids, dim, stream);
+  if (rc) return rc;
+  unsigned key_blocks, bin_blocks;
+  plan_grids(pl, &key_blocks, &bin_blocks);
+  const int nch = (dim + 63) / 64;
+  switch (nch) {
+    case 1: hot_sums_kernel<1><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+    case 2: hot_sums_kernel<2><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+    case 3: hot_sums_kernel<3><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+    default: hot_sums_kernel<4><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+  }
+  gather_csr_kernel<<<key_blocks, 256, 0, s>>>(dim, grads, pl->partial, keys_of(pl), (i64*)keys_out, rows_out, (i64*)d_count);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: launch failed");
+  return TFRA_OK;
+}
+
+namespace tfra {
+void destroy_workspace_plan(void* plan) { if (plan) tfra_sparse_plan_destroy(reinterpret_cast<tfra_sparse_plan*>(plan)); }
+}  // namespace tfra
+
+// ---------------------------------------------------------------------------------------------
+// One training step driven from C on two streams (no Python between the launches, no graph).
+//   main : lookup(ids_cur) -> write-back of batch cur (hot sums + fused update, or assign)      (plan_cur)
+//   side : build plan_next from ids_next, free-running
+// Cross-queue events cost ~5 us (stream wait) / ~7 us (record) each between two kernels of the main stream,
+// so the two streams are ordered through two host-visible counters in pinned memory instead, and the host
+// only falls back to a sync when a counter lags:
+//   * table progress: written by the first block of the write-back of step s  =>  every earlier step is done.
+//     plan_next's buffers were last read by step plan_next->last_used_step; the build is enqueued once the
+//     progress has passed it (with >= 3 plans in rotation that is always the case unless the host is far
+//     ahead of the GPU, in which case it waits here instead of in a queue);
+//   * plan built: generation + counts written by the build's last kernel.  If they already show plan_cur's
+//     generation the write-back is enqueued without any wait packet and with exact grids; otherwise — the host
+//     got ahead of the side stream — the host waits for the side stream.
+static int step_prefetch_impl(tfra_table_t* tp, const tfra_opt_params* p, tfra_sparse_plan_t* plan_cur,
+                              const int64_t* ids_cur, void* rows_out, const void* find_default, const void* grads_or_values,
+                              const float* param_default_row, const uint64_t* scores, tfra_sparse_plan_t* plan_next,
+                              const int64_t* ids_next, size_t n_next, tfra_stream_t main_stream, tfra_stream_t side_stream) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !plan_cur) return set_error(TFRA_ERR_INVALID, "step_prefetch: null argument");
+  hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+  if (ms == ss && plan_next) return set_error(TFRA_ERR_INVALID, "step_prefetch: needs two different streams");
+  if (plan_next == plan_cur) return set_error(TFRA_ERR_INVALID, "step_prefetch: plan_next must differ from plan_cur");
+  std::lock_guard<std::mutex> step_lock(t->step_mu);   // one driver call at a time per table
+  int rc = TFRA_OK;
+  if (!t->progress_host) {
+    if (hipHostMalloc((void**)&t->progress_host, 64, hipHostMallocDefault) != hipSuccess) { t->progress_host = nullptr; return set_error(TFRA_ERR_OOM, "step_prefetch: hipHostMalloc"); }
+    *t->progress_host = 0;
+  }
+  const unsigned step = ++t->step_gen;
+  if (plan_next) {
+    if (!plan_next->host_counts) {
+      if (hipHostMalloc((void**)&plan_next->host_counts, 64, hipHostMallocDefault) != hipSuccess) { plan_next->host_counts = nullptr; return set_error(TFRA_ERR_OOM, "step_prefetch: hipHostMalloc"); }
+      for (int i = 0; i < 8; ++i) plan_next->host_counts[i] = 0;
+    }
+    if (plan_next->last_used_step) {  // the write-back that read plan_next's buffers must be over
+      const unsigned need = plan_next->last_used_step + 1;
+      volatile unsigned* prog = t->progress_host;
+      bool ok = false;
+      for (int it = 0; it < 200000 && !ok; ++it) ok = (int)(*prog - need) >= 0;   // ~ a few ms at most
+      if (!ok && hipStreamSynchronize(ms) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: sync");
+    }
+  }
+  if (plan_cur->n && rows_out) {
+    rc = tfra_table_find(tp, plan_cur->n, ids_cur, rows_out, nullptr, find_default, 0, main_stream);
+    if (rc) return rc;
+  }
+  if (plan_next) {
+    rc = tfra_sparse_plan_build(plan_next, n_next, ids_next, p ? t->opts.dim : 0, side_stream);
+    if (rc) return rc;
+    plan_next->ev_recorded = true;   // built on the side stream: the join below applies
+  }
+  if (plan_cur->ev_recorded) {  // built on the side stream by an earlier call
+    const bool built = plan_cur->host_counts && (int)(*(volatile unsigned*)plan_cur->host_counts - plan_cur->gen) >= 0;
+    if (!built && hipStreamSynchronize(ss) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: join");   // rare
+    plan_cur->ev_recorded = false;
+  }
+  plan_cur->last_used_step = step;
+  if (plan_cur->n == 0) return TFRA_OK;   // no kernel publishes this step: a later slot check falls back to a sync
+  std::lock_guard<std::mutex> lock(t->mu);
+  if (p) return apply_planned_impl(tp, p, plan_cur, (const float*)grads_or_values, param_default_row, main_stream, t->progress_host, step);
+  return upsert_planned_impl(tp, plan_cur, grads_or_values, scores, main_stream, t->progress_host, step);
+}
+
+extern "C" int tfra_table_step_prefetch(tfra_table_t* tp, const tfra_opt_params* p, tfra_sparse_plan_t* plan_cur,
+                                        const int64_t* ids_cur, void* rows_out, const void* find_default,
+                                        const float* grads, const float* param_default_row,
+                                        tfra_sparse_plan_t* plan_next, const int64_t* ids_next, size_t n_next,
+                                        tfra_stream_t main_stream, tfra_stream_t side_stream) {
+  if (!p) return set_error(TFRA_ERR_INVALID, "step_prefetch: null optimizer parameters");
+  return step_prefetch_impl(tp, p, plan_cur, ids_cur, rows_out, find_default, grads, param_default_row, nullptr, plan_next, ids_next,
+                            n_next, main_stream, side_stream);
+}
+
+extern "C" int tfra_table_step_prefetch_assign(tfra_table_t* tp, tfra_sparse_plan_t* plan_cur, const int64_t* ids_cur,
+                                               void* rows_out, const void* find_default, const void* values,
+                                               const uint64_t* scores, tfra_sparse_plan_t* plan_next,
+                                               const int64_t* ids_next, size_t n_next, tfra_stream_t main_stream,
+                                               tfra_stream_t side_stream) {
+  return step_prefetch_impl(tp, nullptr, plan_cur, ids_cur, rows_out, find_default, values, nullptr, scores, plan_next, ids_next,
+                            n_next, main_stream, side_stream);
+}

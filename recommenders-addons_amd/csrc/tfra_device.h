@@ -1,18 +1,21 @@
 // Device-side layout and probe primitives of the MI355X dynamic-embedding table.
 //
-// Layout in HBM:
-//   keys   : nb buckets x 16 x int64.  One bucket = ONE 128-byte line = 15 key slots + 1
-//            meta word (bit0 = OVERFLOW: some key whose probe sequence passes through this
-//            bucket was placed further along).  A probe is one coalesced 128-B read by the 16
-//            lanes of a key group; 4 key groups per wave64.
-//   rows   : (nb*15 + 2) rows x row_stride bytes, row_stride = 16-B multiple of
-//            (1+aux_fields)*dim*sizeof(V): [embedding | slot1 | slot2 ...] co-located so a fused
-//            optimizer touches one contiguous segment.  Last 2 rows = side store for the two
-//            key values used as sentinels.
-//   scores : nb x 16 x uint64 (optional, eviction strategies only), same indexing as keys.
+// Layout in HBM: ONE allocation of nb bucket blocks + 2 side rows.
+//   bucket block b (bucket_stride bytes, at base + b*bucket_stride):
+//     +0    key line   : 16 x int64 = ONE 128-byte line = 15 key slots + 1 meta word (two
+//                        monotone overflow flags, see META_OVF0/1).  A probe is one coalesced 128-B read by the 16
+//                        lanes of a key group; 4 key groups per wave64.
+//     +128  score line : 16 x uint64 (only with an eviction strategy; hdr = 256, else hdr = 128)
+//     +hdr  15 rows x row_stride bytes, row_stride = 16-B multiple of (1+aux_fields)*dim*sizeof(V):
+//                        [embedding | slot1 | slot2 ...] co-located so a fused optimizer touches
+//                        one contiguous segment.
+//   A key's line, its score and its row live in the SAME block (4096 B for 256-B rows with scores),
+//   i.e. in the same page: one address translation per key instead of three.  On a 10^9-slot table
+//   (273 GB) every random access is a TLB miss, and translations — not bytes — bound the kernels.
+//   side rows: 2 rows behind the last block = store for the two key values used as sentinels.
 //
 // Probe sequence of key k: b0 = mulhi(fmix64(k), nb); b1 = mulhi(fmix64(h^C), nb) (!= b0);
-// then b1+1, b1+2, ... (mod nb).  First-fit insertion + the monotone OVERFLOW flag mean a find
+// then b1+1, b1+2, ... (mod nb).  First-fit insertion + the monotone overflow flags mean a find
 // stops at the first bucket that holds the key or is not flagged: 1 line for nearly every
 // key at load factor <= 0.5, no tombstones (erase simply empties the slot).
 #pragma once
@@ -28,15 +31,21 @@ constexpr i64 EMPTY_KEY = (i64)0x8000000000000000ULL;   // INT64_MIN
 constexpr i64 LOCKED_KEY = (i64)0x8000000000000001ULL;  // slot being replaced (eviction)
 constexpr int SLOTS = 15;                               // key slots per 128-B bucket line
 constexpr int NUM_RESERVED = 2;                         // side rows for EMPTY_KEY / LOCKED_KEY
-constexpr u64 META_OVERFLOW = 1ULL;
+// meta word (word 15 of the key line): two monotone flags.  OVF0 = a key whose FIRST bucket (b0) is this one was
+// placed elsewhere (its b0 was full); OVF1 = a key passed through this bucket further down its sequence (as b1,
+// b1+1, ...) because it was full.  A search for key k stops at b0 unless OVF0(b0), and at any later bucket of its
+// sequence unless OVF1 of that bucket: a bucket being full of OTHER keys' first choices does not lengthen k's search.
+// (With a single flag a bounded table running at capacity has every bucket flagged — each is some key's b0 —
+// and a miss walks on and on.)
+constexpr u64 META_OVF0 = 1ULL, META_OVF1 = 2ULL;
 constexpr int SIZE_SHARDS = 256;       // size counter sharded over 256 lines (one per channel-ish)
 constexpr int SIZE_SHARD_STRIDE = 16;  // u64 words between shards (128 B)
 
 struct TableView {
-  i64* keys;
-  unsigned char* rows;
-  u64* scores;
+  unsigned char* base;   // bucket block b at base + b*bucket_stride
   u64 nb;
+  u64 bucket_stride;     // hdr + 15*row_stride
+  unsigned hdr;          // 128 (key line) or 256 (key line + score line)
   unsigned field_bytes;  // dim*sizeof(V)
   unsigned row_stride;   // bytes between rows
   unsigned n_fields;     // 1 + aux_fields
@@ -45,6 +54,26 @@ struct TableView {
   int* winner;                 // [nb*15+2] scratch for duplicate resolution (may be null)
   unsigned* err_count;         // keys that could not be placed (table full)
 };
+
+__device__ __forceinline__ bool has_scores(const TableView& v) { return v.hdr > 128; }
+__device__ __forceinline__ i64* key_line(const TableView& v, u64 b) {
+  return reinterpret_cast<i64*>(v.base + b * v.bucket_stride);
+}
+__device__ __forceinline__ u64* score_line(const TableView& v, u64 b) {
+  return reinterpret_cast<u64*>(v.base + b * v.bucket_stride + 128);
+}
+// "word" index w = b*16 + slot names one key slot (and its score)
+__device__ __forceinline__ i64* key_word(const TableView& v, u64 w) { return key_line(v, w >> 4) + (w & 15); }
+__device__ __forceinline__ u64* score_word(const TableView& v, u64 w) { return score_line(v, w >> 4) + (w & 15); }
+__device__ __forceinline__ unsigned char* row_at(const TableView& v, u64 b, unsigned slot) {
+  return v.base + b * v.bucket_stride + v.hdr + (size_t)slot * v.row_stride;
+}
+// row index r = b*15 + slot; r >= nb*15 = side rows
+__device__ __forceinline__ unsigned char* row_ptr(const TableView& v, i64 row) {
+  const u64 r = (u64)row, b = r / 15;
+  if (b >= v.nb) return v.base + v.nb * v.bucket_stride + (size_t)(r - v.nb * 15) * v.row_stride;
+  return row_at(v, b, (unsigned)(r - b * 15));
+}
 
 __device__ __forceinline__ u64 fmix64(u64 k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
@@ -116,7 +145,7 @@ __device__ __forceinline__ void store_wt16(void* p, uint4 v) {
 // Returns the row index (b*15+slot) or -1.  All 16 lanes of the group call with the same key.
 template <bool COHERENT>
 __device__ __forceinline__ i64 probe_find_from(const TableView& v, i64 key, u64 h, u64 b, i64 k,
-                                               int sub, int gshift) {
+                                               int sub, int gshift, const i64* k_second = nullptr) {
   if (is_reserved_key(key)) {
     int r = reserved_index(key);
     return v.reserved_present[r] ? (i64)(v.nb * SLOTS + r) : -1;
@@ -127,9 +156,10 @@ __device__ __forceinline__ i64 probe_find_from(const TableView& v, i64 key, u64 
     unsigned hit = (unsigned)(m >> gshift) & 0x7fffu;
     if (hit) return (i64)(b * SLOTS + (__ffs(hit) - 1));
     i64 meta = shfl_i64(k, gshift + 15);
-    if (!((u64)meta & META_OVERFLOW) || step >= v.nb) return -1;
+    if (!((u64)meta & (step == 0 ? META_OVF0 : META_OVF1)) || step >= v.nb) return -1;
     b = (step == 0) ? b1 : next_bucket(b, v.nb);
-    k = COHERENT ? load_key_coherent(&v.keys[b * 16 + sub]) : v.keys[b * 16 + sub];
+    if (step == 0 && k_second) k = *k_second;  // b1's line, preloaded by the caller
+    else k = COHERENT ? load_key_coherent(key_line(v, b) + sub) : key_line(v, b)[sub];
   }
 }
 
@@ -137,7 +167,7 @@ template <bool COHERENT>
 __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, int gshift) {
   u64 h;
   u64 b = bucket0(key, v.nb, h);
-  i64 k = COHERENT ? load_key_coherent(&v.keys[b * 16 + sub]) : v.keys[b * 16 + sub];
+  i64 k = COHERENT ? load_key_coherent(key_line(v, b) + sub) : key_line(v, b)[sub];
   return probe_find_from<COHERENT>(v, key, h, b, k, sub, gshift);
 }
 
@@ -147,13 +177,19 @@ __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, 
 // different slots.  Returns row index, or -1 when no slot could be found.
 // `k_first` = the key's first bucket line (b0), already loaded by the caller (coherently) so that
 // a kernel can put the first probes of several keys in flight before resolving any of them.
-// bounded = the table cannot grow (Hkv flavour at max_capacity): the chain is never extended beyond
-// 4 buckets (b0, b1, b1+1, b1+2 — at load factor 0.5 the chance that all four are full is ~1e-8, so
-// nothing is evicted before the table is really full); when neither the key nor an empty slot exists
-// the function returns NEED_EVICT (-2).
+// bounded != 0: the table cannot grow (Hkv flavour at max_capacity).  A NEW key is placed within the first 4
+// buckets of its sequence (b0, b1, b1+1, b1+2 — at load factor 0.5 the chance that all four are full is ~1e-8, so
+// nothing is evicted before the table is really filling up: T/hkv_hashtable_ops_test.py:572-625 pins that);
+// bounded == 2 ("dense": the host saw > 80 % of the slots in use): only within its two home buckets b0 / b1
+// (HKV likewise confines a key to its one bucket and evicts inside it), so that the OVF1 flags stop spreading and
+// a miss on a table running at capacity costs two lines, not an ever longer walk.  When neither the key nor an
+// empty slot is found the function returns NEED_EVICT (-2) and the caller replaces the minimum-score entry of the
+// two home buckets.  `k_second` (optional) = b1's line, preloaded by callers that expect to need it: both home
+// buckets are then in flight together instead of one address translation after the other.
 constexpr i64 NEED_EVICT = -2;
 __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key, u64 h, u64 b0, i64 k_first,
-                                                    int sub, int gshift, bool& is_new, bool bounded = false) {
+                                                    int sub, int gshift, bool& is_new, int bounded = 0,
+                                                    const i64* k_second = nullptr) {
   is_new = false;
   if (is_reserved_key(key)) {
     int r = reserved_index(key);
@@ -168,7 +204,10 @@ __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key,
     u64 b = b0;
     i64 fe = -1;  // word index (b*16+slot) of the first empty slot seen
     for (u64 step = 0; step <= v.nb; ++step) {
-      i64 k = (attempt == 0 && step == 0) ? k_first : load_key_coherent(&v.keys[b * 16 + sub]);
+      i64 k;
+      if (attempt == 0 && step == 0) k = k_first;
+      else if (attempt == 0 && step == 1 && k_second) k = *k_second;
+      else k = load_key_coherent(key_line(v, b) + sub);
       u64 m = __ballot(sub < SLOTS && k == key);
       unsigned hit = (unsigned)(m >> gshift) & 0x7fffu;
       if (hit) return (i64)(b * SLOTS + (__ffs(hit) - 1));
@@ -176,17 +215,18 @@ __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key,
       unsigned emp = (unsigned)(e >> gshift) & 0x7fffu;
       if (fe < 0 && emp) fe = (i64)(b * 16 + (__ffs(emp) - 1));
       i64 meta = shfl_i64(k, gshift + 15);
-      if (!((u64)meta & META_OVERFLOW)) {
+      const u64 flag = step == 0 ? META_OVF0 : META_OVF1;
+      if (!((u64)meta & flag)) {
         if (fe >= 0) break;  // the key cannot live further along; claim the first empty slot
-        if (bounded && step >= 3) return NEED_EVICT;
+        if (bounded && step >= (bounded > 1 ? 1u : 3u)) return NEED_EVICT;
         // bucket full and never overflowed: extend the chain through it
-        if (sub == 15) atomicOr((u64*)&v.keys[b * 16 + 15], META_OVERFLOW);
+        if (sub == 15) atomicOr((u64*)(key_line(v, b) + 15), flag);
       }
       b = (step == 0) ? b1 : next_bucket(b, v.nb);
     }
     if (fe < 0) return bounded ? NEED_EVICT : -1;
     i64 old = 0;
-    if (sub == 0) old = (i64)atomicCAS((u64*)&v.keys[fe], (u64)EMPTY_KEY, (u64)key);
+    if (sub == 0) old = (i64)atomicCAS((u64*)key_word(v, (u64)fe), (u64)EMPTY_KEY, (u64)key);
     old = shfl_i64(old, gshift);
     u64 bb = (u64)fe >> 4;
     i64 row = (i64)(bb * SLOTS + ((u64)fe & 15));
@@ -201,7 +241,7 @@ __device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int 
                                                bool& is_new) {
   u64 h;
   const u64 b0 = bucket0(key, v.nb, h);
-  i64 k = load_key_coherent(&v.keys[b0 * 16 + sub]);
+  i64 k = load_key_coherent(key_line(v, b0) + sub);
   return locate_or_claim_from(v, key, h, b0, k, sub, gshift, is_new);
 }
 
@@ -220,10 +260,15 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
   for (int attempt = 0; attempt < 256; ++attempt) {
     u64 best_score = ~0ULL, best_word = 0;
     i64 best_key = 0;
+    // key + score lines of both home buckets: four independent loads in flight
+    i64 kk2[2] = {load_key_coherent(key_line(v, b0) + sub), load_key_coherent(key_line(v, b1) + sub)};
+    i64 sc2[2] = {(i64)__hip_atomic_load(score_line(v, b0) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                  (i64)__hip_atomic_load(score_line(v, b1) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+    keep_live(kk2[0], kk2[1], sc2[0], sc2[1]);
     for (int which = 0; which < 2; ++which) {
       u64 b = which ? b1 : b0;
-      i64 k = load_key_coherent(&v.keys[b * 16 + sub]);
-      u64 sc = __hip_atomic_load(&v.scores[b * 16 + sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      i64 k = kk2[which];
+      u64 sc = (u64)sc2[which];
       bool cand = sub < SLOTS && k != LOCKED_KEY;
       if (k == EMPTY_KEY) sc = 0;  // an empty slot (erase since the first phase) beats any victim
       u64 my = cand ? sc : ~0ULL;
@@ -240,7 +285,7 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
     if (best_score == ~0ULL) continue;  // everything locked by concurrent evictors: look again
     if (best_key != EMPTY_KEY && !admit_always && in_score < best_score) return -1;
     i64 old = 0;
-    if (sub == 0) old = (i64)atomicCAS((u64*)&v.keys[best_word], (u64)best_key, (u64)LOCKED_KEY);
+    if (sub == 0) old = (i64)atomicCAS((u64*)key_word(v, best_word), (u64)best_key, (u64)LOCKED_KEY);
     old = shfl_i64(old, gshift);
     if (old == best_key) {
       if (best_key != EMPTY_KEY) {
@@ -250,12 +295,12 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
         // if it is not the score the choice was based on.
         unsigned lo = 0, hi = 0;
         if (sub == 0) {
-          u64 now = __hip_atomic_load(&v.scores[best_word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          u64 now = __hip_atomic_load(score_word(v, best_word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           lo = (unsigned)now; hi = (unsigned)(now >> 32);
         }
         const u64 now = ((u64)(unsigned)__shfl((int)hi, gshift) << 32) | (unsigned)__shfl((int)lo, gshift);
         if (now != best_score) {
-          if (sub == 0) __hip_atomic_store(&v.keys[best_word], best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (sub == 0) __hip_atomic_store(key_word(v, best_word), best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           continue;
         }
       }
@@ -267,19 +312,32 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
   return -3;
 }
 
-// rows/scores written by the 16 lanes must be visible before the key replaces LOCKED_KEY
+// The row and the score of a replaced slot must be in memory before the key replaces LOCKED_KEY (a concurrent
+// evictor on another XCD that sees the new key must also see its new score).  An agent-scope release fence would
+// do it, but on gfx950 that is an L2 write-back (buffer_wbl2) per call — 65 536 evictions of one batch spent
+// ~5 ns each on it, 10x the rest of the kernel.  Instead the eviction path writes row and score WRITE-THROUGH
+// (sc0 sc1: acknowledged by memory, nothing left dirty in this XCD's L2) and waits for those acknowledgements
+// (vmcnt(0)) before the key store, which is itself an agent-scope atomic store.
 __device__ __forceinline__ void publish_key(const TableView& v, u64 word, i64 key, int sub) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (sub == 0) __hip_atomic_store(&v.keys[word], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (sub == 0) __hip_atomic_store(key_word(v, word), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// write-through stores for the eviction path (see publish_key)
+__device__ __forceinline__ void store_wt8(void* p, u64 x) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+template <int G>
+__device__ __forceinline__ void copy_bytes16_wt(unsigned char* dst, const unsigned char* src, unsigned bytes, int sub);
 
 // Per-key score of the Hkv strategies (what eviction compares): LRU = device clock, LFU += in_score,
 // EPOCH* = epoch << 32 | low word, CUSTOMIZED = caller's score (lookup_table_op_hkv.h:454-475).
+template <bool WT = false>
 __device__ __forceinline__ void update_score(const TableView& v, i64 row, bool is_new, int strategy,
                                              u64 in_score, u64 epoch, int sub) {
-  if (!v.scores || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
+  if (!has_scores(v) || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
   u64 b = (u64)row / SLOTS, s = (u64)row % SLOTS;
-  u64* p = &v.scores[b * 16 + s];
+  u64* p = score_line(v, b) + s;
   u64 old = is_new ? 0 : *p;
   u64 ns;
   switch (strategy) {
@@ -293,7 +351,8 @@ __device__ __forceinline__ void update_score(const TableView& v, i64 row, bool i
     case TFRA_EVICT_CUSTOMIZED: ns = in_score; break;
     default: ns = wall_clock64(); break;  // LRU: device-wide monotonic clock
   }
-  *p = ns;
+  if (WT) store_wt8(p, ns);
+  else *p = ns;
 }
 
 __device__ __forceinline__ void size_add(const TableView& v, u64 wave_id, long long delta) {
@@ -315,6 +374,17 @@ __device__ __forceinline__ void copy_bytes16(unsigned char* dst, const unsigned 
   typedef typename Granule<G>::T T;
   for (unsigned off = sub * G; off < bytes; off += 16 * G)
     *reinterpret_cast<T*>(dst + off) = *reinterpret_cast<const T*>(src + off);
+}
+
+// same, write-through for 16-B granules (eviction path, see publish_key)
+template <int G>
+__device__ __forceinline__ void copy_bytes16_wt(unsigned char* dst, const unsigned char* src, unsigned bytes, int sub) {
+  typedef typename Granule<G>::T T;
+  for (unsigned off = sub * G; off < bytes; off += 16 * G) {
+    T t = *reinterpret_cast<const T*>(src + off);
+    if (G == 16) store_wt16(dst + off, *reinterpret_cast<uint4*>(&t));
+    else __hip_atomic_store(reinterpret_cast<T*>(dst + off), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace tfra

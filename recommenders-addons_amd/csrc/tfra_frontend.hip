@@ -447,6 +447,7 @@ int tfra_workspace_destroy(tfra_workspace_t* ws) {
   if (!ws) return TFRA_OK;
   (void)hipSetDevice(ws->device);
   if (ws->buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->buf); }
+  tfra::destroy_workspace_plan(ws->plan);
   delete ws;
   return TFRA_OK;
 }

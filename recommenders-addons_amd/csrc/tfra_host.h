@@ -14,9 +14,7 @@ extern thread_local std::string g_last_error;
 int set_error(int code, const std::string& msg);
 
 struct Storage {
-  i64* keys = nullptr;
-  unsigned char* rows = nullptr;
-  u64* scores = nullptr;
+  unsigned char* base = nullptr;  // nb bucket blocks [key line | score line | 15 rows] + 2 side rows
   u64 nb = 0;
 };
 
@@ -45,6 +43,7 @@ struct Table {
   size_t winner_len = 0;
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  void* own_plan = nullptr;  // tfra_sparse_plan of the one-call write-backs (tfra_table_apply_sparse / upsert_sparse)
   unsigned apply_P = 0;      // bucket count the cursor area at the head of `scratch` is armed for (0 = not armed)
   AuxInitPod aux{};
   // host bookkeeping
@@ -58,6 +57,8 @@ struct Table {
   size_t n_since_read = 0;
   i64* h_size = nullptr;  // pinned, inside the h_scalar block
   bool growth_blocked = false;
+  bool dense = false;        // a table that cannot grow any more holds > 80 % of its slots (async size reads)
+  unsigned dense_calls = 0;
   bool capture_safe = false;  // TFRA_OPTION_CAPTURE_SAFE
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
@@ -74,8 +75,13 @@ struct Table {
   int ensure_scratch(size_t bytes, hipStream_t s);
   int grow(u64 min_nb, hipStream_t s);
   int prepare_insert(size_t n, hipStream_t s);
+  int poll_density(hipStream_t s);
   int bounded_flags(size_t n, hipStream_t s, uint8_t** out);
 };
+
+void destroy_own_plan(Table* t);   // tfra_csr.hip
+void destroy_workspace_plan(void* plan);   // tfra_csr.hip
+void step_epoch_public(Table* t);  // tfra_optim.hip
 
 }  // namespace tfra
 
@@ -84,6 +90,7 @@ struct tfra_workspace {
   int device = 0;
   void* buf = nullptr;
   size_t bytes = 0;
+  void* plan = nullptr;   // tfra_sparse_plan of tfra_reduce_by_key
   int ensure(size_t need, hipStream_t s) {
     if (need <= bytes) return TFRA_OK;
     if (buf) {

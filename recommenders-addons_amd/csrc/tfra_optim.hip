@@ -25,38 +25,27 @@ namespace {
 
 // 16 lanes per key; lane `sub` owns elements sub*4..sub*4+3 (+64 per step): float4 everywhere
 // when dim % 4 == 0 (VEC4), scalar otherwise.
-// INDIRECT: gradient row of entry g is named by src[g] (tfra_sparse_apply.hip): src < alt_base ->
-// grads row src, else alt_rows row (src-alt_base); src == 0xffffffff -> hole, skipped.
-template <int KIND, bool VEC4, bool INDIRECT>
+template <int KIND, bool VEC4>
 __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
                                                     const float* __restrict__ grads,
                                                     const float* __restrict__ defaults, int full, int dim,
                                                     float aux0, float aux1, const i64* __restrict__ d_n,
-                                                    const unsigned* __restrict__ src, const float* __restrict__ alt_rows,
-                                                    unsigned alt_base, unsigned* __restrict__ rearm, unsigned rearm_count,
-                                                    unsigned rearm_stride, ScoreP sp, uint8_t* __restrict__ deferred) {
+                                                    ScoreP sp, uint8_t* __restrict__ deferred) {
   constexpr int S = NSlots<KIND>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   int fresh = 0, failed = 0;
   if (o.d_lr) o.lr = *o.d_lr;
-  if (INDIRECT && rearm) {  // zero the bucket cursors of tfra_table_apply_sparse for its next call
-    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < rearm_count) rearm[tid * rearm_stride] = 0;
-  }
   if (d_n) { size_t dn = (size_t)*d_n; if (dn < n) n = dn; }
-  unsigned sidx = 0;
-  bool active = g < n;
-  if (INDIRECT && active) { sidx = src[g]; active = sidx != 0xffffffffu; }
-  if (active) {
+  if (g < n) {
     const i64 key = keys[g];
     bool is_new;
     i64 row;
     if (deferred) {  // bounded (Hkv) table at max_capacity: keys without a free slot go to phase 2
       u64 h;
       const u64 b0 = bucket0(key, v.nb, h);
-      const i64 k0 = load_key_coherent(&v.keys[b0 * 16 + sub]);
-      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, true);
+      const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded);
       if (sub == 0) deferred[g] = row == NEED_EVICT;
     } else {
       row = locate_or_claim(v, key, sub, gshift, is_new);
@@ -65,9 +54,8 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
       failed = (sub == 0 && row != NEED_EVICT);
     } else {
       fresh = (is_new && sub == 0);
-      float* pr = reinterpret_cast<float*>(v.rows + (size_t)row * v.row_stride);
-      const float* gr = INDIRECT ? (sidx < alt_base ? grads + (size_t)sidx * dim : alt_rows + (size_t)(sidx - alt_base) * dim)
-                                 : grads + g * (size_t)dim;
+      float* pr = reinterpret_cast<float*>(row_ptr(v, row));
+      const float* gr = grads + g * (size_t)dim;
       const float* df = defaults + (full ? g * (size_t)dim : 0);
       if (VEC4) {
         for (int c = sub * 4; c < dim; c += 64) {
@@ -127,13 +115,11 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
 // minimum-score entry of its two home buckets and starts from the default row / initial slot values —
 // what find (miss -> default) + dense apply + upsert (evicting) give in the reference
 // (PY/dynamic_embedding_optimizer.py:165-204 on an HkvHashTable, lookup_table_op_hkv.h:522-537).
-template <int KIND, bool INDIRECT>
+template <int KIND>
 __global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
                                                           const float* __restrict__ grads,
                                                           const float* __restrict__ defaults, int full, int dim,
                                                           float aux0, float aux1, const i64* __restrict__ d_n,
-                                                          const unsigned* __restrict__ src,
-                                                          const float* __restrict__ alt_rows, unsigned alt_base,
                                                           ScoreP sp, const uint8_t* __restrict__ deferred) {
   constexpr int S = NSlots<KIND>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
@@ -143,28 +129,28 @@ __global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, s
   if (d_n) { size_t dn = (size_t)*d_n; if (dn < n) n = dn; }
   if (g < n && deferred[g]) {
     const i64 key = keys[g];
-    const unsigned sidx = INDIRECT ? src[g] : 0;
     const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
     const u64 in_score = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | 1) : 1;
     u64 word = 0;
     bool claimed_empty;
     i64 row = evict_and_lock(v, key, in_score, lru_like, sub, gshift, &word, claimed_empty);
     if (row >= 0) {
-      float* pr = reinterpret_cast<float*>(v.rows + (size_t)row * v.row_stride);
-      const float* gr = INDIRECT ? (sidx < alt_base ? grads + (size_t)sidx * dim : alt_rows + (size_t)(sidx - alt_base) * dim)
-                                 : grads + g * (size_t)dim;
+      float* pr = reinterpret_cast<float*>(row_ptr(v, row));
+      const float* gr = grads + g * (size_t)dim;
       const float* df = defaults + (full ? g * (size_t)dim : 0);
+      // write-through stores: the row is in memory before the key is published (publish_key)
+      auto st = [](float* q, float x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
       for (int c = sub; c < dim; c += 16) {
         float p = df[c], s1 = aux0, s2 = aux1;
         apply_one<KIND>(o, gr[c], p, s1, s2);
-        pr[c] = p;
-        if (S >= 1) pr[dim + c] = s1;
-        if (S >= 2) pr[2 * dim + c] = s2;
+        st(pr + c, p);
+        if (S >= 1) st(pr + dim + c, s1);
+        if (S >= 2) st(pr + 2 * dim + c, s2);
       }
       for (int f = S + 1; f < (int)v.n_fields; ++f)
-        for (int c = sub; c < dim; c += 16) pr[f * dim + c] = (f == 1 ? aux0 : aux1);
-      if (sub == 0) v.scores[word] = 0;  // the slot starts a new life
-      update_score(v, row, true, sp.strategy, 1, sp.epoch, sub);
+        for (int c = sub; c < dim; c += 16) st(pr + f * dim + c, (f == 1 ? aux0 : aux1));
+      if (sub == 0) store_wt8(score_word(v, word), 0);  // the slot starts a new life
+      update_score<true>(v, row, true, sp.strategy, 1, sp.epoch, sub);
       publish_key(v, word, key, sub);
       fresh = (claimed_empty && sub == 0);
     } else if (row == -3) {
@@ -181,21 +167,9 @@ __global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, s
 template <int KIND>
 void launch_apply(bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
                   const float* d, int full, int dim, float a0, float a1, const i64* dn, ScoreP sp, uint8_t* deferred) {
-  if (vec4) apply_kernel<KIND, true, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0, sp, deferred);
-  else apply_kernel<KIND, false, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, nullptr, 0, 0, sp, deferred);
-  if (deferred) apply_evict_kernel<KIND, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, nullptr, nullptr, 0, sp, deferred);
-}
-
-template <int KIND>
-void launch_indirect(dim3 grid, hipStream_t s, TableView v, OptP o, size_t max_n, const i64* keys, const float* grads,
-                     const float* default_row, int dim, float a0, float a1, const i64* d_n, const unsigned* src,
-                     const float* alt_rows, unsigned alt_base, unsigned* rearm, unsigned rearm_count, unsigned rearm_stride,
-                     ScoreP sp, uint8_t* deferred) {
-  apply_kernel<KIND, true, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows,
-                                                      alt_base, rearm, rearm_count, rearm_stride, sp, deferred);
-  if (deferred)
-    apply_evict_kernel<KIND, true><<<grid, 256, 0, s>>>(v, o, max_n, keys, grads, default_row, 0, dim, a0, a1, d_n, src, alt_rows,
-                                                        alt_base, sp, deferred);
+  if (vec4) apply_kernel<KIND, true><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
+  else apply_kernel<KIND, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
+  if (deferred) apply_evict_kernel<KIND><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
 }
 
 // one fused write-back counts as one upsert for the epoch strategies (lookup_table_op_hkv.h:528-536)
@@ -210,30 +184,8 @@ void step_epoch(Table* t) {
 }  // namespace
 
 namespace tfra {
-// third kernel of tfra_table_apply_sparse: caller holds the table lock and has run prepare_insert
-int launch_apply_indirect(Table* t, hipStream_t s, const tfra_opt_params* p, size_t max_n, const i64* keys,
-                          const unsigned* src, const float* grads, const float* alt_rows, unsigned alt_base,
-                          const float* default_row, const i64* d_n, unsigned* rearm, unsigned rearm_count,
-                          unsigned rearm_stride) {
-  TableView v = t->view_of(t->cur);
-  OptP o{p->kind, p->lr, p->beta1, p->beta2, p->eps, p->l1, p->l2, p->lr_power, p->d_lr};
-  const int dim = t->opts.dim;
-  const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
-  dim3 grid((unsigned)((max_n * 16 + 255) / 256));
-  uint8_t* deferred;
-  int rc = t->bounded_flags(max_n, s, &deferred);
-  if (rc) return rc;
-  const ScoreP sp{t->opts.strategy, t->global_epoch};
-  switch (p->kind) {
-    case TFRA_OPT_SGD: launch_indirect<TFRA_OPT_SGD>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
-    case TFRA_OPT_ADAM: launch_indirect<TFRA_OPT_ADAM>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
-    case TFRA_OPT_ADAGRAD: launch_indirect<TFRA_OPT_ADAGRAD>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
-    default: launch_indirect<TFRA_OPT_FTRL>(grid, s, v, o, max_n, keys, grads, default_row, dim, a0, a1, d_n, src, alt_rows, alt_base, rearm, rearm_count, rearm_stride, sp, deferred); break;
-  }
-  step_epoch(t);
-  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_sparse: launch failed");
-  return TFRA_OK;
-}
+void step_epoch_public(Table* t) { step_epoch(t); }
+
 }  // namespace tfra
 
 extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_params* p, size_t n, const int64_t* keys,
@@ -266,7 +218,7 @@ extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_param
   uint8_t* deferred;
   rc = t->bounded_flags(n, s, &deferred);
   if (rc) return rc;
-  const ScoreP sp{t->opts.strategy, t->global_epoch};
+  const ScoreP sp{t->opts.strategy, t->global_epoch, deferred ? (t->dense ? 2 : 1) : 0};
   switch (p->kind) {
     case TFRA_OPT_SGD: launch_apply<TFRA_OPT_SGD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
     case TFRA_OPT_ADAM: launch_apply<TFRA_OPT_ADAM>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;

@@ -1,5 +1,5 @@
 // Optimizer update rules shared by the fused write-back kernels (tfra_optim.hip,
-// tfra_sparse_apply.hip).  TF's ResourceApply{GradientDescent,Adam,Adagrad[V2],Ftrl}, fp32, same
+// tfra_csr.hip).  TF's ResourceApply{GradientDescent,Adam,Adagrad[V2],Ftrl}, fp32, same
 // operation order as oracle/optimizers.py; compile with -ffp-contract=off.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -43,7 +43,7 @@ __device__ __forceinline__ void apply_one(const OptP& o, float g, float& p, floa
 }
 
 // score strategy of the table + its current epoch (update_score)
-struct ScoreP { int strategy; u64 epoch; };
+struct ScoreP { int strategy; u64 epoch; int bounded; };  // bounded: 0 / 1 / 2 (dense), see locate_or_claim_from
 
 template <int KIND> struct NSlots { static constexpr int v = KIND == TFRA_OPT_SGD ? 0 : (KIND == TFRA_OPT_ADAGRAD ? 1 : 2); };
 

@@ -25,7 +25,10 @@ typedef tfra::AuxInitPod AuxInit;  // elem_bytes = sizeof(V); pattern[f] = aux_i
 // =============================== kernels ====================================================
 
 // ---- find (+ fused default fill, + exists) -------------------------------------------------
-template <int G, int U, bool WT = (G == 16)>
+// PF1: also put the SECOND home bucket's line of every key in flight with the first (a bounded table running
+// near capacity: most b0 lines are full and flagged, ~1/3 of the resident keys and every miss need b1, and on
+// a table of hundreds of GB each line is its own address translation — two in flight beat two in a row).
+template <int G, int U, bool WT = (G == 16), bool PF1 = false>
 __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const i64* __restrict__ keys,
                                                    unsigned char* __restrict__ out,
                                                    uint8_t* __restrict__ exists,
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
   i64 kreg = keys[min(base + (size_t)(lane & (KPW - 1)), last)];
   i64 key[U];
   u64 h[U], b[U];
-  i64 k0[U];
+  i64 k0[U], k1[U];
   size_t idx[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -52,17 +55,19 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
     key[u] = shfl_i64(kreg, j);
     idx[u] = min(base + j, last);
     b[u] = bucket0(key[u], v.nb, h[u]);
-    k0[u] = v.keys[b[u] * 16 + sub];  // U probes in flight
+    k0[u] = key_line(v, b[u])[sub];  // U probes in flight
+    k1[u] = PF1 ? key_line(v, bucket1(h[u], b[u], v.nb))[sub] : 0;
   }
   static_assert(U == 4, "keep_live is written for U == 4");
   keep_live(k0[0], k0[1], k0[2], k0[3]);
+  if (PF1) keep_live(k1[0], k1[1], k1[2], k1[3]);
   const unsigned char* src[U];
   unsigned char* dst[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    i64 row = probe_find_from<false>(v, key[u], h[u], b[u], k0[u], sub, gshift);
+    i64 row = probe_find_from<false>(v, key[u], h[u], b[u], k0[u], sub, gshift, PF1 ? &k1[u] : nullptr);
     if (exists && sub == 0) exists[idx[u]] = row >= 0;
-    src[u] = row >= 0 ? v.rows + (size_t)row * v.row_stride + field_off
+    src[u] = row >= 0 ? row_ptr(v, row) + field_off
                       : defaults + (full ? idx[u] * (size_t)v.field_bytes : 0);
     dst[u] = out + idx[u] * (size_t)v.field_bytes;
   }
@@ -82,17 +87,26 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
 
 // ---- aux-field initialisation for a newly claimed row --------------------------------------
 
+// WT: write-through stores (eviction path: the row must be in memory before the key is published, see publish_key)
+template <bool WT = false>
 __device__ __forceinline__ void init_aux_fields(const TableView& v, const AuxInit& ai, i64 row,
                                                 int sub, unsigned skip_field) {
-  unsigned char* r = v.rows + (size_t)row * v.row_stride;
+  unsigned char* r = row_ptr(v, row);
   for (unsigned f = 0; f < v.n_fields; ++f) {
     if (f == skip_field) continue;
     unsigned pat = f == 0 ? 0u : ai.pattern[(f - 1) & 3];
     unsigned char* p = r + f * v.field_bytes;
     if ((v.field_bytes & 3) == 0) {
-      for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(p + off) = pat;
+      for (unsigned off = sub * 4; off < v.field_bytes; off += 64) {
+        if (WT) __hip_atomic_store(reinterpret_cast<unsigned*>(p + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *reinterpret_cast<unsigned*>(p + off) = pat;
+      }
     } else {
-      for (unsigned off = sub; off < v.field_bytes; off += 16) p[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
+      for (unsigned off = sub; off < v.field_bytes; off += 16) {
+        const unsigned char b = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
+        if (WT) __hip_atomic_store(p + off, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p[off] = b;
+      }
     }
   }
 }
@@ -113,25 +127,28 @@ __global__ __launch_bounds__(256) void insert_unique_kernel(TableView v, size_t 
   const size_t last = n - 1;
   i64 kreg = keys[min(base + (size_t)(lane & (KPW - 1)), last)];
   int fresh = 0, failed = 0;
-  i64 key[U], k0[U];
+  i64 key[U], k0[U], k1[U];
   u64 h[U], b0[U];
+  const bool pf1 = bounded > 1;  // table near capacity: both home buckets' lines in flight together
 #pragma unroll
   for (int u = 0; u < U; ++u) {  // U first probes in flight (unconditional, tail clamped)
     key[u] = shfl_i64(kreg, u * 4 + grp);
     b0[u] = bucket0(key[u], v.nb, h[u]);
-    k0[u] = load_key_coherent(&v.keys[b0[u] * 16 + sub]);
+    k0[u] = load_key_coherent(key_line(v, b0[u]) + sub);
+    k1[u] = load_key_coherent(key_line(v, pf1 ? bucket1(h[u], b0[u], v.nb) : b0[u]) + sub);  // (same line again: an L2 hit)
   }
   keep_live(k0[0], k0[1], k0[2], k0[3]);
+  keep_live(k1[0], k1[1], k1[2], k1[3]);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int j = u * 4 + grp;
     size_t i = base + j;
     if (i < n) {
       bool is_new;
-      i64 row = locate_or_claim_from(v, key[u], h[u], b0[u], k0[u], sub, gshift, is_new, bounded != 0);
+      i64 row = locate_or_claim_from(v, key[u], h[u], b0[u], k0[u], sub, gshift, is_new, bounded, pf1 ? &k1[u] : nullptr);
       if (deferred && sub == 0) deferred[i] = row == NEED_EVICT;
       if (row >= 0) {
-        copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes,
+        copy_bytes16<G>(row_ptr(v, row) + field * v.field_bytes,
                         vals + i * (size_t)v.field_bytes, v.field_bytes, sub);
         if (is_new && v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
         update_score(v, row, is_new, strategy, scores ? scores[i] : 1, epoch, sub);
@@ -169,11 +186,11 @@ __global__ __launch_bounds__(256) void insert_evict_kernel(TableView v, size_t n
     i64 row = evict_and_lock(v, key, strategy == TFRA_EVICT_EPOCHLFU ? ((epoch << 32) | in_score) : in_score, lru_like, sub,
                              gshift, &word, claimed_empty);
     if (row >= 0) {
-      copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes, vals + i * (size_t)v.field_bytes,
-                      v.field_bytes, sub);
-      if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, field);
-      if (sub == 0) v.scores[word] = 0;  // the slot starts a new life: scores count from zero
-      update_score(v, row, true, strategy, in_score, epoch, sub);
+      copy_bytes16_wt<G>(row_ptr(v, row) + field * v.field_bytes, vals + i * (size_t)v.field_bytes,
+                         v.field_bytes, sub);
+      if (v.n_fields > 1) init_aux_fields<true>(v, ai, row, sub, field);
+      if (sub == 0) store_wt8(score_word(v, word), 0);  // the slot starts a new life: scores count from zero
+      update_score<true>(v, row, true, strategy, in_score, epoch, sub);
       publish_key(v, word, key, sub);
       fresh = (claimed_empty && sub == 0);
     } else if (row == -3) {
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) void insert_write_kernel(TableView v, size_t n
     if (strategy == TFRA_EVICT_LFU) update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
     return;
   }
-  copy_bytes16<G>(v.rows + (size_t)row * v.row_stride + field * v.field_bytes,
+  copy_bytes16<G>(row_ptr(v, row) + field * v.field_bytes,
                   vals + i * (size_t)v.field_bytes, v.field_bytes, sub);
   update_score(v, row, is_new, strategy, scores ? scores[i] : 1, epoch, sub);
 }
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const
                                                     const u64* __restrict__ scores, unsigned dim,
                                                     AuxInit ai, int strategy, u64 epoch,
                                                     const int* __restrict__ order, size_t n_order,
-                                                    uint8_t* __restrict__ deferred) {
+                                                    uint8_t* __restrict__ deferred, int bounded_mode) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   const size_t wave = g >> 2;
@@ -316,15 +333,15 @@ __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const
       if (deferred) {  // bounded table at max_capacity: keys without a free slot evict in phase 2
         u64 h;
         const u64 b0 = bucket0(key, v.nb, h);
-        const i64 k0 = load_key_coherent(&v.keys[b0 * 16 + sub]);
-        row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, true);
+        const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+        row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, bounded_mode);
         if (sub == 0) deferred[i] = row == NEED_EVICT;
       } else {
         row = locate_or_claim(v, key, sub, gshift, is_new);
       }
       if (row < 0) failed = (sub == 0 && row != NEED_EVICT);
       else if (is_new) {
-        copy_bytes16<G>(v.rows + (size_t)row * v.row_stride, src, v.field_bytes, sub);
+        copy_bytes16<G>(row_ptr(v, row), src, v.field_bytes, sub);
         if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, 0);
         update_score(v, row, true, strategy, scores ? scores[i] : 1, epoch, sub);
         fresh = (sub == 0);
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const
     } else {
       i64 row = probe_find<true>(v, key, sub, gshift);
       if (row >= 0) {
-        row_add<DT>(v.rows + (size_t)row * v.row_stride, src, dim, sub);
+        row_add<DT>(row_ptr(v, row), src, dim, sub);
         update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
       }  // absent & exists: dropped
       if (deferred && sub == 0) deferred[i] = 0;
@@ -359,8 +376,8 @@ __global__ __launch_bounds__(256) void erase_kernel(TableView v, size_t n, const
       if (row >= 0 && sub == 0) {
         u64 w = ((u64)row / SLOTS) * 16 + (u64)row % SLOTS;
         // CAS so that duplicate keys in one call decrement the size once
-        gone = atomicCAS((u64*)&v.keys[w], (u64)key, (u64)EMPTY_KEY) == (u64)key;
-        if (gone && v.scores) v.scores[w] = 0;
+        gone = atomicCAS((u64*)key_word(v, w), (u64)key, (u64)EMPTY_KEY) == (u64)key;
+        if (gone && has_scores(v)) *score_word(v, w) = 0;
       }
     }
   }
@@ -372,8 +389,8 @@ __global__ __launch_bounds__(256) void erase_kernel(TableView v, size_t n, const
 __global__ void clear_kernel(TableView v, int reset_counters) {
   size_t total = v.nb * 16;
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
-    v.keys[w] = ((w & 15) == 15) ? 0 : EMPTY_KEY;
-    if (v.scores) v.scores[w] = 0;
+    *key_word(v, w) = ((w & 15) == 15) ? 0 : EMPTY_KEY;
+    if (has_scores(v)) *score_word(v, w) = 0;
   }
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (!reset_counters) return;
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(256) void export_kernel(TableView v, u64 first_buck
   for (int it = 0; it < 4; ++it) {
     u64 b = first_bucket + (u64)blockIdx.x * 64 + it * 16 + grp_in_block;
     bool ok = b < last_bucket;
-    k[it] = ok ? v.keys[b * 16 + sub] : EMPTY_KEY;
+    k[it] = ok ? key_line(v, b)[sub] : EMPTY_KEY;
     u64 slot = b * SLOTS + sub;
     bool l = ok && sub < SLOTS && k[it] != EMPTY_KEY && k[it] != LOCKED_KEY && slot >= lo && slot < hi;
     live[it] = (unsigned)(__ballot(l) >> gshift) & 0x7fffu;
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(256) void export_kernel(TableView v, u64 first_buck
     if (m & (1u << sub)) {
       u64 pos = pos0 + __popc(m & ((1u << sub) - 1));
       keys_out[pos] = k[it];
-      if (scores_out) scores_out[pos] = v.scores ? v.scores[b * 16 + sub] : 0;
+      if (scores_out) scores_out[pos] = has_scores(v) ? score_line(v, b)[sub] : 0;
     }
     if (vals_out) {
       unsigned r = 0;
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(256) void export_kernel(TableView v, u64 first_buck
         int s = __ffs(m) - 1;
         m &= m - 1;
         copy_bytes16<G>(vals_out + (pos0 + r) * (size_t)v.field_bytes,
-                        v.rows + (size_t)(b * SLOTS + s) * v.row_stride, v.field_bytes, sub);
+                        row_at(v, b, (unsigned)s), v.field_bytes, sub);
         ++r;
       }
     }
@@ -464,7 +481,7 @@ __global__ void export_reserved_kernel(TableView v, u64 lo, u64 hi, u64* counter
     if (threadIdx.x == 0) { keys_out[pos] = EMPTY_KEY + r; if (scores_out) scores_out[pos] = ~0ULL; }
     if (vals_out)
       for (unsigned off = threadIdx.x; off < v.field_bytes; off += blockDim.x)
-        vals_out[pos * (size_t)v.field_bytes + off] = v.rows[slot * (size_t)v.row_stride + off];
+        vals_out[pos * (size_t)v.field_bytes + off] = row_ptr(v, (i64)slot)[off];
     __syncthreads();
   }
 }
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableView o, TableView v) {
   const u64 b = (((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   int failed = 0;
   if (b < o.nb) {
-    i64 k = o.keys[b * 16 + sub];
+    i64 k = key_line(o, b)[sub];
     unsigned m = (unsigned)(__ballot(sub < SLOTS && k != EMPTY_KEY && k != LOCKED_KEY) >> gshift) & 0x7fffu;
     while (m) {
       int s = __ffs(m) - 1;
@@ -484,16 +501,14 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableView o, TableView v) {
       bool is_new;
       i64 row = locate_or_claim(v, key, sub, gshift, is_new);
       if (row < 0) { failed += (sub == 0); continue; }
-      copy_bytes16<16>(v.rows + (size_t)row * v.row_stride,
-                       o.rows + (size_t)(b * SLOTS + s) * o.row_stride, o.row_stride, sub);
-      if (v.scores && o.scores && sub == 0)
-        v.scores[((u64)row / SLOTS) * 16 + (u64)row % SLOTS] = o.scores[b * 16 + s];
+      copy_bytes16<16>(row_ptr(v, row), row_at(o, b, (unsigned)s), o.row_stride, sub);
+      if (has_scores(v) && has_scores(o) && sub == 0)
+        score_line(v, (u64)row / SLOTS)[(u64)row % SLOTS] = score_line(o, b)[s];
     }
   }
   if (b == 0) {  // side rows
     for (int r = 0; r < NUM_RESERVED; ++r)
-      copy_bytes16<16>(v.rows + (size_t)(v.nb * SLOTS + r) * v.row_stride,
-                       o.rows + (size_t)(o.nb * SLOTS + r) * o.row_stride, o.row_stride, sub);
+      copy_bytes16<16>(row_ptr(v, (i64)(v.nb * SLOTS + r)), row_ptr(o, (i64)(o.nb * SLOTS + r)), o.row_stride, sub);
   }
   for (int off = 32; off > 0; off >>= 1) failed += __shfl_xor(failed, off);
   if (lane == 0 && failed) atomicAdd(v.err_count, (unsigned)failed);
@@ -579,24 +594,26 @@ void Table::dfree(void* p, hipStream_t s) {
   else (void)hipFree(p);
 }
 
+static inline unsigned hdr_bytes(const tfra_table_opts& o) { return o.strategy >= 0 ? 256u : 128u; }
+
 int Table::alloc_storage(u64 nb, Storage* st, hipStream_t s) {
   st->nb = nb;
-  size_t nrows = nb * SLOTS + NUM_RESERVED;
-  st->keys = (i64*)dalloc(nb * 16 * sizeof(i64), s);
-  st->rows = (unsigned char*)dalloc(nrows * (size_t)row_stride, s);
-  st->scores = opts.strategy >= 0 ? (u64*)dalloc(nb * 16 * sizeof(u64), s) : nullptr;
-  if (!st->keys || !st->rows || (opts.strategy >= 0 && !st->scores)) {
-    dfree(st->keys, s); dfree(st->rows, s); dfree(st->scores, s);
+  const size_t bstride = (size_t)hdr_bytes(opts) + (size_t)SLOTS * row_stride;
+  const size_t bytes = nb * bstride + (size_t)NUM_RESERVED * row_stride;
+  st->base = (unsigned char*)dalloc(bytes, s);
+  if (!st->base) {
     *st = Storage();
-    return set_error(TFRA_ERR_OOM, "table storage allocation failed (" + std::to_string(nrows) + " rows x " +
-                                       std::to_string(row_stride) + " B)");
+    return set_error(TFRA_ERR_OOM, "table storage allocation failed (" + std::to_string(nb) + " buckets x " +
+                                       std::to_string(bstride) + " B)");
   }
   return TFRA_OK;
 }
 
 TableView Table::view_of(const Storage& st) const {
   TableView v;
-  v.keys = st.keys; v.rows = st.rows; v.scores = st.scores; v.nb = st.nb;
+  v.base = st.base; v.nb = st.nb;
+  v.hdr = hdr_bytes(opts);
+  v.bucket_stride = (u64)v.hdr + (u64)SLOTS * row_stride;
   v.field_bytes = field_bytes; v.row_stride = row_stride; v.n_fields = 1 + opts.aux_fields;
   v.reserved_present = reserved_present; v.size_shards = size_shards; v.winner = winner;
   v.err_count = err_count;
@@ -697,13 +714,32 @@ int Table::grow(u64 min_nb, hipStream_t s) {
   rehash_kernel<<<(unsigned)((groups * 16 + 255) / 256), 256, 0, s>>>(view_of(old), nv);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));  // old arrays are freed below
-  dfree(old.keys, s); dfree(old.rows, s); dfree(old.scores, s); dfree(old_winner, s);
+  dfree(old.base, s); dfree(old_winner, s);
   cur = nw;
   n_rehash++;
   return TFRA_OK;
 }
 
-// called before inserting up to n new keys
+// A table that cannot grow any more (Hkv flavour at max_capacity): every 16th insert-type call starts an
+// asynchronous size read (size kernel + 8-B D2H + event, no host wait); `dense` = the last completed read saw
+// more than 80 % of the slots in use.  find / insert then put BOTH home buckets' lines in flight at once.
+int Table::poll_density(hipStream_t s) {
+  if (size_pending) {
+    if (hipEventQuery(size_event) != hipSuccess) return TFRA_OK;
+    i64 v = *h_size;
+    dense = (double)(v < 0 ? 0 : v) > 0.8 * (double)(cur.nb * SLOTS);
+    size_pending = false;
+  }
+  if (++dense_calls >= 16 || dense_calls == 1) {
+    if (dense_calls >= 16) dense_calls = 1;
+    size_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1);
+    HIP_TRY(hipMemcpyAsync(h_size, d_scalar + 1, sizeof(i64), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(size_event, s));
+    size_pending = true;
+  }
+  return TFRA_OK;
+}
+
 // Called before an op that may insert up to n new keys.  Growth policy:
 //   * `size_ub` is a host-side UPPER BOUND of the live-key count (every insert-type call adds its
 //     n; exact after a size read).  While size_ub + n <= max_load_factor*slots nothing happens.
@@ -720,7 +756,7 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
   if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
   // at max_capacity (eviction takes over) or after a failed growth there is nothing to decide
   const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb < std::max<u64>(2, opts.max_capacity / SLOTS));
-  if (!can_grow) return TFRA_OK;
+  if (!can_grow) return poll_density(s);
   if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
     size_ub = (v < 0 ? 0 : (size_t)v) + n_since_read;
@@ -779,7 +815,10 @@ static int find_impl(Table* t, hipStream_t s, int field, size_t n, const int64_t
   unsigned char* o = (unsigned char*)values;
   const unsigned char* d = (const unsigned char*)defaults;
   switch (g) {
-    case 16: find_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+    case 16:
+      if (t->dense) find_kernel<16, U, true, true><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo);
+      else find_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo);
+      break;
     case 8: find_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
     case 4: find_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
     case 2: find_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
@@ -824,7 +863,7 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
       deferred = (uint8_t*)t->scratch;
     }
     TableView v = t->view_of(t->cur);
-    const int bd = bounded ? 1 : 0;
+    const int bd = bounded ? (t->dense ? 2 : 1) : 0;
     switch (g) {
       case 16: insert_unique_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
       case 8: insert_unique_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, vals, sc, field, t->aux, strat, epoch, bd, deferred); break;
@@ -872,28 +911,28 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
 template <int DT>
 static void launch_accum(int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k, const unsigned char* vod,
                          const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai, int strat, u64 epoch,
-                         const int* order, size_t n_order, uint8_t* deferred) {
+                         const int* order, size_t n_order, uint8_t* deferred, int bmode) {
   dim3 block(256);
   switch (g) {
-    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
   }
 }
 
 static void launch_accum_dt(int dt, int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k,
                             const unsigned char* vod, const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai,
-                            int strat, u64 epoch, const int* order, size_t n_order, uint8_t* deferred) {
+                            int strat, u64 epoch, const int* order, size_t n_order, uint8_t* deferred, int bmode) {
   switch (dt) {
-    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
-    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred); break;
+    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
   }
 }
 
@@ -954,7 +993,8 @@ int tfra_table_destroy(tfra_table_t* tp) {
   (void)hipSetDevice(t->device);
   (void)hipDeviceSynchronize();
   hipStream_t s = nullptr;
-  t->dfree(t->cur.keys, s); t->dfree(t->cur.rows, s); t->dfree(t->cur.scores, s);
+  destroy_own_plan(t);
+  t->dfree(t->cur.base, s);
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
   t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s);
   if (t->progress_host) (void)hipHostFree(t->progress_host);
@@ -1013,7 +1053,8 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
     rc = t->bounded_flags(n, s, &deferred);
     if (rc) return rc;
     launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
-                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, 0, deferred);
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, 0, deferred,
+                    deferred ? (t->dense ? 2 : 1) : 0);
     if (deferred) {  // phase 2: the absent keys that found no free slot replace a minimum-score entry
       const unsigned char* vals = (const unsigned char*)vod;
       const u64* sc = (const u64*)scores;
@@ -1071,7 +1112,7 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
   for (auto& r : rounds) {
     dim3 grid((unsigned)((r.size() * 16 + 255) / 256));
     launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
-                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, d_order + off, r.size(), nullptr);
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, d_order + off, r.size(), nullptr, 0);
     off += r.size();
   }
   HIP_TRY(hipGetLastError());
@@ -1095,6 +1136,8 @@ int tfra_table_clear(tfra_table_t* tp, tfra_stream_t stream) {
   t->size_ub = 0;
   t->size_pending = false;
   t->n_since_read = 0;
+  t->dense = false;
+  t->dense_calls = 0;
   return TFRA_OK;
 }
 

@@ -83,6 +83,10 @@ _SIGS = {
     "tfra_sparse_plan_build": [_P, _SZ, _P, _I, _P],
     "tfra_table_apply_planned": [_P, ctypes.POINTER(OptParams), _P, _P, _P, _P],
     "tfra_table_step_prefetch": [_P, ctypes.POINTER(OptParams), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P],
+    "tfra_table_step_prefetch_assign": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P],
+    "tfra_table_upsert_sparse": [_P, _SZ, _P, _P, _P, _P],
+    "tfra_table_upsert_planned": [_P, _P, _P, _P, _P],
+    "tfra_sparse_plan_read": [_P, _P, _P, _P, _P, _SZ, _P],
     "tfra_workspace_create": [_I, ctypes.POINTER(_P)],
     "tfra_workspace_destroy": [_P],
     "tfra_unique": [_P, _SZ, _P, _P, _P, _P, _P],

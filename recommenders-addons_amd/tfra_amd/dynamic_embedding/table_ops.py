@@ -341,6 +341,21 @@ class SparsePlan:
       self._built.record(stream)
     return self
 
+  def read(self):
+    """The batch as CSR-by-key, on the host (tests / tools): counts dict, keys [U], cnt [U], positions [n]
+    (the positions of key 0, of key 1, ..., each ascending).  Synchronises the current stream."""
+    import numpy as np
+    counts = (ctypes.c_uint32 * 6)()
+    _capi.call("tfra_sparse_plan_read", self._h, counts, None, None, None, 0, _stream(self._device))
+    u = counts[0] + counts[1]
+    keys = np.empty(u, np.int64)
+    cnt = np.empty(u, np.uint32)
+    pos = np.empty(self.n, np.uint32)
+    _capi.call("tfra_sparse_plan_read", self._h, counts, keys.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p),
+               pos.ctypes.data_as(ctypes.c_void_p), u, _stream(self._device))
+    names = ("many", "few", "partials", "bins", "few_entries", "errors")
+    return dict(zip(names, list(counts))), keys, cnt, pos
+
   def __del__(self):
     try:
       if self._h:
@@ -369,6 +384,40 @@ def _apply_planned(self, params, plan, grads, default_row, sync=True):
 
 
 _DeviceTable.apply_planned = _apply_planned
+
+
+def _upsert_sparse(self, ids, values, scores=None):
+  """insert_or_assign of a batch whose keys may repeat: the LAST occurrence wins (the reference's sequential
+  order), de-duplicated on the device — also on a bounded table at max_capacity."""
+  ids = self._keys(ids).reshape(-1)
+  values = self._values_for(ids, values.reshape(ids.numel(), -1))
+  if scores is not None:
+    scores = scores.to(self._device, torch.int64).contiguous()
+  if ids.numel():
+    _capi.call("tfra_table_upsert_sparse", self._h, ids.numel(), _ptr(ids), _ptr(values), _ptr(scores), _stream(self._device))
+
+
+def _upsert_planned(self, plan, values, scores=None, sync=True):
+  """Assign half of upsert_sparse for a batch whose id-only half was built ahead (`SparsePlan`)."""
+  if plan._device != self._device:
+    raise ValueError("the plan lives on %s" % (plan._device,))
+  values = values.to(self._device).contiguous()
+  if values.dtype != self._value_dtype or values.numel() != plan.n * self._dim:
+    raise ValueError("Expected %s values of shape %s" % (self._value_dtype, [plan.n, self._dim]))
+  if scores is not None:
+    scores = scores.to(self._device, torch.int64).contiguous()
+  stream = torch.cuda.current_stream(self._device)
+  if sync:
+    stream.wait_event(plan._built)
+  _capi.call("tfra_table_upsert_planned", self._h, plan._h, _ptr(values), _ptr(scores), _stream(self._device))
+  if sync:
+    if plan._used is None:
+      plan._used = torch.cuda.Event()
+    plan._used.record(stream)
+
+
+_DeviceTable.upsert_sparse = _upsert_sparse
+_DeviceTable.upsert_planned = _upsert_planned
 
 
 class _LookupInterfaceMirror:

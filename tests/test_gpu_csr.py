@@ -1,0 +1,219 @@
+"""GPU: the CSR-by-key write-back plan (csrc/tfra_csr.hip) and the kernels that consume it.
+
+  * the plan itself (tfra_sparse_plan_read) against numpy: unique keys, counts, positions ascending per key;
+  * tfra_table_apply_sparse at BASELINE's benchmark shape (B = 131 072 Zipf-1.2 over >= 10 M keys, 3 steps) against
+    the reference's write-back sequence with SEQUENTIAL fp32 duplicate sums (what the CPU path does,
+    PY/dynamic_embedding_optimizer.py:177-190): embedding values within 1e-6 (north_star tolerance);
+  * tfra_table_upsert_sparse (repeats: the last occurrence wins) against the oracle table, bit-exact, every dtype,
+    unbounded and bounded-at-capacity tables.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.table_ops import SparsePlan
+  return torch, de, SparsePlan
+
+
+def check_plan(torch, SparsePlan, ids_np, dim=64):
+  plan = SparsePlan("cuda:0", dim)
+  plan.build(torch.from_numpy(ids_np).cuda())
+  counts, keys, cnt, pos = plan.read()
+  assert counts["errors"] == 0
+  uk, uc = np.unique(ids_np, return_counts=True)
+  order = np.argsort(keys, kind="stable")
+  np.testing.assert_array_equal(keys[order], uk)
+  np.testing.assert_array_equal(cnt[order].astype(np.int64), uc)
+  # keys with > 8 occurrences come first
+  many = counts["many"]
+  assert np.all(cnt[:many] > 8) and np.all(cnt[many:] <= 8)
+  off = np.concatenate([[0], np.cumsum(cnt.astype(np.int64))])
+  assert off[-1] == ids_np.size
+  # every key's positions: exactly the positions where it occurs, ascending
+  assert np.array_equal(ids_np[pos], np.repeat(keys, cnt))
+  starts = np.zeros(ids_np.size, bool)
+  starts[off[:-1]] = True
+  asc = np.diff(pos.astype(np.int64)) > 0
+  assert np.all(asc | starts[1:])
+  return counts
+
+
+@pytest.mark.parametrize("n", [1, 7, 511, 512, 513, 4096, 131072, 262144])
+def test_plan_matches_numpy_zipf(env, n):
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(n)
+  ids = (rng.zipf(1.2, size=n) % 1_000_003).astype(np.int64) * 7919 - 5
+  check_plan(torch, SparsePlan, ids)
+
+
+def test_plan_edge_shapes(env):
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(0)
+  n = 100_000
+  check_plan(torch, SparsePlan, np.full(n, 42, np.int64))                      # one key, 195 bins of 512
+  check_plan(torch, SparsePlan, np.arange(n, dtype=np.int64) - 50_000)          # all distinct
+  check_plan(torch, SparsePlan, np.repeat(np.arange(n // 9, dtype=np.int64), 9))   # every key just past the direct limit
+  check_plan(torch, SparsePlan, np.tile(np.arange(n // 2, dtype=np.int64), 2))     # every key in two far-apart tiles
+  check_plan(torch, SparsePlan, rng.integers(0, 40, size=n).astype(np.int64))   # 40 keys, ~2500 each: every tile holds every key
+  check_plan(torch, SparsePlan, np.concatenate([np.full(70_000, np.iinfo(np.int64).min), rng.integers(-3, 3, size=30_000)]).astype(np.int64))
+  k = rng.integers(0, 3000, size=n).astype(np.int64)                            # ~33 each
+  check_plan(torch, SparsePlan, k)
+  # a rebuilt plan forgets the previous batch
+  plan = SparsePlan("cuda:0", 64)
+  for seed in range(3):
+    ids = np.random.default_rng(seed).integers(0, 1000 * (seed + 1), size=50_000).astype(np.int64)
+    plan.build(torch.from_numpy(ids).cuda())
+    counts, keys, cnt, pos = plan.read()
+    assert np.array_equal(np.sort(keys), np.unique(ids)) and np.array_equal(ids[pos], np.repeat(keys, cnt))
+
+
+def test_apply_sparse_benchmark_shape_vs_sequential_oracle(env):
+  """B = 131 072, Zipf-1.2 over 10 M resident keys, 3 Adam steps, one-call path and step driver: embedding values
+  within 1e-6 of the reference's sequence with sequential fp32 duplicate sums; slots within 1e-6 relative."""
+  torch, de, SparsePlan = env
+  from bench import keys_of_ranks, keys_of_ranks_torch, zipf_bounded
+  from oracle import optimizers as oopt
+  N, dim, B = 10_000_000, 64, 131072
+  rng = np.random.default_rng(11)
+  opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
+  hyper = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)
+  for driver in ("one_call", "prefetch"):
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    var = de.Variable(dim=dim, name="csr_bench_%s" % driver, initializer=0.0, init_size=int(N * 1.05),
+                      **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for lo in range(1, N + 1, 2_000_000):
+      k = keys_of_ranks_torch(torch, torch.arange(lo, lo + 2_000_000, dtype=torch.int64, device="cuda"))
+      var.tables[0]._table.upsert(k, torch.randn((k.numel(), dim), generator=gen, device="cuda") * 0.01, unique_keys=True)
+    steps = 3
+    ids = keys_of_ranks(zipf_bounded(rng, steps * B, N)).reshape(steps, B)
+    grads = (rng.standard_normal((steps, B, dim)) * 0.01).astype(np.float32)
+    touched = np.unique(ids)
+    kt = torch.from_numpy(touched).cuda()
+    p0 = var.lookup(kt).cpu().numpy()
+    # the oracles hold only the touched keys (their rows before the steps; slots start at 0):
+    #   state  — duplicate gradients summed SEQUENTIALLY in fp32, batch order (the reference's CPU unsorted_segment_sum)
+    #   exact  — duplicate gradients summed in fp64, rounded once (what every fp32 summation order approximates)
+    state = {"p": p0.copy(), "m": np.zeros_like(p0), "v": np.zeros_like(p0)}
+    exact = {"p": p0.copy(), "m": np.zeros_like(p0), "v": np.zeros_like(p0)}
+    ids_t = torch.from_numpy(ids).cuda()
+    g_t = torch.from_numpy(grads).cuda()
+    ps = de.PrefetchStep(var, deo).prime(ids_t[0]) if driver == "prefetch" else None
+    for s in range(steps):
+      if ps is not None:
+        ps.step(g_t[s], ids_t[s + 1] if s + 1 < steps else None)
+      else:
+        var.lookup(ids_t[s])
+        deo.apply_sparse(var, ids_t[s], g_t[s])
+      # reference: unique + unsorted_segment_sum (sequential fp32, index order) + dense Adam on the unique rows
+      uk, inv = np.unique(ids[s], return_inverse=True)
+      gs = np.zeros((uk.size, dim), np.float32)
+      g64 = np.zeros((uk.size, dim), np.float64)
+      np.add.at(g64, inv, grads[s].astype(np.float64))
+      order = np.argsort(inv, kind="stable")
+      bounds = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=uk.size))])
+      gsorted = grads[s][order]
+      for j in range(uk.size):   # sequential fp32 adds in batch order
+        seg = gsorted[bounds[j]:bounds[j + 1]]
+        gs[j] = seg[0] if seg.shape[0] == 1 else np.add.accumulate(seg, axis=0, dtype=np.float32)[-1]
+      rows = np.searchsorted(touched, uk)
+      p, m, v = oopt.adam(state["p"][rows], state["m"][rows], state["v"][rows], gs, 1e-3, 0.9, 0.999, 1e-8, s + 1)
+      state["p"][rows], state["m"][rows], state["v"][rows] = p, m, v
+      p, m, v = oopt.adam(exact["p"][rows], exact["m"][rows], exact["v"][rows], g64.astype(np.float32), 1e-3, 0.9, 0.999, 1e-8, s + 1)
+      exact["p"][rows], exact["m"][rows], exact["v"][rows] = p, m, v
+    torch.cuda.synchronize()
+    got_p = var.lookup(kt).cpu().numpy()
+    # Adam's update lr*m^/(sqrt(v^)+eps) is ill-conditioned where a gradient sum is ~0 (sensitivity lr*eps/(|g|+eps)^2:
+    # up to 1e5 per unit of g): there the reference's OWN result moves by more than 1e-6 when its duplicate sum is
+    # rounded differently.  Elements where the reference's sequential-fp32 sum and the exactly-rounded sum lead to
+    # embedding values more than 2.5e-7 apart are therefore excluded (a handful in 3 M); everywhere else the
+    # north_star tolerance applies: 1e-6 on float32 embedding values against the reference's sequence.
+    stable = np.abs(state["p"] - exact["p"]) <= 2.5e-7
+    assert (~stable).mean() < 1e-5, (~stable).sum()
+    err_p = float(np.max(np.abs(got_p - state["p"])[stable]))
+    assert err_p <= 1e-6, err_p
+    assert float(np.max(np.abs(got_p - exact["p"])[stable])) <= 1e-6
+    got_m = deo.get_slot(var, "m").lookup(kt).cpu().numpy()
+    got_v = deo.get_slot(var, "v").lookup(kt).cpu().numpy()
+    # The slots see the gradient sum itself (m += 0.1 (g - m)): for the hottest key (~24 000 addends) the
+    # reference's own sequential fp32 sum is ~1e-5 away from the exact sum, so "equal to the reference" cannot be
+    # tighter than that for m.  Pin the slots to the exactly-summed oracle at 1e-6 and to the sequential one at 1e-5,
+    # and require that we are not further from exact than the reference's order is.
+    np.testing.assert_allclose(got_m, exact["m"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got_v, exact["v"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got_m, state["m"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got_v, state["v"], rtol=1e-5, atol=1e-5)
+    e_ours = float(np.max(np.abs(got_m - exact["m"])))
+    e_ref = float(np.max(np.abs(state["m"] - exact["m"])))
+    assert e_ours <= e_ref + 1e-9, (e_ours, e_ref)
+    print("driver %s: max|p - sequential oracle| = %.3g over %d of %d elements (%d ill-conditioned excluded); slot m: "
+          "max|ours - exact| = %.3g, max|sequential - exact| = %.3g" % (driver, err_p, int(stable.sum()), stable.size,
+                                                                          int((~stable).sum()), e_ours, e_ref))
+    del var, deo, ps
+
+
+@pytest.mark.parametrize("dtype_name,dim", [("float32", 64), ("float16", 128), ("int8", 3), ("int64", 10), ("bfloat16", 33)])
+def test_upsert_sparse_last_occurrence_wins(env, dtype_name, dim):
+  import oracle
+  torch, de, SparsePlan = env
+  dt = getattr(torch, dtype_name)
+  npdt = {"float32": np.float32, "float16": np.float16, "int8": np.int8, "int64": np.int64, "bfloat16": np.float32}[dtype_name]
+  rng = np.random.default_rng(dim)
+  t = de.CuckooHashTable(torch.int64, dt, torch.zeros(dim, dtype=dt), device="cuda:0", dim=dim, name="ups_%s" % dtype_name)
+  ref = {}
+  for step in range(3):
+    n = 30_000
+    keys = (rng.zipf(1.3, size=n) % 5000).astype(np.int64) - 7
+    vals = rng.integers(-100, 100, size=(n, dim)).astype(npdt)
+    vt = torch.from_numpy(vals).cuda().to(dt)
+    t._table.upsert_sparse(torch.from_numpy(keys).cuda(), vt)
+    for i in range(n):
+      ref[int(keys[i])] = i
+    uk = np.array(sorted(ref), np.int64)
+    # rows of the LAST occurrence (across steps the latest step wins)
+    if step == 0:
+      want = {int(k): vt[ref[int(k)]].clone() for k in uk}
+    else:
+      for k in np.unique(keys):
+        want[int(k)] = vt[ref[int(k)]].clone()
+  ek, ev = t.export()
+  assert int(t.size().item()) == len(want) == ek.numel()
+  got = t.lookup(torch.from_numpy(uk).cuda())
+  exp = torch.stack([want[int(k)] for k in uk])
+  assert torch.equal(got, exp)
+
+
+def test_upsert_sparse_bounded_table_at_capacity(env):
+  """A bounded (Hkv) table at max_capacity takes batches with repeats through the plan: size <= capacity, every
+  resident key returns the row of its last occurrence."""
+  torch, de, SparsePlan = env
+  dim, cap, B = 16, 60_000, 50_000
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name="ups_bounded")
+  rng = np.random.default_rng(3)
+  latest = {}
+  fresh = 1
+  for step in range(12):
+    old = (rng.zipf(1.2, size=B // 2) % 20_000).astype(np.int64)
+    new = np.arange(fresh, fresh + B // 2, dtype=np.int64) + 1_000_000
+    fresh += B // 2
+    keys = np.concatenate([old, new])
+    rng.shuffle(keys)
+    vals = np.tile((np.arange(B, dtype=np.float32) + step * B)[:, None], (1, dim))
+    t._table.upsert_sparse(torch.from_numpy(keys).cuda(), torch.from_numpy(vals).cuda())
+    for i in range(B):
+      latest[int(keys[i])] = float(vals[i, 0])
+    n = int(t.size().item())
+    assert n <= cap
+  assert int(t.size().item()) > cap * 0.9
+  k, v = t.export()
+  k, v = k.cpu().numpy(), v.cpu().numpy()
+  assert np.unique(k).size == k.size
+  np.testing.assert_array_equal(v[:, 0], np.array([latest[int(x)] for x in k], np.float32))
+  assert np.all(v == v[:, :1])
