@@ -1,19 +1,28 @@
 """bench.py — dynamic-embedding hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--keys N_KEYS] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|m1b] [--slots S] [--keys N_KEYS] [--batch B]
 
-One "step" = one pass of the hot path over one batch of synthetic ids, configuration
-BASELINE.json configs[1] ("1xMI355X: 100M keys, dim=64 fp32, Zipf-1.2 batch=131072,
-lookup+insert+sparse-Adam"):
+One "step" = one pass of the hot path over one batch of synthetic ids.  Configurations (BASELINE.json `configs`):
 
-    forward : embedding lookup of the B Zipf ids  (find, default fill fused)         -> [B,64]
-    backward: gradients [B,64] -> duplicate ids summed -> fused sparse Adam on the unique keys,
-              which is also the write-back/insert of the batch's keys (rows are [p|m|v])
+  c3  (default at N=1: the largest single-GPU configuration, configs[2])
+      bounded (Hkv, LRU) table with 10^9 slots, dim=128 fp16 rows (256 B, the same row bytes as the metric's dim=64
+      fp32), pre-filled to capacity; every batch of B=131072 ids is 50 % Zipf-1.2 over the resident ranks and 50 %
+      never-seen ranks (monotone counter), so the timed region carries inserts AND score-based eviction:
+          lookup(B ids, misses get the default row)  ->  insert_or_assign(B ids, B rows; repeats: last one wins)
+      If 10^9 slots do not allocate, the largest slot count that does is used and named in config.workload.
+  c2  configs[1]: growing table, 100 M resident keys, dim=64 fp32 rows [p|m|v], Zipf-1.2 batch, `--new-key-ratio`
+      (default 0.1) of every batch are never-seen keys:
+          lookup(B) -> gradients [B,64] -> duplicate ids summed -> fused sparse Adam on the unique keys (= the
+          write-back/insert of the batch's keys)
+      Run as a secondary measurement of the default invocation (key "secondary") and as the per-GPU workload of N>1.
+  m1b the metric's own wording on one GPU: dim=64 fp32, 10^9 slots, Zipf-1.2 ids: lookup(B) -> insert_or_assign(B).
 
-`value` = ids looked up AND written back per second (lookup+insert pairs/s), whole job.  Inputs
-(id batches, gradients) are resident in HBM before the timed region.  N>1: one process per GPU,
-tables sharded by key hash, ids/rows/grads routed with alltoall over RCCL (weak scaling: per-GPU
-keys and batch fixed).  Prints ONE JSON line on rank 0.
+`value` = ids looked up AND written back per second (lookup+insert pairs/s), whole job, with the step driven by ONE
+C call per step that also builds the de-duplication plan of batch i+1 on a second HIP stream (the ids of a batch are
+known one batch ahead, as an input pipeline provides them); `value_plain_call` = the same step as the reference's op
+sequence issues it (Find op, then Insert / optimizer op; no look-ahead).  Inputs (id batches, values, gradients) are
+resident in HBM before the timed region.  N>1: one process per GPU, tables sharded by key hash, ids/rows/grads
+routed with alltoall over RCCL (weak scaling: per-GPU keys and batch fixed).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -28,10 +37,9 @@ for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
   if p not in sys.path:
     sys.path.insert(0, p)
 
-DIM = 64
 ZIPF_S = 1.2
 SEED = 20250205
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured for a plain copy)
 
 
 # ------------------------------------------------------------------ synthetic inputs
@@ -90,46 +98,506 @@ def keys_of_ranks_torch(torch, ranks):
   return x
 
 
+def mixed_batches(rng, nbatch, batch, n_resident, new_ratio, fresh_start):
+  """[nbatch, batch] ranks: a Zipf-1.2 draw over the resident ranks with `new_ratio` of the positions (evenly
+  interleaved) replaced by never-seen ranks fresh_start, fresh_start+1, ... (monotone counter)."""
+  ranks = zipf_bounded(rng, nbatch * batch, n_resident).reshape(nbatch, batch)
+  n_new = int(round(batch * new_ratio))
+  if n_new:
+    pos = (np.arange(n_new) * (batch / n_new)).astype(np.int64)
+    fresh = fresh_start + np.arange(nbatch * n_new, dtype=np.int64).reshape(nbatch, n_new)
+    ranks[:, pos] = fresh
+  return ranks, fresh_start + nbatch * n_new
+
+
 # ------------------------------------------------------------------ CPU baseline (reference engine)
-def cpu_baseline(batch, budget_s=15.0):
-  """The reference's CPU path timed on this box's host cores: cuckoohash_map.hh (oracle/_ref,
-  compiled in place from the reference) driven through the reference's write-back sequence
-  (PY/dynamic_embedding_optimizer.py:165-204): unique -> 3 finds -> dense Adam -> 3 upserts."""
+def cpu_baseline(batch, budget_s=20.0):
+  """The reference's CPU table — lib/cuckoo/cuckoohash_map.hh compiled in place (oracle/_ref) behind a restatement of
+  TableWrapperOptimized + the LaunchTensors* launchers (K/cuckoo_hashtable_op.cc:39-182: static split of the keys over
+  a persistent intra-op pool) — timed on this box's host cores: per op (find / insert_or_assign / insert_or_accum),
+  for the full lookup + write-back step, with the table pre-sized (init_size = N) and at the reference default
+  (init_size = 8192, growth included), over a sweep of pool sizes.  dim 64 fp32 rows (256 B; the reference engine's
+  half type needs Eigen, absent here).  A bounded sample: N = 4 M keys, ~20 s of CPU work in total."""
   import oracle
-  from oracle import optimizers as oopt
   kind = "reference" if oracle.available("reference") else "port"
   cores = os.cpu_count() or 1
-  threads = cores if kind == "reference" else 1
-  n_keys = 4_000_000
+  sweep = sorted(set(t for t in (8, 32, 64, cores) if t <= cores)) if kind == "reference" else [1]
+  dim, n_keys = 64, 4_000_000
   rng = np.random.default_rng(SEED)
-  tabs = [oracle.CpuTable(DIM, np.float32, kind=kind, init_size=n_keys, threads=threads) for _ in range(3)]
-  chunk = 500_000
-  for lo in range(1, n_keys + 1, chunk):
-    r = np.arange(lo, min(n_keys, lo + chunk - 1) + 1, dtype=np.int64)
-    k = keys_of_ranks(r)
-    tabs[0].insert(k, (rng.standard_normal((k.size, DIM)) * 0.01).astype(np.float32))
-    z = np.zeros((k.size, DIM), np.float32)
-    tabs[1].insert(k, z); tabs[2].insert(k, z)
-  grads = (rng.standard_normal((batch, DIM)) * 0.01).astype(np.float32)
-  zero = np.zeros(DIM, np.float32)
-  done, t_total, step = 0, 0.0, 0
-  while t_total < budget_s and step < 200:
-    ids = keys_of_ranks(zipf_bounded(rng, batch, n_keys))
+  batches = [keys_of_ranks(zipf_bounded(rng, batch, n_keys)) for _ in range(8)]
+  uniq = [np.unique(b) for b in batches]
+  vals = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
+  zero = np.zeros(dim, np.float32)
+  t_begin = time.perf_counter()
+
+  def fill(init_size, threads):
+    t = oracle.CpuTable(dim, np.float32, kind=kind, init_size=init_size, threads=threads)
     t0 = time.perf_counter()
-    uniq, idx = np.unique(ids, return_inverse=True)
-    g = np.zeros((uniq.size, DIM), np.float32)
-    np.add.at(g, idx, grads)
-    p = tabs[0].find(uniq, zero); m = tabs[1].find(uniq, zero); v = tabs[2].find(uniq, zero)
-    step += 1
-    p, m, v = oopt.adam(p, m, v, g, 1e-3, 0.9, 0.999, 1e-8, step)
-    tabs[0].insert(uniq, p); tabs[1].insert(uniq, m); tabs[2].insert(uniq, v)
-    t_total += time.perf_counter() - t0
-    done += batch
+    for lo in range(1, n_keys + 1, 500_000):
+      k = keys_of_ranks(np.arange(lo, min(n_keys, lo + 499_999) + 1, dtype=np.int64))
+      t.insert(k, np.broadcast_to(vals[:1], (k.size, dim)))
+    return t, time.perf_counter() - t0
+
+  def rate(fn, units, min_s=0.4):
+    fn(0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+      fn(n + 1)
+      n += 1
+      dt = time.perf_counter() - t0
+      if dt >= min_s or n >= 64:
+        return units * n / dt
+
+  per_threads = {}
+  best = None
+  for th in sweep:
+    if time.perf_counter() - t_begin > budget_s * 0.7:
+      break
+    tab, fill_s = fill(n_keys, th)
+    ops = {
+        "find_ops_per_s": rate(lambda i: tab.find(batches[i % 8], zero), batch),
+        # what embedding_lookup issues: unique first (PY/dynamic_embedding_ops.py:99), Find on the distinct ids
+        "find_unique_ids_ops_per_s": rate(lambda i: tab.find(uniq[i % 8], zero), float(np.mean([u.size for u in uniq]))),
+        "insert_or_assign_ops_per_s": rate(lambda i: tab.insert(uniq[i % 8], vals[:uniq[i % 8].size]), float(np.mean([u.size for u in uniq]))),
+        "insert_or_accum_ops_per_s": rate(lambda i: tab.accum(uniq[i % 8], vals[:uniq[i % 8].size], np.ones(uniq[i % 8].size, bool)),
+                                          float(np.mean([u.size for u in uniq]))),
+        # the step as the reference issues it: unique (not timed here, see dedup_ids_per_s), Find(distinct ids),
+        # Insert(distinct ids, their rows); counted in batch ids (pairs) per second
+        "step_pairs_per_s": rate(lambda i: (tab.find(uniq[i % 8], zero), tab.insert(uniq[i % 8], vals[:uniq[i % 8].size])), batch),
+        "prefill_keys_per_s_init_size_N": n_keys / fill_s,
+    }
+    per_threads[th] = {k: round(v) for k, v in ops.items()}
+    if best is None or ops["step_pairs_per_s"] > best[1]["step_pairs_per_s"]:
+      best = (th, ops)
+    del tab
+  th, ops = best
+  t0 = time.perf_counter()
+  for b in batches:
+    np.unique(b, return_inverse=True)
+  dedup_rate = len(batches) * batch / (time.perf_counter() - t0)
+  # growth included: the reference default init_size = 8192 (K/cuckoo_hashtable_op.cc:199-207), same fill
+  grow_rate = None
+  if time.perf_counter() - t_begin < budget_s:
+    tab, fill_s = fill(8192, th)
+    grow_rate = n_keys / fill_s
+    del tab
+  if kind == "reference":
+    try:
+      oracle._load("reference")  # pools are process-wide; nothing else to release
+    except Exception:
+      pass
+  # the whole CPU step = de-duplicate the batch (tf.unique in the reference, single-threaded; numpy's stands in) +
+  # Find + Insert on the distinct ids
+  step_incl_dedup = 1.0 / (1.0 / dedup_rate + 1.0 / ops["step_pairs_per_s"])
   return {
-      "value": done / t_total, "unit": "lookup+insert pairs/s", "cores": threads, "kind": kind,
-      "sample": "%d steps of batch %d (Zipf-1.2 over %d resident keys, dim 64 fp32, unique->3 finds->numpy Adam->3 "
-                "upserts, %.1f s of CPU work)" % (step, batch, n_keys, t_total),
+      "value": step_incl_dedup, "unit": "lookup+insert pairs/s", "cores": th, "kind": kind,
+      "table_ops_only_pairs_per_s": round(ops["step_pairs_per_s"]),
+      "dedup_ids_per_s_numpy_unique_1_core": round(dedup_rate),
+      "sample": "per batch of %d Zipf-1.2 ids: unique + Find(distinct ids) + Insert(distinct ids) on a %d-key table, dim 64 fp32, init_size = N; "
+                "best of pool sizes %s (host has %d cores); %.0f s of CPU work" % (batch, n_keys, list(per_threads), cores,
+                                                                                  time.perf_counter() - t_begin),
+      "per_op": {k: round(v) for k, v in ops.items()},
+      "per_op_per_core": {k: round(v / th) for k, v in ops.items()},
+      "prefill_keys_per_s_init_size_8192_growth_included": round(grow_rate) if grow_rate else None,
+      "by_pool_size": per_threads,
   }
+
+
+# ------------------------------------------------------------------ helpers
+class Timer:
+  def __init__(self, torch):
+    self.torch = torch
+    self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+  def us(self, fn, reps=50, warm=5):
+    """HIP events on torch's current stream (the stream every table call of this process is enqueued on)."""
+    for i in range(warm):
+      fn(i)
+    self.e0.record()
+    for i in range(reps):
+      fn(warm + i)
+    self.e1.record()
+    self.torch.cuda.synchronize()
+    return self.e0.elapsed_time(self.e1) * 1e3 / reps
+
+
+def raw_calls(torch, dev):
+  """Per-kernel timings go through the C ABI with pre-built ctypes arguments: a Python-level table call costs
+  20-40 us of host time, more than most of these kernels, and would time the host instead."""
+  import ctypes
+  from tfra_amd import _capi
+  lib = _capi.lib()
+  st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+  class R:
+    pass
+  r = R()
+  r.find = lambda h, ids, out, dflt: (lambda a=(h, ids.numel(), P(ids), P(out), None, P(dflt), 0, st): _capi.check(lib.tfra_table_find(*a)))
+  r.upsert_planned = lambda h, plan, vals: (lambda a=(h, plan._h, P(vals), None, st): _capi.check(lib.tfra_table_upsert_planned(*a)))
+  r.apply_planned = lambda h, p, plan, grads, dflt: (lambda a=(h, ctypes.byref(p), plan._h, P(grads), P(dflt), st): _capi.check(lib.tfra_table_apply_planned(*a)))
+  r.plan_build = lambda plan, ids, dim: (lambda a=(plan._h, ids.numel(), P(ids), dim, st): _capi.check(lib.tfra_sparse_plan_build(*a)))
+  r.apply_optimizer = lambda h, p, keys, grads, dflt: (lambda a=(h, ctypes.byref(p), keys.numel(), P(keys), P(grads), P(dflt), 0, None, st): _capi.check(lib.tfra_table_apply_optimizer(*a)))
+  return r
+
+
+def timed_steps(torch, dist, world, dev, K, step):
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(K):
+    step(i)
+  host_s = time.perf_counter() - t0
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  return elapsed, host_s
+
+
+def profile_summary():
+  try:
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
+    return json.load(open(os.path.join(ROOT, "profiles", cands[-1]))) if cands else None
+  except (OSError, ValueError):
+    return None
+
+
+def traffic_of(prof, workload, kname):
+  try:
+    return prof["workloads"][workload]["kernels"][kname]["hbm_bytes_per_launch_corrected"]
+  except (TypeError, KeyError):
+    return None
+
+
+# ------------------------------------------------------------------ c3 / m1b: bounded table at 10^9 slots
+def run_bounded(args, torch, de, dev, cfg):
+  """cfg 'c3': dim 128 fp16, 50 % never-seen ids;  'm1b': dim 64 fp32, `--new-key-ratio` (default 0) never-seen ids."""
+  from tfra_amd import _capi
+  from tfra_amd.dynamic_embedding.table_ops import _ptr, _stream
+  B, K, W = args.batch, args.steps, args.warmup
+  dim, dtype = (128, torch.float16) if cfg == "c3" else (64, torch.float32)
+  new_ratio = 0.5 if cfg == "c3" else (args.new_key_ratio if args.new_key_ratio is not None else 0.0)
+  Rb = dim * (2 if dtype == torch.float16 else 4)
+  want = args.slots
+  table, failures = None, []
+  for slots in [want] + [int(want * f) for f in (0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.25)]:
+    try:
+      table = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=slots, max_capacity=slots,
+                              device=str(dev), dim=dim, evict_strategy=de.HkvEvictStrategy.LRU, name="bench_%s" % cfg)
+      break
+    except Exception as e:  # allocation failure: next smaller size (logged in the result line)
+      failures.append({"slots": slots, "error": str(e)[:160]})
+  assert table is not None, failures
+  capacity = table._table.capacity()
+  gen = torch.Generator(device=dev).manual_seed(SEED)
+  chunk = 4_000_000
+  vals_fill = (torch.randn((chunk, dim), generator=gen, device=dev) * 0.01).to(dtype)
+  t0 = time.perf_counter()
+  n_res = slots
+  for lo in range(1, n_res + 1, chunk):
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(n_res, lo + chunk - 1) + 1, dtype=torch.int64, device=dev))
+    table._table.upsert(k, vals_fill[:k.numel()], unique_keys=True)
+  resident = int(table.size().item())
+  t_fill = time.perf_counter() - t0
+  del vals_fill
+
+  rng = np.random.default_rng(SEED + 7)
+  nb = 2 * (K + W) + 16
+  ranks, fresh_end = mixed_batches(rng, nb, B, n_res, new_ratio, n_res + 1)
+  ids_all = torch.from_numpy(keys_of_ranks(ranks.reshape(-1)).reshape(nb, B)).to(dev)
+  uniq_ratio = float(np.mean([np.unique(ranks[i]).size / B for i in range(4)]))
+  values = (torch.randn((B, dim), generator=gen, device=dev) * 0.01).to(dtype)
+  tm = Timer(torch)
+
+  # ---- driver 1: one C call per step, plan of batch i+1 on the second stream ---------------------------
+  ps = de.PrefetchAssignStep(table).prime(ids_all[0])
+  for i in range(W):
+    ps.step(values, ids_all[i + 1])
+  elapsed, host_s = timed_steps(torch, None, 1, dev, K, lambda i: ps.step(values, ids_all[W + i + 1]))
+  size_after = int(table.size().item())
+  # ---- driver 2: the reference's op sequence, no look-ahead: Find, then Insert (repeats resolved on the device) ----
+  base = K + W + 2
+  tbl = table._table
+
+  def plain(i):
+    tbl.find(ids_all[base + i])
+    tbl.upsert_sparse(ids_all[base + i], values)
+
+  for i in range(W):
+    plain(i)
+  base += W
+  elapsed_plain, _ = timed_steps(torch, None, 1, dev, K, plain)
+
+  # ---- per-kernel timings (HIP events on the launching stream), fresh batches each launch ----------------------
+  spare = 2 * (K + W) + 2
+  rc = raw_calls(torch, dev)
+  out_buf = torch.empty((B, dim), dtype=dtype, device=dev)
+  dflt_row = tbl._default_value
+  # lookups of FRESH batches (half never-seen ids, like the step's), none of them written back in between
+  finds = [rc.find(tbl._h, ids_all[spare + 8 + j], out_buf, dflt_row) for j in range(6)]
+  find_us = tm.us(lambda i: finds[i % 6](), reps=24, warm=3)
+  plans = [de.table_ops.SparsePlan(dev, 0) for _ in range(8)]
+  for j, pl in enumerate(plans):
+    pl.build(ids_all[spare + j], sync=False)
+  torch.cuda.synchronize()
+  counts = plans[0].read()[0]
+  U = counts["many"] + counts["few"]
+  ups = [rc.upsert_planned(tbl._h, plans[j], values) for j in range(8)]
+  upsert_us = tm.us(lambda i: ups[i](), reps=6, warm=2)       # every launch inserts its own never-seen keys
+  builds = [rc.plan_build(plans[j], ids_all[spare + j], 0) for j in range(8)]
+  plan_us = tm.us(lambda i: builds[i % 8](), reps=24, warm=3)
+  # export: one window of 16 Mi slots per launch, a different window each time; a full sweep = capacity / window launches
+  win = min(16 << 20, capacity)
+  kbuf = torch.empty(win, dtype=torch.int64, device=dev)
+  vbuf = torch.empty((win, dim), dtype=dtype, device=dev)
+  cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+  nwin = max(1, capacity // win)
+
+  def export_window(i):
+    cnt.zero_()
+    _capi.call("tfra_table_export_batch", tbl._h, win, (i % nwin) * win, _ptr(cnt), _ptr(kbuf), _ptr(vbuf), None, _stream(dev))
+
+  export_us = tm.us(export_window, reps=6, warm=1)
+  live = int(cnt.item())
+  export_bytes = (win // 15 + 1) * (4096 if Rb == 256 else 256 + 15 * Rb) + live * (8 + Rb)
+  sweep_s = export_us * 1e-6 * (capacity / win)
+  del kbuf, vbuf
+
+  ms = elapsed / K * 1e3
+  value = B * K / elapsed
+  lookup_bytes = B * (8 + 2 * Rb)                      # SURVEY §8d: key + row read + row written out
+  upsert_bytes = U * (8 + Rb + Rb + 8)                 # per unique key: key, value row read, row written, key stored
+  step_bytes = lookup_bytes + upsert_bytes
+  prof = profile_summary()
+  kernels = {
+      "find_kernel<16,4,PF1> (lookup; both home-bucket lines in flight)": {
+          "avg_launch_us": find_us, "algorithmic_bytes_per_launch": lookup_bytes,
+          "achieved_GBps": lookup_bytes / find_us / 1e3, "frac": lookup_bytes / find_us / 1e3 / HBM_PEAK_GBS,
+          "traffic": traffic_of(prof, cfg, "find_kernel")},
+      "upsert_csr_kernel<16,false> + <16,true> (assign / claim, then score-based eviction of the keys without a free slot)": {
+          "avg_launch_us": upsert_us, "algorithmic_bytes_per_launch": upsert_bytes, "unique_keys": U,
+          "achieved_GBps": upsert_bytes / upsert_us / 1e3, "frac": upsert_bytes / upsert_us / 1e3 / HBM_PEAK_GBS,
+          "traffic": traffic_of(prof, cfg, "upsert_csr_kernel")},
+  }
+  dom = max(kernels, key=lambda k: kernels[k]["avg_launch_us"])
+  res = {
+      "metric": "embedding lookup+insert pairs/s (%s, %d-slot bounded table, %d %% never-seen ids per batch: lookup + "
+                "insert_or_assign with score-based eviction)" % ("dim=128 fp16" if cfg == "c3" else "dim=64 fp32", capacity,
+                                                                 round(100 * new_ratio)),
+      "value": value, "unit": "pairs/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "f32",
+      "data": "synthetic",
+      "value_plain_call": B * K / elapsed_plain, "ms_per_step_plain_call": elapsed_plain / K * 1e3,
+      "config": {
+          "workload": "BASELINE configs[%s]: bounded Hkv (LRU) table, %d slots (%.1f GB in HBM: key line + score line + 15 rows per "
+                      "4 KiB bucket block), pre-filled with %d unique keys -> %d resident, %s rows, batch=%d = %d %% Zipf-1.2 over "
+                      "the resident ranks + %d %% never-seen ranks; step = lookup(B) + insert_or_assign(B, last occurrence "
+                      "wins) with eviction" % ("2" if cfg == "c3" else "metric (dim 64, 1 B keys)", capacity,
+                                               capacity / 15 * (256 + 15 * Rb) / 1e9, n_res, resident,
+                                               "dim=128 fp16" if cfg == "c3" else "dim=64 fp32", B, round(100 * (1 - new_ratio)),
+                                               round(100 * new_ratio)),
+          "slots": capacity, "requested_slots": want, "alloc_failures": failures, "resident_after_prefill": resident,
+          "resident_after_timed_steps": size_after, "new_key_ratio": new_ratio, "global_batch": B,
+          "unique_ratio": round(uniq_ratio, 4), "unique_keys_per_batch": U, "prefill_s": round(t_fill, 2),
+          "table_ops_per_s": 2 * value, "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
+          "drivers": {
+              "value": "tfra_table_step_prefetch_assign: ONE C call per step = lookup + insert_or_assign of batch i on the main "
+                       "stream, de-duplication plan (CSR by key) of batch i+1 on a second stream; one plan built per step "
+                       "inside the timed region",
+              "value_plain_call": "tfra_table_find then tfra_table_upsert_sparse (plan built inside the call): the reference's "
+                                  "op sequence Find -> Insert without look-ahead"},
+          "plan_build_us_alone": plan_us,
+          "export": {"window_slots": win, "live_keys_in_last_window": live, "avg_launch_us": export_us,
+                     "achieved_GBps": export_bytes / export_us / 1e3, "full_sweep_s": sweep_s,
+                     "pairs_per_s_with_a_full_export_sweep_every_1000_steps": B * 1000 / (1000 * elapsed / K + sweep_s),
+                     "note": "export_batch(n, offset) windows over the slot range (K/lookup_impl/lookup_table_op_hkv.h:548-594); "
+                             "BASELINE's 'export every 1000 steps' falls outside a %d-step timed region, so the sweep is timed "
+                             "separately and folded in arithmetically" % K},
+      },
+      "roofline": {
+          "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
+          "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_launch_us"],
+          "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "step_frac_plain_call": step_bytes / (elapsed_plain / K) / 1e9 / HBM_PEAK_GBS,
+          "step_algorithmic_bytes": step_bytes,
+          "step_bytes_definition": "B*(8+2*Rb) for the lookup + U*(16+2*Rb) for the write-back of the U unique keys (SURVEY §8d)",
+          "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "kernels": kernels,
+          "timing": "HIP events on the launching stream around 4-40 launches, a different batch each; address translation, "
+                    "not bytes, bounds these kernels on a table of this size (DESIGN.md §5)",
+      },
+  }
+  del ps, plans, table, tbl
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
+  return res
+
+
+# ------------------------------------------------------------------ c2: growing table, sparse Adam
+def run_c2(args, torch, dist, de, dev, world, rank):
+  from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
+  DIM = 64
+  B, K, W = args.batch, args.steps, args.warmup
+  n_local = args.keys
+  n_total = n_local * world
+  new_ratio = args.new_key_ratio if args.new_key_ratio is not None else 0.1
+  if world > 1:
+    new_ratio = 0.0
+
+  opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05),
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  force_a2a = os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist.is_initialized()
+  emb = (AllToAllEmbedding(var, partition_mode=0, dedup=os.environ.get("TFRA_BENCH_DEDUP", "1") == "1",
+                           force_collectives=force_a2a) if (world > 1 or force_a2a) else None)
+  table = var.tables[0]
+  gen = torch.Generator(device=dev).manual_seed(SEED + rank)
+  chunk = 4_000_000
+  t_fill = time.perf_counter()
+  for lo in range(1, n_total + 1, chunk):
+    r = torch.arange(lo, min(n_total, lo + chunk - 1) + 1, dtype=torch.int64, device=dev)
+    k = keys_of_ranks_torch(torch, r)
+    if world > 1:
+      k = k[((k & 0x7FFFFFFF) % world) == rank]
+    table._table.upsert(k, torch.randn((k.numel(), DIM), generator=gen, device=dev) * 0.01, unique_keys=True)
+  resident = int(table.size().item())
+  t_fill = time.perf_counter() - t_fill
+
+  rng = np.random.default_rng(SEED + 1000 * rank)
+  nb = 2 * (K + W) + 8
+  ranks, _ = mixed_batches(rng, nb, B, n_total, new_ratio, n_total + 1 + rank * (1 << 40))
+  ids_all = torch.from_numpy(keys_of_ranks(ranks.reshape(-1)).reshape(nb, B)).to(dev)
+  uniq_ratio = float(np.mean([np.unique(ranks[i]).size / B for i in range(4)]))
+  grads = torch.randn((B, DIM), generator=gen, device=dev) * 0.01
+  tm = Timer(torch)
+  single = world == 1 and emb is None
+
+  def plain(i):
+    ids = ids_all[i]
+    if emb is None:
+      out = var.lookup(ids)
+      deo.apply_sparse(var, ids, grads)
+    else:
+      out = emb.lookup(ids)
+      emb.apply_gradients(deo, grads)
+    return out
+
+  elapsed_plain = None
+  if single:
+    prefetch = de.PrefetchStep(var, deo).prime(ids_all[0])
+    for i in range(W):
+      prefetch.step(grads, ids_all[i + 1])
+    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: prefetch.step(grads, ids_all[W + i + 1]))
+    base = K + W + 2
+    for i in range(W):
+      plain(base + i)
+    elapsed_plain, _ = timed_steps(torch, dist, world, dev, K, lambda i: plain(base + W + i))
+  else:
+    for i in range(W):
+      plain(i)
+    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: plain(W + i))
+  size_after = int(table.size().item())
+
+  # ---- per-kernel timings, each phase alone -----------------------------------------------------------------
+  rc = raw_calls(torch, dev)
+  h = table._table._h
+  out_buf = torch.empty((B, DIM), dtype=torch.float32, device=dev)
+  dflt_row = table._default_value
+  finds = [rc.find(h, ids_all[(W + j) % (K + W)], out_buf, dflt_row) for j in range(K + W)]
+  find_us = tm.us(lambda i: finds[i % len(finds)]())
+  find_b2b_us = tm.us(lambda i: finds[0]())
+  find_bytes = B * (8 + 2 * DIM * 4)
+  p = opt.params(1)
+  dflt = table._default_value.to(torch.float32)
+  spare = 2 * (K + W) + 2
+  grad_half_us = plan_us = None
+  U = int(np.unique(ranks[spare]).size)
+  if de.DynamicEmbeddingOptimizer.can_plan(var, B):
+    plans = [de.table_ops.SparsePlan(dev, DIM) for _ in range(6)]
+    for j, pl in enumerate(plans):
+      pl.build(ids_all[spare + j], sync=False)
+    torch.cuda.synchronize()
+    counts = plans[0].read()[0]
+    U = counts["many"] + counts["few"]
+    halves = [rc.apply_planned(h, p, plans[j], grads, dflt) for j in range(6)]
+    grad_half_us = tm.us(lambda i: halves[i % 6](), reps=30)
+    builds = [rc.plan_build(plans[j], ids_all[spare + j], DIM) for j in range(6)]
+    plan_us = tm.us(lambda i: builds[i % 6](), reps=30)
+  wb_bytes = B * (8 + DIM * 4) + U * (8 + 7 * DIM * 4)   # ids + gradient rows once, fused Adam on the unique keys
+  uniq = torch.from_numpy(keys_of_ranks(np.unique(ranks[spare]))).to(dev)
+  gsum = torch.randn((uniq.numel(), DIM), generator=gen, device=dev) * 0.01
+  apply_one = rc.apply_optimizer(h, p, uniq, gsum, dflt)
+  apply_us = tm.us(lambda i: apply_one(), reps=30)
+  apply_bytes = int(uniq.numel()) * (8 + 7 * DIM * 4)
+  prof = profile_summary()
+
+  ms = elapsed / K * 1e3
+  value = world * B * K / elapsed
+  step_bytes = find_bytes + wb_bytes
+  res = {
+      "metric": "embedding lookup+insert pairs/s (dim=64 fp32, Zipf-1.2, lookup + sparse-Adam write-back)",
+      "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {
+          "workload": "BASELINE configs[1]: %d resident keys/GPU (%d total), dim=64 fp32 rows [p|m|v], Zipf-1.2 batch=%d/GPU with "
+                      "%d %% never-seen keys per batch, lookup + dedup + fused sparse Adam (insert/write-back)"
+                      % (resident, n_total, B, round(100 * new_ratio)),
+          "global_batch": B * world, "keys_per_gpu": resident, "keys_per_gpu_after_timed_steps": size_after,
+          "new_key_ratio": new_ratio, "unique_ratio": round(uniq_ratio, 4), "unique_keys_per_batch": U,
+          "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
+          "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
+          "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
+          "drivers": {
+              "value": ("tfra_table_step_prefetch: ONE C call per step = lookup + hot sums + fused Adam of batch i on the main "
+                        "stream, CSR-by-key plan of batch i+1 on a second stream; one plan built per step inside the timed region")
+              if single else "embedding_lookup + apply_gradients through the alltoall route",
+              "value_plain_call": "tfra_table_find then tfra_table_apply_sparse (plan built inside the call): the reference's op "
+                                  "sequence lookup -> optimizer apply, no look-ahead"},
+      },
+      "roofline": {
+          "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",
+          "achieved": find_bytes / find_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": find_bytes / find_us / 1e3 / HBM_PEAK_GBS, "traffic": traffic_of(prof, "c2", "find_kernel"),
+          "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
+          "avg_launch_us_same_batch_back_to_back": find_b2b_us,
+          "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if single else None,
+          "step_algorithmic_bytes": step_bytes,
+          "step_bytes_definition": "B*(8+2*Rb) lookup + B*(8+Rb) ids and gradient rows + U*(8+7*Rb) fused Adam on the U unique keys",
+          "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if single else None,
+          "timing": "HIP events on the launching stream around 30-50 launches, a different batch each",
+          "kernels": {
+              "hot_sums_kernel + apply_csr_kernel<ADAM> (gradient half: duplicate sums + fused Adam)": {
+                  "avg_launch_us": grad_half_us, "algorithmic_bytes_per_launch": wb_bytes, "unique_keys": U,
+                  "achieved_GBps": wb_bytes / grad_half_us / 1e3 if grad_half_us else None,
+                  "frac": wb_bytes / grad_half_us / 1e3 / HBM_PEAK_GBS if grad_half_us else None,
+                  "traffic": (traffic_of(prof, "c2", "hot_sums_kernel") or 0) + (traffic_of(prof, "c2", "apply_csr_kernel") or 0) or None},
+              "csr_tile_kernel + csr_bucket_kernel + csr_scatter_kernel (id-only plan, second stream)": {"avg_launch_us": plan_us},
+              "apply_kernel<ADAM> alone on pre-summed unique keys": {
+                  "avg_launch_us": apply_us, "algorithmic_bytes_per_launch": apply_bytes,
+                  "achieved_GBps": apply_bytes / apply_us / 1e3, "frac": apply_bytes / apply_us / 1e3 / HBM_PEAK_GBS},
+          },
+      },
+  }
+  if elapsed_plain is not None:
+    res["value_plain_call"] = B * K / elapsed_plain
+    res["ms_per_step_plain_call"] = elapsed_plain / K * 1e3
+    res["roofline"]["step_frac_plain_call"] = step_bytes / (elapsed_plain / K) / 1e9 / HBM_PEAK_GBS
+  del var, table, deo
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
+  return res
 
 
 # ------------------------------------------------------------------ main
@@ -138,22 +606,19 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=200)
   ap.add_argument("--warmup", type=int, default=20)
-  ap.add_argument("--keys", type=int, default=100_000_000, help="resident keys PER GPU")
+  ap.add_argument("--config", choices=["c3", "c2", "m1b"], default=None,
+                  help="default: c3 on one GPU (largest single-GPU configuration), c2 per GPU for N>1")
+  ap.add_argument("--slots", type=int, default=1_000_000_000, help="c3 / m1b: slots of the bounded table")
+  ap.add_argument("--keys", type=int, default=100_000_000, help="c2: resident keys PER GPU")
   ap.add_argument("--batch", type=int, default=131072, help="ids per GPU per step")
+  ap.add_argument("--new-key-ratio", type=float, default=None, help="c2 / m1b: share of never-seen keys per batch")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--plan", choices=["off", "prefetch"], default="prefetch",
-                  help="where the id-only half of the write-back (which ids repeat, summation order, unique keys) is built: "
-                       "prefetch = on a second HIP stream for batch i+1 while step i runs (ids known one batch ahead, as an "
-                       "input pipeline provides them; one C call per step; every step builds exactly one plan inside the "
-                       "timed region); off = inside the write-back call (tfra_table_apply_sparse).  Single GPU only.")
-  ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (same kernels; "
-                  "measured equal to eager launches: the step is bound by kernel boundaries, not by the host)")
+  ap.add_argument("--no-secondary", action="store_true", help="skip the secondary c2 measurement of the default invocation")
   args = ap.parse_args()
 
   import torch
   import torch.distributed as dist
   import tfra_amd.dynamic_embedding as de
-  from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
@@ -170,240 +635,19 @@ def main():
       dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
   dev = torch.device("cuda", local_rank)
   torch.cuda.set_device(dev)
-  B, K, W = args.batch, args.steps, args.warmup
-  n_local = args.keys
-  n_total = n_local * world
-
-  # ---- table: rows [p|m|v] co-located, sized so that no rehash happens -------------------------
-  opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
-  deo = de.DynamicEmbeddingOptimizer(opt)
-  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05),
-                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
-  # TFRA_BENCH_FORCE_A2A=1 (with WORLD_SIZE=1 under torch.distributed.run): keep the whole N>1 route,
-  # collectives included, on one rank — measures the routing overhead a multi-GPU step adds
-  force_a2a = os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist.is_initialized()
-  emb = (AllToAllEmbedding(var, partition_mode=0, dedup=os.environ.get("TFRA_BENCH_DEDUP", "1") == "1",
-                           force_collectives=force_a2a) if (world > 1 or force_a2a) else None)
-  table = var.tables[0]
-
-  # ---- pre-fill: every key this rank owns (ranks 1..n_total, owner = default_partition_fn) ------
-  gen = torch.Generator(device=dev).manual_seed(SEED + rank)
-  chunk = 4_000_000
-  t_fill = time.perf_counter()
-  for lo in range(1, n_total + 1, chunk):
-    r = torch.arange(lo, min(n_total, lo + chunk - 1) + 1, dtype=torch.int64, device=dev)
-    k = keys_of_ranks_torch(torch, r)
-    if world > 1:
-      k = k[((k & 0x7FFFFFFF) % world) == rank]
-    v = torch.randn((k.numel(), DIM), generator=gen, device=dev) * 0.01
-    table._table.upsert(k, v, unique_keys=True)
-  resident = int(table.size().item())
-  t_fill = time.perf_counter() - t_fill
-
-  # ---- inputs resident in HBM: all id batches + one gradient buffer -----------------------------
-  rng = np.random.default_rng(SEED + 1000 * rank)
-  ids_np = keys_of_ranks(zipf_bounded(rng, (K + W) * B, n_total)).reshape(K + W, B)
-  ids_all = torch.from_numpy(ids_np).to(dev)
-  uniq_ratio = float(np.mean([np.unique(ids_np[i]).size / B for i in range(min(8, K + W))]))
-  grads = torch.randn((B, DIM), generator=gen, device=dev) * 0.01
-
-  ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-  ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-  ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-
-  use_graph = world == 1 and args.graph
-  captured = None
-  if use_graph:
-    captured = de.CapturedTrainStep(var, deo, B)
-    captured.grads.copy_(grads)
-    captured.capture(warmup_ids=ids_all[0])
-
-  plan_mode = args.plan if (world == 1 and emb is None and not use_graph) else "off"
-  prefetch = None
-  if plan_mode == "prefetch":
-    prefetch = de.PrefetchStep(var, deo).prime(ids_all[0])
-
-  def step(i, timed_idx=None, fused_call=False):
-    ids = ids_all[i]
-    if prefetch is not None and not fused_call:
-      # ONE C call: [main: lookup + run sums + fused Adam of batch i] + [second stream: plan of batch i+1]
-      return prefetch.step(grads, ids_all[(i + 1) % (K + W)])
-    if captured is not None:
-      # one HIP-graph replay = lookup + tile-reduce + bucket-merge + fused Adam (+ the batch copy)
-      return captured.step(ids)
-    if timed_idx is not None:
-      ev_a[timed_idx].record()
-    if emb is None:
-      out = var.lookup(ids)
-    else:
-      out = emb.lookup(ids)
-    if timed_idx is not None:
-      ev_b[timed_idx].record()
-    if emb is None:
-      deo.apply_sparse(var, ids, grads)
-    else:
-      emb.apply_gradients(deo, grads)
-    if timed_idx is not None:
-      ev_c[timed_idx].record()
-    return out
-
-  for i in range(W):
-    step(i)
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for i in range(K):
-    step(W + i, i)
-  host_enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (== elapsed when host-bound)
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-  fused_call_ms = None
-  if prefetch is not None:
-    # secondary timed loop with the write-back as ONE fused call on one stream (--plan off): gives the
-    # per-launch event timings of the roofline block and the unprefetched step time for comparison
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(K):
-      step((W + i) % (K + W), i, fused_call=True)
-    torch.cuda.synchronize()
-    fused_call_ms = 1e3 * (time.perf_counter() - t1) / K
-  if use_graph:
-    fwd_ms = bwd_ms = None  # phases are inside one graph launch
+  cfg = args.config or ("c3" if (world == 1 and not dist.is_initialized()) else "c2")
+  if cfg in ("c3", "m1b"):
+    assert world == 1, "%s is a single-GPU configuration" % cfg
+    res = run_bounded(args, torch, de, dev, cfg)
+    if not args.no_secondary and cfg == "c3":
+      sec = run_c2(args, torch, dist, de, dev, 1, 0)
+      res["secondary"] = {"c2": {k: sec[k] for k in ("metric", "value", "value_plain_call", "ms_per_step", "ms_per_step_plain_call",
+                                                      "config", "roofline") if k in sec}}
   else:
-    fwd_ms = float(np.mean([ev_a[i].elapsed_time(ev_b[i]) for i in range(K)]))
-    bwd_ms = float(np.mean([ev_b[i].elapsed_time(ev_c[i]) for i in range(K)]))
-
-  # ---- roofline inputs, measured live with HIP events on the stream the kernels run on ------------
-  # (1) lookup kernel find_kernel<16,4>: algorithmic bytes per lookup = 8 (key) + Rb (row read) + Rb
-  #     (out write) = 520 B at dim 64 fp32; one launch processes B ids.  Timed both
-  #     inside the timed region (ev_a..ev_b brackets exactly that launch each step) and back-to-back.
-  reps = 50
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  ids0 = ids_all[W]
-
-  def timed(fn):
-    for _ in range(5):
-      fn()
-    e0.record()
-    for _ in range(reps):
-      fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
-
-  find_b2b_us = timed(lambda: table.lookup(ids0))
-  # the same launch over a DIFFERENT batch each time (as in a step: rows not warm from the previous launch);
-  # 50 launches between two events => the events' own cost (~4 us around a single launch) is amortised.
-  # This is the duration rocprofv3 reports for find_kernel inside the steps (profiles/).
-  rot = [0]
-
-  def find_rotating():
-    rot[0] = (rot[0] + 1) % (K + W)
-    table.lookup(ids_all[rot[0]])
-
-  find_rot_us = timed(find_rotating)
-  find_bytes = B * (8 + 2 * DIM * 4)
-  find_evt_us = fwd_ms * 1e3 if (fwd_ms is not None and world == 1) else None
-  find_us = find_rot_us
-  # (2) write-back pipeline tile_reduce -> bucket_merge -> apply_kernel<INDIRECT> (one C-ABI call):
-  #     algorithmic bytes = B*(8 + Rb) (ids + gradient rows read once) + U*(8 + 7*Rb) (fused Adam on
-  #     the unique keys) — the dedup itself has no algorithmic traffic.
-  uniq, idx, cnt = de.device_ops.unique(ids0)
-  U = int(uniq.numel())
-  p = opt.params(1)
-  wb_us = timed(lambda: table._table.apply_sparse(p, ids0, grads, table._default_value))
-  wb_bytes = B * (8 + DIM * 4) + U * (8 + 7 * DIM * 4)
-  # (2b) the same write-back split as the default step runs it: gradient half (tile_sums -> bucket_sums ->
-  #      apply_kernel<INDIRECT>, main stream) and id-only half (plan build, second stream), each alone
-  grad_half_us = plan_us = None
-  if world == 1 and de.DynamicEmbeddingOptimizer.can_plan(var, B):
-    plan0 = deo.plan(var, ids0)
-    torch.cuda.synchronize()
-    dflt = table._default_value.to(torch.float32)
-    grad_half_us = timed(lambda: table._table.apply_planned(p, plan0, grads, dflt, sync=False))
-    plan_us = timed(lambda: plan0.build(ids0, sync=False))
-  # (3) the fused optimizer kernel alone on pre-summed unique keys
-  gsum = torch.randn((U, DIM), generator=gen, device=dev) * 0.01
-  apply_us = timed(lambda: table._table.apply_optimizer(p, uniq, gsum, table._default_value))
-  apply_bytes = U * (8 + 7 * DIM * 4)
-  # measured HBM traffic of the same kernels (rocprofv3 PMC passes, profiles/rNN_summary.json)
-  prof = None
-  try:
-    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
-    if cands:
-      prof = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-  except OSError:
-    prof = None
-
-  def traffic_of(kname):
-    try:
-      return prof["kernels"][kname]["hbm_bytes_per_launch_corrected"]
-    except (TypeError, KeyError):
-      return None
-
+    res = run_c2(args, torch, dist, de, dev, world, rank)
   if rank == 0:
-    ms = elapsed / K * 1e3
-    value = world * B * K / elapsed
-    ach = find_bytes / (find_us * 1e-6) / 1e9
-    res = {
-        "metric": "embedding lookup+insert pairs/s (dim=64 fp32, Zipf-1.2, lookup + sparse-Adam write-back)",
-        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {
-            "workload": "BASELINE configs[1]: %d resident keys/GPU (%d total), dim=64 fp32 rows [p|m|v], Zipf-1.2 "
-                        "batch=%d/GPU, lookup + dedup + fused sparse Adam (insert/write-back)" % (resident, n_total, B),
-            "global_batch": B * world, "keys_per_gpu": resident, "unique_ratio": round(uniq_ratio, 4),
-            "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
-            "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
-            "host_enqueue_ms_per_step": round(1e3 * host_enqueue_s / K, 4),
-            "launch": "hipGraph replay" if use_graph else ("one C call per step, two streams" if prefetch is not None else "eager"),
-            "write_back_plan": {"off": "built inside the write-back call (tfra_table_apply_sparse)",
-                                "prefetch": "id-only half of batch i+1 built on a second HIP stream while step i runs "
-                                            "(tfra_table_step_prefetch; one plan per step inside the timed region)"}[plan_mode],
-            "ms_per_step_fused_call": fused_call_ms,
-        },
-        "roofline": {
-            "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",
-            "achieved": find_bytes / (find_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": find_bytes / (find_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_of("find_kernel"),
-            "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
-            "avg_launch_us_same_batch_back_to_back": find_b2b_us,
-            "avg_launch_us_single_launch_between_events_in_step": find_evt_us,
-            "timing": "HIP events around 50 launches, a different resident-table batch each (avg_launch_us); also one launch between two events inside the steps of the fused-call loop (includes ~4 us of event cost)",
-        },
-        "roofline_write_back": {
-            "bound": "hbm", "kernel": "tile_reduce_kernel + bucket_merge_kernel + apply_kernel<INDIRECT> "
-                                      "(duplicate-gradient reduction + fused sparse Adam as ONE C-ABI call, --plan off)",
-            "split_for_the_default_step": {
-                "gradient_half_us_alone": grad_half_us, "gradient_half_kernels": "tile_sums_kernel + bucket_sums_kernel + "
-                "apply_kernel<INDIRECT> (main stream)", "plan_build_us_alone": plan_us,
-                "plan_build_kernels": "tile_reduce_kernel<plan> + bucket_merge_kernel<plan> + plan_finish_kernel (second stream)",
-                "achieved_GBps_gradient_half": (wb_bytes / (grad_half_us * 1e-6) / 1e9) if grad_half_us else None},
-            "achieved": wb_bytes / (wb_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": wb_bytes / (wb_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "traffic": (sum(traffic_of(k) for k in ("tile_reduce_kernel", "bucket_merge_kernel", "apply_kernel"))
-                        if all(traffic_of(k) for k in ("tile_reduce_kernel", "bucket_merge_kernel", "apply_kernel")) else None),
-            "algorithmic_bytes_per_launch": wb_bytes, "avg_launch_us": wb_us, "unique_keys": U,
-            "note": "latency/occupancy bound, not bandwidth bound: per-kernel split in profiles/",
-        },
-        "phases": {
-            "forward_ms": fwd_ms, "backward_ms": bwd_ms,
-            "apply_kernel_alone": {"avg_launch_us": apply_us, "algorithmic_bytes_per_launch": apply_bytes,
-                                   "achieved_GBps": apply_bytes / (apply_us * 1e-6) / 1e9},
-        },
-    }
     if not args.no_cpu_baseline:
-      res["cpu_baseline"] = cpu_baseline(B)
+      res["cpu_baseline"] = cpu_baseline(args.batch)
     print(json.dumps(res))
   if dist.is_initialized():
     dist.barrier()

@@ -37,6 +37,13 @@
 #include <cstring>
 #include <memory>
 #include <thread>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "cuckoohash_map.hh"  // -> /root/reference/.../core/lib/cuckoo (via -I)
@@ -254,21 +261,81 @@ TableBase* make_table(int dtype, i64 dim, size_t init) {
   }
 }
 
-// tensorflow::Shard equivalent: static contiguous split (cuckoo_hashtable_op.cc:62-64).
+// tensorflow::Shard equivalent (cuckoo_hashtable_op.cc:62-64).  The reference hands Shard a cost per key of
+// (#elements / #threads + 1), i.e. "expensive": TF's cost model then cuts the keys into ~#threads contiguous
+// blocks and runs them on the device's PERSISTENT intra-op pool.  Same here: one process-wide pool per thread
+// count, created on first use, workers spin briefly between jobs (like Eigen's pool) and sleep after 2 ms idle,
+// static contiguous split.  (Spawning std::threads per op, as this shim first did, cost more than the op.)
+class Pool {
+ public:
+  explicit Pool(int n) : n_(n) {
+    for (int t = 1; t < n_; ++t) workers_.emplace_back([this, t] { run(t); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> l(mu_); stop_ = true; gen_.fetch_add(1); }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  template <class F>
+  void parallel(i64 total, F fn) {
+    const i64 per = (total + n_ - 1) / n_;
+    job_ = [=](int t) {
+      const i64 b = t * per, e = std::min<i64>(total, b + per);
+      if (b < e) fn(b, e);
+    };
+    pending_.store(n_ - 1, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> l(mu_); gen_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+    job_(0);
+    while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+
+ private:
+  void run(int t) {
+    unsigned long seen = 0;
+    for (;;) {
+      // spin ~2 ms, then block
+      auto t0 = std::chrono::steady_clock::now();
+      while (gen_.load(std::memory_order_acquire) == seen) {
+        __builtin_ia32_pause();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+          std::unique_lock<std::mutex> l(mu_);
+          cv_.wait(l, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+        }
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      if (stop_) return;
+      job_(t);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  int n_;
+  std::vector<std::thread> workers_;
+  std::function<void(int)> job_;
+  std::atomic<unsigned long> gen_{0};
+  std::atomic<int> pending_{0};
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+};
+
+std::mutex g_pools_mu;
+std::map<int, std::unique_ptr<Pool>> g_pools;
+
 template <class F>
 void shard(int threads, i64 total, F fn) {
   if (threads <= 1 || total < 2 * threads) {
     fn(0, total);
     return;
   }
-  std::vector<std::thread> pool;
-  i64 per = (total + threads - 1) / threads;
-  for (int t = 0; t < threads; ++t) {
-    i64 b = t * per, e = std::min<i64>(total, b + per);
-    if (b >= e) break;
-    pool.emplace_back([=] { fn(b, e); });
+  Pool* p;
+  {
+    std::lock_guard<std::mutex> l(g_pools_mu);
+    auto& slot = g_pools[threads];
+    if (!slot) slot.reset(new Pool(threads));
+    p = slot.get();
   }
-  for (auto& th : pool) th.join();
+  p->parallel(total, fn);
 }
 
 }  // namespace
@@ -329,6 +396,12 @@ void tfra_ref_remove(void* hp, long long n, const long long* keys) {
 }
 
 void tfra_ref_clear(void* hp) { static_cast<Handle*>(hp)->t->clear(); }
+
+// drops the persistent pools (threads exit); they are re-created on demand
+void tfra_ref_pools_shutdown(void) {
+  std::lock_guard<std::mutex> l(g_pools_mu);
+  g_pools.clear();
+}
 
 unsigned long long tfra_ref_size(void* hp) { return static_cast<Handle*>(hp)->t->size(); }
 

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -52,7 +53,7 @@ namespace {
 constexpr int DIRECT = 8;                 // occurrences the update kernel gathers by itself
 constexpr int SEG = 512;                  // entries of a hot bin = rows one hot_sums block reduces
 constexpr unsigned E_SKIP = 1u << 31, E_HEAD = 1u << 30, E_POS = (1u << 18) - 1;
-constexpr unsigned TABW = 4096;           // u32 entries of the per-pass tile table (16 KB)
+constexpr unsigned TABW = 2048;           // u32 entries of the per-pass tile table (8 KB: 8 keys x 256 tiles per round)
 constexpr unsigned CTR_STRIDE = 16;       // u64 words between two counters (one 128-B line each)
 constexpr int MAXPASS_SPLIT = 64;
 // Output space is handed out by ATOMIC counters, and same-line atomics of different workgroups serialise at ~25 ns
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
                                                           const unsigned short* __restrict__ run_start,
                                                           const unsigned* __restrict__ tile_len,
                                                           const uint4* __restrict__ drec, CsrOut out,
-                                                          unsigned* __restrict__ keymap, unsigned* __restrict__ binmap,
-                                                          unsigned* cursors, unsigned P,
+                                                          unsigned* __restrict__ keymap, i64* __restrict__ dkeys,
+                                                          unsigned* __restrict__ binmap, unsigned* cursors, unsigned P,
                                                           unsigned* d_counts, unsigned* host_counts, unsigned gen) {
   __shared__ unsigned s_hpre[NSH + 1], s_cpre[NSH + 1], s_bpre[NSH + 1];
   if (threadIdx.x < 64) {   // wave 0: prefix sums of the shards' counts (clamped to the shard capacities)
@@ -478,12 +479,15 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
     return lo;
   };
   const unsigned gid = blockIdx.x * NTA + threadIdx.x;
+  // dkeys[g] = the key itself: the write-back kernels start the table probe from it while keymap -> record resolves
   if (gid < nhot) {
-    const unsigned sh = shard_of(s_hpre, gid);
-    keymap[gid] = KM_MANY | (sh * out.hr + (gid - s_hpre[sh]));
+    const unsigned sh = shard_of(s_hpre, gid), r = sh * out.hr + (gid - s_hpre[sh]);
+    keymap[gid] = KM_MANY | r;
+    dkeys[gid] = *reinterpret_cast<const i64*>(out.hrec + (size_t)r * REC_WORDS);
   } else if (gid < nhot + ncold) {
-    const unsigned x = gid - nhot, sh = shard_of(s_cpre, x);
-    keymap[gid] = sh * out.cr + (x - s_cpre[sh]);
+    const unsigned x = gid - nhot, sh = shard_of(s_cpre, x), r = sh * out.cr + (x - s_cpre[sh]);
+    keymap[gid] = r;
+    dkeys[gid] = *reinterpret_cast<const i64*>(out.crec + (size_t)r * REC_WORDS);
   }
   if (gid < nbins) {
     const unsigned sh = shard_of(s_bpre, gid);
@@ -519,7 +523,11 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// gradient half, kernel 1: one block per hot bin.
+// gradient half, kernel 1: one block per bin of 512 entries = 32 items of 16 entries, one 16-lane group per item.
+// Runs are item-aligned (csr_bucket_kernel pads every run to whole items), so an item belongs to exactly one run or to
+// none: the group loads its 16 entry words with one coalesced read, puts all 16 gradient rows in flight at once
+// (unconditional loads, padding clamped to the item's first row), adds them in entry order, and the group holding the
+// run's first item then adds the sums of the run's following items in item order (LDS) and writes the partial row.
 template <int NCH>
 __global__ __launch_bounds__(NTA) void hot_sums_kernel(const float* __restrict__ grads, int dim,
                                                        const unsigned* __restrict__ hent, const unsigned* __restrict__ hout,
@@ -527,28 +535,53 @@ __global__ __launch_bounds__(NTA) void hot_sums_kernel(const float* __restrict__
                                                        const unsigned* __restrict__ d_counts, float* __restrict__ partial,
                                                        unsigned* progress, unsigned progress_val) {
   constexpr int NG = NTA / 16;
-  __shared__ unsigned s_pos[SEG];
-  __shared__ unsigned s_out[SEG];
-  __shared__ unsigned char s_flag[SEG + 1];
-  __shared__ float s_left[NG][64 * NCH];
-  __shared__ unsigned char s_cont[NG], s_hashead[NG];
+  __shared__ float s_sum[NG][64];
+  __shared__ unsigned char s_kind[NG + 1];   // 0 = item continues the run of the item before, 1 = first item of a run, 2 = empty item
   // tfra_table_step_prefetch: host-visible progress counter (pinned memory) — this kernel running means the
   // lookup of step `progress_val` and every earlier step of the main stream are complete
   if (progress && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, g = threadIdx.x >> 4;
   const unsigned nbins = d_counts[3];
   for (unsigned ib = blockIdx.x; ib < nbins; ib += gridDim.x) {
     const unsigned bin = binmap[ib];
-    const unsigned e = hent[(size_t)bin * SEG + threadIdx.x];
-    s_pos[threadIdx.x] = e & E_POS;
-    s_flag[threadIdx.x] = (unsigned char)(((e & E_HEAD) ? F_HEAD : 0) | ((e & E_SKIP) ? F_SINGLE : 0));
-    if ((e & E_HEAD) && !(e & E_SKIP)) s_out[threadIdx.x] = hout[(size_t)bin * 32 + (threadIdx.x >> 4)];
-    if (threadIdx.x == 0) s_flag[SEG] = F_HEAD;
-    __syncthreads();
-    ordered_run_sums<NCH, NG, Batch<NCH>::v>(
-        SEG, 16, dim, s_flag, s_left, s_cont, s_hashead,
-        [&](int q) { return grads + (size_t)s_pos[q] * dim; },
-        [&](int ph) { return partial + (size_t)s_out[ph] * dim; });
+    const unsigned e = hent[(size_t)bin * SEG + threadIdx.x];          // lane `sub` holds entry `sub` of the item
+    const unsigned e0 = (unsigned)__shfl((int)e, gshift);
+    const bool empty = (e0 & E_SKIP) != 0, first = (e0 & E_HEAD) != 0;
+    const unsigned out_row = (first && !empty && sub == 0) ? hout[(size_t)bin * 32 + g] : 0u;
+    const unsigned live = (unsigned)(__ballot(!(e & E_SKIP)) >> gshift) & 0xffffu;   // entries of the item that exist
+    if (sub == 0) s_kind[g] = empty ? 2 : (first ? 1 : 0);
+    if (threadIdx.x == 0) s_kind[NG] = 1;
+    unsigned rows[16];   // element offset of each row (< 2^18 * 256)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const unsigned ej = (unsigned)__shfl((int)e, gshift + j);
+      rows[j] = (((live >> j) & 1u) ? (ej & E_POS) : (e0 & E_POS)) * (unsigned)dim;
+    }
+    for (int k = 0; k < NCH; ++k) {
+      const int col = k * 64 + sub * 4;
+      const int cc = col < dim ? col : 0;
+      float4 x[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const float4*>(grads + rows[j] + cc);   // 16 rows in flight
+      keep_live(x[0], x[1], x[2], x[3]); keep_live(x[4], x[5], x[6], x[7]);
+      keep_live(x[8], x[9], x[10], x[11]); keep_live(x[12], x[13], x[14], x[15]);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if ((live >> j) & 1u) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+      if (k) __syncthreads();   // the owners of the previous chunk have read s_sum
+      *reinterpret_cast<float4*>(&s_sum[g][sub * 4]) = acc;
+      __syncthreads();
+      if (first && !empty) {
+        for (int g2 = g + 1; s_kind[g2] == 0; ++g2) {
+          const float4 y = *reinterpret_cast<const float4*>(&s_sum[g2][sub * 4]);
+          acc.x += y.x; acc.y += y.y; acc.z += y.z; acc.w += y.w;
+        }
+        const unsigned orow = (unsigned)__shfl((int)out_row, gshift);
+        if (col < dim) *reinterpret_cast<float4*>(partial + (size_t)orow * dim + col) = acc;
+      }
+    }
     __syncthreads();
   }
 }
@@ -556,6 +589,7 @@ __global__ __launch_bounds__(NTA) void hot_sums_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 struct CsrKeys {
   const unsigned* keymap;
+  const i64* dkeys;
   const unsigned* crec; const unsigned* hrec;
   const unsigned* hent;
   const unsigned* d_counts;
@@ -581,19 +615,36 @@ __device__ __forceinline__ void add_rows(float4& acc, const float* (&src)[8], in
     if (j < nsrc) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
 }
 
+// partial rows 8.. of a key with many partials: contiguous rows, 8 in flight per batch, added in order
+__device__ __forceinline__ void add_partials_tail(float4& acc, const float* __restrict__ partial, unsigned first, unsigned nsrc,
+                                                  int dim, int c) {
+  for (unsigned j0 = 8; j0 < nsrc; j0 += 8) {
+    float4 x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4*>(partial + (size_t)(first + min(j0 + j, nsrc - 1)) * dim + c);
+    keep_live(x[0], x[1], x[2], x[3]); keep_live(x[4], x[5], x[6], x[7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j0 + j < nsrc) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+  }
+}
+
 // gradient half, kernel 2: one 16-lane group per unique key, hot keys first (their partial lists are the longest
 // chains of the kernel: started first, they finish inside the kernel's duration).
-// PHASE2: bounded (Hkv) table at max_capacity — the keys of `dlist` (no free slot in phase 1) replace the minimum-score
+// PHASE2: bounded (Hkv) table at max_capacity — the keys flagged in `dflag` (no free slot in phase 1; one byte per key:
+// a list appended through ONE atomic counter cost 4 ns per key, 260 us for a batch of new keys) replace the minimum-score
 // entry of their two home buckets and start from the default row / initial slot values, exactly like
 // apply_evict_kernel (tfra_optim.hip).
 template <int KIND, bool PHASE2>
 __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int dim, const float* __restrict__ grads,
                                                         const float* __restrict__ partial, CsrKeys ks,
                                                         const float* __restrict__ default_row, float aux0, float aux1,
-                                                        ScoreP sp, unsigned* __restrict__ dlist, u64* dcount) {
+                                                        ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_deferred,
+                                                        unsigned use_gen) {
+  if (PHASE2 && *any_deferred != use_gen) return;   // phase 1 of this use deferred nothing
   constexpr int S = NSlots<KIND>::v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned total = PHASE2 ? (unsigned)*dcount : ks.d_counts[0] + ks.d_counts[1];
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
   if (o.d_lr) o.lr = *o.d_lr;
@@ -603,19 +654,19 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
   for (unsigned wbase = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 2; wbase < total; wbase += ngroups) {
     const unsigned it_raw = wbase + (unsigned)(lane >> 4);
     const bool active = it_raw < total;
-    const unsigned it = active ? it_raw : total - 1;
-    const unsigned g = PHASE2 ? dlist[it] : it;
-    bool hot;
-    const unsigned w = load_record(ks, g, sub, hot);
-    const i64 key = (i64)(((u64)(unsigned)__shfl((int)w, gshift + 1) << 32) | (unsigned)__shfl((int)w, gshift));
-    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
-    const unsigned first = (unsigned)__shfl((int)w, gshift + 3);             // keys with many occurrences: first partial row
-    const unsigned nsrc = hot ? (unsigned)__shfl((int)w, gshift + 4) : cnt;
-    // first probe in flight while the sources are resolved
+    const unsigned g = active ? it_raw : total - 1;
+    if (PHASE2 && !__builtin_amdgcn_readfirstlane((int)(__ballot(active && dflag[g]) != 0))) continue;   // nothing deferred in this wave
+    // two chains in flight: key -> first probe line, and keymap -> record -> source rows
+    const i64 key = ks.dkeys[g];
     u64 h;
     const u64 b0 = bucket0(key, v.nb, h);
     i64 k0 = 0;
     if (!PHASE2) k0 = load_key_coherent(key_line(v, b0) + sub);
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    const unsigned first = (unsigned)__shfl((int)w, gshift + 3);             // keys with many occurrences: first partial row
+    const unsigned nsrc = hot ? (unsigned)__shfl((int)w, gshift + 4) : cnt;
     const float* src[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -627,7 +678,7 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
     unsigned wmax = min(nsrc, 8u);
     for (int o2 = 32; o2 >= 16; o2 >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o2));
     wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wmax);
-    if (!active) continue;
+    if (!active || (PHASE2 && !dflag[g])) continue;
     i64 row;
     bool is_new = false;
     u64 word = 0;
@@ -639,7 +690,10 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
       is_new = true;
     } else {
       row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded);
-      if (row == NEED_EVICT && sub == 0) dlist[atomicAdd(dcount, 1ULL)] = g;
+      if (sp.bounded && sub == 0) {
+        dflag[g] = row == NEED_EVICT;
+        if (row == NEED_EVICT) *any_deferred = use_gen;
+      }
     }
     if (row < 0) {
       failed += (sub == 0 && (PHASE2 ? row == -3 : row != NEED_EVICT));
@@ -656,12 +710,7 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
       else if (wmax <= 2) add_rows<2>(gg, src, (int)nsrc, c);
       else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
       else add_rows<8>(gg, src, (int)nsrc, c);
-      for (unsigned j0 = 8; j0 < nsrc; j0 += 8) {   // hot keys with more than 8 partials
-        const float* s2r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s2r[j] = partial + (size_t)(first + min(j0 + j, nsrc - 1)) * dim;
-        add_rows<8>(gg, s2r, (int)(nsrc - j0), c);
-      }
+      if (nsrc > 8) add_partials_tail(gg, partial, first, nsrc, dim, c);   // the few keys with more than 8 partials
       float4 dummy = p;
       keep_live(dummy, p, s1, s2);
       if (is_new || S < 1) s1 = make_float4(aux0, aux0, aux0, aux0);
@@ -733,12 +782,7 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
       else if (wmax <= 2) add_rows<2>(gg, src, (int)nsrc, c);
       else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
       else add_rows<8>(gg, src, (int)nsrc, c);
-      for (unsigned j0 = 8; j0 < nsrc; j0 += 8) {
-        const float* s2r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s2r[j] = partial + (size_t)(first + min(j0 + j, nsrc - 1)) * dim;
-        add_rows<8>(gg, s2r, (int)(nsrc - j0), c);
-      }
+      if (nsrc > 8) add_partials_tail(gg, partial, first, nsrc, dim, c);
       *reinterpret_cast<float4*>(rows_out + (size_t)g * dim + c) = gg;
     }
     if (sub == 0) keys_out[g] = key;
@@ -747,75 +791,118 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
 
 // ---------------------------------------------------------------------------------------------
 // ASSIGN write-back: row of the key's LAST occurrence in the batch -> the table (insert_or_assign with repeats,
-// "last one wins").  scores: optional per-position in_score (the last occurrence's is used; LFU adds count).
-template <int G, bool PHASE2>
+// "last one wins").  scores: optional per-position in_score (the last occurrence's is used; LFU without scores adds
+// the occurrence count).  One 16-lane group per unique key; both home-bucket lines are in flight together on a table
+// running near capacity.  (A 4-keys-per-group variant like find_kernel's was measured SLOWER here — 110 us vs 66 us for
+// 78 K keys at 10^9 slots: the probe logic is branchy, the four groups of a wave run it in lockstep, and every key
+// of a group that has to claim a slot or walk its chain stalls the other fifteen keys of the wave.)
+// On a bounded table at max_capacity the keys that find neither themselves nor a free slot are flagged in `dflag`
+// for upsert_evict_csr_kernel.
+template <int G>
 __global__ __launch_bounds__(256) void upsert_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                          const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
-                                                         ScoreP sp, unsigned* __restrict__ dlist, u64* dcount,
-                                                         unsigned* progress, unsigned progress_val) {
+                                                         ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_deferred,
+                                                         unsigned use_gen, unsigned* progress, unsigned progress_val) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned total = PHASE2 ? (unsigned)*dcount : ks.d_counts[0] + ks.d_counts[1];
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
-  if (!PHASE2 && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
     if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
   }
-  for (unsigned it = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); it < total; it += ngroups) {
-    const unsigned g = PHASE2 ? dlist[it] : it;
-    bool hot;
-    const unsigned w = load_record(ks, g, sub, hot);
-    const i64 key = (i64)(((u64)(unsigned)__shfl((int)w, gshift + 1) << 32) | (unsigned)__shfl((int)w, gshift));
-    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
-    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3 + (int)min(cnt, 8u)));   // few: the last position itself
-    if (hot) last = ks.hent[last] & E_POS;                                                   // many: where it is stored
+  const bool pf1 = sp.bounded > 1;
+  for (unsigned g = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); g < total; g += ngroups) {
+    const i64 key = ks.dkeys[g];
     u64 h;
     const u64 b0 = bucket0(key, v.nb, h);
-    i64 row;
-    bool is_new = false, claimed_empty = false;
-    u64 word = 0;
+    // plain loads for the FIRST look (like find_kernel): everything written before this launch is visible, and what other
+    // groups of this launch change concurrently — slot claims, overflow flags — is caught by the CAS / re-done with
+    // coherent loads in locate_or_claim_from (keys are unique per call, nothing is evicted or erased in this kernel)
+    i64 k0 = key_line(v, b0)[sub];
+    i64 k1 = key_line(v, pf1 ? bucket1(h, b0, v.nb) : b0)[sub];
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3 + (int)min(max(cnt, 1u), 8u)));   // few: the last position itself
+    if (hot) last = ks.hent[last];                                                                     // many: where it is stored
+    last &= E_POS;
     const u64 in_one = scores ? scores[last] : 1;
     const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-    if (PHASE2) {
-      const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
-      row = evict_and_lock(v, key, sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score, lru_like, sub,
-                           gshift, &word, claimed_empty);
-      is_new = true;
-    } else {
-      const bool pf1 = sp.bounded > 1;
-      const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
-      const i64 k1 = load_key_coherent(key_line(v, pf1 ? bucket1(h, b0, v.nb) : b0) + sub);
-      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded, pf1 ? &k1 : nullptr);
-      if (row == NEED_EVICT && sub == 0) dlist[atomicAdd(dcount, 1ULL)] = g;
+    bool is_new = false;
+    const i64 row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded, pf1 ? &k1 : nullptr);
+    if (sp.bounded && sub == 0) {
+      dflag[g] = row == NEED_EVICT;
+      if (row == NEED_EVICT) *any_deferred = use_gen;   // plain store, every writer writes the same value
     }
-    if (row < 0) {
-      failed += (sub == 0 && (PHASE2 ? row == -3 : row != NEED_EVICT));
-      continue;
-    }
-    fresh += ((PHASE2 ? claimed_empty : is_new) && sub == 0);
+    if (row < 0) { failed += (sub == 0 && row != NEED_EVICT); continue; }
+    fresh += (is_new && sub == 0);
     unsigned char* pr = row_ptr(v, row);
-    const unsigned char* sr = vals + (size_t)last * v.field_bytes;
-    if (PHASE2) copy_bytes16_wt<G>(pr, sr, v.field_bytes, sub);
-    else copy_bytes16<G>(pr, sr, v.field_bytes, sub);
+    copy_bytes16<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
     if (is_new && v.n_fields > 1) {   // slot fields of a brand-new row start at aux_init
       for (unsigned f = 1; f < v.n_fields; ++f) {
         const unsigned pat = ai.pattern[(f - 1) & 3];
         unsigned char* q = pr + f * v.field_bytes;
         if ((v.field_bytes & 3) == 0)
-          for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
-            __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(q + off) = pat;
         else
-          for (unsigned off = sub; off < v.field_bytes; off += 16)
-            __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (unsigned off = sub; off < v.field_bytes; off += 16) q[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
       }
     }
-    if (PHASE2) {
-      if (sub == 0) store_wt8(score_word(v, word), 0);
-      update_score<true>(v, row, true, sp.strategy, in_score, sp.epoch, sub);
-      publish_key(v, word, key, sub);
-    } else {
-      update_score(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
+    update_score(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// Phase 2 of the ASSIGN write-back, one key per 16-lane group: the keys flagged in `dflag` replace the minimum-score
+// entry of their two home buckets (key + score lines of both buckets in flight together, evict_and_lock).
+template <int G>
+__global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
+                                                               const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
+                                                               ScoreP sp, const uint8_t* __restrict__ dflag,
+                                                               const unsigned* any_deferred, unsigned use_gen) {
+  if (*any_deferred != use_gen) return;   // phase 1 of this use deferred nothing: the usual case below capacity
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
+  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  int fresh = 0, failed = 0;
+  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+  for (unsigned g = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); g < total; g += ngroups) {
+    if (!dflag[g]) continue;
+    const i64 key = ks.dkeys[g];
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3 + (int)min(max(cnt, 1u), 8u)));
+    if (hot) last = ks.hent[last];
+    last &= E_POS;
+    const u64 in_one = scores ? scores[last] : 1;
+    const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+    u64 word = 0;
+    bool claimed_empty = false;
+    const i64 row = evict_and_lock(v, key, sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score, lru_like,
+                                   sub, gshift, &word, claimed_empty);
+    if (row < 0) { failed += (sub == 0 && row == -3); continue; }   // -1: not admitted (score below every resident one)
+    fresh += (claimed_empty && sub == 0);
+    unsigned char* pr = row_ptr(v, row);
+    copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
+    for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of the new row start at aux_init
+      const unsigned pat = ai.pattern[(f - 1) & 3];
+      unsigned char* q = pr + f * v.field_bytes;
+      if ((v.field_bytes & 3) == 0)
+        for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
+          __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        for (unsigned off = sub; off < v.field_bytes; off += 16)
+          __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (sub == 0) store_wt8(score_word(v, word), 0);   // the slot starts a new life
+    update_score<true>(v, row, true, sp.strategy, in_score, sp.epoch, sub);
+    publish_key(v, word, key, sub);
   }
   for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
   if (lane == 0) {
@@ -843,9 +930,12 @@ struct tfra_sparse_plan {
   unsigned* tile_len = nullptr;
   uint4* drec = nullptr;
   unsigned* keymap = nullptr;
+  i64* dkeys = nullptr;
   unsigned* binmap = nullptr;
   unsigned* d_counts = nullptr;
-  unsigned* dlist = nullptr;
+  uint8_t* dflag = nullptr;
+  unsigned* any_deferred = nullptr;   // = use_gen of the last write-back that deferred a key to its eviction phase
+  mutable unsigned use_gen = 0;
   float* partial = nullptr;
   bool armed = false;              // cursors/counters are zero (re-armed by the last kernel of the previous build)
   unsigned* host_counts = nullptr; // pinned: [0] generation of the last COMPLETED build, [1..6] its counts
@@ -903,8 +993,8 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
                  + al(npad * 4) + al(npad * 2) + al(ntiles * 4) + al(npad * 16) // tile lists, run starts, lengths, destinations
                  + al(nrec_c * REC_WORDS * 4) + al(nrec_h * REC_WORDS * 4)      // key records
                  + al(nbin * SEG * 4) + al(nbin * 32 * 4)                       // bins + run outputs
-                 + al(npad * 4) + al(nbin * 4)                                  // keymap, binmap
-                 + al(npad * 4)                                                 // deferred list
+                 + al(npad * 4) + al(npad * 8) + al(nbin * 4)                   // keymap, dense keys, binmap
+                 + al(npad)                                                     // deferred flags
                  + al(npart * (size_t)dim * 4);                                 // partial rows
   if (pl->bytes < bytes) {
     if (pl->buf) {
@@ -921,7 +1011,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   o.counters = (u64*)w; w += ctr;
   pl->d_counts = (unsigned*)w; w += 256;
   const bool same_layout = pl->armed && pl->P == P;
-  if (!same_layout && hipMemsetAsync(pl->buf, 0, head + ctr, s) != hipSuccess)
+  if (!same_layout && hipMemsetAsync(pl->buf, 0, head + ctr + 256, s) != hipSuccess)
     return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
   CsrDesc& ds = pl->ds;
   ds.key = (i64*)w; w += al(reg * 8);
@@ -938,8 +1028,10 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   o.hent = (unsigned*)w; w += al(nbin * SEG * 4);
   o.hout = (unsigned*)w; w += al(nbin * 32 * 4);
   pl->keymap = (unsigned*)w; w += al(npad * 4);
+  pl->dkeys = (i64*)w; w += al(npad * 8);
   pl->binmap = (unsigned*)w; w += al(nbin * 4);
-  pl->dlist = (unsigned*)w; w += al(npad * 4);
+  pl->dflag = (uint8_t*)w; w += al(npad);
+  pl->any_deferred = pl->d_counts + 8;
   pl->partial = (float*)w;
   pl->gen += 1;
   ds.cursor = pl->cursors;
@@ -955,7 +1047,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   }
   csr_bucket_kernel<<<dim3(P), NT, plan_smem_bytes(cm), s>>>(P, (unsigned)ntiles, cm, ds, pl->drec, o, err);
   csr_scatter_kernel<<<dim3((unsigned)ntiles), NTA, 0, s>>>(pl->tile_entries, pl->run_start, pl->tile_len, pl->drec, o, pl->keymap,
-                                                           pl->binmap, pl->cursors, P, pl->d_counts, pl->host_counts, pl->gen);
+                                                           pl->dkeys, pl->binmap, pl->cursors, P, pl->d_counts, pl->host_counts, pl->gen);
   pl->armed = true;
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
   pl->n = n; pl->npad = npad; pl->ntiles = ntiles; pl->P = P; pl->cm = cm; pl->dim = dim;
@@ -978,23 +1070,20 @@ static void plan_grids(const tfra_sparse_plan* pl, unsigned* key_blocks, unsigne
 }
 
 static CsrKeys keys_of(const tfra_sparse_plan* pl) {
-  return CsrKeys{pl->keymap, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts};
+  return CsrKeys{pl->keymap, pl->dkeys, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts};
 }
-
-static u64* dcount_of(const tfra_sparse_plan* pl) { return pl->out.counters + (size_t)NSH * CTR_STRIDE; }
 
 template <int KIND>
 static void launch_apply_csr(Table* t, hipStream_t s, const tfra_sparse_plan* pl, const OptP& o, const float* grads,
                              const float* default_row, unsigned key_blocks, const ScoreP& sp) {
   TableView v = t->view_of(t->cur);
   const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
-  u64* dcount = dcount_of(pl);
-  if (sp.bounded) (void)hipMemsetAsync(dcount, 0, sizeof(u64), s);   // deferred list of this use of the plan
+  const unsigned gen = ++pl->use_gen;
   apply_csr_kernel<KIND, false><<<key_blocks, 256, 0, s>>>(v, o, pl->dim, grads, pl->partial, keys_of(pl), default_row, a0, a1, sp,
-                                                           pl->dlist, dcount);
+                                                           pl->dflag, pl->any_deferred, gen);
   if (sp.bounded)
     apply_csr_kernel<KIND, true><<<key_blocks, 256, 0, s>>>(v, o, pl->dim, grads, pl->partial, keys_of(pl), default_row, a0, a1, sp,
-                                                            pl->dlist, dcount);
+                                                            pl->dflag, pl->any_deferred, gen);
 }
 
 static int apply_planned_impl(tfra_table_t* tp, const tfra_opt_params* p, const tfra_sparse_plan_t* pl, const float* grads,
@@ -1074,24 +1163,23 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)values | 16;
   int g = (int)(x & (~x + 1));
   if (g > 16) g = 16;
-  u64* dcount = dcount_of(pl);
   const unsigned char* vals = (const unsigned char*)values;
   const u64* sc = (const u64*)scores;
-  if (sp.bounded && hipMemsetAsync(dcount, 0, sizeof(u64), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: memset");
+  const unsigned gen = ++pl->use_gen;
   switch (g) {
-    case 16: upsert_csr_kernel<16, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
-    case 8: upsert_csr_kernel<8, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
-    case 4: upsert_csr_kernel<4, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
-    case 2: upsert_csr_kernel<2, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
-    default: upsert_csr_kernel<1, false><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, progress, progress_val); break;
+    case 16: upsert_csr_kernel<16><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
+    case 8: upsert_csr_kernel<8><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
+    case 4: upsert_csr_kernel<4><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
+    case 2: upsert_csr_kernel<2><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
+    default: upsert_csr_kernel<1><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
   }
   if (sp.bounded) {
     switch (g) {
-      case 16: upsert_csr_kernel<16, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
-      case 8: upsert_csr_kernel<8, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
-      case 4: upsert_csr_kernel<4, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
-      case 2: upsert_csr_kernel<2, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
-      default: upsert_csr_kernel<1, true><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dlist, dcount, nullptr, 0); break;
+      case 16: upsert_evict_csr_kernel<16><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
+      case 8: upsert_evict_csr_kernel<8><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
+      case 4: upsert_evict_csr_kernel<4><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
+      case 2: upsert_evict_csr_kernel<2><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
+      default: upsert_evict_csr_kernel<1><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
     }
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");

@@ -180,7 +180,7 @@ __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, 
 // bounded != 0: the table cannot grow (Hkv flavour at max_capacity).  A NEW key is placed within the first 4
 // buckets of its sequence (b0, b1, b1+1, b1+2 — at load factor 0.5 the chance that all four are full is ~1e-8, so
 // nothing is evicted before the table is really filling up: T/hkv_hashtable_ops_test.py:572-625 pins that);
-// bounded == 2 ("dense": the host saw > 80 % of the slots in use): only within its two home buckets b0 / b1
+// bounded == 2 ("dense": the host saw > 60 % of the slots in use): only within its two home buckets b0 / b1
 // (HKV likewise confines a key to its one bucket and evicts inside it), so that the OVF1 flags stop spreading and
 // a miss on a table running at capacity costs two lines, not an ever longer walk.  When neither the key nor an
 // empty slot is found the function returns NEED_EVICT (-2) and the caller replaces the minimum-score entry of the
@@ -251,8 +251,11 @@ __device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int 
 // the most recent); otherwise the new key enters only if in_score >= the minimum score.
 // Returns the row whose key word now holds LOCKED_KEY (the caller writes row + score, then publishes
 // the key with publish_key), -1 when the key was not admitted, -3 when no victim could be taken.
+// pre_k / pre_s (optional): key and score lines of (b0, b1) preloaded by the caller — a kernel that handles several keys
+// per group puts all of their lines in flight before resolving any (first attempt only; retries reload).
 __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 in_score, bool admit_always, int sub,
-                                              int gshift, u64* victim_word, bool& claimed_empty) {
+                                              int gshift, u64* victim_word, bool& claimed_empty,
+                                              const i64* pre_k = nullptr, const i64* pre_s = nullptr) {
   u64 h;
   const u64 b0 = bucket0(key, v.nb, h);
   const u64 b1 = bucket1(h, b0, v.nb);
@@ -261,10 +264,15 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
     u64 best_score = ~0ULL, best_word = 0;
     i64 best_key = 0;
     // key + score lines of both home buckets: four independent loads in flight
-    i64 kk2[2] = {load_key_coherent(key_line(v, b0) + sub), load_key_coherent(key_line(v, b1) + sub)};
-    i64 sc2[2] = {(i64)__hip_atomic_load(score_line(v, b0) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                  (i64)__hip_atomic_load(score_line(v, b1) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-    keep_live(kk2[0], kk2[1], sc2[0], sc2[1]);
+    i64 kk2[2], sc2[2];
+    if (attempt == 0 && pre_k) {
+      kk2[0] = pre_k[0]; kk2[1] = pre_k[1]; sc2[0] = pre_s[0]; sc2[1] = pre_s[1];
+    } else {
+      kk2[0] = load_key_coherent(key_line(v, b0) + sub); kk2[1] = load_key_coherent(key_line(v, b1) + sub);
+      sc2[0] = (i64)__hip_atomic_load(score_line(v, b0) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sc2[1] = (i64)__hip_atomic_load(score_line(v, b1) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      keep_live(kk2[0], kk2[1], sc2[0], sc2[1]);
+    }
     for (int which = 0; which < 2; ++which) {
       u64 b = which ? b1 : b0;
       i64 k = kk2[which];
@@ -338,12 +346,12 @@ __device__ __forceinline__ void update_score(const TableView& v, i64 row, bool i
   if (!has_scores(v) || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
   u64 b = (u64)row / SLOTS, s = (u64)row % SLOTS;
   u64* p = score_line(v, b) + s;
-  u64 old = is_new ? 0 : *p;
   u64 ns;
   switch (strategy) {
     case TFRA_EVICT_LFU: atomicAdd(p, in_score); return;  // slots are zeroed on clear/erase
     case TFRA_EVICT_EPOCHLRU: ns = (epoch << 32) | (wall_clock64() & 0xffffffffULL); break;
     case TFRA_EVICT_EPOCHLFU: {
+      const u64 old = is_new ? 0 : *p;   // the only rule that reads the old score (a dependent access on a table of this size)
       u64 cnt = (old & 0xffffffffULL) + in_score;
       if (cnt > 0xffffffffULL) cnt = 0xffffffffULL;
       ns = (epoch << 32) | cnt;

@@ -57,7 +57,7 @@ struct Table {
   size_t n_since_read = 0;
   i64* h_size = nullptr;  // pinned, inside the h_scalar block
   bool growth_blocked = false;
-  bool dense = false;        // a table that cannot grow any more holds > 80 % of its slots (async size reads)
+  bool dense = false;        // a table that cannot grow any more holds > 60 % of its slots (async size reads)
   unsigned dense_calls = 0;
   bool capture_safe = false;  // TFRA_OPTION_CAPTURE_SAFE
   uint64_t global_epoch = 0;

@@ -722,12 +722,15 @@ int Table::grow(u64 min_nb, hipStream_t s) {
 
 // A table that cannot grow any more (Hkv flavour at max_capacity): every 16th insert-type call starts an
 // asynchronous size read (size kernel + 8-B D2H + event, no host wait); `dense` = the last completed read saw
-// more than 80 % of the slots in use.  find / insert then put BOTH home buckets' lines in flight at once.
+// more than 60 % of the slots in use.  From then on new keys are placed in their two home buckets only (below
+// that the chance that both are full is < 1e-3 and a 4-bucket walk keeps every key: the reference never evicts at
+// load factor 0.5), so the OVF1 flags stop spreading while they are still rare, and find / insert put BOTH home
+// buckets' lines in flight at once.
 int Table::poll_density(hipStream_t s) {
   if (size_pending) {
     if (hipEventQuery(size_event) != hipSuccess) return TFRA_OK;
     i64 v = *h_size;
-    dense = (double)(v < 0 ? 0 : v) > 0.8 * (double)(cur.nb * SLOTS);
+    dense = (double)(v < 0 ? 0 : v) > 0.6 * (double)(cur.nb * SLOTS);
     size_pending = false;
   }
   if (++dense_calls >= 16 || dense_calls == 1) {

@@ -443,7 +443,11 @@ class PrefetchStep:
     self.ids[self.cur] = ids
     return self
 
-  def step(self, grads, next_ids=None):
+  def step(self, grads, next_ids=None, next_ids_ready=True):
+    """next_ids_ready: the second stream does NOT wait for the current stream, so `next_ids` must be complete in
+    memory when this is called (a batch staged by the input pipeline).  Pass False when it is still being produced
+    on the current stream (device-side hashing, an async H2D copy): the second stream then waits for it (one
+    cross-stream event per step)."""
     from .table_ops import _ptr
     cur = self.cur
     nxt_slot = (cur + 1) % self.NPLANS
@@ -466,9 +470,70 @@ class PrefetchStep:
       nxt.record_stream(self.side)
       self.ids[nxt_slot] = nxt                      # kept alive until its step has run
     main = torch.cuda.current_stream(self.dev)
+    if nxt is not None and not next_ids_ready:
+      self.side.wait_stream(main)
     _capi.call("tfra_table_step_prefetch", self.table._h, ctypes.byref(p), self.plans[cur]._h, _ptr(ids), _ptr(out),
                _ptr(self.default), _ptr(grads), _ptr(self.default), self.plans[nxt_slot]._h if nxt is not None else None,
                _ptr(nxt), 0 if nxt is None else nxt.numel(), ctypes.c_void_p(main.cuda_stream),
                ctypes.c_void_p(self.side.cuda_stream))
+    self.cur = nxt_slot
+    return out
+
+
+class PrefetchAssignStep:
+  """`PrefetchStep` for a table WITHOUT a fused optimizer (any value dtype, bounded Hkv tables included): one C call
+  per step (`tfra_table_step_prefetch_assign`) = lookup of batch i -> insert_or_assign of batch i's rows (ids may
+  repeat: the last occurrence wins; on a table at max_capacity new keys evict by score) on the main stream, while the
+  de-duplication plan of batch i+1 is built on a second stream.
+
+      ps = PrefetchAssignStep(table); ps.prime(first_ids)
+      for ...: rows = ps.step(values, next_ids)       # values [n, dim]: what batch i writes back
+  """
+  NPLANS = 4
+
+  def __init__(self, table):
+    from .table_ops import SparsePlan
+    self.t = table
+    self.table = table._table if hasattr(table, "_table") else table
+    self.dev = self.table.device
+    self.plans = [SparsePlan(self.dev, 0) for _ in range(self.NPLANS)]
+    self.ids = [None] * self.NPLANS
+    self.default = self.table._default_value
+    self.side = torch.cuda.Stream(device=self.dev)
+    self.cur = 0
+
+  def prime(self, ids):
+    ids = torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+    self.plans[self.cur].build(ids, sync=False)
+    self.ids[self.cur] = ids
+    return self
+
+  def step(self, values, next_ids=None, scores=None, lookup=True, next_ids_ready=True):
+    """next_ids_ready: see PrefetchStep.step."""
+    from .table_ops import _ptr
+    cur = self.cur
+    nxt_slot = (cur + 1) % self.NPLANS
+    ids = self.ids[cur]
+    n = ids.numel()
+    values = values.reshape(n, self.table.dim)
+    if values.dtype != self.table.value_dtype or not values.is_contiguous():
+      values = values.to(self.table.value_dtype).contiguous()
+    out = torch.empty((n, self.table.dim), dtype=self.table.value_dtype, device=self.dev) if lookup else None
+    nxt = None
+    main = torch.cuda.current_stream(self.dev)
+    if next_ids is not None:
+      nxt = next_ids
+      if not (torch.is_tensor(nxt) and nxt.dtype == torch.int64 and nxt.dim() == 1 and nxt.is_contiguous() and
+              nxt.device == self.dev):
+        nxt = torch.as_tensor(next_ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+      nxt.record_stream(self.side)
+      self.ids[nxt_slot] = nxt
+      if not next_ids_ready:
+        self.side.wait_stream(main)
+    if scores is not None:
+      scores = scores.to(self.dev, torch.int64).contiguous()
+    _capi.call("tfra_table_step_prefetch_assign", self.table._h, self.plans[cur]._h, _ptr(ids), _ptr(out), _ptr(self.default),
+               _ptr(values), _ptr(scores), self.plans[nxt_slot]._h if nxt is not None else None, _ptr(nxt),
+               0 if nxt is None else nxt.numel(), ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(self.side.cuda_stream))
     self.cur = nxt_slot
     return out
