@@ -127,6 +127,10 @@ int tfra_table_size(tfra_table_t* t, size_t* out, tfra_stream_t stream);
 int tfra_table_size_to_device(tfra_table_t* t, int64_t* d_out, tfra_stream_t stream);
 /* number of slots export_batch scans (= value to loop `offset` up to) */
 int tfra_table_capacity(tfra_table_t* t, size_t* out);
+/* introspection (tests, tools): out5 = {empty key slots, slots locked by an eviction in progress (0 whenever no
+ * call is running), live key slots, buckets with the OVF0 flag, buckets with the OVF1 flag}.  Host buffer;
+ * synchronises `stream`. */
+int tfra_table_slot_census(tfra_table_t* t, uint64_t* out5, tfra_stream_t stream);
 /* grow (rehash) so that at least `min_slots` slots exist; no-op if already that large */
 int tfra_table_reserve(tfra_table_t* t, size_t min_slots, tfra_stream_t stream);
 

@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "tfra_amd", "lib")
 LIB = os.path.join(LIBDIR, "libtfra_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3"] + os.environ.get("TFRA_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-variable", "-Wno-unused-function", "-Wno-unused-result"]
 
 

@@ -802,17 +802,16 @@ template <int G>
 __global__ __launch_bounds__(256) void upsert_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                          const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
                                                          ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_deferred,
-                                                         unsigned use_gen, unsigned* progress, unsigned progress_val) {
+                                                         unsigned use_gen, const unsigned* any_slow) {
+  // any_slow != nullptr: remainder path of upsert_own_kernel, only the keys it marked (dflag == 4)
+  if (any_slow && *any_slow != use_gen) return;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
-    if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
-  }
   const bool pf1 = sp.bounded > 1;
   for (unsigned g = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); g < total; g += ngroups) {
+    if (any_slow && dflag[g] != 4) continue;
     const i64 key = ks.dkeys[g];
     u64 h;
     const u64 b0 = bucket0(key, v.nb, h);
@@ -909,6 +908,163 @@ __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, cons
     if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
     if (failed) atomicAdd(v.err_count, (unsigned)failed);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ASSIGN write-back, single pass with BUCKET OWNERSHIP (the normal path; the two kernels above are its remainder path).
+// Every bucket has an owner tag (one 32-bit word in a dense side array — NOT in the bucket's key line: an atomic and a
+// load issued together on the same 128-B line cost 41 us per 157 K instead of 11 us on separate lines,
+// scripts/mb/atomic_probe.hip).  Every key of the launch swaps the launch's generation into the tags of its two home
+// buckets (two atomic exchanges in flight with its line loads) and owns a bucket iff the tag it got back is from an
+// older launch.  A key that owns BOTH home buckets is the
+// only writer of the launch that can touch them — every other key of the launch whose sequence includes one of them
+// fails that claim and leaves the table alone — so it resolves hit / free slot / minimum-score eviction with plain
+// loads and stores: no CAS, no LOCKED state, no score re-read, no publish ordering, and ONE dependent round trip (the
+// four lines and the two claims are in flight together) instead of the five of the locked protocol.  Keys that lose a
+// claim (two keys of one batch sharing a home bucket: ~(2U)^2/nb of them) or whose search cannot be decided from the
+// two home buckets (walk flags set) are marked `slow` and go through upsert_csr_kernel + upsert_evict_csr_kernel, which
+// run afterwards and look only at marked keys.
+// Shape like find_kernel: U = 4 keys per 16-lane group, every load and claim of the 4 keys issued before any is used
+// (one key per group kept 16 keys in flight per SIMD and took 48 us for 78 K keys on a 10^9-slot table: the kernel is a
+// chain of three memory round trips and nothing else, only the number of keys in flight matters).
+template <int G, int U>
+__global__ __launch_bounds__(256) void upsert_own_kernel(TableView v, const unsigned char* __restrict__ vals,
+                                                         const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
+                                                         ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_slow,
+                                                         unsigned use_gen, unsigned own_gen, unsigned* __restrict__ tags,
+                                                         unsigned* progress, unsigned progress_val) {
+  static_assert(U == 4, "keep_live is written for U == 4");
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
+  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  int fresh = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
+    if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
+  }
+  const bool with_scores = has_scores(v);
+  const bool dense = sp.bounded > 1 || (sp.bounded == 1 && *v.dense_flag);
+  const bool spec = with_scores && dense;   // an eviction is likely: the score lines travel with the key lines
+  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+  for (unsigned base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4) * U; base < total; base += ngroups * U) {
+    unsigned g[U], km[U];
+    i64 key[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      g[u] = min(base + u, total - 1);   // clamped tail: unconditional loads (find_kernel)
+      key[u] = ks.dkeys[g[u]];
+      km[u] = ks.keymap[g[u]];
+    }
+    keep_live(key[0], key[1], key[2], key[3]);
+    u64 b0[U], b1[U];
+    unsigned t0[U], t1[U], w[U];
+    i64 kk[U][2], sc[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      u64 h;
+      b0[u] = bucket0(key[u], v.nb, h);
+      b1[u] = bucket1(h, b0[u], v.nb);
+      t0[u] = t1[u] = 0;
+      if (sub == 0 && base + u < total) {   // (a clamped duplicate must not claim: it would lock out the real key)
+        t0[u] = atomicExch(tags + b0[u], own_gen);
+        t1[u] = atomicExch(tags + b1[u], own_gen);
+      }
+      // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
+      kk[u][0] = key_line(v, b0[u])[sub];
+      kk[u][1] = key_line(v, b1[u])[sub];
+      sc[u][0] = spec ? (i64)score_line(v, b0[u])[sub] : 0;
+      sc[u][1] = spec ? (i64)score_line(v, b1[u])[sub] : 0;
+      w[u] = ((km[u] & KM_MANY) ? ks.hrec : ks.crec)[(size_t)(km[u] & ~KM_MANY) * REC_WORDS + sub];
+    }
+    keep_live(t0[0], t0[1], t0[2], t0[3]);
+    keep_live(t1[0], t1[1], t1[2], t1[3]);
+    keep_live(kk[0][0], kk[1][0], kk[2][0], kk[3][0]);
+    keep_live(kk[0][1], kk[1][1], kk[2][1], kk[3][1]);
+    keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
+    keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
+    keep_live(w[0], w[1], w[2], w[3]);
+    u64 word[U], in_s[U];
+    unsigned last[U];
+    int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool hot = (km[u] & KM_MANY) != 0;
+      const unsigned cnt = (unsigned)__shfl((int)w[u], gshift + 2);
+      unsigned l = (unsigned)__shfl((int)w[u], gshift + (hot ? 5 : 3 + (int)min(max(cnt, 1u), 8u)));   // few: the last position itself
+      if (hot) l = ks.hent[l];                                                                           // many: where it is stored
+      last[u] = l & E_POS;
+      const u64 in_one = scores ? scores[last[u]] : 1;
+      in_s[u] = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+      const unsigned c0 = (unsigned)__shfl((int)t0[u], gshift), c1 = (unsigned)__shfl((int)t1[u], gshift);
+      act[u] = 0;
+      word[u] = 0;
+      if (base + u >= total) continue;
+      bool slow = c0 == own_gen || c1 == own_gen || is_reserved_key(key[u]);   // a claim lost (or a sentinel key: side rows)
+      if (!slow) {
+        const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
+        const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
+        const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
+        const unsigned emp1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == EMPTY_KEY) >> gshift) & 0x7fffu;
+        const u64 meta0 = (u64)shfl_i64(kk[u][0], gshift + 15), meta1 = (u64)shfl_i64(kk[u][1], gshift + 15);
+        bool flag_b0 = false;   // the key goes to b1 although b0 never overflowed before
+        if (hit0) { word[u] = b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
+        else if (hit1) { word[u] = b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
+        else if ((meta0 & META_OVF0) && (meta1 & META_OVF1)) slow = true;   // the key may live further along: walk
+        else if (emp0) { word[u] = b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
+        else if (emp1) { word[u] = b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
+        else if (spec && !(meta1 & META_OVF1)) {
+          // both home buckets full, nothing further along: replace the minimum-score entry of the 30 slots
+          u64 best_score, best_word;
+          i64 best_key;
+          select_victim(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
+          const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_s[u]) : in_s[u];
+          if (lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
+            word[u] = best_word;
+            act[u] = 3;
+            flag_b0 = (best_word >> 4) == b1[u];
+          }
+        } else slow = true;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
+        if (flag_b0 && !(meta0 & META_OVF0) && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
+      }
+      if (sub == 0) {
+        dflag[g[u]] = slow ? 4 : 0;
+        if (slow) *any_slow = use_gen;   // plain store, every writer writes the same value
+      }
+      fresh += (act[u] == 2 && sub == 0);
+    }
+    // value rows of the U keys: loads together (always from a valid address), stores for the keys that write
+    typedef typename Granule<G>::T T;
+    for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
+      T tmp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(vals + (size_t)last[u] * v.field_bytes + off);
+      keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (act[u]) *reinterpret_cast<T*>(row_at(v, word[u] >> 4, (unsigned)(word[u] & 15)) + off) = tmp[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!act[u]) continue;
+      const i64 row = (i64)((word[u] >> 4) * SLOTS + (word[u] & 15));
+      if (act[u] >= 2) {
+        unsigned char* pr = row_at(v, word[u] >> 4, (unsigned)(word[u] & 15));
+        for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of a brand-new row start at aux_init
+          const unsigned pat = ai.pattern[(f - 1) & 3];
+          unsigned char* q = pr + f * v.field_bytes;
+          if ((v.field_bytes & 3) == 0)
+            for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(q + off) = pat;
+          else
+            for (unsigned off = sub; off < v.field_bytes; off += 16) q[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
+        }
+        if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
+      }
+      if (act[u] == 3 && sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) *score_word(v, word[u]) = in_s[u]; }   // the slot starts a new life
+      else update_score(v, row, act[u] >= 2, sp.strategy, in_s[u], sp.epoch, sub);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
+  if (lane == 0 && fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
 }
 
 }  // namespace
@@ -1166,22 +1322,25 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   const unsigned char* vals = (const unsigned char*)values;
   const u64* sc = (const u64*)scores;
   const unsigned gen = ++pl->use_gen;
+  unsigned* tags = t->ensure_own_tags(s);    // nullptr (allocation failed): every key takes the general two-kernel path
+  if (++t->own_gen == 0) t->own_gen = 1;     // bucket-owner tag of this launch (tags start at 0)
+  const unsigned og = t->own_gen;
+  unsigned* any_slow = pl->d_counts + 9;
+#define TFRA_UPS(GG)                                                                                                          \
+  if (tags)                                                                                                                   \
+    upsert_own_kernel<GG, 4><<<(key_blocks + 3) / 4, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, any_slow, gen, og, \
+                                                                  tags, progress, progress_val);                             \
+  upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,     \
+                                                   tags ? any_slow : nullptr);                                               \
+  if (sp.bounded) upsert_evict_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen)
   switch (g) {
-    case 16: upsert_csr_kernel<16><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
-    case 8: upsert_csr_kernel<8><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
-    case 4: upsert_csr_kernel<4><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
-    case 2: upsert_csr_kernel<2><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
-    default: upsert_csr_kernel<1><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen, progress, progress_val); break;
+    case 16: TFRA_UPS(16); break;
+    case 8: TFRA_UPS(8); break;
+    case 4: TFRA_UPS(4); break;
+    case 2: TFRA_UPS(2); break;
+    default: TFRA_UPS(1); break;
   }
-  if (sp.bounded) {
-    switch (g) {
-      case 16: upsert_evict_csr_kernel<16><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
-      case 8: upsert_evict_csr_kernel<8><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
-      case 4: upsert_evict_csr_kernel<4><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
-      case 2: upsert_evict_csr_kernel<2><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
-      default: upsert_evict_csr_kernel<1><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen); break;
-    }
-  }
+#undef TFRA_UPS
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");
   step_epoch_public(t);
   return TFRA_OK;

@@ -53,26 +53,44 @@ struct TableView {
   u64* size_shards;            // [SIZE_SHARDS*SIZE_SHARD_STRIDE], wrapping signed deltas
   int* winner;                 // [nb*15+2] scratch for duplicate resolution (may be null)
   unsigned* err_count;         // keys that could not be placed (table full)
+  const unsigned* dense_flag;  // device word, != 0 once a bounded table at max_capacity holds > 60 % of its slots
+                               // (set by density_kernel in stream order: the host's view of the size lags by
+                               // however many calls are queued, this one does not)
 };
 
 __device__ __forceinline__ bool has_scores(const TableView& v) { return v.hdr > 128; }
-__device__ __forceinline__ i64* key_line(const TableView& v, u64 b) {
-  return reinterpret_cast<i64*>(v.base + b * v.bucket_stride);
+// Integer instruction count, not HBM bandwidth, bounds these kernels (a wave64 VALU instruction takes 4 cycles, a
+// 32-bit multiply 16: find_kernel was ~1000 instructions per 16 keys, a quarter of its cycles in 64-bit multiplies),
+// so the address arithmetic is kept to ONE v_mad_u64_u32: bucket indices and the bucket stride are < 2^32
+// (tfra_table_create rejects more than 2^32 - 1 buckets).
+__device__ __forceinline__ unsigned char* bucket_ptr(const TableView& v, u64 b) {
+  return v.base + (u64)(unsigned)b * (u64)(unsigned)v.bucket_stride;
 }
-__device__ __forceinline__ u64* score_line(const TableView& v, u64 b) {
-  return reinterpret_cast<u64*>(v.base + b * v.bucket_stride + 128);
-}
+__device__ __forceinline__ i64* key_line(const TableView& v, u64 b) { return reinterpret_cast<i64*>(bucket_ptr(v, b)); }
+__device__ __forceinline__ u64* score_line(const TableView& v, u64 b) { return reinterpret_cast<u64*>(bucket_ptr(v, b) + 128); }
 // "word" index w = b*16 + slot names one key slot (and its score)
 __device__ __forceinline__ i64* key_word(const TableView& v, u64 w) { return key_line(v, w >> 4) + (w & 15); }
 __device__ __forceinline__ u64* score_word(const TableView& v, u64 w) { return score_line(v, w >> 4) + (w & 15); }
 __device__ __forceinline__ unsigned char* row_at(const TableView& v, u64 b, unsigned slot) {
-  return v.base + b * v.bucket_stride + v.hdr + (size_t)slot * v.row_stride;
+  return bucket_ptr(v, b) + (v.hdr + slot * v.row_stride);
+}
+// row index r = b*15 + slot (< 2^36) -> (b, slot) without a 64-bit division: r = hi*2^32 + lo with hi < 16 and
+// 2^32 = 15*286331153 + 1, so r = 15*(hi*286331153) + (hi + lo); the rest (< 2^32 + 16) divides by the usual
+// 32-bit magic (0x88888889 >> 35, exact below 2^35 / 7).
+__device__ __forceinline__ void split_row(u64 r, u64& b, unsigned& slot) {
+  const unsigned hi = (unsigned)(r >> 32);
+  const u64 rest = (u64)hi + (u64)(unsigned)r;
+  const unsigned q = (unsigned)((rest * 0x88888889ULL) >> 35);
+  b = (u64)hi * 286331153ULL + q;
+  slot = (unsigned)(rest - (u64)q * 15);
 }
 // row index r = b*15 + slot; r >= nb*15 = side rows
 __device__ __forceinline__ unsigned char* row_ptr(const TableView& v, i64 row) {
-  const u64 r = (u64)row, b = r / 15;
-  if (b >= v.nb) return v.base + v.nb * v.bucket_stride + (size_t)(r - v.nb * 15) * v.row_stride;
-  return row_at(v, b, (unsigned)(r - b * 15));
+  u64 b;
+  unsigned slot;
+  split_row((u64)row, b, slot);
+  if (b >= v.nb) return bucket_ptr(v, v.nb) + (size_t)((u64)row - v.nb * 15) * v.row_stride;
+  return row_at(v, b, slot);
 }
 
 __device__ __forceinline__ u64 fmix64(u64 k) {
@@ -81,14 +99,23 @@ __device__ __forceinline__ u64 fmix64(u64 k) {
   k ^= k >> 33;
   return k;
 }
+// Two home buckets from ONE 64-bit mix: b0 = the high word of fmix64(key) range-reduced by a 32-bit multiply-high
+// (nb < 2^32), b1 = the low word re-mixed (murmur3 fmix32) and reduced the same way — 10 32-bit multiplies per key
+// instead of the 26 of two fmix64 + two 64-bit multiply-highs.
+__device__ __forceinline__ unsigned fmix32(unsigned x) {
+  x ^= x >> 16; x *= 0x85ebca6bu;
+  x ^= x >> 13; x *= 0xc2b2ae35u;
+  x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ u64 bucket0(i64 key, u64 nb, u64& h) {
   h = fmix64((u64)key);
-  return __umul64hi(h, nb);
+  return (u64)__umulhi((unsigned)(h >> 32), (unsigned)nb);
 }
 __device__ __forceinline__ u64 bucket1(u64 h, u64 b0, u64 nb) {
-  u64 b1 = __umul64hi(fmix64(h ^ 0x9e3779b97f4a7c15ULL), nb);
-  if (b1 == b0) b1 = (b0 + 1 == nb) ? 0 : b0 + 1;
-  return b1;
+  unsigned b1 = __umulhi(fmix32((unsigned)h ^ 0x9e3779b9u), (unsigned)nb);
+  if (b1 == (unsigned)b0) b1 = (b1 + 1 == (unsigned)nb) ? 0u : b1 + 1;
+  return (u64)b1;
 }
 __device__ __forceinline__ u64 next_bucket(u64 b, u64 nb) { return (b + 1 == nb) ? 0 : b + 1; }
 __device__ __forceinline__ bool is_reserved_key(i64 k) { return k <= LOCKED_KEY; }
@@ -163,6 +190,34 @@ __device__ __forceinline__ i64 probe_find_from(const TableView& v, i64 key, u64 
   }
 }
 
+// Same search with both home buckets already hashed by the caller (one lane per key hashes, the group gets b0 / b1
+// by shuffle: a quarter of the hash instructions), returning the slot as a WORD index b*16 + slot (side rows:
+// nb*16 + r) so that the row address needs no division; -1 = absent.
+__device__ __forceinline__ i64 probe_find_word(const TableView& v, i64 key, u64 b0, u64 b1, i64 k, int sub, int gshift,
+                                               const i64* k_second = nullptr) {
+  if (is_reserved_key(key)) {
+    int r = reserved_index(key);
+    return v.reserved_present[r] ? (i64)(v.nb * 16 + r) : -1;
+  }
+  u64 b = b0;
+  for (u64 step = 0;; ++step) {
+    u64 m = __ballot(sub < SLOTS && k == key);
+    unsigned hit = (unsigned)(m >> gshift) & 0x7fffu;
+    if (hit) return (i64)(b * 16 + (__ffs(hit) - 1));
+    i64 meta = shfl_i64(k, gshift + 15);
+    if (!((u64)meta & (step == 0 ? META_OVF0 : META_OVF1)) || step >= v.nb) return -1;
+    b = (step == 0) ? b1 : next_bucket(b, v.nb);
+    if (step == 0 && k_second) k = *k_second;  // b1's line, preloaded by the caller
+    else k = key_line(v, b)[sub];
+  }
+}
+// row of a word index (see probe_find_word); side rows sit behind the last bucket block, without a header
+__device__ __forceinline__ unsigned char* word_row_ptr(const TableView& v, u64 word) {
+  const u64 b = word >> 4;
+  const unsigned slot = (unsigned)word & 15u;
+  return bucket_ptr(v, b) + (slot * v.row_stride + (b >= v.nb ? 0u : v.hdr));
+}
+
 template <bool COHERENT>
 __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, int gshift) {
   u64 h;
@@ -200,6 +255,7 @@ __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key,
     return (i64)(v.nb * SLOTS + r);
   }
   const u64 b1 = bucket1(h, b0, v.nb);
+  if (bounded == 1 && *v.dense_flag) bounded = 2;  // uniform scalar load; see TableView::dense_flag
   for (int attempt = 0; attempt < 1024; ++attempt) {
     u64 b = b0;
     i64 fe = -1;  // word index (b*16+slot) of the first empty slot seen
@@ -245,6 +301,31 @@ __device__ __forceinline__ i64 locate_or_claim(const TableView& v, i64 key, int 
   return locate_or_claim_from(v, key, h, b0, k, sub, gshift, is_new);
 }
 
+// Victim choice among the 30 slots of (b0, b1) from their key lines kk2[] and score lines sc2[] (lane `sub` holds word
+// `sub` of each): minimum score, lowest slot on ties, b0 before b1; an EMPTY slot counts as score 0; LOCKED slots are
+// not candidates.  ALU only (shuffles).  best_score == ~0 when nothing is eligible.
+__device__ __forceinline__ void select_victim(u64 b0, u64 b1, const i64 (&kk2)[2], const i64 (&sc2)[2], int sub, int gshift,
+                                              u64& best_score, u64& best_word, i64& best_key) {
+  best_score = ~0ULL; best_word = 0; best_key = 0;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const u64 b = which ? b1 : b0;
+    const i64 k = kk2[which];
+    u64 sc = (u64)sc2[which];
+    const bool cand = sub < SLOTS && k != LOCKED_KEY;
+    if (k == EMPTY_KEY) sc = 0;  // an empty slot (erase since the first phase) beats any victim
+    u64 my = cand ? sc : ~0ULL;
+    u64 packed_lo = (u64)sub;  // 16-lane min with the lane index as tie-break
+    for (int o = 8; o > 0; o >>= 1) {
+      u64 os = ((u64)(unsigned)__shfl_xor((int)(my >> 32), o) << 32) | (unsigned)__shfl_xor((int)my, o);
+      u64 ol = (u64)(unsigned)__shfl_xor((int)packed_lo, o);
+      if (os < my || (os == my && ol < packed_lo)) { my = os; packed_lo = ol; }
+    }
+    const i64 kk = shfl_i64(k, gshift + (int)packed_lo);
+    if (my < best_score) { best_score = my; best_word = b * 16 + packed_lo; best_key = kk; }
+  }
+}
+
 // ---- eviction (Hkv strategies, table full): replace the minimum-score entry among the 30 slots
 // of the key's two home buckets — HKV's "in-bucket min-score eviction" (SURVEY.md appendix D;
 // behaviour pinned by T/hkv_hashtable_evict_test.py).  admit_always: LRU-type scores (a new key is
@@ -261,8 +342,8 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
   const u64 b1 = bucket1(h, b0, v.nb);
   claimed_empty = false;
   for (int attempt = 0; attempt < 256; ++attempt) {
-    u64 best_score = ~0ULL, best_word = 0;
-    i64 best_key = 0;
+    u64 best_score, best_word;
+    i64 best_key;
     // key + score lines of both home buckets: four independent loads in flight
     i64 kk2[2], sc2[2];
     if (attempt == 0 && pre_k) {
@@ -273,23 +354,7 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
       sc2[1] = (i64)__hip_atomic_load(score_line(v, b1) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       keep_live(kk2[0], kk2[1], sc2[0], sc2[1]);
     }
-    for (int which = 0; which < 2; ++which) {
-      u64 b = which ? b1 : b0;
-      i64 k = kk2[which];
-      u64 sc = (u64)sc2[which];
-      bool cand = sub < SLOTS && k != LOCKED_KEY;
-      if (k == EMPTY_KEY) sc = 0;  // an empty slot (erase since the first phase) beats any victim
-      u64 my = cand ? sc : ~0ULL;
-      // 16-lane min with the lane index as tie-break
-      u64 packed_lo = ((u64)sub);
-      for (int o = 8; o > 0; o >>= 1) {
-        u64 os = ((u64)(unsigned)__shfl_xor((int)(my >> 32), o) << 32) | (unsigned)__shfl_xor((int)my, o);
-        u64 ol = (u64)(unsigned)__shfl_xor((int)packed_lo, o);
-        if (os < my || (os == my && ol < packed_lo)) { my = os; packed_lo = ol; }
-      }
-      i64 kk = shfl_i64(k, gshift + (int)packed_lo);
-      if (my < best_score) { best_score = my; best_word = b * 16 + packed_lo; best_key = kk; }
-    }
+    select_victim(b0, b1, kk2, sc2, sub, gshift, best_score, best_word, best_key);
     if (best_score == ~0ULL) continue;  // everything locked by concurrent evictors: look again
     if (best_key != EMPTY_KEY && !admit_always && in_score < best_score) return -1;
     i64 old = 0;
@@ -344,7 +409,9 @@ template <bool WT = false>
 __device__ __forceinline__ void update_score(const TableView& v, i64 row, bool is_new, int strategy,
                                              u64 in_score, u64 epoch, int sub) {
   if (!has_scores(v) || sub != 0 || row >= (i64)(v.nb * SLOTS)) return;
-  u64 b = (u64)row / SLOTS, s = (u64)row % SLOTS;
+  u64 b;
+  unsigned s;
+  split_row((u64)row, b, s);
   u64* p = score_line(v, b) + s;
   u64 ns;
   switch (strategy) {

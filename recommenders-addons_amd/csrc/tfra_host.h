@@ -32,6 +32,7 @@ struct Table {
   u64* size_shards = nullptr;
   unsigned* reserved_present = nullptr;  // [2] + err_count + d_scalar in one 64-B block
   unsigned* err_count = nullptr;
+  unsigned* d_dense = nullptr;  // TableView::dense_flag
   i64* d_scalar = nullptr;
   i64* h_scalar = nullptr;  // pinned
   unsigned* progress_host = nullptr;  // tfra_table_step_prefetch: pinned progress counter of the main stream
@@ -44,6 +45,9 @@ struct Table {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   void* own_plan = nullptr;  // tfra_sparse_plan of the one-call write-backs (tfra_table_apply_sparse / upsert_sparse)
+  unsigned* own_tags = nullptr;  // [nb] bucket-owner tags (upsert_own_kernel), allocated on first use
+  u64 own_tags_nb = 0;
+  unsigned own_gen = 0;      // bucket-owner tag of the last ownership-based write-back (upsert_own_kernel)
   unsigned apply_P = 0;      // bucket count the cursor area at the head of `scratch` is armed for (0 = not armed)
   AuxInitPod aux{};
   // host bookkeeping
@@ -58,7 +62,6 @@ struct Table {
   i64* h_size = nullptr;  // pinned, inside the h_scalar block
   bool growth_blocked = false;
   bool dense = false;        // a table that cannot grow any more holds > 60 % of its slots (async size reads)
-  unsigned dense_calls = 0;
   bool capture_safe = false;  // TFRA_OPTION_CAPTURE_SAFE
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
@@ -72,6 +75,7 @@ struct Table {
   int read_size(hipStream_t s, size_t* out);
   int check_errors(hipStream_t s);
   int ensure_winner(hipStream_t s);
+  unsigned* ensure_own_tags(hipStream_t s);
   int ensure_scratch(size_t bytes, hipStream_t s);
   int grow(u64 min_nb, hipStream_t s);
   int prepare_insert(size_t n, hipStream_t s);

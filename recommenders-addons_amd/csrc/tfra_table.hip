@@ -36,27 +36,33 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
                                                    int full, unsigned field_off) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const int grp = lane >> 4;
-  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   constexpr int KPW = 4 * U;
-  const size_t base = wave * KPW;
+  const unsigned base = wave * KPW;   // n < 2^32 (find_impl)
   if (base >= n) return;
   // Loads are kept UNCONDITIONAL (tail keys are clamped to the last valid index): a load inside an
   // `if (valid)` block gets its own `s_waitcnt vmcnt(0)` and the U probes / U rows would be fetched
   // one latency after the other instead of all in flight (measured 23 us -> 11 us per 131072 keys).
-  const size_t last = n - 1;
-  i64 kreg = keys[min(base + (size_t)(lane & (KPW - 1)), last)];
+  const unsigned last = (unsigned)n - 1;
+  // ONE LANE PER KEY for the scalar work: lane j (and j+16, j+32, j+48) holds key j of the wave's 16 and hashes it —
+  // one instruction stream for 16 keys; the groups then fetch key / b0 / b1 of "their" key by shuffle.  (Hashing per
+  // group cost 4x the instructions, and instruction issue, not HBM, is what bounds this kernel.)
+  const i64 kreg = keys[min(base + (unsigned)(lane & (KPW - 1)), last)];
+  u64 hreg;
+  const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
+  const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
   i64 key[U];
-  u64 h[U], b[U];
+  unsigned b0[U], b1[U], idx[U];
   i64 k0[U], k1[U];
-  size_t idx[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    int j = u * 4 + grp;
+    const int j = u * 4 + grp;
     key[u] = shfl_i64(kreg, j);
-    idx[u] = min(base + j, last);
-    b[u] = bucket0(key[u], v.nb, h[u]);
-    k0[u] = key_line(v, b[u])[sub];  // U probes in flight
-    k1[u] = PF1 ? key_line(v, bucket1(h[u], b[u], v.nb))[sub] : 0;
+    b0[u] = (unsigned)__shfl((int)b0reg, j);
+    b1[u] = (unsigned)__shfl((int)b1reg, j);
+    idx[u] = min(base + (unsigned)j, last);
+    k0[u] = key_line(v, b0[u])[sub];  // U probes in flight
+    k1[u] = PF1 ? key_line(v, b1[u])[sub] : 0;
   }
   static_assert(U == 4, "keep_live is written for U == 4");
   keep_live(k0[0], k0[1], k0[2], k0[3]);
@@ -65,11 +71,11 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
   unsigned char* dst[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    i64 row = probe_find_from<false>(v, key[u], h[u], b[u], k0[u], sub, gshift, PF1 ? &k1[u] : nullptr);
-    if (exists && sub == 0) exists[idx[u]] = row >= 0;
-    src[u] = row >= 0 ? row_ptr(v, row) + field_off
-                      : defaults + (full ? idx[u] * (size_t)v.field_bytes : 0);
-    dst[u] = out + idx[u] * (size_t)v.field_bytes;
+    const i64 word = probe_find_word(v, key[u], b0[u], b1[u], k0[u], sub, gshift, PF1 ? &k1[u] : nullptr);
+    if (exists && sub == 0) exists[idx[u]] = word >= 0;
+    src[u] = word >= 0 ? word_row_ptr(v, (u64)word) + field_off
+                       : defaults + (full ? (u64)idx[u] * (u64)v.field_bytes : 0);
+    dst[u] = out + (u64)idx[u] * (u64)v.field_bytes;
   }
   typedef typename Granule<G>::T T;
   for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
@@ -374,7 +380,8 @@ __global__ __launch_bounds__(256) void erase_kernel(TableView v, size_t n, const
     } else {
       i64 row = probe_find<true>(v, key, sub, gshift);
       if (row >= 0 && sub == 0) {
-        u64 w = ((u64)row / SLOTS) * 16 + (u64)row % SLOTS;
+        u64 wb; unsigned ws; split_row((u64)row, wb, ws);
+        u64 w = wb * 16 + ws;
         // CAS so that duplicate keys in one call decrement the size once
         gone = atomicCAS((u64*)key_word(v, w), (u64)key, (u64)EMPTY_KEY) == (u64)key;
         if (gone && has_scores(v)) *score_word(v, w) = 0;
@@ -396,7 +403,7 @@ __global__ void clear_kernel(TableView v, int reset_counters) {
   if (!reset_counters) return;
   if (t < SIZE_SHARDS) v.size_shards[t * SIZE_SHARD_STRIDE] = 0;
   if (t < NUM_RESERVED) v.reserved_present[t] = 0;
-  if (t == 0) *v.err_count = 0;
+  if (t == 0) { *v.err_count = 0; *const_cast<unsigned*>(v.dense_flag) = 0; }
 }
 
 __global__ void fill_i32_kernel(int* p, size_t n, int val) {
@@ -412,6 +419,39 @@ __global__ void size_kernel(TableView v, i64* out) {
     __syncthreads();
   }
   if (threadIdx.x == 0) *out = part[0];
+}
+
+// size + the device-side density flag of a bounded table at max_capacity (TableView::dense_flag): monotone until clear
+__global__ void density_kernel(TableView v, i64* out, unsigned* dense_flag, i64 threshold) {
+  __shared__ long long part[SIZE_SHARDS];
+  part[threadIdx.x] = (long long)v.size_shards[threadIdx.x * SIZE_SHARD_STRIDE];
+  __syncthreads();
+  for (int s = SIZE_SHARDS / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *out = part[0];
+    if (part[0] > threshold) *dense_flag = 1u;
+  }
+}
+
+// introspection (tests, tools): counts of empty / locked / live key slots and of flagged buckets
+__global__ void slot_census_kernel(TableView v, u64* out) {
+  u64 e = 0, l = 0, live = 0, f0 = 0, f1 = 0;
+  const size_t total = v.nb * 16;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+    const i64 k = *key_word(v, w);
+    if ((w & 15) == 15) { f0 += ((u64)k & META_OVF0) != 0; f1 += ((u64)k & META_OVF1) != 0; }
+    else if (k == EMPTY_KEY) ++e;
+    else if (k == LOCKED_KEY) ++l;
+    else ++live;
+  }
+  if (e) atomicAdd(out + 0, e);
+  if (l) atomicAdd(out + 1, l);
+  if (live) atomicAdd(out + 2, live);
+  if (f0) atomicAdd(out + 3, f0);
+  if (f1) atomicAdd(out + 4, f1);
 }
 
 // ---- export_batch: slots [offset, offset+n) -> compact (key,row,score) at *counter ----------
@@ -599,6 +639,8 @@ static inline unsigned hdr_bytes(const tfra_table_opts& o) { return o.strategy >
 int Table::alloc_storage(u64 nb, Storage* st, hipStream_t s) {
   st->nb = nb;
   const size_t bstride = (size_t)hdr_bytes(opts) + (size_t)SLOTS * row_stride;
+  if (nb >= (1ULL << 32) - 1 || bstride >= (1ULL << 32))   // 32-bit bucket arithmetic on the device (tfra_device.h)
+    return set_error(TFRA_ERR_INVALID, "table storage: more than 2^32 - 2 buckets or a bucket block of 4 GiB");
   const size_t bytes = nb * bstride + (size_t)NUM_RESERVED * row_stride;
   st->base = (unsigned char*)dalloc(bytes, s);
   if (!st->base) {
@@ -617,6 +659,7 @@ TableView Table::view_of(const Storage& st) const {
   v.field_bytes = field_bytes; v.row_stride = row_stride; v.n_fields = 1 + opts.aux_fields;
   v.reserved_present = reserved_present; v.size_shards = size_shards; v.winner = winner;
   v.err_count = err_count;
+  v.dense_flag = d_dense;
   return v;
 }
 
@@ -658,6 +701,18 @@ int Table::check_errors(hipStream_t s) {
     return set_error(TFRA_ERR_FULL, std::to_string(e) + " keys could not be placed: table full at max_capacity");
   }
   return TFRA_OK;
+}
+
+// bucket-owner tags of the ownership-based write-backs: 4 B per bucket, zeroed; rebuilt after a rehash
+unsigned* Table::ensure_own_tags(hipStream_t s) {
+  if (own_tags && own_tags_nb == cur.nb) return own_tags;
+  if (own_tags) { (void)hipStreamSynchronize(s); dfree(own_tags, s); own_tags = nullptr; }
+  own_tags = (unsigned*)dalloc(cur.nb * sizeof(unsigned), s);
+  if (!own_tags) { g_last_error.clear(); return nullptr; }
+  if (hipMemsetAsync(own_tags, 0, cur.nb * sizeof(unsigned), s) != hipSuccess) { dfree(own_tags, s); own_tags = nullptr; return nullptr; }
+  own_tags_nb = cur.nb;
+  own_gen = 0;
+  return own_tags;
 }
 
 int Table::ensure_winner(hipStream_t s) {
@@ -727,15 +782,19 @@ int Table::grow(u64 min_nb, hipStream_t s) {
 // load factor 0.5), so the OVF1 flags stop spreading while they are still rare, and find / insert put BOTH home
 // buckets' lines in flight at once.
 int Table::poll_density(hipStream_t s) {
-  if (size_pending) {
-    if (hipEventQuery(size_event) != hipSuccess) return TFRA_OK;
+  if (dense) return TFRA_OK;  // monotone until clear()
+  if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
     dense = (double)(v < 0 ? 0 : v) > 0.6 * (double)(cur.nb * SLOTS);
     size_pending = false;
+    if (dense) return TFRA_OK;
   }
-  if (++dense_calls >= 16 || dense_calls == 1) {
-    if (dense_calls >= 16) dense_calls = 1;
-    size_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1);
+  // The kernels decide from the DEVICE flag, refreshed in stream order before every insert-type call of the
+  // transition phase (a 1-block kernel): a caller that queues hundreds of calls ahead of the GPU (a bulk load)
+  // would otherwise fill the table to capacity in 4-bucket-walk mode before the host ever sees a size, and every
+  // later miss would walk the flags that left behind (measured: find 47 us instead of 17 us on a 10^9-slot table).
+  density_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1, d_dense, (i64)(0.6 * (double)(cur.nb * SLOTS)));
+  if (!size_pending) {
     HIP_TRY(hipMemcpyAsync(h_size, d_scalar + 1, sizeof(i64), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(size_event, s));
     size_pending = true;
@@ -806,6 +865,7 @@ static int find_impl(Table* t, hipStream_t s, int field, size_t n, const int64_t
                      uint8_t* exists, const void* defaults, int full) {
   if (n == 0) return TFRA_OK;
   if (!keys || !values || !defaults) return set_error(TFRA_ERR_INVALID, "find: null buffer");
+  if (n >= (1ULL << 32)) return set_error(TFRA_ERR_INVALID, "find: more than 2^32-1 keys per call");
   if (field < 0 || field > t->opts.aux_fields) return set_error(TFRA_ERR_INVALID, "find: bad field");
   TableView v = t->view_of(t->cur);
   unsigned fo = field * t->field_bytes;
@@ -972,9 +1032,10 @@ int tfra_table_create(const tfra_table_opts* o, const tfra_allocator* alloc, tfr
   auto fail = [&](int rc) { tfra_table_destroy(reinterpret_cast<tfra_table_t*>(t)); return rc; };
   size_t ctr_bytes = (SIZE_SHARDS * SIZE_SHARD_STRIDE) * sizeof(u64);
   t->size_shards = (u64*)t->dalloc(ctr_bytes, s);
-  t->reserved_present = (unsigned*)t->dalloc(64, s);
+  t->reserved_present = (unsigned*)t->dalloc(64, s);  // [0,1] sentinel-key presence | +8 err_count | +10 dense flag | +12 two i64 scalars
   if (!t->size_shards || !t->reserved_present) return fail(set_error(TFRA_ERR_OOM, "counter allocation failed"));
   t->err_count = t->reserved_present + 8;
+  t->d_dense = t->reserved_present + 10;
   t->d_scalar = (i64*)(t->reserved_present + 12);
   if (hipHostMalloc((void**)&t->h_scalar, 64) != hipSuccess) return fail(set_error(TFRA_ERR_OOM, "pinned scalar"));
   if (hipEventCreateWithFlags(&t->chain_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
@@ -999,7 +1060,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   destroy_own_plan(t);
   t->dfree(t->cur.base, s);
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
-  t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s);
+  t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s); t->dfree(t->own_tags, s);
   if (t->progress_host) (void)hipHostFree(t->progress_host);
   if (t->h_scalar) (void)hipHostFree(t->h_scalar);
   if (t->chain_event) (void)hipEventDestroy(t->chain_event);
@@ -1140,7 +1201,6 @@ int tfra_table_clear(tfra_table_t* tp, tfra_stream_t stream) {
   t->size_pending = false;
   t->n_since_read = 0;
   t->dense = false;
-  t->dense_calls = 0;
   return TFRA_OK;
 }
 
@@ -1157,6 +1217,19 @@ int tfra_table_size_to_device(tfra_table_t* tp, int64_t* d_out, tfra_stream_t st
   if (!d_out) return set_error(TFRA_ERR_INVALID, "size: null out");
   size_kernel<<<1, SIZE_SHARDS, 0, s>>>(t->view_of(t->cur), (i64*)d_out);
   HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_table_slot_census(tfra_table_t* tp, uint64_t* out5, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (!out5) return set_error(TFRA_ERR_INVALID, "slot_census: null out");
+  u64* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, 5 * sizeof(u64)));
+  HIP_TRY(hipMemsetAsync(d, 0, 5 * sizeof(u64), s));
+  slot_census_kernel<<<2048, 256, 0, s>>>(t->view_of(t->cur), d);
+  HIP_TRY(hipMemcpyAsync(out5, d, 5 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipFree(d));
   return TFRA_OK;
 }
 

@@ -70,6 +70,7 @@ _SIGS = {
     "tfra_table_size": [_P, ctypes.POINTER(_SZ), _P],
     "tfra_table_size_to_device": [_P, _P, _P],
     "tfra_table_capacity": [_P, ctypes.POINTER(_SZ)],
+    "tfra_table_slot_census": [_P, ctypes.POINTER(ctypes.c_uint64), _P],
     "tfra_table_reserve": [_P, _SZ, _P],
     "tfra_table_export_batch": [_P, _SZ, _SZ, _P, _P, _P, _P, _P],
     "tfra_table_set_global_epoch": [_P, ctypes.c_uint64],

@@ -247,6 +247,12 @@ class _DeviceTable:
     _capi.call("tfra_table_capacity", self._h, ctypes.byref(out))
     return out.value
 
+  def slot_census(self):
+    """{empty, locked, live, ovf0, ovf1}: key-slot and bucket-flag counts (introspection; synchronises)."""
+    out = (ctypes.c_uint64 * 5)()
+    _capi.call("tfra_table_slot_census", self._h, out, _stream(self.device))
+    return dict(zip(("empty", "locked", "live", "ovf0", "ovf1"), [int(x) for x in out]))
+
   def set_capture_safe(self, on):
     """While True every op on this table can be captured into a HIP graph (no host sync, no growth)."""
     _capi.call("tfra_table_set_option", self._h, _capi.OPTION_CAPTURE_SAFE, int(bool(on)))
