@@ -61,7 +61,7 @@ constexpr int MAXPASS_SPLIT = 64;
 // shards with private counters and private ranges: bucket b allocates in shard b % NSH (P/NSH = 16 atomics per line),
 // and the last plan kernel publishes dense maps (keymap / binmap) over the shards for the kernels of the other half.
 constexpr unsigned NSH = 64;
-constexpr unsigned REC_WORDS = 16;        // a key record = 64 B: [0,1] key [2] count; few occurrences: [4..11] its batch
+constexpr unsigned REC_WORDS = 16;        // a key record = 64 B: [0,1] key [2] count; few occurrences: [3] last position, [4..11] its batch
                                           // positions, ascending; many: [3] first partial row [4] #partials [5] entry
                                           // address of its last occurrence
 constexpr unsigned KM_MANY = 1u << 31;    // keymap: the record lives in `hrec`
@@ -411,7 +411,11 @@ __global__ __launch_bounds__(NT) void csr_bucket_kernel(unsigned P, unsigned nti
     auto write_entry = [&](unsigned slot, unsigned e, unsigned position) {
       const unsigned tot = s_ct[slot] >> 11;
       if (tot <= (unsigned)DIRECT) {
-        if (cold_ok) out.crec[(size_t)(ckbase + s_a[slot]) * REC_WORDS + 4 + e] = position;
+        if (cold_ok) {
+          unsigned* rec = out.crec + (size_t)(ckbase + s_a[slot]) * REC_WORDS;
+          rec[4 + e] = position;
+          if (e + 1 == tot) rec[3] = position;   // the key's last occurrence (positions ascend with e)
+        }
       } else if (hot_ok) {
         const unsigned nfull = tot >> 9, fullrel = s_a[slot] >> 16;
         size_t addr;
@@ -515,7 +519,12 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
   const unsigned m = te >> 9, position = (unsigned)base + (te & 511u);
   const unsigned rank = (unsigned)q - run_start[base + m];
   const uint4 r = drec[base + m];
-  if (r.w == 0xffffffffu) { out.crec[(size_t)r.x + rank] = position; return; }
+  if (r.w == 0xffffffffu) {
+    const unsigned idx = r.x + rank, rb = idx & ~(REC_WORDS - 1);   // a record is 16 words, positions in words 4..11
+    out.crec[idx] = position;
+    if ((idx & (REC_WORDS - 1)) - 3 == out.crec[rb + 2]) out.crec[rb + 3] = position;   // the key's last occurrence
+    return;
+  }
   if (r.w == 0xfffffffeu) return;
   const unsigned e = r.x + rank, nfull = r.w;
   if (e < nfull * SEG) out.hent[(size_t)r.y + e] = position | ((e & (SEG - 1)) == 0 ? E_HEAD : 0u);
@@ -789,6 +798,24 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
   }
 }
 
+// The keys upsert_own_kernel leaves to the general path are few (tens to hundreds per batch on a big table): it appends
+// them to a list — one atomic add per wave that has any — so that the two remainder kernels run with a handful of blocks
+// instead of scanning every key of the batch (11 us each for a scan of 78 K flags).  Two counters alternate between
+// the uses of a plan: use k counts in ctr[k & 1], and the last kernel of use k zeroes ctr[(k + 1) & 1], which nothing of
+// use k reads, for use k + 1 (stream order makes that safe; no extra launch, no CAS loop).  A count above SLOW_CAP
+// means the list is incomplete and the remainder kernels scan the flags instead.
+constexpr unsigned SLOW_CAP = 8192;
+struct SlowIter {
+  unsigned n;      // iterations: list entries, or every key of the plan (scan)
+  bool listed;
+  __device__ SlowIter(const unsigned* slow_ctr, unsigned total) {
+    if (!slow_ctr) { n = total; listed = false; return; }   // no ownership pass ran: every key
+    const unsigned cnt = *slow_ctr;
+    listed = cnt <= SLOW_CAP;
+    n = listed ? cnt : total;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // ASSIGN write-back: row of the key's LAST occurrence in the batch -> the table (insert_or_assign with repeats,
 // "last one wins").  scores: optional per-position in_score (the last occurrence's is used; LFU without scores adds
@@ -802,16 +829,20 @@ template <int G>
 __global__ __launch_bounds__(256) void upsert_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                          const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
                                                          ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_deferred,
-                                                         unsigned use_gen, const unsigned* any_slow) {
-  // any_slow != nullptr: remainder path of upsert_own_kernel, only the keys it marked (dflag == 4)
-  if (any_slow && *any_slow != use_gen) return;
+                                                         unsigned use_gen, const unsigned* slow_ctr,
+                                                         const unsigned* __restrict__ slow_list, unsigned* zero_ctr) {
+  // slow_ctr != nullptr: remainder path of upsert_own_kernel, only the keys it marked (dflag == 4) — from its list,
+  // or by scanning the flags when the list overflowed
+  const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
+  if (zero_ctr && blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0;   // last kernel of this use: arm the next use's counter
+  if (it.n == 0) return;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
   const bool pf1 = sp.bounded > 1;
-  for (unsigned g = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); g < total; g += ngroups) {
-    if (any_slow && dflag[g] != 4) continue;
+  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
+    const unsigned g = it.listed ? slow_list[i] : i;
+    if (slow_ctr && dflag[g] != 4) continue;
     const i64 key = ks.dkeys[g];
     u64 h;
     const u64 b0 = bucket0(key, v.nb, h);
@@ -863,15 +894,19 @@ template <int G>
 __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                                const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
                                                                ScoreP sp, const uint8_t* __restrict__ dflag,
-                                                               const unsigned* any_deferred, unsigned use_gen) {
+                                                               const unsigned* any_deferred, unsigned use_gen,
+                                                               const unsigned* slow_ctr, const unsigned* __restrict__ slow_list,
+                                                               unsigned* zero_ctr) {
+  if (zero_ctr && blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0;   // last kernel of this use: arm the next use's counter
   if (*any_deferred != use_gen) return;   // phase 1 of this use deferred nothing: the usual case below capacity
+  const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
   const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
-  for (unsigned g = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); g < total; g += ngroups) {
-    if (!dflag[g]) continue;
+  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
+    const unsigned g = it.listed ? slow_list[i] : i;
+    if (dflag[g] != 1) continue;
     const i64 key = ks.dkeys[g];
     bool hot;
     const unsigned w = load_record(ks, g, sub, hot);
@@ -924,99 +959,203 @@ __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, cons
 // claim (two keys of one batch sharing a home bucket: ~(2U)^2/nb of them) or whose search cannot be decided from the
 // two home buckets (walk flags set) are marked `slow` and go through upsert_csr_kernel + upsert_evict_csr_kernel, which
 // run afterwards and look only at marked keys.
-// Shape like find_kernel: U = 4 keys per 16-lane group, every load and claim of the 4 keys issued before any is used
-// (one key per group kept 16 keys in flight per SIMD and took 48 us for 78 K keys on a 10^9-slot table: the kernel is a
-// chain of three memory round trips and nothing else, only the number of keys in flight matters).
-template <int G, int U>
-__global__ __launch_bounds__(256) void upsert_own_kernel(TableView v, const unsigned char* __restrict__ vals,
-                                                         const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
-                                                         ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_slow,
-                                                         unsigned use_gen, unsigned own_gen, unsigned* __restrict__ tags,
-                                                         unsigned* progress, unsigned progress_val) {
-  static_assert(U == 4, "keep_live is written for U == 4");
+// The keys the ownership pass leaves over (its list; the flags when the list overflowed), ONE pass with the locked
+// protocol for every kind of write: locate or claim the key's slot, LOCK it (CAS key -> LOCKED: a concurrent evictor of
+// this pass may have taken it, then start over), or lock a victim (evict_and_lock); write row and score write-through,
+// publish the key.  With every writer of the pass holding its slot locked, an assign can no longer race with the
+// eviction of the same slot, which is what the two separate kernels (assign / claim, then evict) are for when they
+// handle a whole batch — and a batch's few dozen left-over keys cost one kernel boundary instead of two.
+template <int G>
+__global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const unsigned char* __restrict__ vals,
+                                                          const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
+                                                          ScoreP sp, const uint8_t* __restrict__ dflag,
+                                                          const unsigned* slow_ctr, const unsigned* __restrict__ slow_list,
+                                                          unsigned* zero_ctr) {
+  const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0;   // last kernel of this use: arm the next use's counter
+  if (it.n == 0) return;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  int fresh = 0, failed = 0;
+  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
+    const unsigned g = it.listed ? slow_list[i] : i;
+    if (dflag[g] != 4) continue;
+    const i64 key = ks.dkeys[g];
+    bool hot;
+    const unsigned w = load_record(ks, g, sub, hot);
+    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3));
+    if (hot) last = ks.hent[last];
+    last &= E_POS;
+    const u64 in_one = scores ? scores[last] : 1;
+    const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+    const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score;
+    i64 row = -1;
+    u64 word = 0;
+    bool is_new = false, evicted = false, side = false;
+    for (int attempt = 0; attempt < 64 && row < 0; ++attempt) {
+      u64 h;
+      const u64 b0 = bucket0(key, v.nb, h);
+      const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+      bool claimed = false;
+      i64 r = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, claimed, sp.bounded);
+      if (r == NEED_EVICT) {
+        bool ce = false;
+        u64 wd = 0;
+        r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce);
+        if (r == -1) break;                        // not admitted (its score is below every resident one): dropped
+        if (r == -3) { failed += (sub == 0); break; }
+        row = r; word = wd; is_new = true; evicted = !ce;
+        fresh += (ce && sub == 0);
+        break;
+      }
+      if (r < 0) { failed += (sub == 0); break; }
+      fresh += (claimed && sub == 0);
+      is_new = is_new || claimed;
+      if (r >= (i64)(v.nb * SLOTS)) { row = r; side = true; break; }   // sentinel keys live in the side rows: nothing evicts there
+      u64 rb;
+      unsigned rs;
+      split_row((u64)r, rb, rs);
+      const u64 wd = rb * 16 + rs;
+      i64 old = 0;
+      if (sub == 0) old = (i64)atomicCAS((u64*)key_word(v, wd), (u64)key, (u64)LOCKED_KEY);
+      old = shfl_i64(old, gshift);
+      if (old == key) { row = r; word = wd; }   // else: an evictor of this pass took the slot; look again
+    }
+    if (row < 0) continue;
+    unsigned char* pr = row_ptr(v, row);
+    copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
+    if (is_new) {
+      for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of the new row start at aux_init
+        const unsigned pat = ai.pattern[(f - 1) & 3];
+        unsigned char* q = pr + f * v.field_bytes;
+        if ((v.field_bytes & 3) == 0)
+          for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          for (unsigned off = sub; off < v.field_bytes; off += 16)
+            __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (side) continue;
+    if (evicted && sub == 0) store_wt8(score_word(v, word), 0);   // the slot starts a new life
+    update_score<true>(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
+    publish_key(v, word, key, sub);
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// Shape: 16 keys per wave and iteration.  What is scalar per key — the key word, its hash, the two ownership claims,
+// the plan record (count, last position), the input score — is done ONE LANE PER KEY (lane j of every group holds
+// key j; group 0 issues the claims): one instruction stream for 16 keys.  What needs a whole line — the four bucket
+// lines, the ballots, the victim choice, the row copy — is done one 16-lane group per key, 4 keys per group in flight
+// (the scalar results reach the group by shuffle).  Instruction issue, not HBM, bounds these kernels: with everything
+// computed per group the kernel was 4100 instructions per 16 keys and took 41 us for 78 K keys.
+// SIMPLE: the common shape — rows without optimizer slots, LRU scores, no caller scores — with everything else compiled out.
+template <int G, bool SIMPLE>
+__global__ __launch_bounds__(256) void upsert_own_kernel(TableView v, const unsigned char* __restrict__ vals,
+                                                         const u64* __restrict__ scores_in, CsrKeys ks, AuxInitPod ai,
+                                                         ScoreP sp, uint8_t* __restrict__ dflag, unsigned* slow_ctr,
+                                                         unsigned* __restrict__ slow_list, unsigned use_gen, unsigned own_gen,
+                                                         unsigned* __restrict__ tags, unsigned* progress, unsigned progress_val) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
   int fresh = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
     if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
   }
-  const bool with_scores = has_scores(v);
+  const u64* scores = SIMPLE ? nullptr : scores_in;
+  const bool with_scores = SIMPLE || has_scores(v);
   const bool dense = sp.bounded > 1 || (sp.bounded == 1 && *v.dense_flag);
   const bool spec = with_scores && dense;   // an eviction is likely: the score lines travel with the key lines
-  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
-  for (unsigned base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4) * U; base < total; base += ngroups * U) {
-    unsigned g[U], km[U];
-    i64 key[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      g[u] = min(base + u, total - 1);   // clamped tail: unconditional loads (find_kernel)
-      key[u] = ks.dkeys[g[u]];
-      km[u] = ks.keymap[g[u]];
+  const bool lru = SIMPLE || sp.strategy == TFRA_EVICT_LRU;
+  const bool lru_like = lru || sp.strategy == TFRA_EVICT_EPOCHLRU;
+  for (unsigned wbase = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 16; wbase < total; wbase += nwaves * 16) {
+    // ---- one lane per key ------------------------------------------------------------------------------------
+    const bool valid = wbase + sub < total;
+    const unsigned gj = min(wbase + (unsigned)sub, total - 1);   // clamped tail: unconditional loads
+    const i64 kreg = ks.dkeys[gj];
+    const unsigned kmreg = ks.keymap[gj];
+    u64 hreg;
+    const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
+    const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
+    unsigned c0 = 0, c1 = 0;
+    if (grp == 0 && valid) {   // (a clamped duplicate must not claim: it would lock out the real key)
+      c0 = atomicExch(tags + b0reg, own_gen);
+      c1 = atomicExch(tags + b1reg, own_gen);
     }
-    keep_live(key[0], key[1], key[2], key[3]);
-    u64 b0[U], b1[U];
-    unsigned t0[U], t1[U], w[U];
-    i64 kk[U][2], sc[U][2];
+    // ---- one group per key: the lines of 4 keys in flight --------------------------------------------------
+    i64 key[U], kk[U][2], sc[U][2];
+    unsigned b0[U], b1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      u64 h;
-      b0[u] = bucket0(key[u], v.nb, h);
-      b1[u] = bucket1(h, b0[u], v.nb);
-      t0[u] = t1[u] = 0;
-      if (sub == 0 && base + u < total) {   // (a clamped duplicate must not claim: it would lock out the real key)
-        t0[u] = atomicExch(tags + b0[u], own_gen);
-        t1[u] = atomicExch(tags + b1[u], own_gen);
-      }
+      const int j = u * 4 + grp;
+      key[u] = shfl_i64(kreg, j);
+      b0[u] = (unsigned)__shfl((int)b0reg, j);
+      b1[u] = (unsigned)__shfl((int)b1reg, j);
       // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
       kk[u][0] = key_line(v, b0[u])[sub];
       kk[u][1] = key_line(v, b1[u])[sub];
       sc[u][0] = spec ? (i64)score_line(v, b0[u])[sub] : 0;
       sc[u][1] = spec ? (i64)score_line(v, b1[u])[sub] : 0;
-      w[u] = ((km[u] & KM_MANY) ? ks.hrec : ks.crec)[(size_t)(km[u] & ~KM_MANY) * REC_WORDS + sub];
     }
-    keep_live(t0[0], t0[1], t0[2], t0[3]);
-    keep_live(t1[0], t1[1], t1[2], t1[3]);
+    // ---- per key again, while the lines travel: count and last position from the plan record, input score ---
+    const bool hot = (kmreg & KM_MANY) != 0;
+    const unsigned* rec = (hot ? ks.hrec : ks.crec) + (size_t)(kmreg & ~KM_MANY) * REC_WORDS;
+    const uint2 cl = *reinterpret_cast<const uint2*>(rec + 2);   // (count, last position of a key with few occurrences)
+    const unsigned cnt = cl.x;
+    unsigned lastreg = cl.y;
+    if (hot) lastreg = ks.hent[rec[5]];                          // many: where it is stored
+    lastreg &= E_POS;
+    const u64 in_one = scores ? scores[lastreg] : 1;
+    const u64 insreg = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+    const unsigned lostreg = (c0 == own_gen || c1 == own_gen || is_reserved_key(kreg)) ? 1u : 0u;   // (group 0's lanes)
     keep_live(kk[0][0], kk[1][0], kk[2][0], kk[3][0]);
     keep_live(kk[0][1], kk[1][1], kk[2][1], kk[3][1]);
-    keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
-    keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
-    keep_live(w[0], w[1], w[2], w[3]);
+    if (spec) {
+      keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
+      keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
+    }
+    const u64 now = lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
     u64 word[U], in_s[U];
     unsigned last[U];
     int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool hot = (km[u] & KM_MANY) != 0;
-      const unsigned cnt = (unsigned)__shfl((int)w[u], gshift + 2);
-      unsigned l = (unsigned)__shfl((int)w[u], gshift + (hot ? 5 : 3 + (int)min(max(cnt, 1u), 8u)));   // few: the last position itself
-      if (hot) l = ks.hent[l];                                                                           // many: where it is stored
-      last[u] = l & E_POS;
-      const u64 in_one = scores ? scores[last[u]] : 1;
-      in_s[u] = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-      const unsigned c0 = (unsigned)__shfl((int)t0[u], gshift), c1 = (unsigned)__shfl((int)t1[u], gshift);
+      const int j = u * 4 + grp;
+      last[u] = (unsigned)__shfl((int)lastreg, j);
+      in_s[u] = 1;
+      if (!lru_like) in_s[u] = ((u64)(unsigned)__shfl((int)(insreg >> 32), j) << 32) | (unsigned)__shfl((int)insreg, j);
+      bool slow = __shfl((int)lostreg, j) != 0;   // lane j of group 0 made the claims
       act[u] = 0;
       word[u] = 0;
-      if (base + u >= total) continue;
-      bool slow = c0 == own_gen || c1 == own_gen || is_reserved_key(key[u]);   // a claim lost (or a sentinel key: side rows)
+      if (wbase + j >= total) continue;
       if (!slow) {
         const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
         const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
         const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
         const unsigned emp1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == EMPTY_KEY) >> gshift) & 0x7fffu;
-        const u64 meta0 = (u64)shfl_i64(kk[u][0], gshift + 15), meta1 = (u64)shfl_i64(kk[u][1], gshift + 15);
+        const bool ovf0 = ((__ballot(sub == 15 && ((u64)kk[u][0] & META_OVF0)) >> gshift) & 0xffffu) != 0;
+        const bool ovf1 = ((__ballot(sub == 15 && ((u64)kk[u][1] & META_OVF1)) >> gshift) & 0xffffu) != 0;
         bool flag_b0 = false;   // the key goes to b1 although b0 never overflowed before
-        if (hit0) { word[u] = b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
-        else if (hit1) { word[u] = b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
-        else if ((meta0 & META_OVF0) && (meta1 & META_OVF1)) slow = true;   // the key may live further along: walk
-        else if (emp0) { word[u] = b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
-        else if (emp1) { word[u] = b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
-        else if (spec && !(meta1 & META_OVF1)) {
+        if (hit0) { word[u] = (u64)b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
+        else if (hit1) { word[u] = (u64)b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
+        else if (ovf0 && ovf1) slow = true;   // the key may live further along: walk
+        else if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
+        else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
+        else if (spec && !ovf1) {
           // both home buckets full, nothing further along: replace the minimum-score entry of the 30 slots
           u64 best_score, best_word;
           i64 best_key;
-          select_victim(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
+          select_victim_merged(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
           const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_s[u]) : in_s[u];
           if (lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
             word[u] = best_word;
@@ -1024,43 +1163,70 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(TableView v, const unsi
             flag_b0 = (best_word >> 4) == b1[u];
           }
         } else slow = true;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
-        if (flag_b0 && !(meta0 & META_OVF0) && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
+        if (flag_b0 && !ovf0 && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
       }
-      if (sub == 0) {
-        dflag[g[u]] = slow ? 4 : 0;
-        if (slow) *any_slow = use_gen;   // plain store, every writer writes the same value
-      }
+      if (sub == 0) dflag[wbase + j] = slow ? 4 : 0;
+      if (slow) act[u] = -1;
       fresh += (act[u] == 2 && sub == 0);
     }
-    // value rows of the U keys: loads together (always from a valid address), stores for the keys that write
+    {   // left-over keys of the wave -> the list: one atomic add for all of them
+      u64 sm[U];
+      unsigned nslow = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) { sm[u] = __ballot(act[u] < 0 && sub == 0); nslow += (unsigned)__popcll(sm[u]); }
+      if (nslow) {
+        unsigned at = 0;
+        if (lane == 0) at = atomicAdd(slow_ctr, nslow);
+        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (act[u] < 0 && sub == 0) {
+            const unsigned pos = at + (unsigned)__popcll(sm[u] & ((1ULL << lane) - 1));
+            if (pos < SLOW_CAP) slow_list[pos] = wbase + (unsigned)(u * 4 + grp);
+          }
+          at += (unsigned)__popcll(sm[u]);
+          if (act[u] < 0) act[u] = 0;
+        }
+      }
+    }
+    // value rows of the 4 keys: loads together (always from a valid address), stores for the keys that write
     typedef typename Granule<G>::T T;
+    unsigned char* dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[u] = row_at(v, word[u] >> 4, (unsigned)word[u] & 15u);
     for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
       T tmp[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(vals + (size_t)last[u] * v.field_bytes + off);
+      for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(vals + (u64)last[u] * (u64)v.field_bytes + off);
       keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (act[u]) *reinterpret_cast<T*>(row_at(v, word[u] >> 4, (unsigned)(word[u] & 15)) + off) = tmp[u];
+      for (int u = 0; u < U; ++u) {
+        if (!act[u]) continue;
+        // write-through: the rows leave L2 during the kernel instead of at the boundary to the next one
+        if (G == 16) store_wt16(dst[u] + off, *reinterpret_cast<uint4*>(&tmp[u]));
+        else *reinterpret_cast<T*>(dst[u] + off) = tmp[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!act[u]) continue;
-      const i64 row = (i64)((word[u] >> 4) * SLOTS + (word[u] & 15));
       if (act[u] >= 2) {
-        unsigned char* pr = row_at(v, word[u] >> 4, (unsigned)(word[u] & 15));
-        for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of a brand-new row start at aux_init
-          const unsigned pat = ai.pattern[(f - 1) & 3];
-          unsigned char* q = pr + f * v.field_bytes;
-          if ((v.field_bytes & 3) == 0)
-            for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(q + off) = pat;
-          else
-            for (unsigned off = sub; off < v.field_bytes; off += 16) q[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
+        if (!SIMPLE && v.n_fields > 1) {
+          for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of a brand-new row start at aux_init
+            const unsigned pat = ai.pattern[(f - 1) & 3];
+            unsigned char* q = dst[u] + f * v.field_bytes;
+            if ((v.field_bytes & 3) == 0)
+              for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(q + off) = pat;
+            else
+              for (unsigned off = sub; off < v.field_bytes; off += 16) q[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
+          }
         }
         if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
       }
-      if (act[u] == 3 && sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) *score_word(v, word[u]) = in_s[u]; }   // the slot starts a new life
-      else update_score(v, row, act[u] >= 2, sp.strategy, in_s[u], sp.epoch, sub);
+      if (!with_scores) continue;
+      if (lru) { if (sub == 0) *score_word(v, word[u]) = now; }
+      else if (act[u] == 3 && sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) *score_word(v, word[u]) = in_s[u]; }   // the slot starts a new life
+      else update_score(v, (i64)((word[u] >> 4) * SLOTS + (word[u] & 15)), act[u] >= 2, sp.strategy, in_s[u], sp.epoch, sub);
     }
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
@@ -1090,8 +1256,10 @@ struct tfra_sparse_plan {
   unsigned* binmap = nullptr;
   unsigned* d_counts = nullptr;
   uint8_t* dflag = nullptr;
+  unsigned* slow_list = nullptr;   // [SLOW_CAP] keys the ownership pass of a write-back left to the general path
   unsigned* any_deferred = nullptr;   // = use_gen of the last write-back that deferred a key to its eviction phase
   mutable unsigned use_gen = 0;
+  mutable unsigned ups_uses = 0;   // upsert_planned uses: parity selects the left-over counter (SlowIter)
   float* partial = nullptr;
   bool armed = false;              // cursors/counters are zero (re-armed by the last kernel of the previous build)
   unsigned* host_counts = nullptr; // pinned: [0] generation of the last COMPLETED build, [1..6] its counts
@@ -1150,7 +1318,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
                  + al(nrec_c * REC_WORDS * 4) + al(nrec_h * REC_WORDS * 4)      // key records
                  + al(nbin * SEG * 4) + al(nbin * 32 * 4)                       // bins + run outputs
                  + al(npad * 4) + al(npad * 8) + al(nbin * 4)                   // keymap, dense keys, binmap
-                 + al(npad)                                                     // deferred flags
+                 + al(npad) + al((size_t)SLOW_CAP * 4)                          // deferred flags, left-over key list
                  + al(npart * (size_t)dim * 4);                                 // partial rows
   if (pl->bytes < bytes) {
     if (pl->buf) {
@@ -1187,6 +1355,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   pl->dkeys = (i64*)w; w += al(npad * 8);
   pl->binmap = (unsigned*)w; w += al(nbin * 4);
   pl->dflag = (uint8_t*)w; w += al(npad);
+  pl->slow_list = (unsigned*)w; w += al((size_t)SLOW_CAP * 4);
   pl->any_deferred = pl->d_counts + 8;
   pl->partial = (float*)w;
   pl->gen += 1;
@@ -1325,14 +1494,34 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   unsigned* tags = t->ensure_own_tags(s);    // nullptr (allocation failed): every key takes the general two-kernel path
   if (++t->own_gen == 0) t->own_gen = 1;     // bucket-owner tag of this launch (tags start at 0)
   const unsigned og = t->own_gen;
-  unsigned* any_slow = pl->d_counts + 9;
+  const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
+  unsigned* slow_ctr = pl->d_counts + 9 + par;
+  unsigned* next_ctr = pl->d_counts + 9 + (par ^ 1u);
+  // The remainder kernels walk the (short) list of keys the ownership pass left over: two keys of one batch sharing a
+  // home bucket, ~(2n)^2 / nb of them.  A small table makes that most of the batch: full grid (and without tags every
+  // key takes that path).
+  const double expect_slow = 4.0 * (double)pl->n * (double)pl->n / (double)t->cur.nb;
+  const unsigned rem_blocks = (tags && expect_slow < 2048.0) ? 32u : key_blocks;
+  const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !sc;
 #define TFRA_UPS(GG)                                                                                                          \
-  if (tags)                                                                                                                   \
-    upsert_own_kernel<GG, 4><<<(key_blocks + 3) / 4, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, any_slow, gen, og, \
-                                                                  tags, progress, progress_val);                             \
-  upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,     \
-                                                   tags ? any_slow : nullptr);                                               \
-  if (sp.bounded) upsert_evict_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen)
+  if (tags) {                                                                                                                 \
+    if (GG == 16 && simple)                                                                                                   \
+      upsert_own_kernel<16, true><<<(key_blocks + 3) / 4, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,        \
+                                                                       slow_ctr, pl->slow_list, gen, og, tags, progress,     \
+                                                                       progress_val);                                        \
+    else                                                                                                                      \
+      upsert_own_kernel<GG, false><<<(key_blocks + 3) / 4, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,       \
+                                                                        slow_ctr, pl->slow_list, gen, og, tags, progress,    \
+                                                                        progress_val);                                       \
+    upsert_rest_kernel<GG><<<rem_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, slow_ctr,               \
+                                                      pl->slow_list, next_ctr);                                              \
+  } else {                                                                                                                    \
+    upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,   \
+                                                     nullptr, pl->slow_list, nullptr);                                       \
+    if (sp.bounded)                                                                                                           \
+      upsert_evict_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,                  \
+                                                             pl->any_deferred, gen, nullptr, pl->slow_list, nullptr);        \
+  }
   switch (g) {
     case 16: TFRA_UPS(16); break;
     case 8: TFRA_UPS(8); break;

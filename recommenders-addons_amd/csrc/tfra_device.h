@@ -326,6 +326,31 @@ __device__ __forceinline__ void select_victim(u64 b0, u64 b1, const i64 (&kk2)[2
   }
 }
 
+// The same choice with ONE 16-lane reduction: every lane first takes the better of its b0 and b1 candidates (index
+// which*16 + sub: b0's slots order before b1's, the lower index wins ties — the order select_victim produces).
+__device__ __forceinline__ void select_victim_merged(u64 b0, u64 b1, const i64 (&kk2)[2], const i64 (&sc2)[2], int sub,
+                                                     int gshift, u64& best_score, u64& best_word, i64& best_key) {
+  u64 s0 = (u64)sc2[0], s1 = (u64)sc2[1];
+  if (kk2[0] == EMPTY_KEY) s0 = 0;
+  if (kk2[1] == EMPTY_KEY) s1 = 0;
+  if (sub >= SLOTS || kk2[0] == LOCKED_KEY) s0 = ~0ULL;
+  if (sub >= SLOTS || kk2[1] == LOCKED_KEY) s1 = ~0ULL;
+  u64 my = s0;
+  unsigned idx = (unsigned)sub;
+  if (s1 < s0) { my = s1; idx = 16u + (unsigned)sub; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const u64 os = ((u64)(unsigned)__shfl_xor((int)(my >> 32), o) << 32) | (unsigned)__shfl_xor((int)my, o);
+    const unsigned oi = (unsigned)__shfl_xor((int)idx, o);
+    if (os < my || (os == my && oi < idx)) { my = os; idx = oi; }
+  }
+  best_score = my;
+  const int src = gshift + (int)(idx & 15u);
+  const i64 ka = shfl_i64(kk2[0], src), kb = shfl_i64(kk2[1], src);
+  best_key = idx >= 16u ? kb : ka;
+  best_word = (idx >= 16u ? b1 : b0) * 16 + (idx & 15u);
+}
+
 // ---- eviction (Hkv strategies, table full): replace the minimum-score entry among the 30 slots
 // of the key's two home buckets — HKV's "in-bucket min-score eviction" (SURVEY.md appendix D;
 // behaviour pinned by T/hkv_hashtable_evict_test.py).  admit_always: LRU-type scores (a new key is

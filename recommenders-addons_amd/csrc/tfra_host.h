@@ -79,7 +79,7 @@ struct Table {
   int ensure_scratch(size_t bytes, hipStream_t s);
   int grow(u64 min_nb, hipStream_t s);
   int prepare_insert(size_t n, hipStream_t s);
-  int poll_density(hipStream_t s);
+  int poll_density(size_t n, hipStream_t s);
   int bounded_flags(size_t n, hipStream_t s, uint8_t** out);
 };
 

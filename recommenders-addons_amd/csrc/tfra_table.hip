@@ -781,7 +781,7 @@ int Table::grow(u64 min_nb, hipStream_t s) {
 // that the chance that both are full is < 1e-3 and a 4-bucket walk keeps every key: the reference never evicts at
 // load factor 0.5), so the OVF1 flags stop spreading while they are still rare, and find / insert put BOTH home
 // buckets' lines in flight at once.
-int Table::poll_density(hipStream_t s) {
+int Table::poll_density(size_t n, hipStream_t s) {
   if (dense) return TFRA_OK;  // monotone until clear()
   if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
@@ -793,7 +793,8 @@ int Table::poll_density(hipStream_t s) {
   // transition phase (a 1-block kernel): a caller that queues hundreds of calls ahead of the GPU (a bulk load)
   // would otherwise fill the table to capacity in 4-bucket-walk mode before the host ever sees a size, and every
   // later miss would walk the flags that left behind (measured: find 47 us instead of 17 us on a 10^9-slot table).
-  density_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1, d_dense, (i64)(0.6 * (double)(cur.nb * SLOTS)));
+  // (a call that could itself carry the table past the mark — a bulk load in one call — runs dense from its start)
+  density_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1, d_dense, (i64)(0.6 * (double)(cur.nb * SLOTS)) - (i64)n);
   if (!size_pending) {
     HIP_TRY(hipMemcpyAsync(h_size, d_scalar + 1, sizeof(i64), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(size_event, s));
@@ -818,7 +819,7 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
   if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
   // at max_capacity (eviction takes over) or after a failed growth there is nothing to decide
   const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb < std::max<u64>(2, opts.max_capacity / SLOTS));
-  if (!can_grow) return poll_density(s);
+  if (!can_grow) return poll_density(n, s);
   if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
     size_ub = (v < 0 ? 0 : (size_t)v) + n_since_read;
