@@ -1,0 +1,51 @@
+"""Extracts the op surface (names, inputs, outputs, attrs, statefulness) of the reference's `TFRA>HkvHashTable*` ops from
+R/.../core/ops/hkv_hashtable_ops.cc and the GPU kernel registrations from R/.../core/kernels/hkv_hashtable_op_gpu.cu.cc
+into tests/golden/hkv_op_surface.json (the reference tree is absent on the GPU box and in CI images).
+
+  python tests/golden/make_op_surface.py
+"""
+import json
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/tensorflow_recommenders_addons/dynamic_embedding/core"
+
+
+def parse_register_ops(text, prefix_macro=True):
+  """-> {op name: {inputs, outputs, attrs, stateful}} from REGISTER_OP(...) builder chains."""
+  ops = {}
+  for m in re.finditer(r"REGISTER_OP\(\s*([^)]*?\)?)\s*\)\s*((?:\s*\.\w+\((?:[^()]|\([^()]*\))*\))*)", text):
+    raw = m.group(1).strip()
+    mm = re.match(r'PREFIX_OP_NAME\((\w+)\)', raw)
+    name = ("TFRA>" + mm.group(1)) if mm else raw.strip('"')
+    chain = m.group(2)
+    d = {"inputs": re.findall(r'\.Input\("([^"]*)"\)', chain), "outputs": re.findall(r'\.Output\("([^"]*)"\)', chain),
+         "attrs": sorted(re.findall(r'\.Attr\("([^"]*)"\)', chain)), "stateful": ".SetIsStateful()" in chain}
+    ops[name] = d
+  return ops
+
+
+def parse_gpu_registrations(text):
+  """-> (sorted op names registered on DEVICE_GPU, sorted value types of the per-type registration macro)."""
+  names = set()
+  for m in re.finditer(r'Name\(\s*(?:PREFIX_OP_NAME\((\w+)\)|"([^"]+)")\s*\)[\s\\]*\.Device\(DEVICE_GPU\)', text):
+    names.add("TFRA>" + m.group(1) if m.group(1) else m.group(2))
+  types = set()
+  for m in re.finditer(r"^\s*(?:REGISTER_HKV_TABLE\(\s*int64\s*,|TFRA_REGISTER_HKV\()\s*([\w:]+)\s*\)\s*;", text, re.M):
+    types.add({"int8": "int8_t", "int32": "int32_t", "int64": "int64_t"}.get(m.group(1), m.group(1)))
+  return sorted(names), sorted(types)
+
+
+def main():
+  ops = parse_register_ops(open(os.path.join(REF, "ops", "hkv_hashtable_ops.cc")).read())
+  names, types = parse_gpu_registrations(open(os.path.join(REF, "kernels", "hkv_hashtable_op_gpu.cu.cc")).read())
+  out = {"source": ["core/ops/hkv_hashtable_ops.cc:133-339", "core/kernels/hkv_hashtable_op_gpu.cu.cc:809-811,1058-1138"],
+         "ops": ops, "gpu_kernels": names, "gpu_value_types": types}
+  with open(os.path.join(HERE, "hkv_op_surface.json"), "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+  print(len(ops), "ops;", len(names), "GPU kernels;", types)
+
+
+if __name__ == "__main__":
+  main()

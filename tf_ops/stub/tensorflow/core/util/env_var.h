@@ -1,0 +1,6 @@
+/* TEST-ONLY declarations, see framework/op_kernel.h. */
+#ifndef TFRA_STUB_TENSORFLOW_ENV_VAR_H_
+#define TFRA_STUB_TENSORFLOW_ENV_VAR_H_
+#include "tensorflow/core/framework/op_kernel.h"
+namespace tensorflow { Status ReadStringFromEnvVar(const std::string& name, const std::string& default_val, std::string* value); }
+#endif
