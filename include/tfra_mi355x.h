@@ -125,6 +125,11 @@ int tfra_table_clear(tfra_table_t* t, tfra_stream_t stream);
 int tfra_table_size(tfra_table_t* t, size_t* out, tfra_stream_t stream);
 /* device scalar result, no host sync (size_i64, :172-179) */
 int tfra_table_size_to_device(tfra_table_t* t, int64_t* d_out, tfra_stream_t stream);
+/* Keys the device could not place since the last check (table full at max_capacity with nothing evictable, rehash
+ * failure, a write-back plan whose internal capacity overflowed): returns TFRA_ERR_FULL with the count in
+ * tfra_last_error() and clears the counter; TFRA_OK when there were none.  Synchronises `stream`.  tfra_table_size
+ * performs the same check; the stream-ordered entry points never read the counter themselves. */
+int tfra_table_check_errors(tfra_table_t* t, tfra_stream_t stream);
 /* number of slots export_batch scans (= value to loop `offset` up to) */
 int tfra_table_capacity(tfra_table_t* t, size_t* out);
 /* introspection (tests, tools): out5 = {empty key slots, slots locked by an eviction in progress (0 whenever no
@@ -169,6 +174,14 @@ int tfra_table_find_field(tfra_table_t* t, int field, size_t n, const int64_t* k
                           tfra_stream_t stream);
 int tfra_table_insert_field(tfra_table_t* t, int field, size_t n, const int64_t* keys,
                             const void* values, uint32_t flags, tfra_stream_t stream);
+/* KV files of one state vector: the reference checkpoints every slot variable of create_slots as its own table
+ * (`<param>/<opt>/<slot>` -> `<param>_<opt>_<slot>_mht_<i>of<N>-keys/-values`); here the slot is field `field` of the
+ * parameter's rows.  Same format as tfra_table_save / _load (field 0 = the embedding itself).  Load the embedding
+ * first: a key that is not resident yet is created with the parameter's default row. */
+int tfra_table_save_field(tfra_table_t* t, int field, const char* prefix, size_t buffer_keys, int append,
+                          tfra_stream_t stream, size_t* n_saved);
+int tfra_table_load_field(tfra_table_t* t, int field, const char* prefix, size_t buffer_keys, tfra_stream_t stream,
+                          size_t* n_loaded);
 
 /* Fused sparse optimizer write-back: replaces (1+S) finds + dense apply + (1+S) upserts
  * (PY/dynamic_embedding_optimizer.py:165-204) with one pass over rows laid out [p|slot..].

@@ -28,10 +28,11 @@ struct File {
 
 extern "C" {
 
-int tfra_table_save(tfra_table_t* tp, const char* prefix, size_t buffer_keys, int append, tfra_stream_t stream,
-                    size_t* n_saved) {
+static int save_impl(tfra_table_t* tp, int field, const char* prefix, size_t buffer_keys, int append, tfra_stream_t stream,
+                     size_t* n_saved) {
   Table* t = reinterpret_cast<Table*>(tp);
   if (!t || !prefix) return set_error(TFRA_ERR_INVALID, "save: null argument");
+  if (field < 0 || field > t->opts.aux_fields) return set_error(TFRA_ERR_INVALID, "save: bad field");
   if (buffer_keys == 0) buffer_keys = 4194304;  // Python default buffer_size
   hipStream_t s = (hipStream_t)stream;
   size_t cap = 0;
@@ -63,12 +64,17 @@ int tfra_table_save(tfra_table_t* tp, const char* prefix, size_t buffer_keys, in
   for (size_t off = 0; off < cap; off += chunk) {
     size_t len = std::min(chunk, cap - off);
     if (hipMemsetAsync(d_cnt, 0, sizeof(size_t), s) != hipSuccess) { cleanup(); return set_error(TFRA_ERR_HIP, "save: memset"); }
-    rc = tfra_table_export_batch(tp, len, off, d_cnt, (int64_t*)d_keys, d_vals, nullptr, stream);
+    rc = tfra_table_export_batch(tp, len, off, d_cnt, (int64_t*)d_keys, field == 0 ? d_vals : nullptr, nullptr, stream);
     if (rc) { cleanup(); return rc; }
     (void)hipMemcpyAsync(h_cnt, d_cnt, sizeof(size_t), hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cleanup(); return set_error(TFRA_ERR_HIP, "save: sync"); }
     size_t got = *h_cnt;
     if (!got) continue;
+    if (field > 0) {   // a co-located state vector (optimizer slot): read it for the exported keys, same order
+      // every exported key is resident, so the default row is never used: any valid row-sized buffer will do
+      rc = tfra_table_find_field(tp, field, got, (const int64_t*)d_keys, d_vals, nullptr, d_vals, 1, stream);
+      if (rc) { cleanup(); return rc; }
+    }
     (void)hipMemcpyAsync(h_keys, d_keys, got * sizeof(i64), hipMemcpyDeviceToHost, s);
     (void)hipMemcpyAsync(h_vals, d_vals, got * fb, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cleanup(); return set_error(TFRA_ERR_HIP, "save: copy"); }
@@ -87,9 +93,20 @@ int tfra_table_save(tfra_table_t* tp, const char* prefix, size_t buffer_keys, in
   return TFRA_OK;
 }
 
-int tfra_table_load(tfra_table_t* tp, const char* prefix, size_t buffer_keys, tfra_stream_t stream, size_t* n_loaded) {
+int tfra_table_save(tfra_table_t* tp, const char* prefix, size_t buffer_keys, int append, tfra_stream_t stream,
+                    size_t* n_saved) {
+  return save_impl(tp, 0, prefix, buffer_keys, append, stream, n_saved);
+}
+
+int tfra_table_save_field(tfra_table_t* tp, int field, const char* prefix, size_t buffer_keys, int append,
+                          tfra_stream_t stream, size_t* n_saved) {
+  return save_impl(tp, field, prefix, buffer_keys, append, stream, n_saved);
+}
+
+static int load_impl(tfra_table_t* tp, int field, const char* prefix, size_t buffer_keys, tfra_stream_t stream, size_t* n_loaded) {
   Table* t = reinterpret_cast<Table*>(tp);
   if (!t || !prefix) return set_error(TFRA_ERR_INVALID, "load: null argument");
+  if (field < 0 || field > t->opts.aux_fields) return set_error(TFRA_ERR_INVALID, "load: bad field");
   if (buffer_keys == 0) buffer_keys = 4194304;
   hipStream_t s = (hipStream_t)stream;
   const size_t fb = t->field_bytes;
@@ -128,8 +145,12 @@ int tfra_table_load(tfra_table_t* tp, const char* prefix, size_t buffer_keys, tf
     }
     (void)hipMemcpyAsync(d_keys, h_keys, len * sizeof(i64), hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(d_vals, h_vals, len * fb, hipMemcpyHostToDevice, s);
-    // files written by save hold unique keys, but files concatenated by hand may not: stay safe
-    int rc = tfra_table_insert_or_assign(tp, len, (const int64_t*)d_keys, d_vals, nullptr, 0, stream);
+    // Files written by save hold unique keys; files concatenated by hand may not, so a growing table takes the
+    // duplicate-safe path (last one wins).  A bounded (Hkv) table at max_capacity needs one writer per key for its
+    // eviction (HKV's contract, tfra_table_insert_or_assign), so there the keys of a chunk are taken as unique.
+    const uint32_t flags = (t->opts.strategy >= 0 && t->opts.max_capacity) ? TFRA_FLAG_UNIQUE_KEYS : 0u;
+    int rc = field == 0 ? tfra_table_insert_or_assign(tp, len, (const int64_t*)d_keys, d_vals, nullptr, flags, stream)
+                        : tfra_table_insert_field(tp, field, len, (const int64_t*)d_keys, d_vals, flags, stream);
     if (rc) { cleanup(); return rc; }
     if (hipStreamSynchronize(s) != hipSuccess) { cleanup(); return set_error(TFRA_ERR_HIP, "load: sync"); }
     done += len;
@@ -137,6 +158,15 @@ int tfra_table_load(tfra_table_t* tp, const char* prefix, size_t buffer_keys, tf
   cleanup();
   if (n_loaded) *n_loaded = done;
   return TFRA_OK;
+}
+
+int tfra_table_load(tfra_table_t* tp, const char* prefix, size_t buffer_keys, tfra_stream_t stream, size_t* n_loaded) {
+  return load_impl(tp, 0, prefix, buffer_keys, stream, n_loaded);
+}
+
+int tfra_table_load_field(tfra_table_t* tp, int field, const char* prefix, size_t buffer_keys, tfra_stream_t stream,
+                          size_t* n_loaded) {
+  return load_impl(tp, field, prefix, buffer_keys, stream, n_loaded);
 }
 
 }  // extern "C"

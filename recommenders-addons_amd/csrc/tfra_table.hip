@@ -698,7 +698,7 @@ int Table::check_errors(hipStream_t s) {
   memcpy(&e, h_scalar, sizeof(unsigned));
   if (e) {
     HIP_TRY(hipMemsetAsync(err_count, 0, sizeof(unsigned), s));
-    return set_error(TFRA_ERR_FULL, std::to_string(e) + " keys could not be placed: table full at max_capacity");
+    return set_error(TFRA_ERR_FULL, std::to_string(e) + " keys could not be placed: table full at max_capacity (or a write-back plan overflowed)");
   }
   return TFRA_OK;
 }
@@ -1219,6 +1219,11 @@ int tfra_table_size_to_device(tfra_table_t* tp, int64_t* d_out, tfra_stream_t st
   size_kernel<<<1, SIZE_SHARDS, 0, s>>>(t->view_of(t->cur), (i64*)d_out);
   HIP_TRY(hipGetLastError());
   return TFRA_OK;
+}
+
+int tfra_table_check_errors(tfra_table_t* tp, tfra_stream_t stream) {
+  TABLE_ENTER();
+  return t->check_errors(s);
 }
 
 int tfra_table_slot_census(tfra_table_t* tp, uint64_t* out5, tfra_stream_t stream) {

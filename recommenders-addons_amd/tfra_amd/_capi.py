@@ -70,6 +70,7 @@ _SIGS = {
     "tfra_table_size": [_P, ctypes.POINTER(_SZ), _P],
     "tfra_table_size_to_device": [_P, _P, _P],
     "tfra_table_capacity": [_P, ctypes.POINTER(_SZ)],
+    "tfra_table_check_errors": [_P, _P],
     "tfra_table_slot_census": [_P, ctypes.POINTER(ctypes.c_uint64), _P],
     "tfra_table_reserve": [_P, _SZ, _P],
     "tfra_table_export_batch": [_P, _SZ, _SZ, _P, _P, _P, _P, _P],
@@ -77,6 +78,8 @@ _SIGS = {
     "tfra_table_set_option": [_P, _I, ctypes.c_int64],
     "tfra_table_save": [_P, ctypes.c_char_p, _SZ, _I, _P, ctypes.POINTER(_SZ)],
     "tfra_table_load": [_P, ctypes.c_char_p, _SZ, _P, ctypes.POINTER(_SZ)],
+    "tfra_table_save_field": [_P, _I, ctypes.c_char_p, _SZ, _I, _P, ctypes.POINTER(_SZ)],
+    "tfra_table_load_field": [_P, _I, ctypes.c_char_p, _SZ, _P, ctypes.POINTER(_SZ)],
     "tfra_table_apply_optimizer": [_P, ctypes.POINTER(OptParams), _SZ, _P, _P, _P, _I, _P, _P],
     "tfra_table_apply_sparse": [_P, ctypes.POINTER(OptParams), _SZ, _P, _P, _P, _P],
     "tfra_sparse_plan_create": [_I, _P],

@@ -165,8 +165,9 @@ class AllToAllEmbedding:
     out = self.return_rows(rows.reshape(served.numel(), -1))
     return out.reshape(shape + (out.shape[-1],))
 
-  def apply_gradients(self, optimizer, grads):
+  def apply_gradients(self, optimizer, grads, p=None):
     """Backward of the alltoall (Horovod's registered gradient) + local sparse write-back: the owner
-    sums what the ranks sent for one key (<= world parts when dedup) and applies one fused update."""
+    sums what the ranks sent for one key (<= world parts when dedup) and applies one fused update.
+    p: the step's parameters (`optimizer.begin_step()`) when several embeddings share the optimizer."""
     keys, g = self.route_grads(grads)
-    optimizer.apply_sparse(self.local, keys, g)
+    optimizer.apply_sparse(self.local, keys, g, p)

@@ -238,10 +238,16 @@ class DynamicEmbeddingOptimizer:
           "**DynamicEmbeddingOptimizer.variable_kwargs(opt)" %
           (var.name, var.aux_fields, type(self.opt).__name__, len(self.opt.slots)))
 
+  def begin_step(self):
+    """Advance the global step ONCE and return the step's hyper-parameters (Adam's bias-corrected lr_t ...): pass them
+    as `p` to every `apply_sparse` / `AllToAllEmbedding.apply_gradients` of the step when several tables share this
+    optimizer — TF increments `iterations` once per apply_gradients, not once per variable."""
+    self.iterations += 1
+    return self.opt.params(self.iterations)
+
   def apply_gradients(self, grads_and_vars, name=None):
     """grads_and_vars: iterable of (grad[N,dim], TrainableWrapper) — one global step for all pairs."""
-    self.iterations += 1
-    p = self.opt.params(self.iterations)
+    p = self.begin_step()
     for grad, tw in grads_and_vars:
       if not isinstance(tw, TrainableWrapper):
         raise TypeError("expected the TrainableWrapper returned by embedding_lookup(..., return_trainable=True)")
@@ -290,10 +296,10 @@ class DynamicEmbeddingOptimizer:
     return plan.build(ids)
 
   def apply_sparse(self, var, ids, grad, p=None, plan=None):
-    """Sum gradients of duplicate ids, then one fused update per unique key and shard."""
+    """Sum gradients of duplicate ids, then one fused update per unique key and shard.  p: the step's parameters from
+    `begin_step()`; None = this call IS the step (one variable per optimizer): the global step advances here."""
     if p is None:
-      self.iterations += 1
-      p = self.opt.params(self.iterations)
+      p = self.begin_step()
     self._check(var)
     if self.opt.kind is None:
       return self._apply_generic(var, ids, grad)

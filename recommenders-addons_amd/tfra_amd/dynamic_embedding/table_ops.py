@@ -247,6 +247,10 @@ class _DeviceTable:
     _capi.call("tfra_table_capacity", self._h, ctypes.byref(out))
     return out.value
 
+  def check_errors(self):
+    """Raises TfraError if the device dropped keys since the last check (table full, plan overflow); synchronises."""
+    _capi.call("tfra_table_check_errors", self._h, _stream(self.device))
+
   def slot_census(self):
     """{empty, locked, live, ovf0, ovf1}: key-slot and bucket-flag counts (introspection; synchronises)."""
     out = (ctypes.c_uint64 * 5)()
@@ -277,15 +281,18 @@ class _DeviceTable:
       raise RuntimeError("export: table changed during export (%d vs %d)" % (got, n))
     return keys, vals, scores
 
-  def save(self, prefix, buffer_size=4194304, append_to_file=False):
+  def save(self, prefix, buffer_size=4194304, append_to_file=False, field=0):
+    """field > 0: the co-located state vector `field` (an optimizer slot) in the same file format."""
+    self.check_errors()   # a sync point anyway: insert / apply failures must not pass silently into a checkpoint
     out = ctypes.c_size_t()
-    _capi.call("tfra_table_save", self._h, prefix.encode(), int(buffer_size), int(bool(append_to_file)),
+    _capi.call("tfra_table_save_field", self._h, int(field), prefix.encode(), int(buffer_size), int(bool(append_to_file)),
                _stream(self._device), ctypes.byref(out))
     return out.value
 
-  def load(self, prefix, buffer_size=4194304):
+  def load(self, prefix, buffer_size=4194304, field=0):
     out = ctypes.c_size_t()
-    _capi.call("tfra_table_load", self._h, prefix.encode(), int(buffer_size), _stream(self._device), ctypes.byref(out))
+    _capi.call("tfra_table_load_field", self._h, int(field), prefix.encode(), int(buffer_size), _stream(self._device),
+               ctypes.byref(out))
     return out.value
 
   def apply_optimizer(self, params, keys, grads, param_defaults, n_dev=None):

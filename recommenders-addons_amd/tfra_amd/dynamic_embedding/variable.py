@@ -250,33 +250,66 @@ class Variable:
       return self._tables[index].size()
     return torch.stack([t.size().to(self._primary) for t in self._tables]).sum()
 
-  def save_to_file_system(self, dirpath, proc_size=1, proc_rank=0, buffer_size=4194304):
-    """Per-shard files `<name>_mht_<i>of<N>[_rank<r>_size<s>]-keys/-values`
-    (PY/dynamic_embedding_variable.py:1009-1060)."""
-    for idx, t in enumerate(self._tables):
-      fname = self._make_name(idx)
-      if proc_size > 1:
-        fname += "_rank{}_size{}".format(proc_rank, proc_size)
-      t.save_to_file_system(dirpath, file_name=fname, dirpath_env=None, buffer_size=buffer_size)
+  def _slot_file_names(self, optimizer):
+    """{field: base file name} of the co-located state vectors.  With the optimizer: the reference's slot-variable
+    names `<param>/<opt>/<slot>` (create_slots, PY/dynamic_embedding_optimizer.py:870-904; each is a table of its own
+    there and is checkpointed as `<param>_<opt>_<slot>_mht_<i>of<N>`), else `<param>_slot<f>`."""
+    if optimizer is not None:
+      return {v.field: v.name.replace("/", "_") for v in self.get_slot_variables(optimizer)}
+    return {f: "%s_slot%d" % (self.name.replace("/", "_"), f) for f in range(1, self.aux_fields + 1)}
 
-  def load_from_file_system(self, dirpath, proc_size=1, proc_rank=0, buffer_size=4194304):
-    """Reload; when the shard count changed, every `_mht_` file is re-read and re-partitioned
-    through partition_fn (PY/dynamic_embedding_variable.py:200-450, 1062-1131)."""
+  def save_to_file_system(self, dirpath, proc_size=1, proc_rank=0, buffer_size=4194304, optimizer=None):
+    """Per-shard files `<name>_mht_<i>of<N>[_rank<r>_size<s>]-keys/-values`
+    (PY/dynamic_embedding_variable.py:1009-1060) — and the same for every optimizer slot of the rows (the reference
+    saves its slot variables as tables of their own; not saving them would silently reset Adam's m / v, Adagrad's and
+    FTRL's accumulators on restore)."""
     import os
-    files = sorted(f[:-len("-keys")] for f in os.listdir(dirpath)
-                   if f.endswith("-keys") and f.startswith(self.name.replace("/", "_") + "_mht_"))
+    suffix = "_rank{}_size{}".format(proc_rank, proc_size) if proc_size > 1 else ""
+    slots = self._slot_file_names(optimizer)
+    for idx, t in enumerate(self._tables):
+      t.save_to_file_system(dirpath, file_name=self._make_name(idx) + suffix, dirpath_env=None, buffer_size=buffer_size)
+      for f, base in slots.items():
+        t._table.save(os.path.join(dirpath, "{}_mht_{}of{}{}".format(base, idx + 1, self.shard_num, suffix)), buffer_size,
+                      field=f)
+
+  def load_from_file_system(self, dirpath, proc_size=1, proc_rank=0, buffer_size=4194304, optimizer=None):
+    """Reload; when the shard count changed, every `_mht_` file is re-read and re-partitioned
+    through partition_fn (PY/dynamic_embedding_variable.py:200-450, 1062-1131).  Slot files written by
+    save_to_file_system are restored into the rows' state vectors after the embedding itself."""
+    import os
+    import numpy as np
+    own = self.name.replace("/", "_") + "_mht_"
+    files = sorted(f[:-len("-keys")] for f in os.listdir(dirpath) if f.endswith("-keys") and f.startswith(own))
+    slots = self._slot_file_names(optimizer)
+
+    def slot_files(base):
+      return sorted(f[:-len("-keys")] for f in os.listdir(dirpath) if f.endswith("-keys") and f.startswith(base + "_mht_"))
+
     same = all(self._make_name(i) in files for i in range(self.shard_num)) and len(files) == self.shard_num
     if same and proc_size == 1:
       for idx, t in enumerate(self._tables):
         t.load_from_file_system(dirpath, file_name=self._make_name(idx), dirpath_env=None, buffer_size=buffer_size)
+        for f, base in slots.items():
+          p = os.path.join(dirpath, "{}_mht_{}of{}".format(base, idx + 1, self.shard_num))
+          if os.path.exists(p + "-keys"):
+            t._table.load(p, buffer_size, field=f)
       return
-    import numpy as np
     self.clear()
-    for f in files:
-      keys = np.fromfile(os.path.join(dirpath, f + "-keys"), dtype=np.int64)
-      vals = torch.from_numpy(np.fromfile(os.path.join(dirpath, f + "-values"), dtype=np.uint8)).view(
+    for fn in files:
+      keys = np.fromfile(os.path.join(dirpath, fn + "-keys"), dtype=np.int64)
+      vals = torch.from_numpy(np.fromfile(os.path.join(dirpath, fn + "-values"), dtype=np.uint8)).view(
           self.value_dtype).reshape(-1, self.dim)
       self.upsert(torch.from_numpy(keys).to(self._primary), vals.to(self._primary))
+    for f, base in slots.items():   # re-sharded restore of the state vectors: through the same partitioner
+      for fn in slot_files(base):
+        keys = torch.from_numpy(np.fromfile(os.path.join(dirpath, fn + "-keys"), dtype=np.int64)).to(self._primary)
+        vals = torch.from_numpy(np.fromfile(os.path.join(dirpath, fn + "-values"), dtype=np.uint8)).view(
+            self.value_dtype).reshape(-1, self.dim).to(self._primary)
+        kp, perm, counts = self._partition(keys)
+        vp = self._split_rows(vals, perm, counts)
+        for i, t in enumerate(self._tables):
+          if kp[i].numel():
+            t._table.upsert(kp[i].to(t._device), vp[i].to(t._device), field=f)
 
 
 _VARIABLES = {}

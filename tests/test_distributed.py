@@ -92,7 +92,7 @@ class _SgdOpt:
   def __init__(self, lr):
     self.lr = lr
 
-  def apply_sparse(self, shard, ids, grads):
+  def apply_sparse(self, shard, ids, grads, p=None):
     from oracle import optimizers as oopt
     uniq, g, _ = oopt.segment_sum_by_key(ids.numpy(), grads.numpy())
     p = shard.t.find(uniq, np.full(shard.dim, -1.0, np.float32))
