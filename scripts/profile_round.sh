@@ -1,13 +1,18 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round: kernel-trace stats + PMC passes (separately, as the
-# MI355X guide prescribes).  Usage: bash scripts/profile_round.sh r01   (on the GPU box, via gpurun)
-TAG=${1:-r01}
+# Collects the rocprofv3 evidence for one round: per workload (c3 = the default bench line, c2 = its secondary) a
+# kernel-trace + stats run and separate PMC passes (as MI355X_MICROARCH.md prescribes; gpurun refuses --pmc combined
+# with API tracing).   Usage (on the GPU box, via gpurun):  bash scripts/profile_round.sh r02 ["c3 c2"]
+TAG=${1:-r02}
+WORKLOADS=${2:-"c3 c2"}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python /root/repo/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-  N=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -o $TAG -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_pmc_$N.log 2>&1
+for W in $WORKLOADS; do
+  ARGS="--config $W --no-secondary --no-cpu-baseline"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_trace -o $TAG -- python /root/repo/bench.py $ARGS --steps 100 --warmup 10 > $OUT/${W}_bench_trace.log 2>&1
+  for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-24)
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${W}_pmc_$N -o $TAG -- python /root/repo/bench.py $ARGS --steps 20 --warmup 5 > $OUT/${W}_bench_pmc_$N.log 2>&1
+  done
 done
-ls -R $OUT | head -40
+ls $OUT

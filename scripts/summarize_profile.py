@@ -1,11 +1,12 @@
-"""Turns the rocprofv3 output of scripts/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked
-evidence files profiles/<tag>_kernel_stats.csv and profiles/<tag>_summary.json.
+"""Turns the rocprofv3 output of scripts/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked evidence files
+profiles/<tag>_<workload>_kernel_stats.csv and profiles/<tag>_summary.json.
 
-  python scripts/summarize_profile.py r01
+  python scripts/summarize_profile.py r02
 
-HBM traffic per launch = FETCH_SIZE + WRITE_SIZE from the separate --pmc passes, corrected as
-MI355X_MICROARCH.md prescribes (values are KiB; gfx950 reports half of the wide coalesced reads, so
-FETCH_SIZE is doubled)."""
+HBM traffic per launch = FETCH_SIZE + WRITE_SIZE from the separate --pmc passes, corrected as MI355X_MICROARCH.md
+prescribes (values are KiB; gfx950 reports half of the wide coalesced reads, so FETCH_SIZE is doubled).  The SQ pass
+gives instructions and wave cycles per launch (quad-cycle units): what shows that the write-back kernels are bound by
+instruction issue and dependent round trips, not by bytes."""
 import csv
 import json
 import os
@@ -14,31 +15,41 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["insert_unique_kernel", "bucket_merge_kernel", "tile_reduce_kernel", "find_kernel", "apply_kernel",
-           "tile_reduce_kernel<plan>", "bucket_merge_kernel<plan>", "tile_sums_kernel", "bucket_sums_kernel"]
+KERNELS = ["find_kernel", "upsert_own_kernel", "upsert_rest_kernel", "upsert_csr_kernel", "upsert_evict_csr_kernel", "insert_unique_kernel",
+           "insert_evict_kernel", "export_kernel", "csr_tile_kernel", "csr_bucket_kernel", "csr_scatter_kernel", "hot_sums_kernel",
+           "apply_csr_kernel", "apply_kernel", "density_kernel"]
+COMMANDS = {"c3": "python bench.py --config c3 --no-secondary --no-cpu-baseline", "c2": "python bench.py --config c2 --no-secondary --no-cpu-baseline"}
 
 
 def short(name):
-  m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
-  if not m:
+  m = re.search(r"(\w+_kernel)\b", name)
+  return m.group(1) if m and m.group(1) in KERNELS else None
+
+
+def counter_avg(path, names):
+  acc = {}
+  if not os.path.exists(path):
+    return acc
+  with open(path) as f:
+    for row in csv.DictReader(f):
+      k = short(row["Kernel_Name"])
+      if k and row["Counter_Name"] in names:
+        a = acc.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, set()])
+        a[0] += float(row["Counter_Value"])
+        a[1].add(row["Dispatch_Id"])
+  return {k: {c: v[0] / max(len(v[1]), 1) for c, v in d.items()} for k, d in acc.items()}
+
+
+def workload(src, tag, w, out_dir):
+  stats = os.path.join(src, w + "_trace", tag + "_kernel_stats.csv")
+  if not os.path.exists(stats):
     return None
-  k = m.group(1)
-  if k in ("tile_reduce_kernel", "bucket_merge_kernel") and m.group(2) and "true" in m.group(2):
-    k += "<plan>"   # id-only half (tfra_sparse_plan_build)
-  return k
-
-
-def main():
-  tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-  src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-  out_dir = os.path.join(ROOT, "profiles")
-  os.makedirs(out_dir, exist_ok=True)
-  shutil.copy(os.path.join(src, "trace", tag + "_kernel_stats.csv"), os.path.join(out_dir, tag + "_kernel_stats.csv"))
+  shutil.copy(stats, os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, w)))
   kernels = {}
-  with open(os.path.join(src, "trace", tag + "_kernel_stats.csv")) as f:
+  with open(stats) as f:
     for row in csv.DictReader(f):
       k = short(row["Name"])
-      if k in KERNELS:
+      if k:
         d = kernels.setdefault(k, {"calls": 0, "total_ns": 0, "min_us": 1e30, "max_us": 0})
         d["calls"] += int(row["Calls"])
         d["total_ns"] += int(row["TotalDurationNs"])
@@ -47,50 +58,51 @@ def main():
   for d in kernels.values():
     d["avg_us"] = round(d.pop("total_ns") / d["calls"] / 1e3, 2)
     d["min_us"], d["max_us"] = round(d["min_us"], 2), round(d["max_us"], 2)
-
-  def counter_avg(sub, names):
-    acc = {}
-    path = os.path.join(src, sub, tag + "_counter_collection.csv")
-    if not os.path.exists(path):
-      return acc
-    with open(path) as f:
-      for row in csv.DictReader(f):
-        k = short(row["Kernel_Name"])
-        if k in KERNELS and row["Counter_Name"] in names:
-          a = acc.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, set()])
-          a[0] += float(row["Counter_Value"])
-          a[1].add(row["Dispatch_Id"])
-    return {k: {c: v[0] / max(len(v[1]), 1) for c, v in d.items()} for k, d in acc.items()}
-
-  fetch = counter_avg("pmc_FETCH_SIZE", {"FETCH_SIZE"})
-  write = counter_avg("pmc_WRITE_SIZE", {"WRITE_SIZE"})
-  tcc = counter_avg("pmc_TCC_HIT_sum_TCC_MISS_sum", {"TCC_HIT_sum", "TCC_MISS_sum"})
+  cc = lambda sub: os.path.join(src, "%s_pmc_%s" % (w, sub), tag + "_counter_collection.csv")
+  fetch = counter_avg(cc("FETCH_SIZE"), {"FETCH_SIZE"})
+  write = counter_avg(cc("WRITE_SIZE"), {"WRITE_SIZE"})
+  tcc = counter_avg(cc("TCC_HIT_sum_TCC_MISS_sum"), {"TCC_HIT_sum", "TCC_MISS_sum"})
+  sqn = {"SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VMEM"}
+  sq = counter_avg(cc("SQ_WAVES_SQ_INSTS_VALU_S"), sqn)
   for k, d in kernels.items():
-    f = fetch.get(k, {}).get("FETCH_SIZE")
-    w = write.get(k, {}).get("WRITE_SIZE")
-    if f is not None and w is not None:
-      d["FETCH_SIZE_KiB_raw"] = round(f, 1)
-      d["WRITE_SIZE_KiB"] = round(w, 1)
-      d["hbm_bytes_per_launch_corrected"] = int((2 * f + w) * 1024)
+    f, wr = fetch.get(k, {}).get("FETCH_SIZE"), write.get(k, {}).get("WRITE_SIZE")
+    if f is not None and wr is not None:
+      d["FETCH_SIZE_KiB_raw"], d["WRITE_SIZE_KiB"] = round(f, 1), round(wr, 1)
+      d["hbm_bytes_per_launch_corrected"] = int((2 * f + wr) * 1024)
     t = tcc.get(k)
     if t and (t.get("TCC_HIT_sum", 0) + t.get("TCC_MISS_sum", 0)) > 0:
       d["l2_hit_rate"] = round(t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"]), 3)
-  summary = {
-      "round": int(re.sub(r"\D", "", tag) or 0),
-      "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline  [default "
-                 "--plan prefetch: tile_sums/bucket_sums/apply on the main stream, <plan> kernels on the second stream; its "
-                 "secondary fused-call loop contributes tile_reduce/bucket_merge]  (+ separate "
-                 "--pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum passes, --steps 20)  [scripts/profile_round.sh, "
-                 "scripts/summarize_profile.py]",
-      "workload": "BASELINE configs[1]: 100M keys, dim 64 fp32 [p|m|v], Zipf-1.2 batch 131072",
-      "kernels": kernels,
-      "note": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
-              "coalesced reads). apply_kernel mixes the INDIRECT launches of the step with the direct ones bench.py times "
-              "separately.",
-  }
+    s = sq.get(k)
+    if s and s.get("SQ_WAVES"):
+      wv = s["SQ_WAVES"]
+      d["sq_per_wave"] = {"waves_per_launch": round(wv), "valu": round(s.get("SQ_INSTS_VALU", 0) / wv), "salu": round(s.get("SQ_INSTS_SALU", 0) / wv),
+                          "vmem": round(s.get("SQ_INSTS_VMEM", 0) / wv, 1), "wave_quad_cycles": round(s.get("SQ_WAVE_CYCLES", 0) / wv),
+                          "wait_any_frac": round(s.get("SQ_WAIT_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), 3),
+                          "issue_stall_frac": round(s.get("SQ_WAIT_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), 3),
+                          "active_frac": round(s.get("SQ_ACTIVE_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), 3)}
+  return {"command": "rocprofv3 --kernel-trace --stats -- %s --steps 100 --warmup 10  (+ separate --pmc passes FETCH_SIZE / WRITE_SIZE / "
+                     "TCC_HIT_sum TCC_MISS_sum / SQ_*, --steps 20 --warmup 5)" % COMMANDS[w],
+          "kernels": kernels}
+
+
+def main():
+  tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+  src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+  out_dir = os.path.join(ROOT, "profiles")
+  os.makedirs(out_dir, exist_ok=True)
+  summary = {"round": int(re.sub(r"\D", "", tag) or 0), "script": "scripts/profile_round.sh + scripts/summarize_profile.py", "workloads": {},
+             "note": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads). "
+                     "Kernel averages mix the timed steps with the per-kernel timing loops of bench.py (same kernels, same shapes) and, for "
+                     "insert_unique_kernel / insert_evict_kernel, are the 4 M-key pre-fill launches.  sq_per_wave: SQ_* counters per wave "
+                     "(wave_quad_cycles in 4-cycle units; wait_any = parked on s_waitcnt, issue_stall = dependency / pipe stalls)."}
+  for w in ("c3", "c2"):
+    r = workload(src, tag, w, out_dir)
+    if r:
+      summary["workloads"][w] = r
   with open(os.path.join(out_dir, tag + "_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
-  print(json.dumps({k: (v["avg_us"], v.get("hbm_bytes_per_launch_corrected")) for k, v in kernels.items()}))
+  for w, r in summary["workloads"].items():
+    print(w, json.dumps({k: (v["avg_us"], v.get("hbm_bytes_per_launch_corrected")) for k, v in r["kernels"].items()}))
 
 
 if __name__ == "__main__":
