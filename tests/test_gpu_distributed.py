@@ -1,0 +1,88 @@
+"""A15 / (e) with world_size 2 ON THE DEVICE: two processes share cuda:0, each owns the HIP table of its key-hash shard
+and runs the real front-end kernels (tfra_unique / tfra_partition / tfra_reduce_by_key / gather / scatter); the
+collectives go through gloo, staged over the host (RCCL needs one GPU per rank; the N>1 route itself — split sizes,
+owner-major order, the way back, the gradient route — is the same code).  Checked against ONE oracle table that sees
+the union of both ranks' batches: lookups bit-exact, the SGD write-back to <= 1e-6.
+
+Reference: PY/shadow_embedding_ops.py:397-447 (__alltoall_embedding_lookup__), python/kernel_tests/
+horovod_sync_train_test.py:265-376 (sharded training equals the single-table result)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+DIM, STEPS, LR = 8, 3, 0.5
+
+
+def _batch(rank, step):
+  rng = np.random.default_rng(1000 * step + rank)
+  ids = (rng.zipf(1.3, size=(4, 700 + 90 * rank)).astype(np.int64) % 5000) * 7919 - 12345   # negative keys too
+  g = (rng.standard_normal((ids.size, DIM)) * 0.01).astype(np.float32)   # synthetic gradients N(0, 1e-2)
+  return ids, g
+
+
+def _worker(rank, world, port, dedup, out_dir):
+  import torch
+  import torch.distributed as dist
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
+  os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+  try:
+    opt = de.optimizers.SGD(LR)
+    var = de.Variable(dim=DIM, name="a2a_w2_r%d_%d" % (rank, dedup), initializer=0.5, devices=["cuda:0"],
+                      **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    emb = AllToAllEmbedding(var, partition_mode=0, dedup=bool(dedup))
+    assert emb.world == 2 and not emb.passthrough
+    looked = []
+    for step in range(STEPS):
+      ids, g = _batch(rank, step)
+      out = emb.lookup(torch.from_numpy(ids).cuda())
+      looked.append(out.cpu().numpy())
+      emb.apply_gradients(deo, torch.from_numpy(g).cuda())
+    k, v = var.export()
+    k = k.cpu().numpy()
+    assert np.all(((k & 0x7FFFFFFF) % world) == rank)   # default_partition_fn, CUDA-build branch: this shard's keys only
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), keys=k, vals=v.cpu().numpy(), **{"look%d" % i: x for i, x in enumerate(looked)})
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dedup", [1, 0])
+def test_alltoall_world2_real_tables_one_gpu(dedup, tmp_path):
+  import torch
+  import torch.multiprocessing as mp
+  import oracle
+  from oracle import optimizers as oopt
+  assert torch.cuda.is_available()
+  world, port = 2, 29960 + dedup
+  mp.spawn(_worker, args=(world, port, dedup, str(tmp_path)), nprocs=world, join=True)
+  res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+  # the oracle: one table, per step every rank looks up first (synchronous training), then all gradients are applied
+  tab = oracle.CpuTable(DIM)
+  dflt = np.full(DIM, 0.5, np.float32)
+  for step in range(STEPS):
+    batches = [_batch(r, step) for r in range(world)]
+    for r, (ids, g) in enumerate(batches):
+      want = tab.find(ids.reshape(-1), dflt).reshape(ids.shape + (DIM,))
+      np.testing.assert_allclose(res[r]["look%d" % step], want, rtol=1e-6, atol=1e-6)
+    all_ids = np.concatenate([b[0].reshape(-1) for b in batches])
+    all_g = np.concatenate([b[1] for b in batches])
+    uniq, gsum, _ = oopt.segment_sum_by_key(all_ids, all_g)
+    tab.insert(uniq, oopt.sgd(tab.find(uniq, dflt), gsum, LR))
+  ek, ev = tab.export_sorted()
+  gk = np.concatenate([r["keys"] for r in res])
+  gv = np.concatenate([r["vals"] for r in res])
+  o = np.argsort(gk)
+  np.testing.assert_array_equal(gk[o], ek)            # every key lives on exactly one shard
+  np.testing.assert_allclose(gv[o], ev, rtol=1e-6, atol=1e-6)
