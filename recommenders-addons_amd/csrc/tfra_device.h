@@ -9,9 +9,10 @@
 //     +hdr  15 rows x row_stride bytes, row_stride = 16-B multiple of (1+aux_fields)*dim*sizeof(V):
 //                        [embedding | slot1 | slot2 ...] co-located so a fused optimizer touches
 //                        one contiguous segment.
-//   A key's line, its score and its row live in the SAME block (4096 B for 256-B rows with scores),
-//   i.e. in the same page: one address translation per key instead of three.  On a 10^9-slot table
-//   (273 GB) every random access is a TLB miss, and translations — not bytes — bound the kernels.
+//   A key's line, its score and its row live in the SAME block (4096 B for 256-B rows with scores).
+//   (Measured, scripts/mb/tlb_probe.hip: on a 264-GiB allocation a dependent row read costs the same in the
+//   same 4-KiB block as anywhere else — address translation does not bound these kernels; instruction issue
+//   and the number of dependent round trips do.  The block layout is kept because it costs nothing.)
 //   side rows: 2 rows behind the last block = store for the two key values used as sentinels.
 //
 // Probe sequence of key k: b0 = mulhi(fmix64(k), nb); b1 = mulhi(fmix64(h^C), nb) (!= b0);
@@ -240,7 +241,7 @@ __device__ __forceinline__ i64 probe_find(const TableView& v, i64 key, int sub, 
 // a miss on a table running at capacity costs two lines, not an ever longer walk.  When neither the key nor an
 // empty slot is found the function returns NEED_EVICT (-2) and the caller replaces the minimum-score entry of the
 // two home buckets.  `k_second` (optional) = b1's line, preloaded by callers that expect to need it: both home
-// buckets are then in flight together instead of one address translation after the other.
+// buckets are then in flight together instead of one round trip after the other.
 constexpr i64 NEED_EVICT = -2;
 __device__ __forceinline__ i64 locate_or_claim_from(const TableView& v, i64 key, u64 h, u64 b0, i64 k_first,
                                                     int sub, int gshift, bool& is_new, int bounded = 0,

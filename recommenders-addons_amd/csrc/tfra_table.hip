@@ -27,7 +27,7 @@ typedef tfra::AuxInitPod AuxInit;  // elem_bytes = sizeof(V); pattern[f] = aux_i
 // ---- find (+ fused default fill, + exists) -------------------------------------------------
 // PF1: also put the SECOND home bucket's line of every key in flight with the first (a bounded table running
 // near capacity: most b0 lines are full and flagged, ~1/3 of the resident keys and every miss need b1, and on
-// a table of hundreds of GB each line is its own address translation — two in flight beat two in a row).
+// a loaded memory round trip is ~2 us — two in flight beat two in a row).
 template <int G, int U, bool WT = (G == 16), bool PF1 = false>
 __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const i64* __restrict__ keys,
                                                    unsigned char* __restrict__ out,
