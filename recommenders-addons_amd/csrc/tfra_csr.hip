@@ -959,89 +959,98 @@ __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, cons
 // claim (two keys of one batch sharing a home bucket: ~(2U)^2/nb of them) or whose search cannot be decided from the
 // two home buckets (walk flags set) are marked `slow` and go through upsert_csr_kernel + upsert_evict_csr_kernel, which
 // run afterwards and look only at marked keys.
-// The keys the ownership pass leaves over (its list; the flags when the list overflowed), ONE pass with the locked
-// protocol for every kind of write: locate or claim the key's slot, LOCK it (CAS key -> LOCKED: a concurrent evictor of
-// this pass may have taken it, then start over), or lock a victim (evict_and_lock); write row and score write-through,
-// publish the key.  With every writer of the pass holding its slot locked, an assign can no longer race with the
-// eviction of the same slot, which is what the two separate kernels (assign / claim, then evict) are for when they
-// handle a whole batch — and a batch's few dozen left-over keys cost one kernel boundary instead of two.
+// One left-over key with the locked protocol for every kind of write: locate or claim the key's slot, LOCK it (CAS key
+// -> LOCKED: a concurrent evictor of this pass may have taken it, then start over), or lock a victim (evict_and_lock);
+// write row and score write-through, publish the key.  With every writer of the pass holding its slot locked, an assign
+// can no longer race with the eviction of the same slot, which is what the two separate kernels (assign / claim, then
+// evict) are for when they handle a whole batch.
+template <int G>
+__device__ __forceinline__ void locked_upsert_one(const TableView& v, const unsigned char* __restrict__ vals,
+                                                  const u64* __restrict__ scores, const CsrKeys& ks, const AuxInitPod& ai,
+                                                  const ScoreP& sp, unsigned g, int sub, int gshift, int& fresh, int& failed) {
+  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
+  const i64 key = ks.dkeys[g];
+  bool hot;
+  const unsigned w = load_record(ks, g, sub, hot);
+  const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+  unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3));
+  if (hot) last = ks.hent[last];
+  last &= E_POS;
+  const u64 in_one = scores ? scores[last] : 1;
+  const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+  const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score;
+  i64 row = -1;
+  u64 word = 0;
+  bool is_new = false, evicted = false, side = false;
+  for (int attempt = 0; attempt < 64 && row < 0; ++attempt) {
+    u64 h;
+    const u64 b0 = bucket0(key, v.nb, h);
+    const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+    bool claimed = false;
+    i64 r = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, claimed, sp.bounded);
+    if (r == NEED_EVICT) {
+      bool ce = false;
+      u64 wd = 0;
+      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce);
+      if (r == -1) break;                        // not admitted (its score is below every resident one): dropped
+      if (r == -3) { failed += (sub == 0); break; }
+      row = r; word = wd; is_new = true; evicted = !ce;
+      fresh += (ce && sub == 0);
+      break;
+    }
+    if (r < 0) { failed += (sub == 0); break; }
+    fresh += (claimed && sub == 0);
+    is_new = is_new || claimed;
+    if (r >= (i64)(v.nb * SLOTS)) { row = r; side = true; break; }   // sentinel keys live in the side rows: nothing evicts there
+    u64 rb;
+    unsigned rs;
+    split_row((u64)r, rb, rs);
+    const u64 wd = rb * 16 + rs;
+    i64 old = 0;
+    if (sub == 0) old = (i64)atomicCAS((u64*)key_word(v, wd), (u64)key, (u64)LOCKED_KEY);
+    old = shfl_i64(old, gshift);
+    if (old == key) { row = r; word = wd; }   // else: an evictor of this pass took the slot; look again
+  }
+  if (row < 0) return;
+  unsigned char* pr = row_ptr(v, row);
+  copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
+  if (is_new) {
+    for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of the new row start at aux_init
+      const unsigned pat = ai.pattern[(f - 1) & 3];
+      unsigned char* q = pr + f * v.field_bytes;
+      if ((v.field_bytes & 3) == 0)
+        for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
+          __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        for (unsigned off = sub; off < v.field_bytes; off += 16)
+          __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (side) return;
+  if (evicted && sub == 0) store_wt8(score_word(v, word), 0);   // the slot starts a new life
+  update_score<true>(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
+  publish_key(v, word, key, sub);
+}
+
+struct OwnCtrs;
+// The keys the ownership pass leaves over (its list; the flags when the list overflowed) when that pass does not take them
+// itself (small tables, where they are most of the batch): ONE pass of locked_upsert_one.
 template <int G>
 __global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                           const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
                                                           ScoreP sp, const uint8_t* __restrict__ dflag,
                                                           const unsigned* slow_ctr, const unsigned* __restrict__ slow_list,
-                                                          unsigned* zero_ctr) {
+                                                          unsigned* zero4) {
   const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0;   // last kernel of this use: arm the next use's counter
+  if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
   if (it.n == 0) return;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
-  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
   for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
     const unsigned g = it.listed ? slow_list[i] : i;
     if (dflag[g] != 4) continue;
-    const i64 key = ks.dkeys[g];
-    bool hot;
-    const unsigned w = load_record(ks, g, sub, hot);
-    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
-    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3));
-    if (hot) last = ks.hent[last];
-    last &= E_POS;
-    const u64 in_one = scores ? scores[last] : 1;
-    const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-    const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score;
-    i64 row = -1;
-    u64 word = 0;
-    bool is_new = false, evicted = false, side = false;
-    for (int attempt = 0; attempt < 64 && row < 0; ++attempt) {
-      u64 h;
-      const u64 b0 = bucket0(key, v.nb, h);
-      const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
-      bool claimed = false;
-      i64 r = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, claimed, sp.bounded);
-      if (r == NEED_EVICT) {
-        bool ce = false;
-        u64 wd = 0;
-        r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce);
-        if (r == -1) break;                        // not admitted (its score is below every resident one): dropped
-        if (r == -3) { failed += (sub == 0); break; }
-        row = r; word = wd; is_new = true; evicted = !ce;
-        fresh += (ce && sub == 0);
-        break;
-      }
-      if (r < 0) { failed += (sub == 0); break; }
-      fresh += (claimed && sub == 0);
-      is_new = is_new || claimed;
-      if (r >= (i64)(v.nb * SLOTS)) { row = r; side = true; break; }   // sentinel keys live in the side rows: nothing evicts there
-      u64 rb;
-      unsigned rs;
-      split_row((u64)r, rb, rs);
-      const u64 wd = rb * 16 + rs;
-      i64 old = 0;
-      if (sub == 0) old = (i64)atomicCAS((u64*)key_word(v, wd), (u64)key, (u64)LOCKED_KEY);
-      old = shfl_i64(old, gshift);
-      if (old == key) { row = r; word = wd; }   // else: an evictor of this pass took the slot; look again
-    }
-    if (row < 0) continue;
-    unsigned char* pr = row_ptr(v, row);
-    copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
-    if (is_new) {
-      for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of the new row start at aux_init
-        const unsigned pat = ai.pattern[(f - 1) & 3];
-        unsigned char* q = pr + f * v.field_bytes;
-        if ((v.field_bytes & 3) == 0)
-          for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
-            __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-          for (unsigned off = sub; off < v.field_bytes; off += 16)
-            __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (side) continue;
-    if (evicted && sub == 0) store_wt8(score_word(v, word), 0);   // the slot starts a new life
-    update_score<true>(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
-    publish_key(v, word, key, sub);
+    locked_upsert_one<G>(v, vals, scores, ks, ai, sp, g, sub, gshift, fresh, failed);
   }
   for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
   if (lane == 0) {
@@ -1057,180 +1066,218 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const uns
 // (the scalar results reach the group by shuffle).  Instruction issue, not HBM, bounds these kernels: with everything
 // computed per group the kernel was 4100 instructions per 16 keys and took 41 us for 78 K keys.
 // SIMPLE: the common shape — rows without optimizer slots, LRU scores, no caller scores — with everything else compiled out.
+// One batch of 16 keys of one wave (own_batch16).
+struct OwnArgs {
+  TableView v;
+  const unsigned char* vals;
+  const u64* scores;
+  CsrKeys ks;
+  AuxInitPod ai;
+  ScoreP sp;
+  uint8_t* dflag;
+  unsigned* tags;
+  bool with_scores, spec, lru, lru_like;
+};
+
+template <int G, bool SIMPLE>
+__device__ __forceinline__ void own_batch16(const OwnArgs& a, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
+                                            unsigned* __restrict__ slow_list, unsigned list_cap, int lane, int& fresh) {
+  constexpr int U = 4;
+  const TableView& v = a.v;
+  const CsrKeys& ks = a.ks;
+  const int sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  // ---- one lane per key ------------------------------------------------------------------------------------
+  const i64 kreg = ks.dkeys[gj];
+  const unsigned kmreg = ks.keymap[gj];
+  u64 hreg;
+  const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
+  const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
+  unsigned c0 = 0, c1 = 0;
+  if (grp == 0 && valid) {   // (a clamped duplicate must not claim: it would lock out the real key)
+    c0 = atomicExch(a.tags + b0reg, gen);
+    c1 = atomicExch(a.tags + b1reg, gen);
+  }
+  // ---- one group per key: the lines of 4 keys in flight --------------------------------------------------
+  i64 key[U], kk[U][2], sc[U][2];
+  unsigned b0[U], b1[U], gk[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int j = u * 4 + grp;
+    key[u] = shfl_i64(kreg, j);
+    b0[u] = (unsigned)__shfl((int)b0reg, j);
+    b1[u] = (unsigned)__shfl((int)b1reg, j);
+    gk[u] = (unsigned)__shfl((int)gj, j);
+    // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
+    kk[u][0] = key_line(v, b0[u])[sub];
+    kk[u][1] = key_line(v, b1[u])[sub];
+    sc[u][0] = a.spec ? (i64)score_line(v, b0[u])[sub] : 0;
+    sc[u][1] = a.spec ? (i64)score_line(v, b1[u])[sub] : 0;
+  }
+  // ---- per key again, while the lines travel: count and last position from the plan record, input score ---
+  const bool hot = (kmreg & KM_MANY) != 0;
+  const unsigned* rec = (hot ? ks.hrec : ks.crec) + (size_t)(kmreg & ~KM_MANY) * REC_WORDS;
+  const uint2 cl = *reinterpret_cast<const uint2*>(rec + 2);   // (count, last position of a key with few occurrences)
+  const unsigned cnt = cl.x;
+  unsigned lastreg = cl.y;
+  if (hot) lastreg = ks.hent[rec[5]];                          // many: where it is stored
+  lastreg &= E_POS;
+  const u64 in_one = a.scores ? a.scores[lastreg] : 1;
+  const u64 insreg = a.sp.strategy == TFRA_EVICT_LFU ? (a.scores ? in_one : (u64)cnt) : in_one;
+  const unsigned lostreg = (c0 == gen || c1 == gen || is_reserved_key(kreg)) ? 1u : 0u;   // (group 0's lanes)
+  keep_live(kk[0][0], kk[1][0], kk[2][0], kk[3][0]);
+  keep_live(kk[0][1], kk[1][1], kk[2][1], kk[3][1]);
+  if (a.spec) {
+    keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
+    keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
+  }
+  const u64 now = a.lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
+  u64 word[U], in_s[U];
+  unsigned last[U];
+  int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry, -1 left over
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int j = u * 4 + grp;
+    last[u] = (unsigned)__shfl((int)lastreg, j);
+    in_s[u] = 1;
+    if (!a.lru_like) in_s[u] = ((u64)(unsigned)__shfl((int)(insreg >> 32), j) << 32) | (unsigned)__shfl((int)insreg, j);
+    bool slow = __shfl((int)lostreg, j) != 0;   // lane j of group 0 made the claims
+    const bool on = __shfl((int)valid, j) != 0;
+    act[u] = 0;
+    word[u] = 0;
+    if (!on) continue;
+    if (!slow) {
+      const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
+      const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
+      const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
+      const unsigned emp1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == EMPTY_KEY) >> gshift) & 0x7fffu;
+      const bool ovf0 = ((__ballot(sub == 15 && ((u64)kk[u][0] & META_OVF0)) >> gshift) & 0xffffu) != 0;
+      const bool ovf1 = ((__ballot(sub == 15 && ((u64)kk[u][1] & META_OVF1)) >> gshift) & 0xffffu) != 0;
+      bool flag_b0 = false;   // the key goes to b1 although b0 never overflowed before
+      if (hit0) { word[u] = (u64)b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
+      else if (hit1) { word[u] = (u64)b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
+      else if (ovf0 && ovf1) slow = true;   // the key may live further along: walk
+      else if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
+      else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
+      else if (a.spec && !ovf1) {
+        // both home buckets full, nothing further along: replace the minimum-score entry of the 30 slots
+        u64 best_score, best_word;
+        i64 best_key;
+        select_victim_merged(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
+        const u64 cmp = a.sp.strategy == TFRA_EVICT_EPOCHLFU ? ((a.sp.epoch << 32) | in_s[u]) : in_s[u];
+        if (a.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
+          word[u] = best_word;
+          act[u] = 3;
+          flag_b0 = (best_word >> 4) == b1[u];
+        }
+      } else slow = true;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
+      if (flag_b0 && !ovf0 && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
+    }
+    if (sub == 0) a.dflag[gk[u]] = slow ? 4 : 0;
+    if (slow) act[u] = -1;
+    fresh += (act[u] == 2 && sub == 0);
+  }
+  {   // left-over keys of the wave -> the list: one atomic add for all of them
+    u64 sm[U];
+    unsigned nslow = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { sm[u] = __ballot(act[u] < 0 && sub == 0); nslow += (unsigned)__popcll(sm[u]); }
+    if (nslow) {
+      unsigned at = 0;
+      if (lane == 0) at = atomicAdd(slow_ctr, nslow);
+      at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (act[u] < 0 && sub == 0) {
+          const unsigned pos = at + (unsigned)__popcll(sm[u] & ((1ULL << lane) - 1));
+          if (pos < list_cap) slow_list[pos] = gk[u];
+        }
+        at += (unsigned)__popcll(sm[u]);
+        if (act[u] < 0) act[u] = 0;
+      }
+    }
+  }
+  // value rows of the 4 keys: loads together (always from a valid address), stores for the keys that write
+  typedef typename Granule<G>::T T;
+  unsigned char* dst[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) dst[u] = row_at(v, word[u] >> 4, (unsigned)word[u] & 15u);
+  for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
+    T tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(a.vals + (u64)last[u] * (u64)v.field_bytes + off);
+    keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!act[u]) continue;
+      // write-through: the rows leave L2 during the kernel instead of at the boundary to the next one
+      if (G == 16) store_wt16(dst[u] + off, *reinterpret_cast<uint4*>(&tmp[u]));
+      else __hip_atomic_store(reinterpret_cast<T*>(dst[u] + off), tmp[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (!act[u]) continue;
+    if (act[u] >= 2) {
+      if (!SIMPLE && v.n_fields > 1) {
+        for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of a brand-new row start at aux_init
+          const unsigned pat = a.ai.pattern[(f - 1) & 3];
+          unsigned char* q = dst[u] + f * v.field_bytes;
+          if ((v.field_bytes & 3) == 0)
+            for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
+              __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            for (unsigned off = sub; off < v.field_bytes; off += 16)
+              __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % a.ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
+    }
+    if (!a.with_scores) continue;
+    if (a.lru) { if (sub == 0) *score_word(v, word[u]) = now; }
+    else if (act[u] == 3 && a.sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) store_wt8(score_word(v, word[u]), in_s[u]); }   // the slot starts a new life
+    else update_score<true>(v, (i64)((word[u] >> 4) * SLOTS + (word[u] & 15)), act[u] >= 2, a.sp.strategy, in_s[u], a.sp.epoch, sub);
+  }
+}
+
+// Counters of one use of a plan by the ownership write-back (two sets alternate, the kernel of use k zeroes the set of
+// use k+1 at its start: nothing of use k-1 is still running by stream order).
+struct OwnCtrs { unsigned n_a, spare[3]; };
+
+// (Tried and removed: taking the left-over keys in a second ownership round INSIDE this kernel — co-resident persistent
+// grid, the blocks holding a share of the list wait for all blocks to finish round 1 — instead of a remainder kernel.
+// It saves a boundary and was still slower, 82 vs 48 us at 10^9 slots: fewer, longer-lived blocks hide less latency
+// than the hardware's own block scheduling, and the second round's code doubles the kernel's registers.)
 template <int G, bool SIMPLE>
 __global__ __launch_bounds__(256) void upsert_own_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                          const u64* __restrict__ scores_in, CsrKeys ks, AuxInitPod ai,
-                                                         ScoreP sp, uint8_t* __restrict__ dflag, unsigned* slow_ctr,
-                                                         unsigned* __restrict__ slow_list, unsigned use_gen, unsigned own_gen,
-                                                         unsigned* __restrict__ tags, unsigned* progress, unsigned progress_val) {
-  constexpr int U = 4;
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+                                                         ScoreP sp, uint8_t* __restrict__ dflag, OwnCtrs* ctr,
+                                                         unsigned* __restrict__ slow_list, unsigned list_cap, unsigned own_gen, unsigned* __restrict__ tags,
+                                                         unsigned* progress, unsigned progress_val) {
+  const int lane = threadIdx.x & 63;
   const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-  int fresh = 0;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int fresh = 0, failed = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
     if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
   }
-  const u64* scores = SIMPLE ? nullptr : scores_in;
-  const bool with_scores = SIMPLE || has_scores(v);
+  OwnArgs a;
+  a.v = v; a.vals = vals; a.scores = SIMPLE ? nullptr : scores_in; a.ks = ks; a.ai = ai; a.sp = sp; a.dflag = dflag; a.tags = tags;
+  a.with_scores = SIMPLE || has_scores(v);
   const bool dense = sp.bounded > 1 || (sp.bounded == 1 && *v.dense_flag);
-  const bool spec = with_scores && dense;   // an eviction is likely: the score lines travel with the key lines
-  const bool lru = SIMPLE || sp.strategy == TFRA_EVICT_LRU;
-  const bool lru_like = lru || sp.strategy == TFRA_EVICT_EPOCHLRU;
-  for (unsigned wbase = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 16; wbase < total; wbase += nwaves * 16) {
-    // ---- one lane per key ------------------------------------------------------------------------------------
-    const bool valid = wbase + sub < total;
-    const unsigned gj = min(wbase + (unsigned)sub, total - 1);   // clamped tail: unconditional loads
-    const i64 kreg = ks.dkeys[gj];
-    const unsigned kmreg = ks.keymap[gj];
-    u64 hreg;
-    const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
-    const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
-    unsigned c0 = 0, c1 = 0;
-    if (grp == 0 && valid) {   // (a clamped duplicate must not claim: it would lock out the real key)
-      c0 = atomicExch(tags + b0reg, own_gen);
-      c1 = atomicExch(tags + b1reg, own_gen);
-    }
-    // ---- one group per key: the lines of 4 keys in flight --------------------------------------------------
-    i64 key[U], kk[U][2], sc[U][2];
-    unsigned b0[U], b1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = u * 4 + grp;
-      key[u] = shfl_i64(kreg, j);
-      b0[u] = (unsigned)__shfl((int)b0reg, j);
-      b1[u] = (unsigned)__shfl((int)b1reg, j);
-      // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
-      kk[u][0] = key_line(v, b0[u])[sub];
-      kk[u][1] = key_line(v, b1[u])[sub];
-      sc[u][0] = spec ? (i64)score_line(v, b0[u])[sub] : 0;
-      sc[u][1] = spec ? (i64)score_line(v, b1[u])[sub] : 0;
-    }
-    // ---- per key again, while the lines travel: count and last position from the plan record, input score ---
-    const bool hot = (kmreg & KM_MANY) != 0;
-    const unsigned* rec = (hot ? ks.hrec : ks.crec) + (size_t)(kmreg & ~KM_MANY) * REC_WORDS;
-    const uint2 cl = *reinterpret_cast<const uint2*>(rec + 2);   // (count, last position of a key with few occurrences)
-    const unsigned cnt = cl.x;
-    unsigned lastreg = cl.y;
-    if (hot) lastreg = ks.hent[rec[5]];                          // many: where it is stored
-    lastreg &= E_POS;
-    const u64 in_one = scores ? scores[lastreg] : 1;
-    const u64 insreg = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-    const unsigned lostreg = (c0 == own_gen || c1 == own_gen || is_reserved_key(kreg)) ? 1u : 0u;   // (group 0's lanes)
-    keep_live(kk[0][0], kk[1][0], kk[2][0], kk[3][0]);
-    keep_live(kk[0][1], kk[1][1], kk[2][1], kk[3][1]);
-    if (spec) {
-      keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
-      keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
-    }
-    const u64 now = lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
-    u64 word[U], in_s[U];
-    unsigned last[U];
-    int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = u * 4 + grp;
-      last[u] = (unsigned)__shfl((int)lastreg, j);
-      in_s[u] = 1;
-      if (!lru_like) in_s[u] = ((u64)(unsigned)__shfl((int)(insreg >> 32), j) << 32) | (unsigned)__shfl((int)insreg, j);
-      bool slow = __shfl((int)lostreg, j) != 0;   // lane j of group 0 made the claims
-      act[u] = 0;
-      word[u] = 0;
-      if (wbase + j >= total) continue;
-      if (!slow) {
-        const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
-        const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
-        const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
-        const unsigned emp1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == EMPTY_KEY) >> gshift) & 0x7fffu;
-        const bool ovf0 = ((__ballot(sub == 15 && ((u64)kk[u][0] & META_OVF0)) >> gshift) & 0xffffu) != 0;
-        const bool ovf1 = ((__ballot(sub == 15 && ((u64)kk[u][1] & META_OVF1)) >> gshift) & 0xffffu) != 0;
-        bool flag_b0 = false;   // the key goes to b1 although b0 never overflowed before
-        if (hit0) { word[u] = (u64)b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
-        else if (hit1) { word[u] = (u64)b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
-        else if (ovf0 && ovf1) slow = true;   // the key may live further along: walk
-        else if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
-        else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
-        else if (spec && !ovf1) {
-          // both home buckets full, nothing further along: replace the minimum-score entry of the 30 slots
-          u64 best_score, best_word;
-          i64 best_key;
-          select_victim_merged(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
-          const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_s[u]) : in_s[u];
-          if (lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
-            word[u] = best_word;
-            act[u] = 3;
-            flag_b0 = (best_word >> 4) == b1[u];
-          }
-        } else slow = true;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
-        if (flag_b0 && !ovf0 && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
-      }
-      if (sub == 0) dflag[wbase + j] = slow ? 4 : 0;
-      if (slow) act[u] = -1;
-      fresh += (act[u] == 2 && sub == 0);
-    }
-    {   // left-over keys of the wave -> the list: one atomic add for all of them
-      u64 sm[U];
-      unsigned nslow = 0;
-#pragma unroll
-      for (int u = 0; u < U; ++u) { sm[u] = __ballot(act[u] < 0 && sub == 0); nslow += (unsigned)__popcll(sm[u]); }
-      if (nslow) {
-        unsigned at = 0;
-        if (lane == 0) at = atomicAdd(slow_ctr, nslow);
-        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (act[u] < 0 && sub == 0) {
-            const unsigned pos = at + (unsigned)__popcll(sm[u] & ((1ULL << lane) - 1));
-            if (pos < SLOW_CAP) slow_list[pos] = wbase + (unsigned)(u * 4 + grp);
-          }
-          at += (unsigned)__popcll(sm[u]);
-          if (act[u] < 0) act[u] = 0;
-        }
-      }
-    }
-    // value rows of the 4 keys: loads together (always from a valid address), stores for the keys that write
-    typedef typename Granule<G>::T T;
-    unsigned char* dst[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) dst[u] = row_at(v, word[u] >> 4, (unsigned)word[u] & 15u);
-    for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
-      T tmp[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(vals + (u64)last[u] * (u64)v.field_bytes + off);
-      keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (!act[u]) continue;
-        // write-through: the rows leave L2 during the kernel instead of at the boundary to the next one
-        if (G == 16) store_wt16(dst[u] + off, *reinterpret_cast<uint4*>(&tmp[u]));
-        else *reinterpret_cast<T*>(dst[u] + off) = tmp[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!act[u]) continue;
-      if (act[u] >= 2) {
-        if (!SIMPLE && v.n_fields > 1) {
-          for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of a brand-new row start at aux_init
-            const unsigned pat = ai.pattern[(f - 1) & 3];
-            unsigned char* q = dst[u] + f * v.field_bytes;
-            if ((v.field_bytes & 3) == 0)
-              for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(q + off) = pat;
-            else
-              for (unsigned off = sub; off < v.field_bytes; off += 16) q[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
-          }
-        }
-        if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
-      }
-      if (!with_scores) continue;
-      if (lru) { if (sub == 0) *score_word(v, word[u]) = now; }
-      else if (act[u] == 3 && sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) *score_word(v, word[u]) = in_s[u]; }   // the slot starts a new life
-      else update_score(v, (i64)((word[u] >> 4) * SLOTS + (word[u] & 15)), act[u] >= 2, sp.strategy, in_s[u], sp.epoch, sub);
-    }
+  a.spec = a.with_scores && dense;   // an eviction is likely: the score lines travel with the key lines
+  a.lru = SIMPLE || sp.strategy == TFRA_EVICT_LRU;
+  a.lru_like = a.lru || sp.strategy == TFRA_EVICT_EPOCHLRU;
+  for (unsigned wbase = wave * 16; wbase < total; wbase += nwaves * 16) {
+    const unsigned i = wbase + (unsigned)(lane & 15);
+    own_batch16<G, SIMPLE>(a, min(i, total - 1), i < total, own_gen, &ctr->n_a, slow_list, list_cap, lane, fresh);
   }
-  for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
-  if (lane == 0 && fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
 }
 
 }  // namespace
@@ -1495,26 +1542,25 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   if (++t->own_gen == 0) t->own_gen = 1;     // bucket-owner tag of this launch (tags start at 0)
   const unsigned og = t->own_gen;
   const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
-  unsigned* slow_ctr = pl->d_counts + 9 + par;
-  unsigned* next_ctr = pl->d_counts + 9 + (par ^ 1u);
-  // The remainder kernels walk the (short) list of keys the ownership pass left over: two keys of one batch sharing a
-  // home bucket, ~(2n)^2 / nb of them.  A small table makes that most of the batch: full grid (and without tags every
-  // key takes that path).
-  const double expect_slow = 4.0 * (double)pl->n * (double)pl->n / (double)t->cur.nb;
-  const unsigned rem_blocks = (tags && expect_slow < 2048.0) ? 32u : key_blocks;
+  OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
+  OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
+  // Left-over keys of the ownership pass: two keys of one batch sharing a home bucket, ~2 U^2 / nb of them.  Few (a big
+  // table): the remainder kernel walks their list with a handful of blocks.  Many (a small table): full grid.  Without
+  // tags every key takes the general two-kernel path.
+  const double nkeys = (double)key_blocks * 16.0;   // unique keys of the plan when its counts have arrived, else the id count
+  const double expect_slow = 2.0 * nkeys * nkeys / (double)t->cur.nb;
+  const unsigned rem_blocks = expect_slow < 2048.0 ? 32u : key_blocks;
   const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !sc;
+  const unsigned own_blocks = (key_blocks + 3) / 4;
+#define TFRA_OWN(GG, SS)                                                                                                      \
+  upsert_own_kernel<GG, SS><<<own_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, ctr, pl->slow_list,     \
+                                                       SLOW_CAP, og, tags, progress, progress_val)
 #define TFRA_UPS(GG)                                                                                                          \
   if (tags) {                                                                                                                 \
-    if (GG == 16 && simple)                                                                                                   \
-      upsert_own_kernel<16, true><<<(key_blocks + 3) / 4, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,        \
-                                                                       slow_ctr, pl->slow_list, gen, og, tags, progress,     \
-                                                                       progress_val);                                        \
-    else                                                                                                                      \
-      upsert_own_kernel<GG, false><<<(key_blocks + 3) / 4, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,       \
-                                                                        slow_ctr, pl->slow_list, gen, og, tags, progress,    \
-                                                                        progress_val);                                       \
-    upsert_rest_kernel<GG><<<rem_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, slow_ctr,               \
-                                                      pl->slow_list, next_ctr);                                              \
+    if (GG == 16 && simple) TFRA_OWN(16, true);                                                                               \
+    else TFRA_OWN(GG, false);                                                                                                 \
+    upsert_rest_kernel<GG><<<rem_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, &ctr->n_a,              \
+                                                      pl->slow_list, reinterpret_cast<unsigned*>(next_ctr));                 \
   } else {                                                                                                                    \
     upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,   \
                                                      nullptr, pl->slow_list, nullptr);                                       \
@@ -1529,6 +1575,7 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
     case 2: TFRA_UPS(2); break;
     default: TFRA_UPS(1); break;
   }
+#undef TFRA_OWN
 #undef TFRA_UPS
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");
   step_epoch_public(t);
