@@ -601,13 +601,102 @@ def run_c2(args, torch, dist, de, dev, world, rank):
   return res
 
 
+# ------------------------------------------------------------------ c5: 26 tables on one GPU, FTRL
+def run_c5(args, torch, de, dev):
+  """BASELINE configs[4] on ONE GPU: 26 tables, key counts log-spaced and scaled so that the rows [p|accum|linear] fill
+  most of the HBM, dims cycling {16, 32, 64, 128}, one id per table per sample (batch B per table), combined lookup +
+  FTRL write-back.  One C call per step for all tables (tfra_multi_step_prefetch) vs one PrefetchStep call per table vs
+  plain per-table calls."""
+  NT, B, K, W = 26, args.batch, max(10, args.steps // 4), max(3, args.warmup // 4)
+  dims = [16, 32, 64, 128]
+  free, _ = torch.cuda.mem_get_info()
+  budget = 0.70 * free   # bytes for the rows of all tables at load factor <= 0.75
+  shape = np.logspace(7.0, 9.0, NT)          # 10 M ... 1 B before scaling
+  row_bytes = np.array([3 * dims[i % 4] * 4 + 8.6 for i in range(NT)])
+  scale = budget * 0.70 / float(np.sum(shape * row_bytes))
+  sizes = np.maximum((shape * scale).astype(np.int64), 100_000)
+  rng = np.random.default_rng(SEED + 5)
+  opt = de.optimizers.Ftrl(0.05, l1_regularization_strength=1e-3, l2_regularization_strength=1e-3)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  tabs, ids, grads = [], [], []
+  gen = torch.Generator(device=dev).manual_seed(SEED)
+  t0 = time.perf_counter()
+  for i in range(NT):
+    d, n = dims[i % 4], int(sizes[i])
+    v = de.Variable(dim=d, name="c5_%d" % i, initializer=0.0, init_size=int(n * 1.05), devices=[str(dev)],
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    zero = torch.zeros((4_000_000, d), device=dev)
+    for lo in range(1, n + 1, 4_000_000):
+      k = keys_of_ranks_torch(torch, torch.arange(lo, min(n, lo + 3_999_999) + 1, dtype=torch.int64, device=dev) + (i << 40))
+      v.tables[0]._table.upsert(k, zero[:k.numel()], unique_keys=True)
+    del zero
+    tabs.append(v)
+    ranks = zipf_bounded(rng, 4 * B, n).reshape(4, B)
+    ids.append([keys_of_ranks_torch(torch, torch.from_numpy(ranks[j]).to(dev) + (i << 40)) for j in range(4)])
+    grads.append(torch.randn((B, d), generator=gen, device=dev) * 0.01)
+  torch.cuda.synchronize()
+  t_fill = time.perf_counter() - t0
+  total_keys = int(sum(int(v.size().item()) for v in tabs))
+
+  def timed(step, sync):
+    for s_ in range(W):
+      step(s_)
+    sync()
+    t1 = time.perf_counter()
+    for s_ in range(K):
+      step(W + s_)
+    sync()
+    return (time.perf_counter() - t1) / K
+
+  ms = de.MultiTablePrefetchStep(tabs, deo, streams=args.c5_streams, workers=args.c5_workers).prime([x[0] for x in ids])
+  t_multi = timed(lambda s_: ms.step(grads, [x[(s_ + 1) & 3] for x in ids]), lambda: (ms.synchronize(), torch.cuda.synchronize()))
+  pss = [de.PrefetchStep(v, deo).prime(ids[i][0]) for i, v in enumerate(tabs)]
+
+  def per_table(s_):
+    for i, ps in enumerate(pss):
+      ps.step(grads[i], ids[i][(s_ + 1) & 3])
+  t_pre = timed(per_table, torch.cuda.synchronize)
+
+  def plain(s_):
+    p = deo.begin_step()
+    for i, v in enumerate(tabs):
+      v.lookup(ids[i][s_ & 3])
+      deo.apply_sparse(v, ids[i][s_ & 3], grads[i], p)
+  t_plain = timed(plain, torch.cuda.synchronize)
+  Rb = np.array([dims[i % 4] * 4 for i in range(NT)], dtype=np.float64)
+  uniq = np.array([float(torch.unique(ids[i][0]).numel()) for i in range(NT)])
+  step_bytes = float(np.sum(B * (8 + 2 * Rb) + B * (8 + Rb) + uniq * (8 + 7 * Rb)))
+  res = {
+      "metric": "embedding lookup+insert pairs/s (26 tables on one GPU, dims {16,32,64,128}, Zipf-1.2, lookup + fused FTRL write-back)",
+      "value": NT * B / t_multi, "unit": "pairs/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": t_multi * 1e3,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "value_one_call_per_table": NT * B / t_pre, "ms_per_step_one_call_per_table": t_pre * 1e3,
+      "value_plain_call": NT * B / t_plain, "ms_per_step_plain_call": t_plain * 1e3,
+      "config": {
+          "workload": "BASELINE configs[4] on one GPU: 26 tables, %d resident keys in total (%d ... %d per table, log-spaced, scaled to "
+                      "%.0f GB of rows [p|accum|linear]), dims cycling {16,32,64,128} fp32, batch=%d ids per table and step (Zipf-1.2), "
+                      "lookup + duplicate sums + fused FTRL" % (total_keys, int(sizes.min()), int(sizes.max()),
+                                                                float(np.sum(sizes * row_bytes)) / 1e9, B),
+          "tables": NT, "global_batch": NT * B, "prefill_s": round(t_fill, 1), "streams": args.c5_streams, "host_threads": args.c5_workers,
+          "drivers": {"value": "tfra_multi_step_prefetch: ONE C call per step for all 26 tables (host-thread pool, stream pairs round-robin)",
+                      "value_one_call_per_table": "tfra_table_step_prefetch per table from one Python thread",
+                      "value_plain_call": "Find + apply_sparse per table (the reference's op sequence)"}},
+      "roofline": {"bound": "hbm", "kernel": "whole step (26 tables x find + hot_sums + apply_csr<FTRL>)", "achieved": step_bytes / t_multi / 1e9,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / t_multi / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                   "step_algorithmic_bytes": step_bytes, "step_frac": step_bytes / t_multi / 1e9 / HBM_PEAK_GBS},
+  }
+  return res
+
+
 # ------------------------------------------------------------------ main
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=200)
   ap.add_argument("--warmup", type=int, default=20)
-  ap.add_argument("--config", choices=["c3", "c2", "m1b"], default=None,
+  ap.add_argument("--c5-streams", type=int, default=4)
+  ap.add_argument("--c5-workers", type=int, default=1)
+  ap.add_argument("--config", choices=["c3", "c2", "m1b", "c5"], default=None,
                   help="default: c3 on one GPU (largest single-GPU configuration), c2 per GPU for N>1")
   ap.add_argument("--slots", type=int, default=1_000_000_000, help="c3 / m1b: slots of the bounded table")
   ap.add_argument("--keys", type=int, default=100_000_000, help="c2: resident keys PER GPU")
@@ -645,6 +734,9 @@ def main():
       m1b = run_bounded(args, torch, de, dev, "m1b")   # the metric's own wording: dim 64 fp32, 10^9 slots, Zipf-1.2 ids
       sec = run_c2(args, torch, dist, de, dev, 1, 0)
       res["secondary"] = {"m1b": {k: m1b[k] for k in keep if k in m1b}, "c2": {k: sec[k] for k in keep if k in sec}}
+  elif cfg == "c5":
+    assert world == 1, "c5 here is the one-GPU form of configs[4]"
+    res = run_c5(args, torch, de, dev)
   else:
     res = run_c2(args, torch, dist, de, dev, world, rank)
   if rank == 0:

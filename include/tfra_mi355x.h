@@ -269,6 +269,33 @@ int tfra_table_step_prefetch_assign(tfra_table_t* t, tfra_sparse_plan_t* plan_cu
                                     const int64_t* ids_next, size_t n_next, tfra_stream_t main_stream,
                                     tfra_stream_t side_stream);
 
+/* Many tables on one GPU (BASELINE configs[4]: 26 embedding tables): the step of every table — the arguments of
+ * tfra_table_step_prefetch (opt != NULL: grads_or_values = float gradients) or tfra_table_step_prefetch_assign (opt ==
+ * NULL: grads_or_values = rows of the table's dtype) — issued from a pool of `n_workers` host threads (0 = 4), tables
+ * dealt out dynamically.  Give the tables of one call disjoint stream pairs (or a few pairs round-robin) so that their
+ * launches and kernels overlap; the call returns when every step has been ENQUEUED (like the single-table form it does
+ * not wait for the GPU).  The first error of any table is returned.  In TensorFlow this is the inter-op thread pool
+ * running the per-table op sequences of one session.run. */
+typedef struct {
+  uint32_t struct_size;              /* = sizeof(tfra_step_desc) */
+  uint32_t reserved;
+  tfra_table_t* table;
+  const tfra_opt_params* opt;
+  tfra_sparse_plan_t* plan_cur;
+  const int64_t* ids_cur;
+  void* rows_out;
+  const void* find_default;
+  const void* grads_or_values;
+  const float* param_default_row;
+  const uint64_t* scores;
+  tfra_sparse_plan_t* plan_next;
+  const int64_t* ids_next;
+  size_t n_next;
+  tfra_stream_t main_stream;
+  tfra_stream_t side_stream;
+} tfra_step_desc;
+int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n_workers);
+
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 
 /* Scratch for unique/partition; grows on demand, reusable across calls on one stream. */

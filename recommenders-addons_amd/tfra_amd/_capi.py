@@ -55,6 +55,17 @@ class OptParams(ctypes.Structure):
 
 
 _P = ctypes.c_void_p
+
+
+class StepDesc(ctypes.Structure):
+  """tfra_step_desc (include/tfra_mi355x.h): one table's step in tfra_multi_step_prefetch."""
+  _fields_ = [
+      ("struct_size", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("table", ctypes.c_void_p), ("opt", ctypes.c_void_p),
+      ("plan_cur", ctypes.c_void_p), ("ids_cur", ctypes.c_void_p), ("rows_out", ctypes.c_void_p), ("find_default", ctypes.c_void_p),
+      ("grads_or_values", ctypes.c_void_p), ("param_default_row", ctypes.c_void_p), ("scores", ctypes.c_void_p),
+      ("plan_next", ctypes.c_void_p), ("ids_next", ctypes.c_void_p), ("n_next", ctypes.c_size_t), ("main_stream", ctypes.c_void_p),
+      ("side_stream", ctypes.c_void_p),
+  ]
 _SZ = ctypes.c_size_t
 _I = ctypes.c_int
 _SIGS = {
@@ -70,6 +81,7 @@ _SIGS = {
     "tfra_table_size": [_P, ctypes.POINTER(_SZ), _P],
     "tfra_table_size_to_device": [_P, _P, _P],
     "tfra_table_capacity": [_P, ctypes.POINTER(_SZ)],
+    "tfra_multi_step_prefetch": [_SZ, _P, _I],
     "tfra_table_check_errors": [_P, _P],
     "tfra_table_slot_census": [_P, ctypes.POINTER(ctypes.c_uint64), _P],
     "tfra_table_reserve": [_P, _SZ, _P],

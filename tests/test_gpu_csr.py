@@ -217,3 +217,43 @@ def test_upsert_sparse_bounded_table_at_capacity(env):
   assert np.unique(k).size == k.size
   np.testing.assert_array_equal(v[:, 0], np.array([latest[int(x)] for x in k], np.float32))
   assert np.all(v == v[:, :1])
+
+
+def test_multi_table_step_matches_per_table_steps(env):
+  """tfra_multi_step_prefetch (host-thread pool, several stream pairs) == one PrefetchStep per table, bit for bit: the
+  tables are independent, only who issues the launches differs.  26-table shape of BASELINE configs[4] in small."""
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(5)
+  dims = [16, 32, 64, 128]
+  nt, B, steps = 7, 4096, 4
+
+  def build(tag):
+    opt = de.optimizers.Ftrl(0.05, l1_regularization_strength=1e-3, l2_regularization_strength=1e-3)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    vs = [de.Variable(dim=dims[i % 4], name="mt_%s_%d" % (tag, i), initializer=0.1, devices=["cuda:0"],
+                      **de.DynamicEmbeddingOptimizer.variable_kwargs(opt)) for i in range(nt)]
+    return deo, vs
+
+  ids = [[torch.from_numpy((rng.zipf(1.2, size=B) % (3000 + 500 * i)).astype(np.int64) * 7919 + i).cuda() for _ in range(steps + 1)]
+         for i in range(nt)]
+  grads = [[torch.from_numpy((rng.standard_normal((B, dims[i % 4])) * 0.01).astype(np.float32)).cuda() for _ in range(steps)]
+           for i in range(nt)]
+  deo_a, va = build("a")
+  deo_b, vb = build("b")
+  ms = de.MultiTablePrefetchStep(va, deo_a, streams=3, workers=3).prime([ids[i][0] for i in range(nt)])
+  pss = [de.PrefetchStep(v, deo_b).prime(ids[i][0]) for i, v in enumerate(vb)]
+  for s in range(steps):
+    outs = ms.step([grads[i][s] for i in range(nt)], [ids[i][s + 1] for i in range(nt)])
+    ms.synchronize()
+    deo_b.iterations = s   # one global step per training step (PrefetchStep advances it once per table)
+    for i, ps in enumerate(pss):
+      deo_b.iterations = s
+      ref = ps.step(grads[i][s], ids[i][s + 1])
+      assert torch.equal(outs[i], ref), (s, i)
+  torch.cuda.synchronize()
+  assert deo_a.iterations == steps
+  for a, b in zip(va, vb):
+    ka, xa = a.export()
+    kb, xb = b.export()
+    oa, ob = torch.argsort(ka), torch.argsort(kb)
+    assert torch.equal(ka[oa], kb[ob]) and torch.equal(xa[oa], xb[ob])
