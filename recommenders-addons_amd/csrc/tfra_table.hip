@@ -15,6 +15,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "../../include/tfra_mi355x.h"
 #include "tfra_device.h"
 #include "tfra_host.h"
@@ -315,55 +317,91 @@ __device__ __forceinline__ void row_add(unsigned char* row, const unsigned char*
 
 // ---- accum_or_assign.  ROUND >= 0: duplicate-safe mode, processes only the occurrence that is
 // currently first-in-line for its key (election word), see host loop. -------------------------
+// one (key, values-or-delta, exists) triple: absent & !exists -> insert, present & exists -> row += delta, else nothing
+template <int DT, int G>
+__device__ __forceinline__ void accum_one(const TableView& v, size_t i, const i64* __restrict__ keys,
+                                          const unsigned char* __restrict__ vod, const uint8_t* __restrict__ exists,
+                                          const u64* __restrict__ scores, unsigned dim, const AuxInit& ai, int strategy, u64 epoch,
+                                          uint8_t* __restrict__ deferred, int bounded_mode, int sub, int gshift, int& fresh,
+                                          int& failed) {
+  const i64 key = keys[i];
+  const bool ex = exists[i] != 0;
+  const unsigned char* src = vod + i * (size_t)v.field_bytes;
+  if (!ex) {
+    bool is_new;
+    i64 row;
+    if (deferred) {  // bounded table at max_capacity: keys without a free slot evict in phase 2
+      u64 h;
+      const u64 b0 = bucket0(key, v.nb, h);
+      const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+      row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, bounded_mode);
+      if (sub == 0) deferred[i] = row == NEED_EVICT;
+    } else {
+      row = locate_or_claim(v, key, sub, gshift, is_new);
+    }
+    if (row < 0) failed += (sub == 0 && row != NEED_EVICT);
+    else if (is_new) {
+      copy_bytes16<G>(row_ptr(v, row), src, v.field_bytes, sub);
+      if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, 0);
+      update_score(v, row, true, strategy, scores ? scores[i] : 1, epoch, sub);
+      fresh += (sub == 0);
+    }  // present & !exists: dropped
+  } else {
+    i64 row = probe_find<true>(v, key, sub, gshift);
+    if (row >= 0) {
+      row_add<DT>(row_ptr(v, row), src, dim, sub);
+      update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
+    }  // absent & exists: dropped
+    if (deferred && sub == 0) deferred[i] = 0;
+  }
+}
+
 template <int DT, int G>
 __global__ __launch_bounds__(256) void accum_kernel(TableView v, size_t n, const i64* __restrict__ keys,
                                                     const unsigned char* __restrict__ vod,
                                                     const uint8_t* __restrict__ exists,
                                                     const u64* __restrict__ scores, unsigned dim,
                                                     AuxInit ai, int strategy, u64 epoch,
-                                                    const int* __restrict__ order, size_t n_order,
                                                     uint8_t* __restrict__ deferred, int bounded_mode) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const size_t g = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
   const size_t wave = g >> 2;
-  const size_t cnt = order ? n_order : n;
   int fresh = 0, failed = 0;
-  if (g < cnt) {
-    const size_t i = order ? (size_t)order[g] : g;
-    const i64 key = keys[i];
-    const bool ex = exists[i] != 0;
-    const unsigned char* src = vod + i * (size_t)v.field_bytes;
-    if (!ex) {
-      bool is_new;
-      i64 row;
-      if (deferred) {  // bounded table at max_capacity: keys without a free slot evict in phase 2
-        u64 h;
-        const u64 b0 = bucket0(key, v.nb, h);
-        const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
-        row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, bounded_mode);
-        if (sub == 0) deferred[i] = row == NEED_EVICT;
-      } else {
-        row = locate_or_claim(v, key, sub, gshift, is_new);
+  if (g < n) accum_one<DT, G>(v, g, keys, vod, exists, scores, dim, ai, strategy, epoch, deferred, bounded_mode, sub, gshift, fresh, failed);
+  for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
+  if (lane == 0) {
+    if (fresh) size_add(v, wave, fresh);
+    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+  }
+}
+
+// Keys that repeat within one call: the reference applies the triples one after the other in index order
+// (LaunchTensorsAccum on one thread; accumrase_fn, cuckoohash_map.hh:619-633), and the outcome of an occurrence depends
+// on the ones before it (an insert makes the key present for the next).  The (key, index) pairs arrive sorted by key
+// (stable radix sort: indices ascend within a key); the group of a key's FIRST sorted position walks the key's
+// occurrences in index order, every step through memory (a key that repeats thousands of times is one long chain —
+// exact, not fast: TFRA de-duplicates before accum, PY/dynamic_embedding_variable.py:1377-1378).
+template <int DT, int G>
+__global__ __launch_bounds__(256) void accum_segments_kernel(TableView v, size_t n, const i64* __restrict__ keys,
+                                                             const unsigned char* __restrict__ vod,
+                                                             const uint8_t* __restrict__ exists, const u64* __restrict__ scores,
+                                                             unsigned dim, AuxInit ai, int strategy, u64 epoch,
+                                                             const u64* __restrict__ sorted_keys, const unsigned* __restrict__ sorted_idx) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const size_t p = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  int fresh = 0, failed = 0;
+  if (p < n) {
+    const u64 k = sorted_keys[p];
+    if (p == 0 || sorted_keys[p - 1] != k) {
+      for (size_t q = p; q < n && sorted_keys[q] == k; ++q) {
+        accum_one<DT, G>(v, (size_t)sorted_idx[q], keys, vod, exists, scores, dim, ai, strategy, epoch, nullptr, 0, sub, gshift, fresh, failed);
+        __threadfence_block();   // the next occurrence reads what this one wrote (other lanes of the group, same row)
       }
-      if (row < 0) failed = (sub == 0 && row != NEED_EVICT);
-      else if (is_new) {
-        copy_bytes16<G>(row_ptr(v, row), src, v.field_bytes, sub);
-        if (v.n_fields > 1) init_aux_fields(v, ai, row, sub, 0);
-        update_score(v, row, true, strategy, scores ? scores[i] : 1, epoch, sub);
-        fresh = (sub == 0);
-      }  // present & !exists: dropped
-    } else {
-      i64 row = probe_find<true>(v, key, sub, gshift);
-      if (row >= 0) {
-        row_add<DT>(row_ptr(v, row), src, dim, sub);
-        update_score(v, row, false, strategy, scores ? scores[i] : 1, epoch, sub);
-      }  // absent & exists: dropped
-      if (deferred && sub == 0) deferred[i] = 0;
     }
   }
   for (int o = 32; o > 0; o >>= 1) { fresh += __shfl_xor(fresh, o); failed += __shfl_xor(failed, o); }
   if (lane == 0) {
-    if (fresh) size_add(v, wave, fresh);
+    if (fresh) size_add(v, p >> 2, fresh);
     if (failed) atomicAdd(v.err_count, (unsigned)failed);
   }
 }
@@ -404,6 +442,11 @@ __global__ void clear_kernel(TableView v, int reset_counters) {
   if (t < SIZE_SHARDS) v.size_shards[t * SIZE_SHARD_STRIDE] = 0;
   if (t < NUM_RESERVED) v.reserved_present[t] = 0;
   if (t == 0) { *v.err_count = 0; *const_cast<unsigned*>(v.dense_flag) = 0; }
+}
+
+__global__ void iota_u32_kernel(unsigned* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (unsigned)i;
 }
 
 __global__ void fill_i32_kernel(int* p, size_t n, int val) {
@@ -975,28 +1018,38 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
 template <int DT>
 static void launch_accum(int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k, const unsigned char* vod,
                          const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai, int strat, u64 epoch,
-                         const int* order, size_t n_order, uint8_t* deferred, int bmode) {
+                         const u64* sorted_keys, const unsigned* sorted_idx, uint8_t* deferred, int bmode) {
   dim3 block(256);
+  if (sorted_keys) {
+    switch (g) {
+      case 16: accum_segments_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx); break;
+      case 8: accum_segments_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx); break;
+      case 4: accum_segments_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx); break;
+      case 2: accum_segments_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx); break;
+      default: accum_segments_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx); break;
+    }
+    return;
+  }
   switch (g) {
-    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case 16: accum_kernel<DT, 16><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, deferred, bmode); break;
+    case 8: accum_kernel<DT, 8><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, deferred, bmode); break;
+    case 4: accum_kernel<DT, 4><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, deferred, bmode); break;
+    case 2: accum_kernel<DT, 2><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, deferred, bmode); break;
+    default: accum_kernel<DT, 1><<<grid, block, 0, s>>>(v, n, k, vod, ex, sc, dim, ai, strat, epoch, deferred, bmode); break;
   }
 }
 
 static void launch_accum_dt(int dt, int g, dim3 grid, hipStream_t s, TableView v, size_t n, const i64* k,
                             const unsigned char* vod, const uint8_t* ex, const u64* sc, unsigned dim, AuxInit ai,
-                            int strat, u64 epoch, const int* order, size_t n_order, uint8_t* deferred, int bmode) {
+                            int strat, u64 epoch, const u64* sorted_keys, const unsigned* sorted_idx, uint8_t* deferred, int bmode) {
   switch (dt) {
-    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
-    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, order, n_order, deferred, bmode); break;
+    case TFRA_F32: launch_accum<TFRA_F32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
+    case TFRA_F16: launch_accum<TFRA_F16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
+    case TFRA_BF16: launch_accum<TFRA_BF16>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
+    case TFRA_I8: launch_accum<TFRA_I8>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
+    case TFRA_I32: launch_accum<TFRA_I32>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
+    case TFRA_I64: launch_accum<TFRA_I64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
+    default: launch_accum<TFRA_F64>(g, grid, s, v, n, k, vod, ex, sc, dim, ai, strat, epoch, sorted_keys, sorted_idx, deferred, bmode); break;
   }
 }
 
@@ -1118,7 +1171,7 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
     rc = t->bounded_flags(n, s, &deferred);
     if (rc) return rc;
     launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
-                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, 0, deferred,
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, nullptr, nullptr, deferred,
                     deferred ? (t->dense ? 2 : 1) : 0);
     if (deferred) {  // phase 2: the absent keys that found no free slot replace a minimum-score entry
       const unsigned char* vals = (const unsigned char*)vod;
@@ -1145,43 +1198,29 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
       return set_error(TFRA_ERR_UNSUPPORTED, "accum: a bounded (Hkv) table at max_capacity needs TFRA_FLAG_UNIQUE_KEYS "
                                              "(HKV's unique-keys contract) so that eviction is well defined");
   }
-  // Duplicate-safe mode: the reference applies duplicates sequentially in index order
-  // (LaunchTensorsAccum on one thread).  Group occurrences by key on the host and run one
-  // launch per "occurrence rank": launch r handles the r-th occurrence of every key, so adds to
-  // one row happen in index order.  Costs a D2H copy of the keys; the unique-keys flag is the
-  // production path (TFRA de-duplicates before accum).
-  std::vector<i64> hk(n);
-  HIP_TRY(hipMemcpyAsync(hk.data(), keys, n * sizeof(i64), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  std::vector<int> idx(n);
-  for (size_t i = 0; i < n; ++i) idx[i] = (int)i;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hk[a] < hk[b]; });
-  std::vector<int> rank(n);
-  int max_rank = 0;
-  for (size_t p = 0; p < n; ++p) {
-    rank[p] = (p > 0 && hk[idx[p]] == hk[idx[p - 1]]) ? rank[p - 1] + 1 : 0;
-    max_rank = std::max(max_rank, rank[p]);
-  }
-  std::vector<std::vector<int>> rounds(max_rank + 1);
-  for (size_t p = 0; p < n; ++p) rounds[rank[p]].push_back(idx[p]);
-  rc = t->ensure_scratch(n * sizeof(int), s);
-  if (rc) return rc;
-  t->apply_P = 0;  // scratch head is overwritten below
-  int* d_order = (int*)t->scratch;
-  size_t off = 0;
-  for (auto& r : rounds) {
-    HIP_TRY(hipMemcpyAsync(d_order + off, r.data(), r.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    off += r.size();
-  }
-  off = 0;
-  for (auto& r : rounds) {
-    dim3 grid((unsigned)((r.size() * 16 + 255) / 256));
+  // Duplicate-safe mode: the reference applies the triples sequentially in index order (LaunchTensorsAccum on one
+  // thread).  All on the device, no host copy and no synchronisation: a stable radix sort of (key, index) groups the
+  // occurrences of a key with their indices ascending, and accum_segments_kernel walks each group in that order.
+  {
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, (const u64*)nullptr, (u64*)nullptr, (const unsigned*)nullptr,
+                                      (unsigned*)nullptr, n, 0u, 64u, s));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    rc = t->ensure_scratch(al(n * 8) + 2 * al(n * 4) + al(tmp_bytes), s);
+    if (rc) return rc;
+    t->apply_P = 0;  // scratch head is overwritten below
+    unsigned char* w = (unsigned char*)t->scratch;
+    u64* sorted_keys = (u64*)w; w += al(n * 8);
+    unsigned* iota = (unsigned*)w; w += al(n * 4);
+    unsigned* sorted_idx = (unsigned*)w; w += al(n * 4);
+    void* tmp = w;
+    iota_u32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(iota, n);
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const u64*)keys, sorted_keys, (const unsigned*)iota, sorted_idx, n, 0u, 64u, s));
+    dim3 grid((unsigned)((n * 16 + 255) / 256));
     launch_accum_dt(t->opts.value_dtype, g, grid, s, v, n, k, (const unsigned char*)vod, exists, (const u64*)scores,
-                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, d_order + off, r.size(), nullptr, 0);
-    off += r.size();
+                    (unsigned)t->opts.dim, t->aux, t->opts.strategy, t->global_epoch, sorted_keys, sorted_idx, nullptr, 0);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s));  // host vectors feeding the H2D copies die here
   return TFRA_OK;
 }
 

@@ -195,3 +195,24 @@ def test_save_load_files_match_reference_format(hip, tmp_path):
   t3 = hip.HipTable(dim, np.float32)
   t3.t.load_from_file_system(str(tmp_path), file_name="x", dirpath_env=None, load_entire_dir=True)
   assert t3.size() == keys.size
+
+
+def test_accum_hot_duplicates_on_device_index_order(hip):
+  """accum with a key that repeats thousands of times in one call (Zipf head), mixed exists flags: applied in index
+  order ON THE DEVICE (stable sort + per-key walk; no host copy of the keys) — bit-exact vs the sequential reference
+  engine, including insert-then-add and add-before-insert (dropped) sequences.  cuckoohash_map.hh:619-633."""
+  rng = np.random.default_rng(2024)
+  dim = 24
+  a = oracle.CpuTable(dim, np.float32, kind="reference" if oracle.available("reference") else "port")
+  b = hip.HipTable(dim, np.float32, init_size=0)
+  n = 40_000
+  keys = (rng.zipf(1.2, size=n) % 3000).astype(np.int64) * 104729 - 7
+  assert np.bincount((keys + 7) // 104729).max() > 3000
+  for rnd in range(2):
+    v = (rng.standard_normal((n, dim)) * 3).astype(np.float32)
+    ex = rng.random(n) < (0.3 if rnd == 0 else 0.8)
+    a.accum(keys, v, ex); b.accum(keys, v, ex)
+    assert a.size() == b.size()
+  (ka, va), (kb, vb) = a.export_sorted(), b.export_sorted()
+  np.testing.assert_array_equal(ka, kb)
+  np.testing.assert_array_equal(va.view(np.uint8), vb.view(np.uint8))
