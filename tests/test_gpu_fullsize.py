@@ -136,3 +136,48 @@ def test_c5_26_tables_mixed_dims_ftrl(env):
     ek, ev = tabs[0].export_sorted()
     np.testing.assert_array_equal(k.cpu().numpy()[o], ek)
     np.testing.assert_allclose(val.cpu().numpy()[o], ev, rtol=5e-6, atol=5e-6)
+
+
+def test_c3_1e8_slots_bench_path_properties(env):
+  """configs[2] at 10^8 slots through the path bench.py times: a bounded LRU table pre-filled to capacity, batches of
+  131 072 ids WITH repeats = 50 % resident + 50 % never-seen, lookup then upsert_sparse (plan + single-pass ownership
+  write-back with eviction).  Size-independent properties: size <= capacity, a resident key returns its own row (bit
+  exact), never-seen keys miss before their write-back and hit after it, no slot is left locked, keys stay unique."""
+  torch, de = env
+  dim, cap, B = 128, 100_000_000, 131072
+  t = de.HkvHashTable(torch.int64, torch.float16, torch.zeros(dim, dtype=torch.float16), init_capacity=cap, max_capacity=cap,
+                      device="cuda:0", dim=dim, evict_strategy=de.HkvEvictStrategy.LRU, name="c3_1e8")
+  for lo in range(1, cap + 1, 4_000_000):
+    k = torch.arange(lo, min(cap, lo + 3_999_999) + 1, dtype=torch.int64, device="cuda") * 7919
+    t._table.upsert(k, row_of(torch, k, dim, torch.float16), unique_keys=True)
+  n0 = int(t.size().item())
+  assert 0.9 * cap < n0 <= cap
+  gen = torch.Generator(device="cuda").manual_seed(9)
+  fresh = 1
+  for step in range(12):
+    old = torch.randint(1, cap + 1, (B // 2,), generator=gen, device="cuda") * 7919
+    old[: B // 8] = old[0]                              # a hot id: thousands of repeats in the batch
+    new = -(torch.arange(fresh, fresh + B // 2, dtype=torch.int64, device="cuda") * 104729) - 5   # never seen before (negative)
+    fresh += B // 2
+    ids = torch.cat([old, new])[torch.randperm(B, generator=gen, device="cuda")]
+    out, ex = t.lookup(ids, return_exists=True)
+    want = row_of(torch, ids, dim, torch.float16)
+    assert torch.equal(out[ex], want[ex])
+    assert not bool(ex[ids < 0].any())
+    t._table.upsert_sparse(ids, want)
+    out2, ex2 = t.lookup(ids, return_exists=True)
+    assert float(ex2.float().mean()) > 0.999             # written back (LRU: the newest entries are not the victims)
+    assert torch.equal(out2[ex2], want[ex2])
+    assert int(t.size().item()) <= cap
+  c = t._table.slot_census()
+  assert c["locked"] == 0 and c["live"] == int(t.size().item())
+  t._table.check_errors()
+  kbuf = torch.empty(4_000_000, dtype=torch.int64, device="cuda")
+  vbuf = torch.empty((4_000_000, dim), dtype=torch.float16, device="cuda")
+  cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+  from tfra_amd import _capi
+  from tfra_amd.dynamic_embedding.table_ops import _ptr, _stream
+  _capi.call("tfra_table_export_batch", t._table._h, 3_000_000, 40_000_000, _ptr(cnt), _ptr(kbuf), _ptr(vbuf), None, _stream(t._table.device))
+  m = int(cnt.item())
+  assert m > 2_000_000 and kbuf[:m].unique().numel() == m
+  assert torch.equal(vbuf[:50_000], row_of(torch, kbuf[:50_000], dim, torch.float16))
