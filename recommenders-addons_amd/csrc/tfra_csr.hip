@@ -983,15 +983,26 @@ __device__ __forceinline__ void locked_upsert_one(const TableView& v, const unsi
   u64 word = 0;
   bool is_new = false, evicted = false, side = false;
   for (int attempt = 0; attempt < 64 && row < 0; ++attempt) {
+    // This pass is one wave-lifetime of dependent round trips (~1.2 us each): both home buckets' key AND score lines
+    // travel together up front (first attempt) instead of b0 -> b1 -> score lines one after the other.
     u64 h;
     const u64 b0 = bucket0(key, v.nb, h);
-    const i64 k0 = load_key_coherent(key_line(v, b0) + sub);
+    const u64 b1 = bucket1(h, b0, v.nb);
+    const bool pre = attempt == 0 && has_scores(v) && sp.bounded != 0;
+    i64 kk2[2], sc2[2] = {0, 0};
+    kk2[0] = load_key_coherent(key_line(v, b0) + sub);
+    kk2[1] = pre ? load_key_coherent(key_line(v, b1) + sub) : 0;
+    if (pre) {
+      sc2[0] = (i64)__hip_atomic_load(score_line(v, b0) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sc2[1] = (i64)__hip_atomic_load(score_line(v, b1) + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      keep_live(kk2[0], kk2[1], sc2[0], sc2[1]);
+    }
     bool claimed = false;
-    i64 r = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, claimed, sp.bounded);
+    i64 r = locate_or_claim_from(v, key, h, b0, kk2[0], sub, gshift, claimed, sp.bounded, pre ? &kk2[1] : nullptr);
     if (r == NEED_EVICT) {
       bool ce = false;
       u64 wd = 0;
-      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce);
+      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce, pre ? kk2 : nullptr, pre ? sc2 : nullptr);
       if (r == -1) break;                        // not admitted (its score is below every resident one): dropped
       if (r == -3) { failed += (sub == 0); break; }
       row = r; word = wd; is_new = true; evicted = !ce;
