@@ -324,6 +324,14 @@ int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, c
 int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int dim, const float* in,
                        int64_t* keys_out, float* rows_out, int64_t* d_count, tfra_stream_t stream);
 
+/* The reduction half of tfra_reduce_by_key for a batch whose plan was built AHEAD (tfra_sparse_plan_build with dim = the
+ * rows' dim, any stream): rows_out[dest[p], :] = sum of the rows of `grads` whose id equals ids[p] (same summation tree,
+ * bit-reproducible).  dest [n] int32 maps batch positions to output rows and must be equal for all positions of one id —
+ * e.g. position -> owner-major index of the multi-GPU gradient route, which depends on the ids alone and is computed
+ * one batch ahead together with the plan (PY/shadow_embedding_ops.py:397-447 does unique + partition at lookup time). */
+int tfra_plan_reduce_to(const tfra_sparse_plan_t* plan, const float* grads, const int32_t* dest, float* rows_out,
+                        tfra_stream_t stream);
+
 /* out[i,:] = rows[idx[i],:] (tf.gather after unique). row_bytes = dim*sizeof(V). */
 int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out,
                      tfra_stream_t stream);

@@ -756,14 +756,17 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
 
 // ---------------------------------------------------------------------------------------------
 // tfra_reduce_by_key epilogue: the same per-key sums as apply_csr_kernel, written out instead of applied.
+// dest != nullptr (tfra_plan_reduce_to): the sum of a key goes to row dest[p], p = the key's last batch position — the
+// caller's map from batch positions to output rows (equal for all positions of a key), e.g. position -> owner-major
+// index of the multi-GPU gradient route; keys_out / d_count are not written then.
 __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* __restrict__ grads,
                                                          const float* __restrict__ partial, CsrKeys ks,
                                                          i64* __restrict__ keys_out, float* __restrict__ rows_out,
-                                                         i64* __restrict__ d_count) {
+                                                         i64* __restrict__ d_count, const int* __restrict__ dest) {
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const unsigned total = ks.d_counts[0] + ks.d_counts[1];
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *d_count = ks.d_counts[5] ? (i64)-1 : (i64)total;
+  if (d_count && blockIdx.x == 0 && threadIdx.x == 0) *d_count = ks.d_counts[5] ? (i64)-1 : (i64)total;
   for (unsigned wbase = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 2; wbase < total; wbase += ngroups) {
     const unsigned it_raw = wbase + (unsigned)(lane >> 4);
     const bool active = it_raw < total;
@@ -785,6 +788,12 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
     for (int o2 = 32; o2 >= 16; o2 >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o2));
     wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wmax);
     if (!active) continue;
+    size_t orow = g;
+    if (dest) {
+      unsigned lastp = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3));   // few: the last position itself; many: where it is stored
+      if (hot) lastp = ks.hent[lastp];
+      orow = (size_t)dest[lastp & E_POS];
+    }
     for (int c = sub * 4; c < dim; c += 64) {
       float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
       if (wmax <= 1) add_rows<1>(gg, src, (int)nsrc, c);
@@ -792,9 +801,9 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
       else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
       else add_rows<8>(gg, src, (int)nsrc, c);
       if (nsrc > 8) add_partials_tail(gg, partial, first, nsrc, dim, c);
-      *reinterpret_cast<float4*>(rows_out + (size_t)g * dim + c) = gg;
+      *reinterpret_cast<float4*>(rows_out + orow * dim + c) = gg;
     }
-    if (sub == 0) keys_out[g] = key;
+    if (keys_out && sub == 0) keys_out[g] = key;
   }
 }
 
@@ -1752,8 +1761,37 @@ extern "C" int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t*
     case 3: hot_sums_kernel<3><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
     default: hot_sums_kernel<4><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
   }
-  gather_csr_kernel<<<key_blocks, 256, 0, s>>>(dim, grads, pl->partial, keys_of(pl), (i64*)keys_out, rows_out, (i64*)d_count);
+  gather_csr_kernel<<<key_blocks, 256, 0, s>>>(dim, grads, pl->partial, keys_of(pl), (i64*)keys_out, rows_out, (i64*)d_count, nullptr);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "reduce_by_key: launch failed");
+  return TFRA_OK;
+}
+
+// The per-key gradient sums of a batch whose plan was built ahead (tfra_sparse_plan_build with the table's dim, on any
+// stream): hot sums + gather, the reduction half of tfra_reduce_by_key with the same summation tree, written to
+// rows_out[dest[p]] where p is a position of the key.  dest [n] int32: the caller's map from batch positions to output
+// rows, the same for every position of a key (e.g. position -> owner-major index of the multi-GPU gradient route, which
+// is known from the ids alone).  rows_out must have a row for every value in dest; rows no key maps to are not written.
+extern "C" int tfra_plan_reduce_to(const tfra_sparse_plan_t* pl, const float* grads, const int32_t* dest, float* rows_out,
+                                   tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pl) return set_error(TFRA_ERR_INVALID, "plan_reduce_to: null plan");
+  if (pl->n == 0) return TFRA_OK;
+  if (!grads || !dest || !rows_out) return set_error(TFRA_ERR_INVALID, "plan_reduce_to: null buffer");
+  const int dim = pl->dim;
+  if (dim <= 0 || (((uintptr_t)grads | (uintptr_t)rows_out) & 15))
+    return set_error(TFRA_ERR_INVALID, "plan_reduce_to: the plan must have been built with the rows' dim; buffers 16-B aligned");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != pl->device) { if (hipSetDevice(pl->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "plan_reduce_to: hipSetDevice"); } }
+  unsigned key_blocks, bin_blocks;
+  plan_grids(pl, &key_blocks, &bin_blocks);
+  const int nch = (dim + 63) / 64;
+  switch (nch) {
+    case 1: hot_sums_kernel<1><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+    case 2: hot_sums_kernel<2><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+    case 3: hot_sums_kernel<3><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+    default: hot_sums_kernel<4><<<bin_blocks, NTA, 0, s>>>(grads, dim, pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->partial, nullptr, 0); break;
+  }
+  gather_csr_kernel<<<key_blocks, 256, 0, s>>>(dim, grads, pl->partial, keys_of(pl), nullptr, rows_out, nullptr, (const int*)dest);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "plan_reduce_to: launch failed");
   return TFRA_OK;
 }
 

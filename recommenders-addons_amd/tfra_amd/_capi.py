@@ -82,6 +82,7 @@ _SIGS = {
     "tfra_table_size_to_device": [_P, _P, _P],
     "tfra_table_capacity": [_P, ctypes.POINTER(_SZ)],
     "tfra_multi_step_prefetch": [_SZ, _P, _I],
+    "tfra_plan_reduce_to": [_P, _P, _P, _P, _P],
     "tfra_table_check_errors": [_P, _P],
     "tfra_table_slot_census": [_P, ctypes.POINTER(ctypes.c_uint64), _P],
     "tfra_table_reserve": [_P, _SZ, _P],

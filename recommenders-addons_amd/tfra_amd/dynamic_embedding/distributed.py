@@ -171,3 +171,163 @@ class AllToAllEmbedding:
     p: the step's parameters (`optimizer.begin_step()`) when several embeddings share the optimizer."""
     keys, g = self.route_grads(grads)
     optimizer.apply_sparse(self.local, keys, g, p)
+
+
+class RoutedPrefetchStep:
+  """The sharded training step with the id-only half of the route done AHEAD on a second stream — the multi-GPU
+  counterpart of `PrefetchStep`.
+
+  Everything the route needs before rows or gradients exist depends on the ids alone: the distinct ids of the batch and
+  the position -> distinct-id map (`tfra_unique`), their owner-major order and per-owner counts (`tfra_partition`), the
+  count exchange and the host read of the split sizes, the id alltoall itself, the de-duplication plans of the local
+  batch (for the gradient sums) and of the ids received from the other ranks (for the owner's fused update).  `feed()`
+  starts that for a batch as soon as its ids exist (keep two batches fed ahead: the split sizes are then copied to pinned
+  memory one whole step before they are needed, and the host never waits for them).  What is left on the critical path:
+
+      lookup : local find of the received ids -> alltoall(rows) -> ONE gather (position -> row of the returned block)
+      apply  : per-key gradient sums written straight into owner-major order (tfra_plan_reduce_to) -> alltoall(grads)
+               -> tfra_table_apply_planned at the owner (sums the <= world parts of a key, one fused update)
+
+  i.e. two collectives and three kernels around the local step instead of five collectives, a host read and eight
+  kernels.  The keys are not sent again with the gradients: the owner keeps the ids it received for the lookup, and the
+  gradient rows arrive in the same order.  Every rank must call feed / lookup / apply in the same sequence (the
+  collectives are issued in program order).  Reference: PY/shadow_embedding_ops.py:397-447 (routes at lookup time,
+  synchronously, through Horovod).
+
+      rs = RoutedPrefetchStep(var, deo); rs.feed(ids0); rs.feed(ids1)
+      for i in ...:
+        rows = rs.lookup()                    # [n, dim] rows of the oldest fed batch, in its id order
+        ...                                   # forward / backward of the model
+        rs.apply(grads)                       # gradients of those rows: route + fused update at the owners
+        rs.feed(ids_{i+2})                    # ids must be complete in memory (the second stream does not wait for yours)
+  """
+  NSLOTS = 4
+
+  def __init__(self, var, optimizer, group=None, partition_mode=0, force_collectives=False):
+    from .optimizer import DynamicEmbeddingOptimizer
+    from .table_ops import SparsePlan
+    if var.shard_num != 1 or not DynamicEmbeddingOptimizer.can_plan(var, 1):
+      raise ValueError("RoutedPrefetchStep needs a single-shard fp32 local Variable with dim % 4 == 0, dim <= 256")
+    optimizer._check(var)
+    self.var, self.deo = var, optimizer
+    self.group, self.mode = group, partition_mode
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    self.collectives = dist.is_initialized() and (self.world > 1 or force_collectives)
+    self.t = var.tables[0]
+    self.table = self.t._table
+    self.dev = self.table.device
+    self.ops = _DeviceOps()
+    self.side = torch.cuda.Stream(device=self.dev)
+    self.slots = [dict(plan_local=SparsePlan(self.dev, var.dim), plan_remote=SparsePlan(self.dev, var.dim), state=0,
+                       host_counts=torch.empty((2, self.world), dtype=torch.int64).pin_memory()) for _ in range(self.NSLOTS)]
+    self.head = 0      # oldest fed batch = the one lookup / apply work on
+    self.tail = 0      # next free slot
+    self.fed = 0       # batches fed and not yet applied
+    self.default = self.t._default_value.to(device=self.dev, dtype=torch.float32).contiguous()
+    self._iota = None
+
+  def _a2a(self, out, inp, out_splits=None, in_splits=None):
+    if not self.collectives:
+      out.copy_(inp)
+      return
+    if inp.is_cuda and dist.get_backend(self.group) == "gloo":   # host-staged (tests on one GPU)
+      o = torch.empty(out.shape, dtype=out.dtype)
+      dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+      out.copy_(o)
+    else:
+      dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
+
+  def feed(self, ids, ids_ready=True):
+    """First half of the id-only route of one batch, on the second stream: distinct ids, owner-major order, count
+    exchange, split sizes on their way to pinned memory.  ids_ready=False: the ids are still being produced on the
+    current stream (the second stream then waits for it)."""
+    if self.fed >= self.NSLOTS - 1:
+      raise RuntimeError("RoutedPrefetchStep: %d batches are fed ahead already" % self.fed)
+    sl = self.slots[self.tail]
+    ids = torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+    if not ids_ready:
+      self.side.wait_stream(torch.cuda.current_stream(self.dev))
+    if sl.get("done") is not None:
+      self.side.wait_event(sl["done"])    # the slot's plans were last read by the step that applied it (NSLOTS steps ago)
+    with torch.cuda.stream(self.side):
+      uniq, idx, cnt = self.ops.unique_no_sync(ids)
+      owner_major, perm, counts = self.ops.partition(uniq, self.world, self.mode, n_dev=cnt)
+      recv_counts = torch.empty_like(counts)
+      self._a2a(recv_counts, counts)
+      sl["host_counts"].copy_(torch.stack([counts, recv_counts]), non_blocking=True)
+      ev = sl.get("counts_ev") or torch.cuda.Event()
+      ev.record(self.side)
+      sl["plan_local"].build(ids, sync=False)
+    for tns in (ids, uniq, idx, owner_major, perm, counts, recv_counts):
+      tns.record_stream(self.side)
+    sl.update(ids=ids, n=ids.numel(), idx=idx, owner_major=owner_major, perm=perm, counts_ev=ev, state=1)
+    self.tail = (self.tail + 1) % self.NSLOTS
+    self.fed += 1
+
+  def _finish(self, sl):
+    """Second half, once the split sizes are on the host (no wait when the batch was fed a step earlier): the id
+    alltoall, the position -> returned-row map, the plan of the ids this rank serves."""
+    if sl["state"] != 1:
+      return
+    sl["counts_ev"].synchronize()
+    hc = sl["host_counts"]
+    send, recv = [int(x) for x in hc[0]], [int(x) for x in hc[1]]
+    u = sum(send)
+    with torch.cuda.stream(self.side):
+      remote_ids = torch.empty(sum(recv), dtype=torch.int64, device=self.dev)
+      self._a2a(remote_ids, sl["owner_major"][:u].contiguous(), recv, send)
+      # position -> row of the owner-major block: inverse of perm (owner-major j holds distinct id perm[j]), through idx —
+      # two row moves of 4-byte rows (a scatter and a gather) instead of four framework ops
+      if self._iota is None or self._iota.numel() < max(u, 1):
+        self._iota = torch.arange(max(u, 1, sl["n"]), dtype=torch.int32, device=self.dev).reshape(-1, 1)
+      inv = self.ops.scatter_rows(self._iota[:max(u, 1)], sl["perm"][:max(u, 1)] if u else self._iota[:1, 0])
+      pos2row = self.ops.gather_rows(inv, sl["idx"]).reshape(-1)
+      sl["plan_remote"].build(remote_ids, sync=False)
+      ready = sl.get("ready") or torch.cuda.Event()
+      ready.record(self.side)
+    for tns in (remote_ids, inv, pos2row):
+      tns.record_stream(self.side)
+    sl.update(u=u, send=send, recv=recv, remote_ids=remote_ids, pos2row=pos2row, ready=ready, state=2)
+
+  def lookup(self):
+    if self.fed == 0:
+      raise RuntimeError("RoutedPrefetchStep.lookup: no batch fed")
+    sl = self.slots[self.head]
+    self._finish(sl)
+    main = torch.cuda.current_stream(self.dev)
+    main.wait_event(sl["ready"])
+    rows = self.t.lookup(sl["remote_ids"]).reshape(sl["remote_ids"].numel(), self.var.dim)
+    back = torch.empty((max(sl["u"], 1), self.var.dim), dtype=rows.dtype, device=self.dev)
+    self._a2a(back[:sl["u"]], rows.contiguous(), sl["send"], sl["recv"])
+    return self.ops.gather_rows(back, sl["pos2row"])
+
+  def apply(self, grads, p=None):
+    if self.fed == 0:
+      raise RuntimeError("RoutedPrefetchStep.apply: no batch fed")
+    sl = self.slots[self.head]
+    self._finish(sl)
+    if p is None:
+      p = self.deo.begin_step()
+    main = torch.cuda.current_stream(self.dev)
+    main.wait_event(sl["ready"])
+    g = grads.reshape(sl["n"], self.var.dim)
+    if g.dtype != torch.float32 or not g.is_contiguous():
+      g = g.to(torch.float32).contiguous()
+    gsum = torch.empty((max(sl["u"], 1), self.var.dim), dtype=torch.float32, device=self.dev)
+    sl["plan_local"].reduce_to(g, sl["pos2row"], gsum, sync=False)
+    nr = sl["remote_ids"].numel()
+    remote = torch.empty((max(nr, 1), self.var.dim), dtype=torch.float32, device=self.dev)
+    self._a2a(remote[:nr], gsum[:sl["u"]], sl["recv"], sl["send"])
+    if nr:
+      if getattr(self.var, "restrict_policy", None) is not None:
+        self.var.restrict_policy.apply_update(sl["remote_ids"])
+      self.table.apply_planned(p, sl["plan_remote"], remote[:nr], self.default, sync=False)
+    done = sl.get("done") or torch.cuda.Event()
+    done.record(main)
+    sl["done"] = done
+    sl["state"] = 0
+    self.head = (self.head + 1) % self.NSLOTS
+    self.fed -= 1
+    if self.fed:      # the next batch: its split sizes arrived during this step — finish its route now, off the critical path
+      self._finish(self.slots[self.head])

@@ -354,6 +354,24 @@ class SparsePlan:
       self._built.record(stream)
     return self
 
+  def reduce_to(self, grads, dest, rows_out, sync=True):
+    """rows_out[dest[p], :] = sum of the gradient rows of the id at position p (tfra_plan_reduce_to): the per-key sums of
+    the plan's batch, scattered by a caller-supplied position -> row map (equal for all positions of an id)."""
+    grads = grads.to(self._device, torch.float32).contiguous()
+    if grads.numel() != self.n * self._dim:
+      raise ValueError("Expected shape %s for grads, got %s" % ([self.n, self._dim], list(grads.shape)))
+    if dest.dtype != torch.int32 or dest.numel() != self.n or not dest.is_contiguous():
+      raise ValueError("dest must be a contiguous int32 tensor with one entry per id")
+    stream = torch.cuda.current_stream(self._device)
+    if sync:
+      stream.wait_event(self._built)
+    _capi.call("tfra_plan_reduce_to", self._h, _ptr(grads), _ptr(dest), _ptr(rows_out), _stream(self._device))
+    if sync:
+      if self._used is None:
+        self._used = torch.cuda.Event()
+      self._used.record(stream)
+    return rows_out
+
   def read(self):
     """The batch as CSR-by-key, on the host (tests / tools): counts dict, keys [U], cnt [U], positions [n]
     (the positions of key 0, of key 1, ..., each ascending).  Synchronises the current stream."""

@@ -19,7 +19,7 @@ for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
 
 pytestmark = pytest.mark.gpu
 
-DIM, STEPS, LR = 8, 3, 0.5
+DIM, STEPS, LR = 8, 5, 0.5
 
 
 def _batch(rank, step):
@@ -30,6 +30,8 @@ def _batch(rank, step):
 
 
 def _worker(rank, world, port, dedup, out_dir):
+  if dedup == 2:
+    return _worker_prefetched(rank, world, port, out_dir)
   import torch
   import torch.distributed as dist
   import tfra_amd.dynamic_embedding as de
@@ -58,7 +60,44 @@ def _worker(rank, world, port, dedup, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dedup", [1, 0])
+def _worker_prefetched(rank, world, port, out_dir):
+  """The same training run through RoutedPrefetchStep: the id-only half of the route two batches ahead on a second stream."""
+  import torch
+  import torch.distributed as dist
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import RoutedPrefetchStep
+  os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+  try:
+    opt = de.optimizers.SGD(LR)
+    var = de.Variable(dim=DIM, name="a2a_w2p_r%d" % rank, initializer=0.5, devices=["cuda:0"],
+                      **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    rs = RoutedPrefetchStep(var, deo, partition_mode=0)
+    assert rs.world == 2 and rs.collectives
+    batches = [_batch(rank, s) for s in range(STEPS)]
+    dev_ids = [torch.from_numpy(b[0]).cuda() for b in batches]
+    torch.cuda.synchronize()
+    for s in range(min(2, STEPS)):
+      rs.feed(dev_ids[s])
+    looked = []
+    for step in range(STEPS):
+      out = rs.lookup()
+      looked.append(out.cpu().numpy().reshape(batches[step][0].shape + (DIM,)))
+      rs.apply(torch.from_numpy(batches[step][1]).cuda())
+      if step + 2 < STEPS:
+        rs.feed(dev_ids[step + 2])
+    assert deo.iterations == STEPS
+    k, v = var.export()
+    k = k.cpu().numpy()
+    assert np.all(((k & 0x7FFFFFFF) % world) == rank)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), keys=k, vals=v.cpu().numpy(), **{"look%d" % i: x for i, x in enumerate(looked)})
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dedup", [1, 0, 2])   # 2 = RoutedPrefetchStep (route prepared two batches ahead)
 def test_alltoall_world2_real_tables_one_gpu(dedup, tmp_path):
   import torch
   import torch.multiprocessing as mp

@@ -184,6 +184,47 @@ def test_alltoall_route_single_rank(env, backend, dedup):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_routed_prefetch_step_single_rank(env, backend):
+  """RoutedPrefetchStep on ONE rank with the collectives forced on (RCCL moves device buffers, gloo is host-staged): the
+  route prepared two batches ahead gives the rows of the direct single-table path bit for bit and the same table after
+  training (the gradient sums take the same tree as tfra_reduce_by_key)."""
+  torch, de = env
+  import torch.distributed as dist
+  from tfra_amd.dynamic_embedding.distributed import RoutedPrefetchStep
+  port = 29920 + (1 if backend == "gloo" else 0)
+  dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                          **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+  try:
+    rng = np.random.default_rng(12)
+    opt = de.optimizers.Adam(1e-2)
+    kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
+    a = de.Variable(dim=16, name="rps_a_%s" % backend, initializer=0.25, **kw)
+    b = de.Variable(dim=16, name="rps_b_%s" % backend, initializer=0.25, **kw)
+    oa, ob = de.DynamicEmbeddingOptimizer(opt), de.DynamicEmbeddingOptimizer(de.optimizers.Adam(1e-2))
+    rs = RoutedPrefetchStep(a, oa, partition_mode=0, force_collectives=True)
+    assert rs.collectives
+    steps = 6
+    ids = [T(torch, (rng.zipf(1.25, size=3000).astype(np.int64) % 4000) * 7919 - 5) for _ in range(steps)]
+    grads = [T(torch, (rng.standard_normal((3000, 16)) * 0.01).astype(np.float32)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    rs.feed(ids[0]); rs.feed(ids[1])
+    for s in range(steps):
+      out = rs.lookup()
+      ref = b.lookup(ids[s])
+      np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+      rs.apply(grads[s])
+      ob.apply_sparse(b, ids[s], grads[s])
+      if s + 2 < steps:
+        rs.feed(ids[s + 2])
+    ka, va = a.export(); kb, vb = b.export()
+    ia, ib = np.argsort(ka.cpu().numpy()), np.argsort(kb.cpu().numpy())
+    np.testing.assert_array_equal(ka.cpu().numpy()[ia], kb.cpu().numpy()[ib])
+    np.testing.assert_allclose(va.cpu().numpy()[ia], vb.cpu().numpy()[ib], rtol=1e-6, atol=1e-6)
+  finally:
+    dist.destroy_process_group()
+
+
 def test_k7_k8_sharding(env):
   """K7: default partitioner over 2 shards (T/dynamic_embedding_ops_test.py:324-349);
   K8: custom partitioner keys%2 over 3 shards (:382-408)."""
