@@ -47,7 +47,15 @@ class HkvEvictStrategy(enum.IntEnum):
   CUSTOMIZED = 4
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+  """The current HIP stream of `device` as a void*.  torch.cuda.current_stream() builds a Stream object through several
+  Python layers (5 us per call, 18 calls in one routed multi-GPU step): the raw getter is the same value in 0.3 us."""
+  if _raw_stream is not None:
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    return ctypes.c_void_p(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
   return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
