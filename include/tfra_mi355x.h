@@ -149,8 +149,10 @@ int tfra_table_export_batch(tfra_table_t* t, size_t n, size_t offset, size_t* d_
 /* -- run-time options.  TFRA_OPTION_CAPTURE_SAFE = 1 makes every table entry point safe to call
  *    while `stream` is being captured into a hipGraph (no host synchronisation, no event
  *    record/query, no growth): the caller guarantees capacity (tfra_table_reserve beforehand) and
- *    keeps using ONE stream.  Scratch buffers must have been sized by an identical warm-up call. */
-typedef enum { TFRA_OPTION_CAPTURE_SAFE = 1 } tfra_option;
+ *    keeps using ONE stream.  Scratch buffers must have been sized by an identical warm-up call.
+ *    TFRA_OPTION_NO_OWNER_TAGS = 1 makes the planned write-backs take the general two-kernel path
+ *    (the one used when the 4 B/bucket owner-tag array cannot be allocated); same results.      */
+typedef enum { TFRA_OPTION_CAPTURE_SAFE = 1, TFRA_OPTION_NO_OWNER_TAGS = 2 } tfra_option;
 int tfra_table_set_option(tfra_table_t* t, int option, int64_t value);
 
 /* -- set_global_epoch (lookup_table_op_hkv.h:499,507,533) --------------------------------- */

@@ -63,6 +63,7 @@ struct Table {
   bool growth_blocked = false;
   bool dense = false;        // a table that cannot grow any more holds > 60 % of its slots (async size reads)
   bool capture_safe = false;  // TFRA_OPTION_CAPTURE_SAFE
+  bool no_owner_tags = false; // TFRA_OPTION_NO_OWNER_TAGS
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
   int n_rehash = 0;

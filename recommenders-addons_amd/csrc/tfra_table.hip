@@ -748,6 +748,7 @@ int Table::check_errors(hipStream_t s) {
 
 // bucket-owner tags of the ownership-based write-backs: 4 B per bucket, zeroed; rebuilt after a rehash
 unsigned* Table::ensure_own_tags(hipStream_t s) {
+  if (no_owner_tags) return nullptr;
   if (own_tags && own_tags_nb == cur.nb) return own_tags;
   if (own_tags) { (void)hipStreamSynchronize(s); dfree(own_tags, s); own_tags = nullptr; }
   own_tags = (unsigned*)dalloc(cur.nb * sizeof(unsigned), s);
@@ -1325,6 +1326,7 @@ int tfra_table_set_option(tfra_table_t* tp, int option, int64_t value) {
   if (!t) return set_error(TFRA_ERR_INVALID, "null table");
   std::lock_guard<std::mutex> lock(t->mu);
   if (option == TFRA_OPTION_CAPTURE_SAFE) { t->capture_safe = value != 0; return TFRA_OK; }
+  if (option == TFRA_OPTION_NO_OWNER_TAGS) { t->no_owner_tags = value != 0; return TFRA_OK; }
   return set_error(TFRA_ERR_INVALID, "unknown option");
 }
 

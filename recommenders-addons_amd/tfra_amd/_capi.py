@@ -14,6 +14,7 @@ TFRA_F32, TFRA_F16, TFRA_BF16, TFRA_I8, TFRA_I32, TFRA_I64, TFRA_F64 = range(7)
 FLAG_UNIQUE_KEYS = 1
 OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_FTRL = range(4)
 OPTION_CAPTURE_SAFE = 1
+OPTION_NO_OWNER_TAGS = 2
 
 
 class TfraError(RuntimeError):

@@ -269,6 +269,10 @@ class _DeviceTable:
     """While True every op on this table can be captured into a HIP graph (no host sync, no growth)."""
     _capi.call("tfra_table_set_option", self._h, _capi.OPTION_CAPTURE_SAFE, int(bool(on)))
 
+  def set_owner_tags(self, on):
+    """False: planned write-backs take the general two-kernel path (what runs when the tag array cannot be allocated)."""
+    _capi.call("tfra_table_set_option", self._h, _capi.OPTION_NO_OWNER_TAGS, int(not on))
+
   def reserve(self, n_slots):
     _capi.call("tfra_table_reserve", self._h, int(n_slots), _stream(self._device))
 

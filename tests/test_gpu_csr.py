@@ -158,14 +158,16 @@ def test_apply_sparse_benchmark_shape_vs_sequential_oracle(env):
     del var, deo, ps
 
 
+@pytest.mark.parametrize("owner_tags", [True, False])
 @pytest.mark.parametrize("dtype_name,dim", [("float32", 64), ("float16", 128), ("int8", 3), ("int64", 10), ("bfloat16", 33)])
-def test_upsert_sparse_last_occurrence_wins(env, dtype_name, dim):
+def test_upsert_sparse_last_occurrence_wins(env, dtype_name, dim, owner_tags):
   import oracle
   torch, de, SparsePlan = env
   dt = getattr(torch, dtype_name)
   npdt = {"float32": np.float32, "float16": np.float16, "int8": np.int8, "int64": np.int64, "bfloat16": np.float32}[dtype_name]
   rng = np.random.default_rng(dim)
   t = de.CuckooHashTable(torch.int64, dt, torch.zeros(dim, dtype=dt), device="cuda:0", dim=dim, name="ups_%s" % dtype_name)
+  t._table.set_owner_tags(owner_tags)   # False: the general two-kernel write-back (runs when the tag array cannot be allocated)
   ref = {}
   for step in range(3):
     n = 30_000
@@ -189,13 +191,15 @@ def test_upsert_sparse_last_occurrence_wins(env, dtype_name, dim):
   assert torch.equal(got, exp)
 
 
-def test_upsert_sparse_bounded_table_at_capacity(env):
+@pytest.mark.parametrize("owner_tags", [True, False])
+def test_upsert_sparse_bounded_table_at_capacity(env, owner_tags):
   """A bounded (Hkv) table at max_capacity takes batches with repeats through the plan: size <= capacity, every
   resident key returns the row of its last occurrence."""
   torch, de, SparsePlan = env
   dim, cap, B = 16, 60_000, 50_000
   t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
                       evict_strategy=de.HkvEvictStrategy.LRU, name="ups_bounded")
+  t._table.set_owner_tags(owner_tags)
   rng = np.random.default_rng(3)
   latest = {}
   fresh = 1
