@@ -504,7 +504,27 @@ def run_c2(args, torch, dist, de, dev, world, rank):
     for i in range(W):
       plain(base + i)
     elapsed_plain, _ = timed_steps(torch, dist, world, dev, K, lambda i: plain(base + W + i))
-  elif os.environ.get("TFRA_BENCH_ROUTE", "prefetch") == "prefetch":
+  elif os.environ.get("TFRA_BENCH_ROUTE", "native") == "native":
+    # N > 1 (or the collectives forced on one GPU): the same prepared-ahead route as RoutedPrefetchStep below, issued from C
+    # (tfra_route_*: three calls per step, grouped ncclSend/ncclRecv on the driver's own RCCL communicators)
+    from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
+    rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B)
+    rs.feed(ids_all[0]); rs.feed(ids_all[1])
+
+    def routed(i):
+      out = rs.lookup()
+      rs.apply(grads)
+      rs.feed(ids_all[i + 2])
+      return out
+
+    for i in range(W):
+      routed(i)
+    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: routed(W + i))
+    for _ in range(2):   # drain the batches fed ahead
+      rs.lookup(); rs.apply(grads)
+    torch.cuda.synchronize()
+    rs.close()
+  elif os.environ.get("TFRA_BENCH_ROUTE") == "prefetch":
     # N > 1 (or the collectives forced on one GPU): the id-only half of the route — distinct ids, owner-major order, count
     # exchange, id alltoall, both de-duplication plans — runs two batches ahead on a second stream (RoutedPrefetchStep);
     # per step: local find -> alltoall(rows) -> gather, gradient sums -> alltoall(grads) -> fused update at the owner
@@ -581,10 +601,13 @@ def run_c2(args, torch, dist, de, dev, world, rank):
           "drivers": {
               "value": ("tfra_table_step_prefetch: ONE C call per step = lookup + hot sums + fused Adam of batch i on the main "
                         "stream, CSR-by-key plan of batch i+1 on a second stream; one plan built per step inside the timed region")
-              if single else ("RoutedPrefetchStep: id-only half of the alltoall route two batches ahead on a second stream; per step "
-                              "find -> alltoall(rows) -> gather, gradient sums -> alltoall(grads) -> fused Adam at the owner"
-                              if os.environ.get("TFRA_BENCH_ROUTE", "prefetch") == "prefetch" else
-                              "embedding_lookup + apply_gradients through the alltoall route (exact split sizes, no look-ahead)"),
+              if single else {
+                  "native": "tfra_route_* (C driver, grouped ncclSend/ncclRecv): id-only half of the alltoall route two batches "
+                            "ahead on a second stream; per step find -> alltoall(rows) -> gather, gradient sums -> alltoall(grads) "
+                            "-> fused Adam at the owner",
+                  "prefetch": "RoutedPrefetchStep (the same sequence driven from Python through torch.distributed)",
+              }.get(os.environ.get("TFRA_BENCH_ROUTE", "native"),
+                    "embedding_lookup + apply_gradients through the alltoall route (exact split sizes, no look-ahead)"),
               "value_plain_call": "tfra_table_find then tfra_table_apply_sparse (plan built inside the call): the reference's op "
                                   "sequence lookup -> optimizer apply, no look-ahead"},
       },
@@ -764,7 +787,9 @@ def main():
   if rank == 0:
     if not args.no_cpu_baseline:
       res["cpu_baseline"] = cpu_baseline(args.batch)
-    print(json.dumps(res))
+    import ctypes
+    ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: out before the JSON line, not after it
+    print(json.dumps(res), flush=True)
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()

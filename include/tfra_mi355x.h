@@ -334,6 +334,16 @@ int tfra_reduce_by_key(tfra_workspace_t* ws, size_t n, const int64_t* ids, int d
 int tfra_plan_reduce_to(const tfra_sparse_plan_t* plan, const float* grads, const int32_t* dest, float* rows_out,
                         tfra_stream_t stream);
 
+/* The distinct ids of a built plan in place of tfra_unique, for a caller that needs them grouped by owner (the multi-GPU
+ * route; PY/shadow_embedding_ops.py:316,397-422 does unique then dynamic_partition):
+ *   tfra_plan_partition   = tfra_partition over the plan's distinct keys (order unspecified): keys_out owner-major,
+ *                           perm_out[j] = the plan's index of the key in owner-major row j, d_counts[num_shards];
+ *   tfra_plan_positions_to: dest_out[p] = j for every batch position p whose id is the key of owner-major row j —
+ *                           the position -> row map for tfra_gather_rows (lookup) and tfra_plan_reduce_to (gradients). */
+int tfra_plan_partition(const tfra_sparse_plan_t* plan, tfra_workspace_t* ws, int num_shards, int mode,
+                        int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream);
+int tfra_plan_positions_to(const tfra_sparse_plan_t* plan, const int32_t* perm, int32_t* dest_out, tfra_stream_t stream);
+
 /* out[i,:] = rows[idx[i],:] (tf.gather after unique). row_bytes = dim*sizeof(V). */
 int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out,
                      tfra_stream_t stream);
@@ -372,6 +382,49 @@ int tfra_scatter_rows(size_t n, size_t row_bytes, const void* in, const int32_t*
  * Feed keys_out to tfra_table_erase of the parameter table and of the status table.            */
 int tfra_select_lowest(tfra_workspace_t* ws, size_t n, const int64_t* keys, const void* status,
                        int status_dtype, size_t k, int64_t* keys_out, tfra_stream_t stream);
+
+/* -- multi-GPU routed step issued from C (the route of HvdAllToAllEmbedding,
+ *    PY/shadow_embedding_ops.py:397-447 / DE/python/keras/layers/embedding.py:545-594, prepared ahead of the step).
+ *
+ *    A transport moves peer-major device buffers between the ranks of one job: send_bytes[r] bytes go to rank r,
+ *    recv_bytes[r] bytes arrive from it (an alltoallv), enqueued on `stream`.  channel 0 carries rows and gradients
+ *    (the critical path of a step), channel 1 the counts and ids of later batches; the two never wait for each other.
+ *    Every rank issues the same sequence of calls.  tfra_rccl_transport_* is the RCCL one (grouped ncclSend/ncclRecv
+ *    over xGMI, one communicator per channel; librccl is dlopen()ed from `librccl_path`, the copy the host framework
+ *    already loaded); tests plug a host-staged transport into the same driver.                                       */
+typedef struct {
+  void* ctx;
+  int rank, world;
+  int (*alltoallv)(void* ctx, int channel, const void* send, const size_t* send_bytes, void* recv,
+                   const size_t* recv_bytes, tfra_stream_t stream);
+} tfra_transport;
+#define TFRA_RCCL_ID_BYTES 128
+int tfra_rccl_unique_id(const char* librccl_path, void* id_out /* TFRA_RCCL_ID_BYTES, host */);
+/* ids: 2 x TFRA_RCCL_ID_BYTES (one per channel), made by rank 0 and distributed by the caller; call on every rank */
+int tfra_rccl_transport_create(const char* librccl_path, const void* ids, int rank, int world, int device,
+                               tfra_transport* out);
+int tfra_rccl_transport_destroy(tfra_transport* tr);
+
+/*    The driver.  feed() starts the id-only half of the route of one batch on the driver's second stream: distinct
+ *    ids, owner-major order, count exchange, split sizes on their way to pinned memory, the de-duplication plan of the
+ *    batch.  Keep two batches fed ahead of the one being looked up: the id exchange, the position -> returned-row map
+ *    and the plan of the ids this rank serves are then issued one whole step early and the host never waits.
+ *      lookup : rows_out[i,:] = row of ids[i] of the OLDEST fed batch (owner's find, default row for missing keys,
+ *               alltoall of the rows, one gather)
+ *      apply  : gradient rows of that batch -> per-key sums in owner-major order -> alltoall -> fused sparse update at
+ *               the owner (tfra_table_apply_planned: sums the <= world parts of a key in a fixed order); retires it
+ *    transport NULL: one rank, buffers are copied on the device.  fp32 rows, dim % 4 == 0, dim <= 256, batches of at
+ *    most max_batch <= 2^18 ids; the ids a rank serves per batch must not exceed 2^18.  One caller thread.          */
+typedef struct tfra_route tfra_route_t;
+int tfra_route_create(tfra_table_t* table, const tfra_transport* transport, int partition_mode, size_t max_batch,
+                      tfra_route_t** out);
+int tfra_route_destroy(tfra_route_t* r);
+int tfra_route_feed(tfra_route_t* r, size_t n, const int64_t* d_ids, int ids_ready, tfra_stream_t stream);
+int tfra_route_lookup(tfra_route_t* r, float* d_rows_out, const float* default_row, tfra_stream_t stream);
+int tfra_route_apply(tfra_route_t* r, const tfra_opt_params* p, const float* d_grads, const float* param_default_row,
+                     tfra_stream_t stream);
+/* ids this rank serves for the oldest fed batch (device pointer valid until its apply; waits for the split sizes) */
+int tfra_route_served_ids(tfra_route_t* r, const int64_t** d_ids, size_t* n, size_t* n_distinct_local);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
     res = list(ex.map(lambda s: _compile(s, force, newest), srcs))
   objs = [o for o, _ in res]
   if force or any(ch for _, ch in res) or not os.path.exists(LIB):
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB])
     if verbose:
       print("built", LIB)
   return LIB

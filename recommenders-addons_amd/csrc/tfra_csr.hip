@@ -504,6 +504,7 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
       cursors[(size_t)(P + 1) * CSTRIDE] = 0;
       const unsigned v[6] = {nhot, ncold, 0u, nbins, 0u, e};
       for (int k = 0; k < 6; ++k) d_counts[k] = v[k];
+      *reinterpret_cast<i64*>(d_counts + 32) = (i64)nhot + (i64)ncold;   // tfra_plan_partition: the count as tfra_partition reads it
       if (host_counts) {
         for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1328,6 +1329,7 @@ struct tfra_sparse_plan {
   mutable unsigned use_gen = 0;
   mutable unsigned ups_uses = 0;   // upsert_planned uses: parity selects the left-over counter (SlowIter)
   float* partial = nullptr;
+  int* prow_dest = nullptr;        // [partial rows] scratch of tfra_plan_positions_to
   bool armed = false;              // cursors/counters are zero (re-armed by the last kernel of the previous build)
   unsigned* host_counts = nullptr; // pinned: [0] generation of the last COMPLETED build, [1..6] its counts
   unsigned gen = 0;                // generation of the last enqueued build
@@ -1386,6 +1388,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
                  + al(nbin * SEG * 4) + al(nbin * 32 * 4)                       // bins + run outputs
                  + al(npad * 4) + al(npad * 8) + al(nbin * 4)                   // keymap, dense keys, binmap
                  + al(npad) + al((size_t)SLOW_CAP * 4)                          // deferred flags, left-over key list
+                 + al(npart * 4)                                                // partial row -> destination (route helpers)
                  + al(npart * (size_t)dim * 4);                                 // partial rows
   if (pl->bytes < bytes) {
     if (pl->buf) {
@@ -1424,6 +1427,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   pl->dflag = (uint8_t*)w; w += al(npad);
   pl->slow_list = (unsigned*)w; w += al((size_t)SLOW_CAP * 4);
   pl->any_deferred = pl->d_counts + 8;
+  pl->prow_dest = (int*)w; w += al(npart * 4);
   pl->partial = (float*)w;
   pl->gen += 1;
   ds.cursor = pl->cursors;
@@ -1792,6 +1796,75 @@ extern "C" int tfra_plan_reduce_to(const tfra_sparse_plan_t* pl, const float* gr
   }
   gather_csr_kernel<<<key_blocks, 256, 0, s>>>(dim, grads, pl->partial, keys_of(pl), nullptr, rows_out, nullptr, (const int*)dest);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "plan_reduce_to: launch failed");
+  return TFRA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Route helpers: the distinct keys of a built plan stand in for tf.unique (PY/shadow_embedding_ops.py:316 does unique,
+// then partitions the distinct ids by owner).  tfra_plan_partition = tfra_partition over the plan's keys;
+// tfra_plan_positions_to expands its perm to every batch position: dest[p] = j for the positions p of key perm[j].
+__global__ __launch_bounds__(256) void plan_dest_keys_kernel(CsrKeys ks, const int* __restrict__ perm, int* __restrict__ dest,
+                                                             int* __restrict__ prow_dest) {
+  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    const unsigned km = ks.keymap[perm[j]];
+    if (km & KM_MANY) {   // its positions sit in the bins: tag the key's partial rows, plan_dest_bins_kernel does the rest
+      const unsigned* rec = ks.hrec + (size_t)(km & ~KM_MANY) * REC_WORDS;
+      const unsigned first = rec[3], nsrc = rec[4];
+      for (unsigned t = 0; t < nsrc; ++t) prow_dest[first + t] = (int)j;
+    } else {
+      const unsigned* rec = ks.crec + (size_t)km * REC_WORDS;
+      const unsigned cnt = rec[2];
+      for (unsigned e = 0; e < cnt; ++e) dest[rec[4 + e]] = (int)j;
+    }
+  }
+}
+
+// one block per bin of 512 entries, a 16-lane group per item (the layout hot_sums_kernel reduces)
+__global__ __launch_bounds__(NTA) void plan_dest_bins_kernel(const unsigned* __restrict__ hent, const unsigned* __restrict__ hout,
+                                                             const unsigned* __restrict__ binmap, const unsigned* __restrict__ d_counts,
+                                                             const int* __restrict__ prow_dest, int* __restrict__ dest) {
+  constexpr int NG = NTA / 16;
+  __shared__ unsigned char s_kind[NG];   // 0 = continues the run of the item before, 1 = first item of a run, 2 = empty item
+  __shared__ unsigned s_row[NG];
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, g = threadIdx.x >> 4;
+  const unsigned nbins = d_counts[3];
+  for (unsigned ib = blockIdx.x; ib < nbins; ib += gridDim.x) {
+    const unsigned bin = binmap[ib];
+    const unsigned e = hent[(size_t)bin * SEG + threadIdx.x];
+    const unsigned e0 = (unsigned)__shfl((int)e, gshift);
+    const bool empty = (e0 & E_SKIP) != 0, first = (e0 & E_HEAD) != 0;
+    if (sub == 0) {
+      s_kind[g] = empty ? 2 : (first ? 1 : 0);
+      s_row[g] = (first && !empty) ? hout[(size_t)bin * 32 + g] : 0u;
+    }
+    __syncthreads();
+    if (!empty && !(e & E_SKIP)) {
+      int g2 = g;
+      while (g2 > 0 && s_kind[g2] == 0) --g2;
+      dest[e & E_POS] = prow_dest[s_row[g2]];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int tfra_plan_partition(const tfra_sparse_plan_t* pl, tfra_workspace_t* ws, int num_shards, int mode,
+                                   int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream) {
+  if (!pl || pl->n == 0) return set_error(TFRA_ERR_INVALID, "plan_partition: no built plan");
+  return tfra_partition(ws, pl->n, reinterpret_cast<const int64_t*>(pl->d_counts + 32), (const int64_t*)pl->dkeys, num_shards, mode,
+                        keys_out, perm_out, d_counts, stream);
+}
+
+extern "C" int tfra_plan_positions_to(const tfra_sparse_plan_t* pl, const int32_t* perm, int32_t* dest_out, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!pl || pl->n == 0) return set_error(TFRA_ERR_INVALID, "plan_positions_to: no built plan");
+  if (!perm || !dest_out) return set_error(TFRA_ERR_INVALID, "plan_positions_to: null buffer");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != pl->device) { if (hipSetDevice(pl->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "plan_positions_to: hipSetDevice"); } }
+  unsigned key_blocks, bin_blocks;
+  plan_grids(pl, &key_blocks, &bin_blocks);
+  plan_dest_keys_kernel<<<(unsigned)std::min<size_t>(2048, (pl->n + 255) / 256), 256, 0, s>>>(keys_of(pl), perm, dest_out, pl->prow_dest);
+  plan_dest_bins_kernel<<<bin_blocks, NTA, 0, s>>>(pl->out.hent, pl->out.hout, pl->binmap, pl->d_counts, pl->prow_dest, dest_out);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "plan_positions_to: launch failed");
   return TFRA_OK;
 }
 

@@ -67,6 +67,18 @@ class StepDesc(ctypes.Structure):
       ("plan_next", ctypes.c_void_p), ("ids_next", ctypes.c_void_p), ("n_next", ctypes.c_size_t), ("main_stream", ctypes.c_void_p),
       ("side_stream", ctypes.c_void_p),
   ]
+
+
+ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t),
+                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p)
+
+
+class Transport(ctypes.Structure):
+  """tfra_transport (include/tfra_mi355x.h): the alltoallv the routed step driver exchanges buffers through."""
+  _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int), ("alltoallv", ALLTOALLV_FN)]
+
+
+RCCL_ID_BYTES = 128
 _SZ = ctypes.c_size_t
 _I = ctypes.c_int
 _SIGS = {
@@ -116,6 +128,17 @@ _SIGS = {
     "tfra_scatter_rows": [_SZ, _SZ, _P, _P, _P, _P],
     "tfra_reduce_by_key": [_P, _SZ, _P, _I, _P, _P, _P, _P, _P],
     "tfra_select_lowest": [_P, _SZ, _P, _P, _I, _SZ, _P, _P],
+    "tfra_plan_partition": [_P, _P, _I, _I, _P, _P, _P, _P],
+    "tfra_plan_positions_to": [_P, _P, _P, _P],
+    "tfra_rccl_unique_id": [ctypes.c_char_p, _P],
+    "tfra_rccl_transport_create": [ctypes.c_char_p, _P, _I, _I, _I, ctypes.POINTER(Transport)],
+    "tfra_rccl_transport_destroy": [ctypes.POINTER(Transport)],
+    "tfra_route_create": [_P, ctypes.POINTER(Transport), _I, _SZ, ctypes.POINTER(_P)],
+    "tfra_route_destroy": [_P],
+    "tfra_route_feed": [_P, _SZ, _P, _I, _P],
+    "tfra_route_lookup": [_P, _P, _P, _P],
+    "tfra_route_apply": [_P, ctypes.POINTER(OptParams), _P, _P, _P],
+    "tfra_route_served_ids": [_P, ctypes.POINTER(_P), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
 }
 
 _lib = None

@@ -331,3 +331,191 @@ class RoutedPrefetchStep:
     self.fed -= 1
     if self.fed:      # the next batch: its split sizes arrived during this step — finish its route now, off the critical path
       self._finish(self.slots[self.head])
+
+
+def _loaded_librccl():
+  """Path of the librccl the process already has mapped (torch's), so the driver's communicators and torch's come from
+  one copy of the library."""
+  try:
+    with open("/proc/self/maps") as f:
+      for line in f:
+        if "librccl" in line:
+          return line.split()[-1]
+  except OSError:
+    pass
+  import os
+  cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+  return cand if os.path.exists(cand) else "librccl.so"
+
+
+_HIP = None
+
+
+def _hip():
+  global _HIP
+  if _HIP is None:
+    import ctypes
+    h = ctypes.CDLL("libamdhip64.so")
+    h.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    h.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    h.hipDeviceSynchronize.argtypes = []
+    _HIP = h
+  return _HIP
+
+
+class _StagedTransport:
+  """Host-staged alltoallv through a torch.distributed group (gloo): lets the tests run the C driver with two ranks
+  that share ONE GPU, where RCCL cannot form a communicator.  Not a product path."""
+
+  def __init__(self, group, device):
+    import ctypes
+    from .. import _capi
+    self.group, self.device = group, device
+    self.error = None
+    hip = _hip()
+    world = dist.get_world_size(group)
+
+    def fn(ctx, channel, send, send_bytes, recv, recv_bytes, stream):
+      try:
+        sb = [int(send_bytes[i]) for i in range(world)]
+        rb = [int(recv_bytes[i]) for i in range(world)]
+        hip.hipStreamSynchronize(stream)
+        src = torch.empty(max(sum(sb), 1), dtype=torch.uint8)
+        if sum(sb):
+          assert hip.hipMemcpy(src.data_ptr(), send, sum(sb), 2) == 0
+        dst = torch.empty(max(sum(rb), 1), dtype=torch.uint8)
+        dist.all_to_all_single(dst[:sum(rb)], src[:sum(sb)], rb, sb, group=group)
+        if sum(rb):
+          assert hip.hipMemcpy(recv, dst.data_ptr(), sum(rb), 1) == 0
+        return 0
+      except BaseException as e:   # never unwind through the C frames
+        self.error = e
+        return 4
+    self._fn = _capi.ALLTOALLV_FN(fn)
+    self.struct = _capi.Transport(None, dist.get_rank(group), world, self._fn)
+
+
+class NativeRoutedStep:
+  """`RoutedPrefetchStep` with the whole sequence issued from C (`tfra_route_*`, csrc/tfra_route.hip): three ctypes
+  calls per step instead of ~18 plus four torch.distributed calls, and the collectives are grouped ncclSend/ncclRecv on
+  the driver's own RCCL communicators (one for rows/gradients, one for the counts/ids of later batches).  Same
+  results as `RoutedPrefetchStep` / `AllToAllEmbedding` (same kernels, same summation order).
+
+      rs = NativeRoutedStep(var, deo); rs.feed(ids0); rs.feed(ids1)
+      for i in ...:
+        rows = rs.lookup(); ...; rs.apply(grads); rs.feed(ids_{i+2})
+
+  transport: "rccl" (default when torch.distributed runs on nccl), "staged" (host-staged through the group; tests),
+  None (single rank, device copies).  Reference: PY/shadow_embedding_ops.py:397-447."""
+
+  def __init__(self, var, optimizer, group=None, partition_mode=0, force_collectives=False, transport="auto", max_batch=1 << 18):
+    import ctypes
+    from .. import _capi
+    from .optimizer import DynamicEmbeddingOptimizer
+    if var.shard_num != 1 or not DynamicEmbeddingOptimizer.can_plan(var, 1):
+      raise ValueError("NativeRoutedStep needs a single-shard fp32 local Variable with dim % 4 == 0, dim <= 256")
+    optimizer._check(var)
+    self.var, self.deo = var, optimizer
+    self.t = var.tables[0]
+    self.table = self.t._table
+    self.dev = self.table.device
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    collectives = dist.is_initialized() and (self.world > 1 or force_collectives)
+    if transport == "auto":
+      transport = None if not collectives else ("rccl" if dist.get_backend(group) == "nccl" else "staged")
+    self._staged = None
+    self._rccl = None
+    tr = None
+    if transport == "rccl":
+      lib = _loaded_librccl().encode()
+      ids = torch.zeros(2 * _capi.RCCL_ID_BYTES, dtype=torch.uint8)
+      if self.rank == 0:
+        buf = (ctypes.c_char * (2 * _capi.RCCL_ID_BYTES))()
+        for ch in range(2):
+          _capi.call("tfra_rccl_unique_id", lib, ctypes.byref(buf, ch * _capi.RCCL_ID_BYTES))
+        ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+      on_dev = dist.get_backend(group) == "nccl"
+      ids_x = ids.to(self.dev) if on_dev else ids
+      if self.world > 1:
+        dist.broadcast(ids_x, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+      raw = bytes(ids_x.cpu().numpy().tobytes())
+      self._rccl = _capi.Transport()
+      _capi.call("tfra_rccl_transport_create", lib, raw, self.rank, self.world, self.dev.index or 0, ctypes.byref(self._rccl))
+      tr = ctypes.byref(self._rccl)
+    elif transport == "staged":
+      self._staged = _StagedTransport(group, self.dev)
+      tr = ctypes.byref(self._staged.struct)
+    elif transport is not None:
+      raise ValueError("transport: 'auto', 'rccl', 'staged' or None")
+    self._h = ctypes.c_void_p()
+    _capi.call("tfra_route_create", self.table._h, tr, int(partition_mode), int(max_batch), ctypes.byref(self._h))
+    self.default = self.t._default_value.to(device=self.dev, dtype=torch.float32).contiguous()
+    self._ids = []     # fed batches, oldest first (kept alive until applied)
+    self._capi, self._ctypes = _capi, ctypes
+
+  def _call(self, name, *args):
+    try:
+      self._capi.call(name, *args)
+    except self._capi.TfraError:
+      if self._staged is not None and self._staged.error is not None:
+        e, self._staged.error = self._staged.error, None
+        raise e
+      raise
+
+  def _stream(self):
+    return self._ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self.dev.index or 0))
+
+  def feed(self, ids, ids_ready=True):
+    ids = torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+    self._call("tfra_route_feed", self._h, ids.numel(), self._ctypes.c_void_p(ids.data_ptr()), 1 if ids_ready else 0, self._stream())
+    self._ids.append(ids)
+
+  def served_ids(self):
+    """The ids this rank serves for the oldest fed batch (a view of the driver's buffer, valid until its apply)."""
+    p, n, u = self._ctypes.c_void_p(), self._ctypes.c_size_t(), self._ctypes.c_size_t()
+    self._call("tfra_route_served_ids", self._h, self._ctypes.byref(p), self._ctypes.byref(n), self._ctypes.byref(u))
+    return p.value, int(n.value), int(u.value)
+
+  def lookup(self):
+    if not self._ids:
+      raise RuntimeError("NativeRoutedStep.lookup: no batch fed")
+    n = self._ids[0].numel()
+    out = torch.empty((n, self.var.dim), dtype=torch.float32, device=self.dev)
+    self._call("tfra_route_lookup", self._h, self._ctypes.c_void_p(out.data_ptr()), self._ctypes.c_void_p(self.default.data_ptr()), self._stream())
+    return out
+
+  def apply(self, grads, p=None):
+    if not self._ids:
+      raise RuntimeError("NativeRoutedStep.apply: no batch fed")
+    n = self._ids[0].numel()
+    if p is None:
+      p = self.deo.begin_step()
+    g = grads.reshape(n, self.var.dim)
+    if g.dtype != torch.float32 or not g.is_contiguous():
+      g = g.to(torch.float32).contiguous()
+    if getattr(self.var, "restrict_policy", None) is not None:
+      ptr, nr, _ = self.served_ids()
+      if nr:
+        served = torch.empty(nr, dtype=torch.int64, device=self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()   # the ids arrived on the driver's second stream
+        if _hip().hipMemcpy(served.data_ptr(), ptr, nr * 8, 3) != 0:
+          raise RuntimeError("NativeRoutedStep: copy of the served ids failed")
+        self.var.restrict_policy.apply_update(served)
+    self._call("tfra_route_apply", self._h, self._ctypes.byref(p), self._ctypes.c_void_p(g.data_ptr()),
+               self._ctypes.c_void_p(self.default.data_ptr()), self._stream())
+    self._ids.pop(0)
+
+  def close(self):
+    if getattr(self, "_h", None) is not None and self._h:
+      self._capi.call("tfra_route_destroy", self._h)
+      self._h = None
+    if self._rccl is not None:
+      self._capi.call("tfra_rccl_transport_destroy", self._ctypes.byref(self._rccl))
+      self._rccl = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -366,6 +366,26 @@ class SparsePlan:
       self._built.record(stream)
     return self
 
+  def partition(self, num_shards, mode=0):
+    """The plan's distinct ids grouped by owner (tfra_plan_partition: tfra_partition over the plan's keys, in place of
+    tf.unique + dynamic_partition): owner-major ids [n], perm [n] (plan index of each owner-major row), counts
+    [num_shards] (device).  Entries past sum(counts) are unspecified.  Runs on the current stream after the build."""
+    from .device_ops import _workspace
+    dev = self._device
+    keys_out = torch.empty(self.n, dtype=torch.int64, device=dev)
+    perm = torch.empty(self.n, dtype=torch.int32, device=dev)
+    counts = torch.zeros(num_shards, dtype=torch.int64, device=dev)
+    torch.cuda.current_stream(dev).wait_event(self._built)
+    _capi.call("tfra_plan_partition", self._h, _workspace(dev), int(num_shards), int(mode), _ptr(keys_out), _ptr(perm), _ptr(counts),
+               _stream(dev))
+    return keys_out, perm, counts
+
+  def positions_to(self, perm):
+    """dest[p] = j for every batch position p whose id is the key of owner-major row j (tfra_plan_positions_to)."""
+    dest = torch.empty(self.n, dtype=torch.int32, device=self._device)
+    _capi.call("tfra_plan_positions_to", self._h, _ptr(perm), _ptr(dest), _stream(self._device))
+    return dest
+
   def reduce_to(self, grads, dest, rows_out, sync=True):
     """rows_out[dest[p], :] = sum of the gradient rows of the id at position p (tfra_plan_reduce_to): the per-key sums of
     the plan's batch, scattered by a caller-supplied position -> row map (equal for all positions of an id)."""

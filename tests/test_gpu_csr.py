@@ -73,6 +73,34 @@ def test_plan_edge_shapes(env):
     assert np.array_equal(np.sort(keys), np.unique(ids)) and np.array_equal(ids[pos], np.repeat(keys, cnt))
 
 
+@pytest.mark.parametrize("world,mode", [(1, 0), (2, 0), (8, 0), (8, 1), (5, 2)])
+def test_plan_partition_and_positions(env, world, mode):
+  """tfra_plan_partition / tfra_plan_positions_to (the route's stand-in for tf.unique + dynamic_partition): the plan's
+  distinct ids grouped by owner, and for every batch position the owner-major row of its id."""
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(100 * world + mode)
+  shapes = [np.full(70_000, -9, np.int64), np.arange(5000, dtype=np.int64) * 3 - 7000,
+            (rng.zipf(1.2, size=131072) % 1_000_003).astype(np.int64) * 7919 - 5, rng.integers(-20, 20, size=40_000).astype(np.int64),
+            np.array([5], np.int64), np.repeat(np.arange(3000, dtype=np.int64), 9)]
+  plan = SparsePlan("cuda:0", 16)
+  for ids in shapes:
+    plan.build(torch.from_numpy(ids).cuda())
+    keys_out, perm, counts = plan.partition(world, mode)
+    dest = plan.positions_to(perm)
+    torch.cuda.synchronize()
+    counts = counts.cpu().numpy(); keys_out = keys_out.cpu().numpy(); dest = dest.cpu().numpy()
+    u = int(counts.sum())
+    uniq = np.unique(ids)
+    assert u == uniq.size
+    assert np.array_equal(np.sort(keys_out[:u]), uniq)
+    if mode != 2:   # (hash mode has no reference twin)
+      owner = (keys_out[:u] & 0x7FFFFFFF) % world if mode == 0 else np.mod(keys_out[:u], world)
+      assert np.all(np.diff(owner) >= 0)                                        # owner-major
+      assert np.array_equal(np.bincount(owner, minlength=world), counts)
+    assert dest.min() >= 0 and dest.max() < u
+    assert np.array_equal(keys_out[dest], ids)                                  # every position maps to the row of its id
+
+
 def test_apply_sparse_benchmark_shape_vs_sequential_oracle(env):
   """B = 131 072, Zipf-1.2 over 10 M resident keys, 3 Adam steps, one-call path and step driver: embedding values
   within 1e-6 of the reference's sequence with sequential fp32 duplicate sums; slots within 1e-6 relative."""

@@ -30,8 +30,8 @@ def _batch(rank, step):
 
 
 def _worker(rank, world, port, dedup, out_dir):
-  if dedup == 2:
-    return _worker_prefetched(rank, world, port, out_dir)
+  if dedup >= 2:
+    return _worker_prefetched(rank, world, port, out_dir, native=dedup == 3)
   import torch
   import torch.distributed as dist
   import tfra_amd.dynamic_embedding as de
@@ -60,12 +60,13 @@ def _worker(rank, world, port, dedup, out_dir):
     dist.destroy_process_group()
 
 
-def _worker_prefetched(rank, world, port, out_dir):
-  """The same training run through RoutedPrefetchStep: the id-only half of the route two batches ahead on a second stream."""
+def _worker_prefetched(rank, world, port, out_dir, native=False):
+  """The same training run through RoutedPrefetchStep: the id-only half of the route two batches ahead on a second stream.
+  native: through the C driver (tfra_route_*) with the host-staged transport (RCCL cannot pair two ranks on one GPU)."""
   import torch
   import torch.distributed as dist
   import tfra_amd.dynamic_embedding as de
-  from tfra_amd.dynamic_embedding.distributed import RoutedPrefetchStep
+  from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep, RoutedPrefetchStep
   os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
   torch.cuda.set_device(0)
   dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -74,8 +75,12 @@ def _worker_prefetched(rank, world, port, out_dir):
     var = de.Variable(dim=DIM, name="a2a_w2p_r%d" % rank, initializer=0.5, devices=["cuda:0"],
                       **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
     deo = de.DynamicEmbeddingOptimizer(opt)
-    rs = RoutedPrefetchStep(var, deo, partition_mode=0)
-    assert rs.world == 2 and rs.collectives
+    if native:
+      rs = NativeRoutedStep(var, deo, partition_mode=0, transport="staged", max_batch=4096)
+      assert rs.world == 2
+    else:
+      rs = RoutedPrefetchStep(var, deo, partition_mode=0)
+      assert rs.world == 2 and rs.collectives
     batches = [_batch(rank, s) for s in range(STEPS)]
     dev_ids = [torch.from_numpy(b[0]).cuda() for b in batches]
     torch.cuda.synchronize()
@@ -89,6 +94,9 @@ def _worker_prefetched(rank, world, port, out_dir):
       if step + 2 < STEPS:
         rs.feed(dev_ids[step + 2])
     assert deo.iterations == STEPS
+    if native:
+      torch.cuda.synchronize()
+      rs.close()
     k, v = var.export()
     k = k.cpu().numpy()
     assert np.all(((k & 0x7FFFFFFF) % world) == rank)
@@ -97,7 +105,7 @@ def _worker_prefetched(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dedup", [1, 0, 2])   # 2 = RoutedPrefetchStep (route prepared two batches ahead)
+@pytest.mark.parametrize("dedup", [1, 0, 2, 3])   # 2 = RoutedPrefetchStep (route prepared two batches ahead), 3 = the C driver
 def test_alltoall_world2_real_tables_one_gpu(dedup, tmp_path):
   import torch
   import torch.multiprocessing as mp

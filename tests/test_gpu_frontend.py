@@ -225,6 +225,55 @@ def test_routed_prefetch_step_single_rank(env, backend):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", [None, "rccl", "staged"])
+def test_native_routed_step_single_rank(env, transport):
+  """The C driver of the routed step (tfra_route_*) on ONE rank: no transport (device copies), its own RCCL
+  communicators (grouped ncclSend/ncclRecv to itself) and the host-staged test transport.  Rows bit for bit those of the
+  direct single-table path; the same table after training."""
+  torch, de = env
+  import torch.distributed as dist
+  from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
+  backend = {None: None, "rccl": "nccl", "staged": "gloo"}[transport]
+  if backend:
+    port = 29930 + (1 if backend == "gloo" else 0)
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+  try:
+    rng = np.random.default_rng(13)
+    opt = de.optimizers.Adam(1e-2)
+    kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
+    tag = str(transport)
+    a = de.Variable(dim=16, name="nrs_a_%s" % tag, initializer=0.25, **kw)
+    b = de.Variable(dim=16, name="nrs_b_%s" % tag, initializer=0.25, **kw)
+    oa, ob = de.DynamicEmbeddingOptimizer(opt), de.DynamicEmbeddingOptimizer(de.optimizers.Adam(1e-2))
+    rs = NativeRoutedStep(a, oa, partition_mode=0, force_collectives=True, max_batch=4096)
+    steps = 7
+    sizes = [3000, 1, 4096, 17, 3000, 2999, 64]
+    ids = [T(torch, (rng.zipf(1.25, size=n).astype(np.int64) % 4000) * 7919 - 5) for n in sizes]
+    grads = [T(torch, (rng.standard_normal((n, 16)) * 0.01).astype(np.float32)) for n in sizes]
+    torch.cuda.synchronize()
+    rs.feed(ids[0]); rs.feed(ids[1])
+    for s in range(steps):
+      out = rs.lookup()
+      ref = b.lookup(ids[s])
+      np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
+      rs.apply(grads[s])
+      ob.apply_sparse(b, ids[s], grads[s])
+      if s + 2 < steps:
+        rs.feed(ids[s + 2])
+    with pytest.raises(RuntimeError):
+      rs.lookup()
+    ka, va = a.export(); kb, vb = b.export()
+    ia, ib = np.argsort(ka.cpu().numpy()), np.argsort(kb.cpu().numpy())
+    np.testing.assert_array_equal(ka.cpu().numpy()[ia], kb.cpu().numpy()[ib])
+    np.testing.assert_allclose(va.cpu().numpy()[ia], vb.cpu().numpy()[ib], rtol=1e-6, atol=1e-6)
+    torch.cuda.synchronize()
+    rs.close()
+  finally:
+    if backend:
+      dist.destroy_process_group()
+
+
 def test_k7_k8_sharding(env):
   """K7: default partitioner over 2 shards (T/dynamic_embedding_ops_test.py:324-349);
   K8: custom partitioner keys%2 over 3 shards (:382-408)."""
