@@ -508,19 +508,22 @@ def run_c2(args, torch, dist, de, dev, world, rank):
     # N > 1 (or the collectives forced on one GPU): the same prepared-ahead route as RoutedPrefetchStep below, issued from C
     # (tfra_route_*: three calls per step, grouped ncclSend/ncclRecv on the driver's own RCCL communicators)
     from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
-    rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B)
-    rs.feed(ids_all[0]); rs.feed(ids_all[1])
+    rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B,
+                          threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
+    ahead = int(os.environ.get("TFRA_ROUTE_AHEAD", "3"))   # batches whose ids are known before their step (input pipeline)
+    for j in range(ahead):
+      rs.feed(ids_all[j])
 
     def routed(i):
       out = rs.lookup()
       rs.apply(grads)
-      rs.feed(ids_all[i + 2])
+      rs.feed(ids_all[i + ahead])
       return out
 
     for i in range(W):
       routed(i)
     elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: routed(W + i))
-    for _ in range(2):   # drain the batches fed ahead
+    for _ in range(ahead):   # drain the batches fed ahead
       rs.lookup(); rs.apply(grads)
     torch.cuda.synchronize()
     rs.close()
@@ -602,9 +605,9 @@ def run_c2(args, torch, dist, de, dev, world, rank):
               "value": ("tfra_table_step_prefetch: ONE C call per step = lookup + hot sums + fused Adam of batch i on the main "
                         "stream, CSR-by-key plan of batch i+1 on a second stream; one plan built per step inside the timed region")
               if single else {
-                  "native": "tfra_route_* (C driver, grouped ncclSend/ncclRecv): id-only half of the alltoall route two batches "
-                            "ahead on a second stream; per step find -> alltoall(rows) -> gather, gradient sums -> alltoall(grads) "
-                            "-> fused Adam at the owner",
+                  "native": "tfra_route_* (C driver, grouped ncclSend/ncclRecv): id-only half of the alltoall route up to three "
+                            "batches ahead on its own streams; per step find -> alltoall(rows) -> gather, gradient sums -> "
+                            "alltoall(grads) -> fused Adam at the owner",
                   "prefetch": "RoutedPrefetchStep (the same sequence driven from Python through torch.distributed)",
               }.get(os.environ.get("TFRA_BENCH_ROUTE", "native"),
                     "embedding_lookup + apply_gradients through the alltoall route (exact split sizes, no look-ahead)"),

@@ -405,19 +405,24 @@ int tfra_rccl_transport_create(const char* librccl_path, const void* ids, int ra
                                tfra_transport* out);
 int tfra_rccl_transport_destroy(tfra_transport* tr);
 
-/*    The driver.  feed() starts the id-only half of the route of one batch on the driver's second stream: distinct
- *    ids, owner-major order, count exchange, split sizes on their way to pinned memory, the de-duplication plan of the
- *    batch.  Keep two batches fed ahead of the one being looked up: the id exchange, the position -> returned-row map
- *    and the plan of the ids this rank serves are then issued one whole step early and the host never waits.
+/*    The driver.  feed() hands a batch to the id-only half of the route, which runs ahead of the step on the driver's
+ *    own streams: the de-duplication plan of the batch and its distinct ids grouped by owner (a helper thread launches
+ *    these), the count exchange, the split sizes on their way to pinned memory, the id exchange, the position ->
+ *    returned-row map and the plan of the ids this rank serves.  A batch moves one stage per step, so keep THREE batches
+ *    fed ahead of the one being looked up and nothing ever waits (fewer works too: the missing stages then run, and
+ *    stall, inside lookup).  Every collective is issued by the calling thread at points that depend on the call
+ *    sequence alone, so all ranks issue them in the same order.
  *      lookup : rows_out[i,:] = row of ids[i] of the OLDEST fed batch (owner's find, default row for missing keys,
  *               alltoall of the rows, one gather)
  *      apply  : gradient rows of that batch -> per-key sums in owner-major order -> alltoall -> fused sparse update at
  *               the owner (tfra_table_apply_planned: sums the <= world parts of a key in a fixed order); retires it
  *    transport NULL: one rank, buffers are copied on the device.  fp32 rows, dim % 4 == 0, dim <= 256, batches of at
- *    most max_batch <= 2^18 ids; the ids a rank serves per batch must not exceed 2^18.  One caller thread.          */
+ *    most max_batch <= 2^18 ids; the ids a rank serves per batch must not exceed 2^18.  One caller thread.
+ *    flags: TFRA_ROUTE_NO_THREAD = everything is issued by the calling thread.                                      */
+#define TFRA_ROUTE_NO_THREAD 1u
 typedef struct tfra_route tfra_route_t;
 int tfra_route_create(tfra_table_t* table, const tfra_transport* transport, int partition_mode, size_t max_batch,
-                      tfra_route_t** out);
+                      uint32_t flags, tfra_route_t** out);
 int tfra_route_destroy(tfra_route_t* r);
 int tfra_route_feed(tfra_route_t* r, size_t n, const int64_t* d_ids, int ids_ready, tfra_stream_t stream);
 int tfra_route_lookup(tfra_route_t* r, float* d_rows_out, const float* default_row, tfra_stream_t stream);

@@ -79,6 +79,7 @@ class Transport(ctypes.Structure):
 
 
 RCCL_ID_BYTES = 128
+ROUTE_NO_THREAD = 1
 _SZ = ctypes.c_size_t
 _I = ctypes.c_int
 _SIGS = {
@@ -133,7 +134,7 @@ _SIGS = {
     "tfra_rccl_unique_id": [ctypes.c_char_p, _P],
     "tfra_rccl_transport_create": [ctypes.c_char_p, _P, _I, _I, _I, ctypes.POINTER(Transport)],
     "tfra_rccl_transport_destroy": [ctypes.POINTER(Transport)],
-    "tfra_route_create": [_P, ctypes.POINTER(Transport), _I, _SZ, ctypes.POINTER(_P)],
+    "tfra_route_create": [_P, ctypes.POINTER(Transport), _I, _SZ, ctypes.c_uint32, ctypes.POINTER(_P)],
     "tfra_route_destroy": [_P],
     "tfra_route_feed": [_P, _SZ, _P, _I, _P],
     "tfra_route_lookup": [_P, _P, _P, _P],

@@ -401,14 +401,18 @@ class NativeRoutedStep:
   the driver's own RCCL communicators (one for rows/gradients, one for the counts/ids of later batches).  Same
   results as `RoutedPrefetchStep` / `AllToAllEmbedding` (same kernels, same summation order).
 
-      rs = NativeRoutedStep(var, deo); rs.feed(ids0); rs.feed(ids1)
+      rs = NativeRoutedStep(var, deo); rs.feed(ids0); rs.feed(ids1); rs.feed(ids2)
       for i in ...:
-        rows = rs.lookup(); ...; rs.apply(grads); rs.feed(ids_{i+2})
+        rows = rs.lookup(); ...; rs.apply(grads); rs.feed(ids_{i+3})
+
+  Keep three batches fed ahead (a batch moves one stage of the route per step; fewer works, with stalls).  threaded: a
+  helper thread launches the kernels of the id-only half (the collectives always come from the calling thread).
 
   transport: "rccl" (default when torch.distributed runs on nccl), "staged" (host-staged through the group; tests),
   None (single rank, device copies).  Reference: PY/shadow_embedding_ops.py:397-447."""
 
-  def __init__(self, var, optimizer, group=None, partition_mode=0, force_collectives=False, transport="auto", max_batch=1 << 18):
+  def __init__(self, var, optimizer, group=None, partition_mode=0, force_collectives=False, transport="auto", max_batch=1 << 18,
+               threaded=True):
     import ctypes
     from .. import _capi
     from .optimizer import DynamicEmbeddingOptimizer
@@ -449,7 +453,8 @@ class NativeRoutedStep:
     elif transport is not None:
       raise ValueError("transport: 'auto', 'rccl', 'staged' or None")
     self._h = ctypes.c_void_p()
-    _capi.call("tfra_route_create", self.table._h, tr, int(partition_mode), int(max_batch), ctypes.byref(self._h))
+    _capi.call("tfra_route_create", self.table._h, tr, int(partition_mode), int(max_batch),
+               0 if threaded else _capi.ROUTE_NO_THREAD, ctypes.byref(self._h))
     self.default = self.t._default_value.to(device=self.dev, dtype=torch.float32).contiguous()
     self._ids = []     # fed batches, oldest first (kept alive until applied)
     self._capi, self._ctypes = _capi, ctypes

@@ -24,13 +24,15 @@ for lo in range(1, N + 1, 4_000_000):
 rng = np.random.default_rng(0)
 ids = [torch.from_numpy(keys_of_ranks(zipf_bounded(rng, B, N))).cuda() for _ in range(8)]
 g = torch.randn((B, DIM), device="cuda") * 0.01
-rs = NativeRoutedStep(var, deo, force_collectives=True, max_batch=B)
-rs.feed(ids[0]); rs.feed(ids[1])
+AHEAD = int(os.environ.get("TFRA_ROUTE_AHEAD", "3"))
+rs = NativeRoutedStep(var, deo, force_collectives=True, max_batch=B, threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
+for j in range(AHEAD):
+  rs.feed(ids[j])
 T = {"lookup": 0.0, "apply": 0.0, "feed": 0.0}
 
 
 def step(i, sync=False):
-  for name, fn in (("lookup", rs.lookup), ("apply", lambda: rs.apply(g)), ("feed", lambda: rs.feed(ids[(i + 2) & 7]))):
+  for name, fn in (("lookup", rs.lookup), ("apply", lambda: rs.apply(g)), ("feed", lambda: rs.feed(ids[(i + AHEAD) & 7]))):
     t0 = time.perf_counter()
     fn()
     if sync:
@@ -50,7 +52,8 @@ for sync in (False, True):
   torch.cuda.synchronize()
   tot = (time.perf_counter() - t0) * 1e6 / 200
   print("sync after each call" if sync else "free running", "us per step %.1f" % tot, {k: round(v * 1e6 / 200, 1) for k, v in T.items()})
-rs.lookup(); rs.apply(g); rs.lookup(); rs.apply(g)
+for _ in range(AHEAD):
+  rs.lookup(); rs.apply(g)
 torch.cuda.synchronize()
 rs.close()
 if mode == "rccl":

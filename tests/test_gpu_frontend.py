@@ -225,8 +225,9 @@ def test_routed_prefetch_step_single_rank(env, backend):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transport", [None, "rccl", "staged"])
-def test_native_routed_step_single_rank(env, transport):
+@pytest.mark.parametrize("transport,threaded,ahead", [(None, True, 3), ("rccl", True, 3), ("rccl", False, 2), ("staged", True, 1),
+                                                      (None, False, 4)])
+def test_native_routed_step_single_rank(env, transport, threaded, ahead):
   """The C driver of the routed step (tfra_route_*) on ONE rank: no transport (device copies), its own RCCL
   communicators (grouped ncclSend/ncclRecv to itself) and the host-staged test transport.  Rows bit for bit those of the
   direct single-table path; the same table after training."""
@@ -242,25 +243,26 @@ def test_native_routed_step_single_rank(env, transport):
     rng = np.random.default_rng(13)
     opt = de.optimizers.Adam(1e-2)
     kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
-    tag = str(transport)
+    tag = "%s_%d_%d" % (transport, threaded, ahead)
     a = de.Variable(dim=16, name="nrs_a_%s" % tag, initializer=0.25, **kw)
     b = de.Variable(dim=16, name="nrs_b_%s" % tag, initializer=0.25, **kw)
     oa, ob = de.DynamicEmbeddingOptimizer(opt), de.DynamicEmbeddingOptimizer(de.optimizers.Adam(1e-2))
-    rs = NativeRoutedStep(a, oa, partition_mode=0, force_collectives=True, max_batch=4096)
+    rs = NativeRoutedStep(a, oa, partition_mode=0, force_collectives=True, max_batch=4096, threaded=threaded)
     steps = 7
     sizes = [3000, 1, 4096, 17, 3000, 2999, 64]
     ids = [T(torch, (rng.zipf(1.25, size=n).astype(np.int64) % 4000) * 7919 - 5) for n in sizes]
     grads = [T(torch, (rng.standard_normal((n, 16)) * 0.01).astype(np.float32)) for n in sizes]
     torch.cuda.synchronize()
-    rs.feed(ids[0]); rs.feed(ids[1])
+    for s in range(ahead):
+      rs.feed(ids[s])
     for s in range(steps):
       out = rs.lookup()
       ref = b.lookup(ids[s])
       np.testing.assert_array_equal(out.cpu().numpy(), ref.cpu().numpy())
       rs.apply(grads[s])
       ob.apply_sparse(b, ids[s], grads[s])
-      if s + 2 < steps:
-        rs.feed(ids[s + 2])
+      if s + ahead < steps:
+        rs.feed(ids[s + ahead])
     with pytest.raises(RuntimeError):
       rs.lookup()
     ka, va = a.export(); kb, vb = b.export()
