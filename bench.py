@@ -510,6 +510,8 @@ def run_c2(args, torch, dist, de, dev, world, rank):
     from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
     rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B,
                           threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
+    if dist.is_initialized() and rank == 0:
+      print("[bench] route: native C driver, world %d" % world, file=sys.stderr, flush=True)
     ahead = int(os.environ.get("TFRA_ROUTE_AHEAD", "3"))   # batches whose ids are known before their step (input pipeline)
     for j in range(ahead):
       rs.feed(ids_all[j])

@@ -433,17 +433,26 @@ class NativeRoutedStep:
     tr = None
     if transport == "rccl":
       lib = _loaded_librccl().encode()
-      ids = torch.zeros(2 * _capi.RCCL_ID_BYTES, dtype=torch.uint8)
+      # rank 0 makes the two unique ids; a status byte travels with them so that a failure there raises on EVERY rank
+      # instead of leaving the others waiting in the broadcast
+      ids = torch.zeros(2 * _capi.RCCL_ID_BYTES + 1, dtype=torch.uint8)
+      err0 = None
       if self.rank == 0:
         buf = (ctypes.c_char * (2 * _capi.RCCL_ID_BYTES))()
-        for ch in range(2):
-          _capi.call("tfra_rccl_unique_id", lib, ctypes.byref(buf, ch * _capi.RCCL_ID_BYTES))
-        ids = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        try:
+          for ch in range(2):
+            _capi.call("tfra_rccl_unique_id", lib, ctypes.byref(buf, ch * _capi.RCCL_ID_BYTES))
+          ids = torch.frombuffer(bytearray(buf.raw) + bytearray([1]), dtype=torch.uint8).clone()
+        except Exception as e:   # noqa: BLE001 — reported below, on every rank
+          err0 = e
       on_dev = dist.get_backend(group) == "nccl"
       ids_x = ids.to(self.dev) if on_dev else ids
       if self.world > 1:
         dist.broadcast(ids_x, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
       raw = bytes(ids_x.cpu().numpy().tobytes())
+      if raw[-1] != 1:
+        raise RuntimeError("NativeRoutedStep: rank 0 could not create the RCCL unique ids (%s)" % (err0 or "see rank 0"))
+      raw = raw[:-1]
       self._rccl = _capi.Transport()
       _capi.call("tfra_rccl_transport_create", lib, raw, self.rank, self.world, self.dev.index or 0, ctypes.byref(self._rccl))
       tr = ctypes.byref(self._rccl)

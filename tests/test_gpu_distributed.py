@@ -133,3 +133,25 @@ def test_alltoall_world2_real_tables_one_gpu(dedup, tmp_path):
   o = np.argsort(gk)
   np.testing.assert_array_equal(gk[o], ek)            # every key lives on exactly one shard
   np.testing.assert_allclose(gv[o], ev, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("route", ["native", "prefetch"])
+def test_bench_two_ranks_one_gpu(route, tmp_path):
+  """The driver's N > 1 invocation of bench.py (torch.distributed.run, one process per rank) in small: two ranks share
+  cuda:0, collectives host-staged through gloo (RCCL cannot pair two ranks on one GPU).  One JSON line from rank 0 with
+  the contract's fields; throughput > 0."""
+  import json
+  import subprocess
+  import sys
+  env = dict(os.environ, TFRA_BENCH_BACKEND="gloo", TFRA_BENCH_ROUTE=route, HSA_ENABLE_IPC_MODE_LEGACY="0")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(29990 + (route == "native")), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+         "--keys", "300000", "--batch", "8192", "--no-cpu-baseline"]
+  p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-3000:]
+  lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, p.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+  assert d["config"]["global_batch"] == 2 * 8192
+  assert "roofline" in d and d["unit"] == "pairs/s"
