@@ -132,6 +132,11 @@ int tfra_table_size_to_device(tfra_table_t* t, int64_t* d_out, tfra_stream_t str
 int tfra_table_check_errors(tfra_table_t* t, tfra_stream_t stream);
 /* number of slots export_batch scans (= value to loop `offset` up to) */
 int tfra_table_capacity(tfra_table_t* t, size_t* out);
+/* Growth so far (introspection): out4 = {growths, of which in place, storage is a mapped address range (0/1), bytes
+ * mapped}.  Tables of TFRA_VMM_THRESHOLD_MB (env, default 4096) or more live in a reserved virtual address range and grow
+ * by mapping more memory behind the table and splitting every bucket into its children where it is — peak memory = the
+ * new size; smaller tables, and tables on a caller-supplied allocator, grow by copying (old + new coexist). */
+int tfra_table_growth_stats(tfra_table_t* t, uint64_t* out4);
 /* introspection (tests, tools): out5 = {empty key slots, slots locked by an eviction in progress (0 whenever no
  * call is running), live key slots, buckets with the OVF0 flag, buckets with the OVF1 flag}.  Host buffer;
  * synchronises `stream`. */

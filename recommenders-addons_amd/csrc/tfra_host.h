@@ -4,6 +4,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/tfra_mi355x.h"
 #include "tfra_device.h"
@@ -16,6 +17,11 @@ int set_error(int code, const std::string& msg);
 struct Storage {
   unsigned char* base = nullptr;  // nb bucket blocks [key line | score line | 15 rows] + 2 side rows
   u64 nb = 0;
+  // big tables: physical memory mapped chunk by chunk into ONE reserved virtual range (hipMemAddressReserve / hipMemMap),
+  // so that growth maps more memory behind the table and splits the buckets in place (Table::grow_in_place)
+  bool vmm = false;
+  size_t va_bytes = 0, mapped = 0, chunk_bytes = 0;   // every chunk has the same size (see vmm_map_more)
+  std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> chunks;
 };
 
 struct AuxInitPod {
@@ -79,6 +85,9 @@ struct Table {
   unsigned* ensure_own_tags(hipStream_t s);
   int ensure_scratch(size_t bytes, hipStream_t s);
   int grow(u64 min_nb, hipStream_t s);
+  int grow_in_place(u64 min_nb, hipStream_t s);   // TFRA_ERR_UNSUPPORTED: not possible here, copy instead
+  void free_storage(Storage& st, hipStream_t s);
+  int n_split = 0;                                // in-place growths so far
   int prepare_insert(size_t n, hipStream_t s);
   int poll_density(size_t n, hipStream_t s);
   int bounded_flags(size_t n, hipStream_t s, uint8_t** out);

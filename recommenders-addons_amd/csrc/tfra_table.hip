@@ -597,6 +597,112 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableView o, TableView v) {
   if (lane == 0 && failed) atomicAdd(v.err_count, (unsigned)failed);
 }
 
+// ---- growth in place (storage mapped into a reserved virtual range): nb -> F * nb buckets, F a power of two ---------
+// b0 = mulhi(h_hi, nb) and b1 = mulhi(fmix32(..), nb) are RANGE reductions: with F * nb buckets a key's home bucket is one
+// of the F children [F*b, F*b + F) of its old home b.  So every old bucket splits into its children independently of all
+// others, top-down (children of [lo, hi) lie in [F*lo, F*hi), beyond every bucket still to be split), without a second
+// copy of the table.  A key goes to its new b0 if that is a child of the bucket it sat in, else to its new b1 if that
+// is, else (it sat in a chain bucket, or its b1 was the b0+1 substitute: ~nb^-1 of the keys) onto a spill list that is
+// re-inserted the general way afterwards.  Children inherit the parent's overflow flags (a superset of what they need:
+// flags only lengthen searches); keys are packed from slot 0.
+struct SpillBuf {
+  i64* keys; u64* scores; unsigned char* rows; unsigned long long* count; u64 cap;
+};
+
+__device__ __forceinline__ unsigned split_child(const TableView& nv, i64 k, u64 b, unsigned shift) {
+  u64 h;
+  const u64 b0 = bucket0(k, nv.nb, h);
+  if ((b0 >> shift) == b) return (unsigned)(b0 - (b << shift));
+  const u64 b1 = bucket1(h, b0, nv.nb);
+  if ((b1 >> shift) == b) return (unsigned)(b1 - (b << shift));
+  return 0xffu;
+}
+
+__device__ __forceinline__ int nth_set_bit(unsigned m, int n) {   // position of the n-th (0-based) set bit, -1 if fewer
+  for (int i = 0; i < n; ++i) m &= m - 1;
+  return m ? __ffs(m) - 1 : -1;
+}
+
+__global__ __launch_bounds__(256) void split_count_kernel(TableView o, TableView nv, unsigned shift, unsigned long long* count) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  int spilled = 0;
+  for (u64 b = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; b < o.nb; b += ((u64)gridDim.x * blockDim.x) >> 4) {
+    const i64 k = key_line(o, b)[sub];
+    const bool live = sub < SLOTS && k != EMPTY_KEY && k != LOCKED_KEY;
+    spilled += live && split_child(nv, k, b, shift) == 0xffu;
+  }
+  for (int off = 32; off > 0; off >>= 1) spilled += __shfl_xor(spilled, off);
+  if (lane == 0 && spilled) atomicAdd(count, (unsigned long long)spilled);
+}
+
+// buckets [lo, hi) of the old numbering; `self`: lo == 0 and bucket 0's first child is bucket 0 itself — the keys that
+// stay keep their slots, only the others move
+__global__ __launch_bounds__(256) void split_kernel(TableView o, TableView nv, unsigned shift, u64 lo, u64 hi, SpillBuf sp) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const u64 b = lo + ((((u64)blockIdx.x * blockDim.x + threadIdx.x)) >> 4);
+  if (b >= hi) return;
+  const unsigned F = 1u << shift;
+  const bool scored = has_scores(o);
+  const i64 k = key_line(o, b)[sub];                       // lane 15: the meta word
+  const u64 sc = scored ? score_line(o, b)[sub] : 0;
+  const bool live = sub < SLOTS && k != EMPTY_KEY && k != LOCKED_KEY;
+  const unsigned child = live ? split_child(nv, k, b, shift) : 0xfeu;
+  // spill list first: the rows are still where they were
+  unsigned ms = (unsigned)(__ballot(child == 0xffu) >> gshift) & 0x7fffu;
+  while (ms) {
+    const int s = __ffs(ms) - 1;
+    ms &= ms - 1;
+    unsigned long long idx = 0;
+    if (sub == 0) idx = atomicAdd(sp.count, 1ULL);
+    idx = (unsigned long long)shfl_i64((i64)idx, gshift);
+    const i64 ks = shfl_i64(k, gshift + s);
+    const u64 ssc = (u64)shfl_i64((i64)sc, gshift + s);
+    if (idx < sp.cap) {
+      if (sub == 0) { sp.keys[idx] = ks; if (scored) sp.scores[idx] = ssc; }
+      copy_bytes16<16>(sp.rows + idx * (u64)o.row_stride, row_at(o, b, (unsigned)s), o.row_stride, sub);
+    } else if (sub == 0) {
+      atomicAdd(nv.err_count, 1u);   // cannot happen: the list was sized by split_count_kernel
+    }
+  }
+  for (unsigned c = 0; c < F; ++c) {
+    const unsigned mc = (unsigned)(__ballot(child == c) >> gshift) & 0x7fffu;
+    const u64 nb_c = (b << shift) + c;
+    if (nb_c == b) {   // bucket 0 onto itself: stay in place
+      const i64 kout = sub == 15 ? k : ((mc >> sub) & 1u ? k : EMPTY_KEY);
+      key_line(nv, nb_c)[sub] = kout;
+      continue;
+    }
+    const int cnt = __popc(mc);
+    const int src = sub < SLOTS ? nth_set_bit(mc, sub) : -1;
+    const i64 ksrc = shfl_i64(k, gshift + (src < 0 ? 0 : src));
+    const u64 ssrc = (u64)shfl_i64((i64)sc, gshift + (src < 0 ? 0 : src));
+    key_line(nv, nb_c)[sub] = sub == 15 ? k : (src < 0 ? EMPTY_KEY : ksrc);
+    if (scored) score_line(nv, nb_c)[sub] = src < 0 ? 0 : ssrc;
+    for (int j = 0; j < cnt; ++j) {
+      const int sj = nth_set_bit(mc, j);
+      copy_bytes16<16>(row_at(nv, nb_c, (unsigned)j), row_at(o, b, (unsigned)sj), o.row_stride, sub);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spill_reinsert_kernel(TableView v, SpillBuf sp, u64 n) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  int failed = 0;
+  if (i < n) {
+    bool is_new;
+    const i64 row = locate_or_claim(v, sp.keys[i], sub, gshift, is_new);
+    if (row < 0) {
+      failed = sub == 0;
+    } else {
+      copy_bytes16<16>(row_ptr(v, row), sp.rows + i * (u64)v.row_stride, v.row_stride, sub);
+      if (has_scores(v) && sub == 0) score_line(v, (u64)row / SLOTS)[(u64)row % SLOTS] = sp.scores[i];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) failed += __shfl_xor(failed, off);
+  if (lane == 0 && failed) atomicAdd(v.err_count, (unsigned)failed);
+}
+
 // =============================== host side ==================================================
 
 namespace tfra {
@@ -679,12 +785,85 @@ void Table::dfree(void* p, hipStream_t s) {
 
 static inline unsigned hdr_bytes(const tfra_table_opts& o) { return o.strategy >= 0 ? 256u : 128u; }
 
+// Tables of TFRA_VMM_THRESHOLD_MB (default 4096) or more live in a reserved virtual range with physical memory mapped
+// chunk by chunk, so that they can grow in place; smaller ones (and every table of a caller-supplied allocator) are one
+// plain allocation and grow by copying, which costs them nothing.  A negative threshold turns the mapping off.
+static long long vmm_threshold_bytes() {   // read at every (rare) storage allocation: tests switch it per table
+  const char* e = getenv("TFRA_VMM_THRESHOLD_MB");
+  const long long mb = e ? atoll(e) : 4096;
+  return mb < 0 ? -1LL : mb * (1LL << 20);
+}
+// Chunks of ONE size per table (a power of two between 2 MiB and 1 GiB, about the table's first size): on ROCm 7.2
+// hipMemSetAccess rejects some mappings whose size differs from their neighbours' (2 MiB then 4 MiB: invalid argument;
+// scripts/mb/vmm_probe2.hip), equal-sized chunks were accepted in every trial (200 x 2 MiB ... 8 x 4 GiB).
+constexpr size_t VMM_ALIGN = (size_t)2 << 20, VMM_CHUNK_MAX = (size_t)1 << 30;
+
+static int vmm_map_more(Storage* st, size_t need, int device) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  const size_t sz = st->chunk_bytes;
+  need = (need + sz - 1) / sz * sz;
+  if (need > st->va_bytes) return set_error(TFRA_ERR_OOM, "table storage: beyond the reserved address range");
+  while (st->mapped < need) {
+    hipMemGenericAllocationHandle_t h;
+    hipError_t e = hipMemCreate(&h, sz, &prop, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(TFRA_ERR_OOM, std::string("table storage: hipMemCreate: ") + hipGetErrorString(e)); }
+    e = hipMemMap(st->base + st->mapped, sz, 0, h, 0);
+    if (e == hipSuccess) e = hipMemSetAccess(st->base + st->mapped, sz, &acc, 1);
+    if (e != hipSuccess) {
+      (void)hipMemUnmap(st->base + st->mapped, sz); (void)hipMemRelease(h); (void)hipGetLastError();
+      return set_error(TFRA_ERR_OOM, std::string("table storage: hipMemMap: ") + hipGetErrorString(e));
+    }
+    st->chunks.emplace_back(h, sz);
+    st->mapped += sz;
+  }
+  return TFRA_OK;
+}
+
+void Table::free_storage(Storage& st, hipStream_t s) {
+  if (st.vmm) {
+    size_t off = 0;
+    for (auto& c : st.chunks) { (void)hipMemUnmap(st.base + off, c.second); (void)hipMemRelease(c.first); off += c.second; }
+    if (st.base) (void)hipMemAddressFree(st.base, st.va_bytes);
+  } else {
+    dfree(st.base, s);
+  }
+  st = Storage();
+}
+
 int Table::alloc_storage(u64 nb, Storage* st, hipStream_t s) {
+  *st = Storage();
   st->nb = nb;
   const size_t bstride = (size_t)hdr_bytes(opts) + (size_t)SLOTS * row_stride;
   if (nb >= (1ULL << 32) - 1 || bstride >= (1ULL << 32))   // 32-bit bucket arithmetic on the device (tfra_device.h)
     return set_error(TFRA_ERR_INVALID, "table storage: more than 2^32 - 2 buckets or a bucket block of 4 GiB");
   const size_t bytes = nb * bstride + (size_t)NUM_RESERVED * row_stride;
+  const long long thr = vmm_threshold_bytes();
+  if (!alloc.alloc && thr >= 0 && bytes >= (size_t)thr) {
+    // address range: what the table can ever need — max_capacity, else the whole device
+    size_t total = 0, free_b = 0;
+    (void)hipMemGetInfo(&free_b, &total);
+    size_t want = total ? total : bytes;
+    if (opts.max_capacity) want = std::min(want, (size_t)(std::max<u64>(2, opts.max_capacity / SLOTS)) * bstride + (size_t)NUM_RESERVED * row_stride);
+    want = std::max(want, bytes);
+    size_t chunk = VMM_ALIGN;
+    while (chunk < bytes && chunk < VMM_CHUNK_MAX) chunk <<= 1;
+    want = (want + chunk - 1) / chunk * chunk + chunk;
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, want, VMM_ALIGN, nullptr, 0) == hipSuccess) {
+      st->base = (unsigned char*)va; st->vmm = true; st->va_bytes = want; st->chunk_bytes = chunk;
+      if (vmm_map_more(st, bytes, device) == TFRA_OK) return TFRA_OK;
+      free_storage(*st, s);
+      st->nb = nb;
+    }
+    (void)hipGetLastError();
+    g_last_error.clear();   // fall back to one plain allocation
+  }
   st->base = (unsigned char*)dalloc(bytes, s);
   if (!st->base) {
     *st = Storage();
@@ -800,6 +979,11 @@ int Table::ensure_scratch(size_t bytes, hipStream_t s) {
 // grow to at least min_nb buckets: new arrays, rehash kernel, free the old ones.
 int Table::grow(u64 min_nb, hipStream_t s) {
   if (min_nb <= cur.nb) return TFRA_OK;
+  if (cur.vmm) {
+    int rc = grow_in_place(min_nb, s);
+    if (rc != TFRA_ERR_UNSUPPORTED) return rc;
+    g_last_error.clear();
+  }
   Storage nw;
   int rc = alloc_storage(min_nb, &nw, s);
   if (rc) return rc;
@@ -813,9 +997,63 @@ int Table::grow(u64 min_nb, hipStream_t s) {
   rehash_kernel<<<(unsigned)((groups * 16 + 255) / 256), 256, 0, s>>>(view_of(old), nv);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));  // old arrays are freed below
-  dfree(old.base, s); dfree(old_winner, s);
+  free_storage(old, s); dfree(old_winner, s);
   cur = nw;
   n_rehash++;
+  return TFRA_OK;
+}
+
+// nb -> F * nb buckets inside the table's address range (see split_kernel), F the smallest power of two reaching min_nb
+// that max_capacity allows.  Peak memory = the new size (+ the spill list); the copying path needs old + new.
+int Table::grow_in_place(u64 min_nb, hipStream_t s) {
+  const u64 max_nb = opts.max_capacity ? std::max<u64>(2, opts.max_capacity / SLOTS) : ((1ULL << 32) - 2);
+  unsigned shift = 1;
+  while ((cur.nb << shift) < min_nb && shift < 8) ++shift;
+  while (shift > 0 && (cur.nb << shift) > max_nb) --shift;
+  if (shift == 0) return set_error(TFRA_ERR_UNSUPPORTED, "in-place growth: no power-of-two factor fits max_capacity");
+  const u64 nbn = cur.nb << shift;
+  const size_t bstride = (size_t)hdr_bytes(opts) + (size_t)SLOTS * row_stride;
+  const size_t side = (size_t)NUM_RESERVED * row_stride, new_bytes = nbn * bstride + side;
+  if (nbn >= (1ULL << 32) - 1 || new_bytes > cur.va_bytes) return set_error(TFRA_ERR_UNSUPPORTED, "in-place growth: beyond the address range");
+  int rc = vmm_map_more(&cur, new_bytes, device);
+  if (rc) return rc;   // out of memory: the caller keeps running denser
+  Storage nw = cur;    // same range, new bucket count
+  nw.nb = nbn;
+  const TableView ov = view_of(cur), nv = view_of(nw);
+  // how many keys cannot stay with their bucket's children
+  unsigned long long* d_count = reinterpret_cast<unsigned long long*>(d_scalar);
+  HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+  split_count_kernel<<<2048, 256, 0, s>>>(ov, nv, shift, d_count);
+  HIP_TRY(hipMemcpyAsync(h_scalar, d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const u64 nspill = (u64)*reinterpret_cast<unsigned long long*>(h_scalar);
+  SpillBuf sp{nullptr, nullptr, nullptr, d_count, nspill};
+  if (nspill) {
+    sp.keys = (i64*)dalloc(nspill * sizeof(i64), s);
+    sp.scores = (u64*)dalloc(nspill * sizeof(u64), s);
+    sp.rows = (unsigned char*)dalloc(nspill * (size_t)row_stride, s);
+    if (!sp.keys || !sp.scores || !sp.rows) {
+      dfree(sp.keys, s); dfree(sp.scores, s); dfree(sp.rows, s);
+      return set_error(TFRA_ERR_OOM, "in-place growth: spill list allocation failed");
+    }
+  }
+  HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s));
+  // the side rows move behind the new last bucket (that place is beyond every old bucket)
+  HIP_TRY(hipMemcpyAsync(cur.base + nbn * bstride, cur.base + cur.nb * bstride, side, hipMemcpyDeviceToDevice, s));
+  const u64 F = 1ULL << shift;
+  for (u64 hi = cur.nb; hi > 0;) {
+    const u64 lo = hi == 1 ? 0 : (hi + F - 1) / F;   // children of [lo, hi) start at F*lo >= hi
+    const u64 groups = hi - lo;
+    split_kernel<<<(unsigned)((groups * 16 + 255) / 256), 256, 0, s>>>(ov, nv, shift, lo, hi, sp);
+    hi = lo;
+  }
+  if (nspill) spill_reinsert_kernel<<<(unsigned)((nspill * 16 + 255) / 256), 256, 0, s>>>(nv, sp, nspill);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  dfree(sp.keys, s); dfree(sp.scores, s); dfree(sp.rows, s);
+  dfree(winner, s); winner = nullptr; winner_len = 0;   // sized per storage; rebuilt lazily
+  cur = nw;
+  n_rehash++; n_split++;
   return TFRA_OK;
 }
 
@@ -1113,7 +1351,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   (void)hipDeviceSynchronize();
   hipStream_t s = nullptr;
   destroy_own_plan(t);
-  t->dfree(t->cur.base, s);
+  t->free_storage(t->cur, s);
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
   t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s); t->dfree(t->own_tags, s);
   if (t->progress_host) (void)hipHostFree(t->progress_host);
@@ -1284,6 +1522,14 @@ int tfra_table_capacity(tfra_table_t* tp, size_t* out) {
   if (!t || !out) return set_error(TFRA_ERR_INVALID, "capacity: null argument");
   std::lock_guard<std::mutex> lock(t->mu);
   *out = t->cur.nb * SLOTS + NUM_RESERVED;
+  return TFRA_OK;
+}
+
+int tfra_table_growth_stats(tfra_table_t* tp, uint64_t* out4) {
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (!t || !out4) return set_error(TFRA_ERR_INVALID, "growth_stats: null argument");
+  std::lock_guard<std::mutex> lock(t->mu);
+  out4[0] = (uint64_t)t->n_rehash; out4[1] = (uint64_t)t->n_split; out4[2] = t->cur.vmm ? 1 : 0; out4[3] = (uint64_t)t->cur.mapped;
   return TFRA_OK;
 }
 

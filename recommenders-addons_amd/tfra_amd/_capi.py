@@ -95,6 +95,7 @@ _SIGS = {
     "tfra_table_size": [_P, ctypes.POINTER(_SZ), _P],
     "tfra_table_size_to_device": [_P, _P, _P],
     "tfra_table_capacity": [_P, ctypes.POINTER(_SZ)],
+    "tfra_table_growth_stats": [_P, ctypes.POINTER(ctypes.c_uint64)],
     "tfra_multi_step_prefetch": [_SZ, _P, _I],
     "tfra_plan_reduce_to": [_P, _P, _P, _P, _P],
     "tfra_table_check_errors": [_P, _P],

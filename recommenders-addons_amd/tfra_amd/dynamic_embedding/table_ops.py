@@ -265,6 +265,12 @@ class _DeviceTable:
     _capi.call("tfra_table_slot_census", self._h, out, _stream(self.device))
     return dict(zip(("empty", "locked", "live", "ovf0", "ovf1"), [int(x) for x in out]))
 
+  def growth_stats(self):
+    """{growths, in_place, mapped_range, mapped_bytes} (tfra_table_growth_stats)."""
+    out = (ctypes.c_uint64 * 4)()
+    _capi.call("tfra_table_growth_stats", self._h, out)
+    return dict(zip(("growths", "in_place", "mapped_range", "mapped_bytes"), [int(x) for x in out]))
+
   def set_capture_safe(self, on):
     """While True every op on this table can be captured into a HIP graph (no host sync, no growth)."""
     _capi.call("tfra_table_set_option", self._h, _capi.OPTION_CAPTURE_SAFE, int(bool(on)))
