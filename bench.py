@@ -278,6 +278,43 @@ def traffic_of(prof, workload, kname):
 
 
 # ------------------------------------------------------------------ c3 / m1b: bounded table at 10^9 slots
+def measure_growth(torch, de, dev, dim, dtype, slots):
+  """configs[2] names "dynamic growth": a table of `slots` slots (a quarter of the benchmark's), half full, doubles IN PLACE
+  (mapped address range, every bucket splits into its two children where it is: DESIGN §3).  Timed alone, then freed."""
+  try:
+    # (an Hkv table is created for init_capacity keys at load factor 0.5, on the lattice max_capacity / 2^j)
+    t = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=slots // 2 - 1000, max_capacity=4 * slots, device=str(dev),
+                        dim=dim, evict_strategy=de.HkvEvictStrategy.LRU, name="bench_growth")
+    cap0 = t._table.capacity() - 2
+    n = int(cap0 * 0.45)
+    chunk = 4_000_000
+    vals = torch.zeros((chunk, dim), dtype=dtype, device=dev)
+    for lo in range(1, n + 1, chunk):
+      k = keys_of_ranks_torch(torch, torch.arange(lo, min(n, lo + chunk - 1) + 1, dtype=torch.int64, device=dev))
+      t._table.upsert(k, vals[:k.numel()], unique_keys=True)
+    size0 = int(t.size().item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t._table.reserve(2 * cap0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = t._table.growth_stats()
+    cap1 = t._table.capacity() - 2
+    probe = keys_of_ranks_torch(torch, torch.arange(1, 1_000_001, dtype=torch.int64, device=dev))
+    _, ex = t.lookup(probe, return_exists=True)
+    ok = bool(ex.all()) and int(t.size().item()) == size0
+    block = 256 + 15 * dim * (2 if dtype == torch.float16 else 4)
+    res = {"slots_before": cap0, "slots_after": cap1, "live_keys": size0, "seconds": round(dt, 3), "in_place": st["in_place"] == 1,
+           "bytes_before": cap0 // 15 * block, "bytes_after": cap1 // 15 * block, "all_keys_still_found": ok,
+           "note": "tfra_table_reserve(2 x slots) on a half-full table: map the second half of the address range, split every bucket "
+                   "into its two children where it is; peak memory = the new size (a copying growth would need old + new)"}
+    del t, vals
+    torch.cuda.empty_cache()
+    return res
+  except Exception as e:   # never lose the bench line over the side measurement
+    return {"error": str(e)[:200]}
+
+
 def run_bounded(args, torch, de, dev, cfg):
   """cfg 'c3': dim 128 fp16, 50 % never-seen ids;  'm1b': dim 64 fp32, `--new-key-ratio` (default 0) never-seen ids."""
   from tfra_amd import _capi
@@ -287,6 +324,7 @@ def run_bounded(args, torch, de, dev, cfg):
   new_ratio = 0.5 if cfg == "c3" else (args.new_key_ratio if args.new_key_ratio is not None else 0.0)
   Rb = dim * (2 if dtype == torch.float16 else 4)
   want = args.slots
+  growth = measure_growth(torch, de, dev, dim, dtype, want // 4) if cfg == "c3" else None
   table, failures = None, []
   for slots in [want] + [int(want * f) for f in (0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.25)]:
     try:
@@ -296,7 +334,6 @@ def run_bounded(args, torch, de, dev, cfg):
     except Exception as e:  # allocation failure: next smaller size (logged in the result line)
       failures.append({"slots": slots, "error": str(e)[:160]})
   assert table is not None, failures
-  capacity = table._table.capacity()
   gen = torch.Generator(device=dev).manual_seed(SEED)
   chunk = 4_000_000
   vals_fill = (torch.randn((chunk, dim), generator=gen, device=dev) * 0.01).to(dtype)
@@ -308,6 +345,7 @@ def run_bounded(args, torch, de, dev, cfg):
   resident = int(table.size().item())
   t_fill = time.perf_counter() - t0
   del vals_fill
+  capacity = table._table.capacity()
 
   rng = np.random.default_rng(SEED + 7)
   nb = 2 * (K + W) + 16
@@ -404,7 +442,8 @@ def run_bounded(args, torch, de, dev, cfg):
                                                capacity / 15 * (256 + 15 * Rb) / 1e9, n_res, resident,
                                                "dim=128 fp16" if cfg == "c3" else "dim=64 fp32", B, round(100 * (1 - new_ratio)),
                                                round(100 * new_ratio)),
-          "slots": capacity, "requested_slots": want, "alloc_failures": failures, "resident_after_prefill": resident,
+          "slots": capacity, "requested_slots": want, "alloc_failures": failures, "growth_in_place": growth,
+          "resident_after_prefill": resident,
           "resident_after_timed_steps": size_after, "new_key_ratio": new_ratio, "global_batch": B,
           "unique_ratio": round(uniq_ratio, 4), "unique_keys_per_batch": U, "prefill_s": round(t_fill, 2),
           "table_ops_per_s": 2 * value, "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),

@@ -85,6 +85,8 @@ struct Table {
   unsigned* ensure_own_tags(hipStream_t s);
   int ensure_scratch(size_t bytes, hipStream_t s);
   int grow(u64 min_nb, hipStream_t s);
+  u64 lattice_nb(u64 min_nb) const;
+  bool at_max_capacity() const;
   int grow_in_place(u64 min_nb, hipStream_t s);   // TFRA_ERR_UNSUPPORTED: not possible here, copy instead
   void free_storage(Storage& st, hipStream_t s);
   int n_split = 0;                                // in-place growths so far

@@ -603,8 +603,8 @@ __global__ __launch_bounds__(256) void rehash_kernel(TableView o, TableView v) {
 // others, top-down (children of [lo, hi) lie in [F*lo, F*hi), beyond every bucket still to be split), without a second
 // copy of the table.  A key goes to its new b0 if that is a child of the bucket it sat in, else to its new b1 if that
 // is, else (it sat in a chain bucket, or its b1 was the b0+1 substitute: ~nb^-1 of the keys) onto a spill list that is
-// re-inserted the general way afterwards.  Children inherit the parent's overflow flags (a superset of what they need:
-// flags only lengthen searches); keys are packed from slot 0.
+// re-inserted the general way afterwards.  Children start without overflow flags; split_flags_kernel then sets exactly the
+// ones the new placement needs.  Keys are packed from slot 0.
 struct SpillBuf {
   i64* keys; u64* scores; unsigned char* rows; unsigned long long* count; u64 cap;
 };
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void split_kernel(TableView o, TableView nv, u
     const unsigned mc = (unsigned)(__ballot(child == c) >> gshift) & 0x7fffu;
     const u64 nb_c = (b << shift) + c;
     if (nb_c == b) {   // bucket 0 onto itself: stay in place
-      const i64 kout = sub == 15 ? k : ((mc >> sub) & 1u ? k : EMPTY_KEY);
+      const i64 kout = sub == 15 ? 0 : ((mc >> sub) & 1u ? k : EMPTY_KEY);
       key_line(nv, nb_c)[sub] = kout;
       continue;
     }
@@ -676,11 +676,27 @@ __global__ __launch_bounds__(256) void split_kernel(TableView o, TableView nv, u
     const int src = sub < SLOTS ? nth_set_bit(mc, sub) : -1;
     const i64 ksrc = shfl_i64(k, gshift + (src < 0 ? 0 : src));
     const u64 ssrc = (u64)shfl_i64((i64)sc, gshift + (src < 0 ? 0 : src));
-    key_line(nv, nb_c)[sub] = sub == 15 ? k : (src < 0 ? EMPTY_KEY : ksrc);
+    key_line(nv, nb_c)[sub] = sub == 15 ? 0 : (src < 0 ? EMPTY_KEY : ksrc);   // flags: split_flags_kernel
     if (scored) score_line(nv, nb_c)[sub] = src < 0 ? 0 : ssrc;
     for (int j = 0; j < cnt; ++j) {
       const int sj = nth_set_bit(mc, j);
       copy_bytes16<16>(row_at(nv, nb_c, (unsigned)j), row_at(o, b, (unsigned)sj), o.row_stride, sub);
+    }
+  }
+}
+
+// After the split every key sits in its new b0 or b1 and the children carry no flags: set exactly the ones searches need —
+// OVF0 on the b0 of every key that lives in its b1 (inheriting the parents' flags instead would hand every child the
+// overflow history of a bucket that was 92 % full: measured, lookups of absent keys 40x slower on the grown table).
+// The spill list is re-inserted afterwards by locate_or_claim, which sets its own flags.
+__global__ __launch_bounds__(256) void split_flags_kernel(TableView nv) {
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  for (u64 b = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; b < nv.nb; b += ((u64)gridDim.x * blockDim.x) >> 4) {
+    const i64 k = key_line(nv, b)[sub];
+    if (sub < SLOTS && k != EMPTY_KEY && k != LOCKED_KEY) {
+      u64 h;
+      const u64 b0 = bucket0(k, nv.nb, h);
+      if (b0 != b) atomicOr(reinterpret_cast<unsigned long long*>(key_line(nv, b0) + 15), (unsigned long long)META_OVF0);
     }
   }
 }
@@ -953,8 +969,7 @@ int Table::ensure_winner(hipStream_t s) {
 // two-phase (place, then evict) write; nullptr while the table can still grow or is unbounded.
 int Table::bounded_flags(size_t n, hipStream_t s, uint8_t** out) {
   *out = nullptr;
-  const u64 max_nb_b = opts.max_capacity ? std::max<u64>(2, opts.max_capacity / SLOTS) : 0;
-  if (!(opts.strategy >= 0 && max_nb_b && cur.nb >= max_nb_b)) return TFRA_OK;
+  if (!at_max_capacity()) return TFRA_OK;
   if (evict_flags_cap < n) {
     if (evict_flags) { HIP_TRY(hipStreamSynchronize(s)); dfree(evict_flags, s); }
     evict_flags = (uint8_t*)dalloc(n, s);
@@ -985,7 +1000,7 @@ int Table::grow(u64 min_nb, hipStream_t s) {
     g_last_error.clear();
   }
   Storage nw;
-  int rc = alloc_storage(min_nb, &nw, s);
+  int rc = alloc_storage(lattice_nb(min_nb), &nw, s);
   if (rc) return rc;
   Storage old = cur;
   int* old_winner = winner;
@@ -1001,6 +1016,22 @@ int Table::grow(u64 min_nb, hipStream_t s) {
   cur = nw;
   n_rehash++;
   return TFRA_OK;
+}
+
+// Bucket counts of a bounded table sit on the lattice max_nb / 2^j, so that doubling in place ends exactly at
+// max_capacity (a table that reached, say, 60 % of it by copying could neither double nor, past a third of the HBM, copy).
+// a bounded (Hkv) table that cannot double any more: eviction takes over
+bool Table::at_max_capacity() const {
+  return opts.strategy >= 0 && opts.max_capacity && cur.nb * 2 > std::max<u64>(2, opts.max_capacity / SLOTS);
+}
+
+u64 Table::lattice_nb(u64 min_nb) const {
+  if (!opts.max_capacity) return min_nb;
+  const u64 max_nb = std::max<u64>(2, opts.max_capacity / SLOTS);
+  if (min_nb >= max_nb) return max_nb;
+  unsigned j = 0;
+  while ((max_nb >> (j + 1)) >= min_nb && (max_nb >> (j + 1)) >= 2) ++j;
+  return max_nb >> j;
 }
 
 // nb -> F * nb buckets inside the table's address range (see split_kernel), F the smallest power of two reaching min_nb
@@ -1047,6 +1078,7 @@ int Table::grow_in_place(u64 min_nb, hipStream_t s) {
     split_kernel<<<(unsigned)((groups * 16 + 255) / 256), 256, 0, s>>>(ov, nv, shift, lo, hi, sp);
     hi = lo;
   }
+  split_flags_kernel<<<4096, 256, 0, s>>>(nv);
   if (nspill) spill_reinsert_kernel<<<(unsigned)((nspill * 16 + 255) / 256), 256, 0, s>>>(nv, sp, nspill);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
@@ -1092,23 +1124,27 @@ int Table::poll_density(size_t n, hipStream_t s) {
 //     pay a host sync per call: an ASYNC size read (size kernel + 8-B D2H into pinned memory +
 //     event) refreshes the bound; the call proceeds optimistically while the bound stays under
 //     the hard threshold (92 % of the slots, where first-fit probing still terminates quickly).
-//   * Only when the bound passes the hard threshold do we synchronise, and grow if the TRUE size
-//     needs it.  An out-of-memory during growth is not an error unless the keys cannot fit at all.
+//   * When the bound passes the hard threshold, or a completed read shows that the TRUE size is past
+//     the soft one, we synchronise and grow if the true size needs it.  An out-of-memory during growth
+//     is not an error unless the keys cannot fit at all.
 int Table::prepare_insert(size_t n, hipStream_t s) {
   if (capture_safe) return TFRA_OK;  // capacity is the caller's responsibility while capturing
   const double slots = (double)(cur.nb * SLOTS);
   const double soft = opts.max_load_factor * slots, hard = 0.92 * slots;
   if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
   // at max_capacity (eviction takes over) or after a failed growth there is nothing to decide
-  const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb < std::max<u64>(2, opts.max_capacity / SLOTS));
+  // (bounded tables sit on the lattice max_nb / 2^j: the last doubling lands on max_nb, give or take the rounding)
+  const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb * 2 <= std::max<u64>(2, opts.max_capacity / SLOTS));
   if (!can_grow) return poll_density(n, s);
+  bool truly_past_soft = false;   // a completed read saw more live keys than max_load_factor allows: grow now, not at 92 %
   if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
     size_ub = (v < 0 ? 0 : (size_t)v) + n_since_read;
     size_pending = false;
     if ((double)(size_ub + n) <= soft) { size_ub += n; return TFRA_OK; }
+    truly_past_soft = (double)(v < 0 ? 0 : v) > soft;
   }
-  if ((double)(size_ub + n) <= hard) {
+  if ((double)(size_ub + n) <= hard && !truly_past_soft) {
     if (!size_pending) {
       size_kernel<<<1, SIZE_SHARDS, 0, s>>>(view_of(cur), d_scalar + 1);
       HIP_TRY(hipMemcpyAsync(h_size, d_scalar + 1, sizeof(i64), hipMemcpyDeviceToHost, s));
@@ -1195,8 +1231,7 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
   size_t waves = (n + 4 * U - 1) / (4 * U);
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   // Hkv flavour at max_capacity: the table cannot grow, full home buckets evict by score (2 phases)
-  const u64 max_nb_b = t->opts.max_capacity ? std::max<u64>(2, t->opts.max_capacity / SLOTS) : 0;
-  const bool bounded = t->opts.strategy >= 0 && max_nb_b && t->cur.nb >= max_nb_b && field == 0;
+  const bool bounded = t->at_max_capacity() && field == 0;
   if (bounded && !(flags & TFRA_FLAG_UNIQUE_KEYS))
     return set_error(TFRA_ERR_UNSUPPORTED, "insert: a bounded (Hkv) table at max_capacity needs TFRA_FLAG_UNIQUE_KEYS "
                                            "(HKV's unique-keys contract) so that eviction is well defined");
@@ -1335,7 +1370,7 @@ int tfra_table_create(const tfra_table_opts* o, const tfra_allocator* alloc, tfr
   if (hipEventCreateWithFlags(&t->size_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
   t->h_size = t->h_scalar + 4;
   u64 nb = std::max<u64>(2, (u64)((double)t->opts.init_capacity / t->opts.max_load_factor / SLOTS) + 1);
-  if (t->opts.max_capacity) nb = std::min<u64>(nb, std::max<u64>(2, t->opts.max_capacity / SLOTS));  // slots <= max_capacity
+  nb = t->lattice_nb(nb);   // bounded tables: slots <= max_capacity, and doublings end exactly there
   int rc = t->alloc_storage(nb, &t->cur, s);
   if (rc) return fail(rc);
   clear_kernel<<<2048, 256, 0, s>>>(t->view_of(t->cur), 1);
