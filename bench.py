@@ -496,7 +496,10 @@ def run_c2(args, torch, dist, de, dev, world, rank):
 
   opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
   deo = de.DynamicEmbeddingOptimizer(opt)
-  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05),
+  # init_size: the resident keys plus room for the never-seen ids of every batch of the run (warm-up and both drivers), so
+  # that the table does not grow inside a timed region (it grows as soon as its true size passes max_load_factor)
+  headroom = int(2.2 * (K + W + 8) * B * max(new_ratio, 0.0)) + (1 << 20)
+  var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05) + headroom,
                     **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
   force_a2a = os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist.is_initialized()
   emb = (AllToAllEmbedding(var, partition_mode=0, dedup=os.environ.get("TFRA_BENCH_DEDUP", "1") == "1",
