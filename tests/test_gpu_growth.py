@@ -151,3 +151,37 @@ def test_table_past_a_third_of_hbm_grows_in_place():
     assert bool(ex.all()) and torch.equal(got, row_of(torch, kk, dim))
   _, ex = t.lookup(torch.arange(1, 100_000, device="cuda", dtype=torch.int64) * 2654435761 + 18, return_exists=True)
   assert int(ex.sum()) == 0
+
+
+@pytest.mark.parametrize("threshold_mb", ["0", "-1"])          # growth in place / by copying
+@pytest.mark.parametrize("init,maxcap", [(1000, 10_000), (2048, 2048 * 8), (5000, 7000), (100, 100_000)])
+def test_bounded_table_grows_to_max_capacity_then_evicts(monkeypatch, init, maxcap, threshold_mb):
+  """An Hkv table created below max_capacity: it grows until it can double no more (slots <= max_capacity and more than half
+  of it), then evicts by score — the batch with the highest scores survives (T/hkv_hashtable_evict_test.py:527-573)."""
+  monkeypatch.setenv("TFRA_VMM_THRESHOLD_MB", threshold_mb)
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  dim = 4
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=init, max_capacity=maxcap, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.CUSTOMIZED, name="bounded_grow_%d_%d_%s" % (init, maxcap, threshold_mb))
+  assert t._table.capacity() - 2 <= maxcap
+  rng = np.random.default_rng(init)
+  keys = np.unique(rng.integers(1, 2**60, size=4 * maxcap + 1000).astype(np.int64))[:3 * maxcap]
+  rng.shuffle(keys)
+  vip = keys[:maxcap // 4]                       # inserted first with the highest scores
+  batches = [(vip, 1_000_000)] + [(keys[lo:lo + 2000], 10) for lo in range(vip.size, keys.size, 2000)]
+  for k, score in batches:
+    kk = torch.from_numpy(k).cuda()
+    t._table.upsert(kk, row_of(torch, kk, dim), scores=torch.full((k.size,), score, dtype=torch.int64, device="cuda"), unique_keys=True)
+    assert int(t.size().item()) <= maxcap
+  slots = t._table.capacity() - 2
+  assert maxcap // 2 < slots <= maxcap, (slots, maxcap)
+  st = t._table.growth_stats()
+  if init * 4 < maxcap:
+    assert st["growths"] >= 1 and (st["in_place"] == st["growths"]) == (threshold_mb == "0"), st
+  size = int(t.size().item())
+  assert size > 0.85 * slots                       # ran full: the rest was evicted, nothing was refused
+  assert t._table.check_errors() is None
+  kv = torch.from_numpy(vip).cuda()
+  got, ex = t.lookup(kv, return_exists=True)
+  assert bool(ex.all()) and torch.equal(got, row_of(torch, kv, dim))
