@@ -216,14 +216,17 @@ int tfra_table_apply_optimizer(tfra_table_t* t, const tfra_opt_params* p, size_t
  * ids are summed in a fixed order (deterministic; ids occurring <= 8 times in the batch: strictly in batch order),
  * then one fused update per unique key as above.  = _resource_apply_sparse_duplicate_indices + the write-back
  * sequence (PY/dynamic_embedding_optimizer.py:165-204).  param_default_row: [dim] fp32, used for unseen keys.
- * Requires float32 values, dim % 4 == 0, dim <= 256, n <= 2^18 (262 144) ids per call. */
+ * Requires float32 values, dim % 4 == 0, dim <= 256.  More than 2^18 (262 144) ids per call take a slower path (chunk-wise
+ * sums, then every key once; host reads of the counts, scratch allocated per call) with the same result up to the
+ * association of the sums. */
 int tfra_table_apply_sparse(tfra_table_t* t, const tfra_opt_params* p, size_t n, const int64_t* ids,
                             const float* grads, const float* param_default_row, tfra_stream_t stream);
 
 /* insert_or_assign of a batch whose keys MAY repeat — the LAST occurrence wins, like the reference's sequential
  * LaunchTensorsInsert (K/cuckoo_hashtable_op.cc:104-140) — de-duplicated on the device, also on a bounded (Hkv)
  * table running at max_capacity (eviction needs one writer per key).  values [n,dim] of the table's dtype;
- * scores [n] or NULL (the last occurrence's score; LFU without scores counts the occurrences).  n <= 2^18. */
+ * scores [n] or NULL (the last occurrence's score; LFU without scores counts the occurrences).  More than 2^18 ids are
+ * written chunk after chunk on the stream. */
 int tfra_table_upsert_sparse(tfra_table_t* t, size_t n, const int64_t* ids, const void* values,
                              const uint64_t* scores, tfra_stream_t stream);
 

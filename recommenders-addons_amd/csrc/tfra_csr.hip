@@ -1684,9 +1684,90 @@ static int own_plan(Table* t, tfra_sparse_plan** out) {
 
 namespace tfra {
 void destroy_own_plan(Table* t) {
+  if (t->big_ws) { tfra_workspace_destroy(reinterpret_cast<tfra_workspace_t*>(t->big_ws)); t->big_ws = nullptr; }
   if (t->own_plan) { tfra_sparse_plan_destroy(reinterpret_cast<tfra_sparse_plan*>(t->own_plan)); t->own_plan = nullptr; }
 }
 }  // namespace tfra
+
+// tfra_table_apply_sparse for more ids than a plan holds (2^18).  Equal ids must still meet in ONE update, whatever
+// chunk they sit in:
+//   1. per chunk of 2^18 ids: unique + per-key gradient sums (tfra_reduce_by_key) into one concatenated list — a key now
+//      occurs at most once per chunk, so even the hottest id of a Zipf batch is a handful of entries;
+//   2. the list fits a plan: one planned write-back sums a key's entries in chunk order and applies it;
+//      else the list is split by key hash (tfra_partition, mode 2) into parts that fit — a key's entries stay together,
+//      the parts are disjoint key sets — and each part is written back on its own.
+// A slow path (host reads of the counts, scratch allocated per call); results are deterministic, the association of the
+// sums is (within chunk) + (across chunks in order).
+static int apply_sparse_big(Table* t, tfra_table_t* tp, tfra_sparse_plan* pl, const tfra_opt_params* p, size_t n, const int64_t* ids,
+                            const float* grads, const float* param_default_row, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int dim = t->opts.dim;
+  if (!t->big_ws) {
+    tfra_workspace_t* w = nullptr;
+    int rc = tfra_workspace_create(t->device, &w);
+    if (rc) return rc;
+    t->big_ws = w;
+  }
+  tfra_workspace_t* ws = reinterpret_cast<tfra_workspace_t*>(t->big_ws);
+  i64 *keys_cat = nullptr, *d_cnt = nullptr, *keys_part = nullptr, *d_counts = nullptr;
+  float *sums_cat = nullptr, *sums_part = nullptr;
+  int* perm = nullptr;
+  auto cleanup = [&](int rc) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(keys_cat); (void)hipFree(d_cnt); (void)hipFree(keys_part); (void)hipFree(d_counts); (void)hipFree(sums_cat);
+    (void)hipFree(sums_part); (void)hipFree(perm);
+    return rc;
+  };
+  auto oom = [&]() { return cleanup(set_error(TFRA_ERR_OOM, "apply_sparse: scratch for a batch of more than 2^18 ids")); };
+  if (hipMalloc((void**)&keys_cat, n * sizeof(i64)) != hipSuccess || hipMalloc((void**)&sums_cat, n * (size_t)dim * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&d_cnt, sizeof(i64)) != hipSuccess)
+    return oom();
+  size_t T = 0;
+  for (size_t off = 0; off < n; off += MAX_IDS) {
+    const size_t m = std::min<size_t>(MAX_IDS, n - off);
+    int rc = tfra_reduce_by_key(ws, m, ids + off, dim, grads + off * (size_t)dim, (int64_t*)keys_cat + T, sums_cat + T * (size_t)dim,
+                                (int64_t*)d_cnt, stream);
+    if (rc) return cleanup(rc);
+    i64 c = 0;
+    if (hipMemcpyAsync(&c, d_cnt, sizeof(i64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return cleanup(set_error(TFRA_ERR_HIP, "apply_sparse: count read"));
+    if (c < 0) return cleanup(set_error(TFRA_ERR_FULL, "apply_sparse: a de-duplication plan overflowed"));
+    T += (size_t)c;
+  }
+  if (T <= MAX_IDS) {
+    int rc = tfra_sparse_plan_build(pl, T, (const int64_t*)keys_cat, dim, stream);
+    if (!rc) rc = apply_planned_impl(tp, p, pl, sums_cat, param_default_row, stream, nullptr, 0);
+    return cleanup(rc);
+  }
+  if (hipMalloc((void**)&keys_part, T * sizeof(i64)) != hipSuccess || hipMalloc((void**)&perm, T * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&sums_part, T * (size_t)dim * sizeof(float)) != hipSuccess)
+    return oom();
+  for (size_t P = (T + (MAX_IDS / 2) - 1) / (MAX_IDS / 2); P <= 2048; P *= 2) {
+    (void)hipFree(d_counts); d_counts = nullptr;
+    if (hipMalloc((void**)&d_counts, P * sizeof(i64)) != hipSuccess) return oom();
+    int rc = tfra_partition(ws, T, nullptr, (const int64_t*)keys_cat, (int)P, 2, (int64_t*)keys_part, perm, (int64_t*)d_counts, stream);
+    if (rc) return cleanup(rc);
+    std::vector<i64> counts(P);
+    if (hipMemcpyAsync(counts.data(), d_counts, P * sizeof(i64), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return cleanup(set_error(TFRA_ERR_HIP, "apply_sparse: count read"));
+    bool fits = true;
+    for (i64 c : counts) fits = fits && (size_t)c <= MAX_IDS;
+    if (!fits) continue;   // a part too large (skewed hash): more parts
+    rc = tfra_gather_rows(T, (size_t)dim * sizeof(float), sums_cat, perm, sums_part, stream);
+    if (rc) return cleanup(rc);
+    size_t off = 0;
+    for (i64 c : counts) {
+      if (c > 0) {
+        rc = tfra_sparse_plan_build(pl, (size_t)c, (const int64_t*)keys_part + off, dim, stream);
+        if (!rc) rc = apply_planned_impl(tp, p, pl, sums_part + off * (size_t)dim, param_default_row, stream, nullptr, 0);
+        if (rc) return cleanup(rc);
+      }
+      off += (size_t)c;
+    }
+    return cleanup(TFRA_OK);
+  }
+  return cleanup(set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: could not split the batch into parts of 2^18 ids"));
+}
 
 extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* p, size_t n, const int64_t* ids,
                                        const float* grads, const float* param_default_row, tfra_stream_t stream) {
@@ -1699,15 +1780,13 @@ extern "C" int tfra_table_apply_sparse(tfra_table_t* tp, const tfra_opt_params* 
   if (dim % 4 != 0 || dim > 64 * MAXCH || (((uintptr_t)grads | (uintptr_t)param_default_row) & 15))
     return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: needs dim % 4 == 0, dim <= 256 and 16-B aligned buffers "
                                            "(use tfra_unique + tfra_segment_sum + tfra_table_apply_optimizer otherwise)");
-  if (n > MAX_IDS)
-    return set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: at most 2^18 ids per call; split the batch or use the unique + "
-                                           "segment_sum path");
   tfra_sparse_plan* pl;
   std::lock_guard<std::mutex> lock(t->mu);
   int rc = t->enter((hipStream_t)stream);   // orders the rebuild of the table's own plan behind its previous use
   if (rc) return rc;
   rc = own_plan(t, &pl);
   if (rc) return rc;
+  if (n > MAX_IDS) return apply_sparse_big(t, tp, pl, p, n, ids, grads, param_default_row, stream);
   rc = tfra_sparse_plan_build(pl, n, ids, dim, stream);
   if (rc) return rc;
   return apply_planned_impl(tp, p, pl, grads, param_default_row, stream, nullptr, 0);
@@ -1720,16 +1799,23 @@ extern "C" int tfra_table_upsert_sparse(tfra_table_t* tp, size_t n, const int64_
   if (!t) return set_error(TFRA_ERR_INVALID, "upsert_sparse: null table");
   if (n == 0) return TFRA_OK;
   if (!ids || !values) return set_error(TFRA_ERR_INVALID, "upsert_sparse: null buffer");
-  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "upsert_sparse: at most 2^18 ids per call");
   tfra_sparse_plan* pl;
   std::lock_guard<std::mutex> lock(t->mu);
   int rc = t->enter((hipStream_t)stream);
   if (rc) return rc;
   rc = own_plan(t, &pl);
   if (rc) return rc;
-  rc = tfra_sparse_plan_build(pl, n, ids, 0, stream);
-  if (rc) return rc;
-  return upsert_planned_impl(tp, pl, values, scores, stream, nullptr, 0);
+  // more ids than a plan holds: chunk after chunk on the stream — a later chunk overwrites an earlier one, which is
+  // "the last occurrence wins" across chunks too
+  for (size_t off = 0; off < n; off += MAX_IDS) {
+    const size_t m = std::min<size_t>(MAX_IDS, n - off);
+    rc = tfra_sparse_plan_build(pl, m, ids + off, 0, stream);
+    if (rc) return rc;
+    rc = upsert_planned_impl(tp, pl, (const unsigned char*)values + off * (size_t)t->field_bytes, scores ? scores + off : nullptr, stream,
+                             nullptr, 0);
+    if (rc) return rc;
+  }
+  return TFRA_OK;
 }
 
 // unique + unsorted_segment_sum in one call = the plan + the hot sums + a gather (the reduction half of

@@ -51,6 +51,7 @@ struct Table {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   void* own_plan = nullptr;  // tfra_sparse_plan of the one-call write-backs (tfra_table_apply_sparse / upsert_sparse)
+  void* big_ws = nullptr;    // tfra_workspace of tfra_table_apply_sparse with more than 2^18 ids
   unsigned* own_tags = nullptr;  // [nb] bucket-owner tags (upsert_own_kernel), allocated on first use
   u64 own_tags_nb = 0;
   unsigned own_gen = 0;      // bucket-owner tag of the last ownership-based write-back (upsert_own_kernel)

@@ -316,9 +316,9 @@ class DynamicEmbeddingOptimizer:
       return
     if getattr(var, "restrict_policy", None) is not None:  # PY/embedding_weights.py:441-442
       var.restrict_policy.apply_update(ids)
-    if (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and
-        n <= (1 << 18) and not self.exact_order):
-      # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic
+    if var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and not self.exact_order:
+      # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic.  (More than 2^18
+      # ids: the library reduces chunk by chunk and applies every key once — tfra_csr.hip: apply_sparse_big.)
       t = var._tables[0]
       t._table.apply_sparse(p, ids, grad, t._default_value.to(torch.float32))
       return
