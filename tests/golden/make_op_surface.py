@@ -1,6 +1,8 @@
 """Extracts the op surface (names, inputs, outputs, attrs, statefulness) of the reference's `TFRA>HkvHashTable*` ops from
 R/.../core/ops/hkv_hashtable_ops.cc and the GPU kernel registrations from R/.../core/kernels/hkv_hashtable_op_gpu.cu.cc
-into tests/golden/hkv_op_surface.json (the reference tree is absent on the GPU box and in CI images).
+into tests/golden/hkv_op_surface.json, and the same for the `TFRA>CuckooHashTable*` ops (core/ops/cuckoo_hashtable_ops.cc,
+core/kernels/cuckoo_hashtable_op_gpu.cu.cc) into tests/golden/cuckoo_op_surface.json (the reference tree is absent on the
+GPU box and in CI images).
 
   python tests/golden/make_op_surface.py
 """
@@ -37,6 +39,30 @@ def parse_gpu_registrations(text):
   return sorted(names), sorted(types)
 
 
+def parse_cuckoo_gpu_types(text):
+  """-> sorted [key type, value type] pairs of the per-type registration macro of the cuckoo GPU kernels
+  (`REGISTER_KERNEL(int64, float);` in the reference, `TFRA_REGISTER_CUCKOO(float);` = int64 keys in the shim)."""
+  norm = {"int8": "int8_t", "int32": "int32_t", "int64": "int64_t"}
+  pairs = set()
+  for m in re.finditer(r"^\s*REGISTER_KERNEL\(\s*([\w:]+)\s*,\s*([\w:]+)\s*\)\s*;", text, re.M):
+    pairs.add((norm.get(m.group(1), m.group(1)), norm.get(m.group(2), m.group(2))))
+  for m in re.finditer(r"^\s*TFRA_REGISTER_CUCKOO\(\s*([\w:]+)\s*\)\s*;", text, re.M):
+    pairs.add(("int64_t", norm.get(m.group(1), m.group(1))))
+  return sorted(list(p) for p in pairs)
+
+
+def parse_gpu_registrations_detailed(text):
+  """-> {op name: sorted type-constraint attr names ([] = registered once, unconstrained)} for DEVICE_GPU registrations."""
+  out = {}
+  for m in re.finditer(r'Name\(\s*(?:PREFIX_OP_NAME\((\w+)\)|"([^"]+)")\s*\)((?:[\s\\]*\.\w+(?:<[^>]*>)?\([^()]*\))*)', text):
+    chain = m.group(3)
+    if ".Device(DEVICE_GPU)" not in chain:
+      continue
+    name = "TFRA>" + m.group(1) if m.group(1) else m.group(2)
+    out[name] = sorted(re.findall(r'\.TypeConstraint<[^>]*>\("(\w+)"\)', chain))
+  return out
+
+
 def main():
   ops = parse_register_ops(open(os.path.join(REF, "ops", "hkv_hashtable_ops.cc")).read())
   names, types = parse_gpu_registrations(open(os.path.join(REF, "kernels", "hkv_hashtable_op_gpu.cu.cc")).read())
@@ -45,6 +71,13 @@ def main():
   with open(os.path.join(HERE, "hkv_op_surface.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
   print(len(ops), "ops;", len(names), "GPU kernels;", types)
+  cops = parse_register_ops(open(os.path.join(REF, "ops", "cuckoo_hashtable_ops.cc")).read())
+  ctext = open(os.path.join(REF, "kernels", "cuckoo_hashtable_op_gpu.cu.cc")).read()
+  out = {"source": ["core/ops/cuckoo_hashtable_ops.cc:134-310", "core/kernels/cuckoo_hashtable_op_gpu.cu.cc:698-1058"],
+         "ops": cops, "gpu_kernels": parse_gpu_registrations_detailed(ctext), "gpu_type_pairs": parse_cuckoo_gpu_types(ctext)}
+  with open(os.path.join(HERE, "cuckoo_op_surface.json"), "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+  print(len(cops), "cuckoo ops;", len(out["gpu_kernels"]), "GPU kernels;", out["gpu_type_pairs"])
 
 
 if __name__ == "__main__":

@@ -17,21 +17,7 @@
  * the reference's REGISTER_OP text and compiles this file with -fsyntax-only against the declarations in tf_ops/stub/
  * (a few hundred lines naming exactly the TensorFlow API used here).
  */
-#include <hip/hip_runtime_api.h>
-
-#include <algorithm>
-#include <cstdlib>
-#include <string>
-#include <vector>
-
-#include "tensorflow/core/framework/lookup_interface.h"
-#include "tensorflow/core/framework/op.h"
-#include "tensorflow/core/framework/op_kernel.h"
-#include "tensorflow/core/framework/resource_mgr.h"
-#include "tensorflow/core/framework/shape_inference.h"
-#include "tensorflow/core/lib/io/path.h"
-#include "tensorflow/core/util/env_var.h"
-#include "tfra_mi355x.h"
+#include "mi355x_table_ops.h"
 
 namespace tensorflow {
 namespace tfra_mi355x {
@@ -40,7 +26,6 @@ using shape_inference::DimensionHandle;
 using shape_inference::InferenceContext;
 using shape_inference::ShapeAndType;
 using shape_inference::ShapeHandle;
-using GPUDevice = Eigen::GpuDevice;
 
 // =========================================== op registrations ===========================================
 // Shape functions: what the reference's do (hkv_hashtable_ops.cc:47-131), written once.
@@ -259,430 +244,6 @@ REGISTER_OP("TFRA>HkvHashTableLoadFromFileSystem")
     .Attr("load_entire_dir: bool")
     .Attr("buffer_size: int >= 1");
 
-// =========================================== the table resource ===========================================
-
-static int TfraDtypeOf(DataType dt) {
-  switch (dt) {
-    case DT_FLOAT: return TFRA_F32;
-    case DT_HALF: return TFRA_F16;
-    case DT_BFLOAT16: return TFRA_BF16;
-    case DT_INT8: return TFRA_I8;
-    case DT_INT32: return TFRA_I32;
-    case DT_INT64: return TFRA_I64;
-    default: return -1;
-  }
-}
-
-static Status ToStatus(int rc) {
-  if (rc == TFRA_OK) return OkStatus();
-  const char* msg = tfra_last_error();
-  if (rc == TFRA_ERR_INVALID) return errors::InvalidArgument(msg);
-  if (rc == TFRA_ERR_OOM) return errors::ResourceExhausted(msg);
-  return errors::Internal(msg);   // the reference maps every engine exception to kInternal (lookup_table_op_hkv.h:54-60)
-}
-
-static tfra_stream_t StreamOf(OpKernelContext* ctx) {
-  return reinterpret_cast<tfra_stream_t>(ctx->eigen_device<GPUDevice>().stream());   // hipStream_t on ROCm TensorFlow
-}
-
-// device bytes come from TensorFlow's GPU allocator, like TFOrDefaultAllocator (lookup_table_op_hkv.h:329-426), so the
-// table counts against `allow_growth` / the process' memory fraction instead of going around it
-struct TfAllocator {
-  Allocator* device;
-  static void* Alloc(void* user, int kind, size_t bytes, tfra_stream_t) {
-    if (kind != 0) return nullptr;   // pinned / host staging: the library's own hipHostMalloc / malloc
-    return static_cast<TfAllocator*>(user)->device->AllocateRaw(256, bytes);
-  }
-  static void Free(void* user, int kind, void* p, tfra_stream_t) {
-    if (kind == 0 && p) static_cast<TfAllocator*>(user)->device->DeallocateRaw(p);
-  }
-};
-
-// One class for every value dtype: the engine takes the dtype at run time (no template per (K, V) pair).
-class MI355XHashTable final : public lookup::LookupInterface {
- public:
-  MI355XHashTable(OpKernelContext* ctx, OpKernel* kernel) {
-    const NodeDef& def = kernel->def();
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "key_dtype", &key_dtype_));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "value_dtype", &value_dtype_));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "value_shape", &value_shape_));
-    OP_REQUIRES(ctx, TensorShapeUtils::IsVector(value_shape_),
-                errors::InvalidArgument("Default value must be a vector, got shape ", value_shape_.DebugString()));
-    OP_REQUIRES(ctx, key_dtype_ == DT_INT64 && TfraDtypeOf(value_dtype_) >= 0,
-                errors::InvalidArgument("HkvHashTable on MI355X: int64 keys and float / half / bfloat16 / int8 / int32 / int64 values"));
-    int64_t init_capacity = 0, max_capacity = 0, max_hbm = 0, step_per_epoch = 0;
-    int strategy = 0, reserved_bit = 0;
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "init_capacity", &init_capacity));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "max_capacity", &max_capacity));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "max_hbm_for_vectors", &max_hbm));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "strategy", &strategy));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "step_per_epoch", &step_per_epoch));
-    OP_REQUIRES_OK(ctx, GetNodeAttr(def, "reserved_key_start_bit", &reserved_bit));
-    OP_REQUIRES(ctx, max_hbm >= 0, errors::InvalidArgument("params max_hbm_for_vectors less than 0"));
-    if (max_capacity == 0) {   // hkv_hashtable_op_gpu.cu.cc:108-119
-      const char* env = std::getenv("TFRA_GPU_HASHTABLE_UPLIMIT_SIZE");
-      OP_REQUIRES(ctx, env != nullptr,
-                  errors::InvalidArgument("max_capaicty=0 and TFRA_GPU_HASHTABLE_UPLIMIT_SIZE not set is not valid."));
-      max_capacity = std::atoll(env);
-    }
-    tfra_table_opts o = {};
-    o.struct_size = sizeof(o);
-    o.value_dtype = TfraDtypeOf(value_dtype_);
-    o.dim = static_cast<int32_t>(value_shape_.dim_size(0));
-    o.init_capacity = static_cast<uint64_t>(init_capacity);   // 0 -> 1 Mi, max < init -> max = init: done by the engine
-    o.max_capacity = static_cast<uint64_t>(max_capacity);
-    o.max_hbm_for_vectors = static_cast<uint64_t>(max_hbm);
-    o.strategy = strategy;
-    o.step_per_epoch = step_per_epoch;
-    o.reserved_key_start_bit = reserved_bit;
-    o.device = -1;
-    AllocatorAttributes attr;
-    alloc_user_.device = ctx->device()->GetAllocator(attr);
-    tfra_allocator bridge = {&TfAllocator::Alloc, &TfAllocator::Free, &alloc_user_};
-    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_create(&o, &bridge, &table_)));
-  }
-  ~MI355XHashTable() override { tfra_table_destroy(table_); }
-
-  size_t dim() const { return static_cast<size_t>(value_shape_.dim_size(0)); }
-
-  // ---- LookupInterface -------------------------------------------------------------------------------
-  size_t size() const override {
-    size_t n = 0;
-    tfra_table_size(table_, &n, nullptr);   // host result: synchronises the null stream, like the reference's private stream
-    return n;
-  }
-  Status Find(OpKernelContext* ctx, const Tensor& keys, Tensor* values, const Tensor& default_value) override {
-    return FindImpl(ctx, keys, values, default_value, nullptr);
-  }
-  Status FindWithExists(OpKernelContext* ctx, const Tensor& keys, Tensor* values, const Tensor& default_value, Tensor* exists) {
-    return FindImpl(ctx, keys, values, default_value, exists);
-  }
-  Status Insert(OpKernelContext* ctx, const Tensor& keys, const Tensor& values) override {
-    return InsertWithScores(ctx, keys, values, nullptr);
-  }
-  // `scores` = the op's int64 input, nullptr / empty tensor = none (hkv_hashtable_op_gpu.cu.cc:758-762)
-  Status InsertWithScores(OpKernelContext* ctx, const Tensor& keys, const Tensor& values, const Tensor* scores) {
-    const size_t n = static_cast<size_t>(keys.NumElements());
-    return ToStatus(tfra_table_insert_or_assign(table_, n, Data<int64_t>(keys), values.tensor_data().data(), ScoresOf(scores),
-                                                TFRA_FLAG_UNIQUE_KEYS, StreamOf(ctx)));   // HKV's unique-keys contract
-  }
-  Status Accum(OpKernelContext* ctx, const Tensor& keys, const Tensor& values_or_deltas, const Tensor& exists, const Tensor* scores) {
-    const size_t n = static_cast<size_t>(keys.NumElements());
-    return ToStatus(tfra_table_accum_or_assign(table_, n, Data<int64_t>(keys), values_or_deltas.tensor_data().data(),
-                                               reinterpret_cast<const uint8_t*>(exists.tensor_data().data()), ScoresOf(scores),
-                                               TFRA_FLAG_UNIQUE_KEYS, StreamOf(ctx)));
-  }
-  Status Remove(OpKernelContext* ctx, const Tensor& keys) override {
-    return ToStatus(tfra_table_erase(table_, static_cast<size_t>(keys.NumElements()), Data<int64_t>(keys), StreamOf(ctx)));
-  }
-  Status Clear(OpKernelContext* ctx) { return ToStatus(tfra_table_clear(table_, StreamOf(ctx))); }
-  Status SizeToDevice(OpKernelContext* ctx, int64_t* d_out) { return ToStatus(tfra_table_size_to_device(table_, d_out, StreamOf(ctx))); }
-  Status ImportValues(OpKernelContext* ctx, const Tensor& keys, const Tensor& values) override {   // = clear + insert (:407-409)
-    TF_RETURN_IF_ERROR(Clear(ctx));
-    return InsertWithScores(ctx, keys, values, nullptr);
-  }
-  Status ExportValues(OpKernelContext* ctx) override { return Export(ctx, /*values=*/true, /*scores=*/false); }
-  // keys [size], values [size, dim] (when asked), scores [size] (when asked): outputs are sized from a size read, the
-  // table is then scanned once over its whole slot range (export_batch appends at a device counter)
-  Status Export(OpKernelContext* ctx, bool with_values, bool with_scores) {
-    size_t n = 0, capacity = 0;
-    tfra_stream_t stream = StreamOf(ctx);
-    TF_RETURN_IF_ERROR(ToStatus(tfra_table_size(table_, &n, stream)));
-    TF_RETURN_IF_ERROR(ToStatus(tfra_table_capacity(table_, &capacity)));
-    Tensor *keys = nullptr, *values = nullptr, *scores = nullptr;
-    const int64_t size = static_cast<int64_t>(n);
-    TF_RETURN_IF_ERROR(ctx->allocate_output("keys", TensorShape({size}), &keys));
-    if (with_values) TF_RETURN_IF_ERROR(ctx->allocate_output("values", TensorShape({size, static_cast<int64_t>(dim())}), &values));
-    if (with_scores) TF_RETURN_IF_ERROR(ctx->allocate_output("scores", TensorShape({size}), &scores));
-    if (n == 0) return OkStatus();
-    Tensor counter;
-    TF_RETURN_IF_ERROR(ctx->allocate_temp(DT_UINT64, TensorShape({}), &counter));
-    size_t* d_counter = reinterpret_cast<size_t*>(const_cast<char*>(counter.tensor_data().data()));
-    if (hipMemsetAsync(d_counter, 0, sizeof(size_t), static_cast<hipStream_t>(stream)) != hipSuccess)
-      return errors::Internal("export: hipMemsetAsync failed");
-    return ToStatus(tfra_table_export_batch(table_, capacity, 0, d_counter, MutableData<int64_t>(keys),
-                                            values ? const_cast<char*>(values->tensor_data().data()) : nullptr,
-                                            scores ? MutableData<uint64_t>(scores) : nullptr, stream));
-  }
-  Status SaveToFile(OpKernelContext* ctx, const std::string& prefix, size_t buffer_keys, bool append) {
-    size_t saved = 0;
-    return ToStatus(tfra_table_save(table_, prefix.c_str(), buffer_keys, append ? 1 : 0, StreamOf(ctx), &saved));
-  }
-  // the GPU op clears first (hkv_hashtable_op_gpu.cu.cc:619), then loads one file pair or every `<name>_mht_*` pair
-  Status LoadFromFiles(OpKernelContext* ctx, const std::vector<std::string>& prefixes, size_t buffer_keys) {
-    TF_RETURN_IF_ERROR(Clear(ctx));
-    for (const std::string& p : prefixes) {
-      size_t loaded = 0;
-      TF_RETURN_IF_ERROR(ToStatus(tfra_table_load(table_, p.c_str(), buffer_keys, StreamOf(ctx), &loaded)));
-    }
-    return OkStatus();
-  }
-
-  DataType key_dtype() const override { return key_dtype_; }
-  DataType value_dtype() const override { return value_dtype_; }
-  TensorShape key_shape() const override { return TensorShape(); }
-  TensorShape value_shape() const override { return value_shape_; }
-  int64_t MemoryUsed() const override {
-    size_t capacity = 0;
-    tfra_table_capacity(table_, &capacity);
-    return static_cast<int64_t>(sizeof(*this) + capacity * (16 + dim() * DataTypeSize(value_dtype_)));
-  }
-
- private:
-  template <class T>
-  static const T* Data(const Tensor& t) { return reinterpret_cast<const T*>(t.tensor_data().data()); }
-  template <class T>
-  static T* MutableData(Tensor* t) { return reinterpret_cast<T*>(const_cast<char*>(t->tensor_data().data())); }
-  static const uint64_t* ScoresOf(const Tensor* scores) {
-    return (scores && scores->NumElements() > 0) ? Data<uint64_t>(*scores) : nullptr;
-  }
-  Status FindImpl(OpKernelContext* ctx, const Tensor& keys, Tensor* values, const Tensor& default_value, Tensor* exists) {
-    const size_t n = static_cast<size_t>(keys.NumElements());
-    if (n == 0) return OkStatus();
-    // is_full_default = (value.size() == default.size()) (hkv_hashtable_op_gpu.cu.cc:186-190)
-    const int full = values->NumElements() == default_value.NumElements() ? 1 : 0;
-    return ToStatus(tfra_table_find(table_, n, Data<int64_t>(keys), const_cast<char*>(values->tensor_data().data()),
-                                    exists ? MutableData<uint8_t>(exists) : nullptr, default_value.tensor_data().data(), full,
-                                    StreamOf(ctx)));
-  }
-
-  DataType key_dtype_ = DT_INT64, value_dtype_ = DT_FLOAT;
-  TensorShape value_shape_;
-  TfAllocator alloc_user_{nullptr};
-  tfra_table_t* table_ = nullptr;
-};
-
-// =========================================== op kernels ===========================================
-
-static Status TableOf(OpKernelContext* ctx, MI355XHashTable** out, core::RefCountPtr<lookup::LookupInterface>* hold) {
-  lookup::LookupInterface* table = nullptr;
-  TF_RETURN_IF_ERROR(LookupResource(ctx, HandleFromInput(ctx, 0), &table));
-  hold->reset(table);
-  *out = dynamic_cast<MI355XHashTable*>(table);
-  if (*out == nullptr) return errors::InvalidArgument("table_handle is not a TFRA MI355X hash table");
-  return OkStatus();
-}
-
-// creator: one resource per (container, shared_name), deleted with the kernel when private to it
-// (the reference's HashTableGpuOp, cuckoo_hashtable_op_gpu.h:43-139)
-class TableOfTensorsOp : public OpKernel {
- public:
-  explicit TableOfTensorsOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("use_node_name_sharing", &use_node_name_sharing_));
-  }
-  ~TableOfTensorsOp() override {
-    if (created_ && cinfo_.resource_is_private_to_kernel())
-      cinfo_.resource_manager()->Delete<lookup::LookupInterface>(cinfo_.container(), cinfo_.name()).IgnoreError();
-  }
-  void Compute(OpKernelContext* ctx) override {
-    mutex_lock l(mu_);
-    if (!created_) OP_REQUIRES_OK(ctx, cinfo_.Init(ctx->resource_manager(), def(), use_node_name_sharing_));
-    lookup::LookupInterface* table = nullptr;
-    OP_REQUIRES_OK(ctx, cinfo_.resource_manager()->LookupOrCreate<lookup::LookupInterface>(
-                            cinfo_.container(), cinfo_.name(), &table, [ctx, this](lookup::LookupInterface** ret) {
-                              lookup::LookupInterface* t = new MI355XHashTable(ctx, this);
-                              if (!ctx->status().ok()) {
-                                t->Unref();
-                                return ctx->status();
-                              }
-                              *ret = t;
-                              return OkStatus();
-                            }));
-    core::ScopedUnref unref(table);
-    created_ = true;
-    Tensor* handle = nullptr;
-    AllocatorAttributes host;
-    host.set_on_host(true);
-    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({}), &handle, host));
-    handle->scalar<ResourceHandle>()() = MakeResourceHandle<lookup::LookupInterface>(ctx, cinfo_.container(), cinfo_.name());
-  }
-
- private:
-  mutex mu_;
-  bool created_ = false;
-  bool use_node_name_sharing_ = false;
-  ContainerInfo cinfo_;
-};
-
-#define TFRA_TABLE_OR_RETURN(ctx, t)                        \
-  MI355XHashTable* t = nullptr;                             \
-  core::RefCountPtr<lookup::LookupInterface> t##_hold;      \
-  OP_REQUIRES_OK(ctx, TableOf(ctx, &t, &t##_hold))
-
-static TensorShape ValuesShapeFor(const Tensor& keys, MI355XHashTable* t) {
-  TensorShape s = keys.shape();
-  s.AppendShape(t->value_shape());
-  return s;
-}
-
-class FindOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype()}, {t->value_dtype()}));
-    const Tensor& keys = ctx->input(1);
-    Tensor* values = nullptr;
-    OP_REQUIRES_OK(ctx, ctx->allocate_output("values", ValuesShapeFor(keys, t), &values));
-    OP_REQUIRES_OK(ctx, t->Find(ctx, keys, values, ctx->input(2)));
-  }
-};
-
-class FindWithExistsOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype()}, {t->value_dtype(), DT_BOOL}));
-    const Tensor& keys = ctx->input(1);
-    Tensor *values = nullptr, *exists = nullptr;
-    OP_REQUIRES_OK(ctx, ctx->allocate_output("values", ValuesShapeFor(keys, t), &values));
-    OP_REQUIRES_OK(ctx, ctx->allocate_output("exists", keys.shape(), &exists));
-    OP_REQUIRES_OK(ctx, t->FindWithExists(ctx, keys, values, ctx->input(2), exists));
-  }
-};
-
-class InsertOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype(), DT_INT64}, {}));
-    OP_REQUIRES_OK(ctx, t->CheckKeyAndValueTensorsForInsert(ctx->input(1), ctx->input(2)));
-    OP_REQUIRES_OK(ctx, t->InsertWithScores(ctx, ctx->input(1), ctx->input(2), &ctx->input(3)));
-  }
-};
-
-class AccumOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype(), DT_BOOL, DT_INT64}, {}));
-    OP_REQUIRES_OK(ctx, t->CheckKeyAndValueTensorsForInsert(ctx->input(1), ctx->input(2)));
-    OP_REQUIRES_OK(ctx, t->Accum(ctx, ctx->input(1), ctx->input(2), ctx->input(3), &ctx->input(4)));
-  }
-};
-
-class RemoveOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype()}, {}));
-    OP_REQUIRES_OK(ctx, t->CheckKeyTensorForRemove(ctx->input(1)));
-    OP_REQUIRES_OK(ctx, t->Remove(ctx, ctx->input(1)));
-  }
-};
-
-class ClearOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, t->Clear(ctx));
-  }
-};
-
-class SizeOp : public OpKernel {   // device scalar, no host sync (the reference's size_i64, :172-179)
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    Tensor* out = nullptr;
-    OP_REQUIRES_OK(ctx, ctx->allocate_output("size", TensorShape({}), &out));
-    OP_REQUIRES_OK(ctx, t->SizeToDevice(ctx, reinterpret_cast<int64_t*>(const_cast<char*>(out->tensor_data().data()))));
-  }
-};
-
-template <bool VALUES, bool SCORES>
-class ExportOp : public OpKernel {   // Export / ExportWithScores / ExportKeysAndScores (split_size: one scan here)
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, t->Export(ctx, VALUES, SCORES));
-  }
-};
-
-class ImportOp : public OpKernel {
- public:
-  using OpKernel::OpKernel;
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype()}, {}));
-    OP_REQUIRES_OK(ctx, t->CheckKeyAndValueTensorsForImport(ctx->input(1), ctx->input(2)));
-    OP_REQUIRES_OK(ctx, t->ImportValues(ctx, ctx->input(1), ctx->input(2)));
-  }
-};
-
-// directory: the environment variable named by `dirpath_env` wins over the `dirpath` input (:929-941)
-static Status ResolvePath(OpKernelContext* ctx, const std::string& dirpath_env, std::string* dir, std::string* file) {
-  TF_RETURN_IF_ERROR(ReadStringFromEnvVar(dirpath_env, "NotFound", dir));
-  if (*dir == "NotFound") {
-    const Tensor& d = ctx->input(1);
-    if (!TensorShapeUtils::IsScalar(d.shape())) return errors::InvalidArgument("directory path must be scalar.");
-    *dir = std::string(d.scalar<tstring>()().data());
-  }
-  const Tensor& f = ctx->input(2);
-  if (!TensorShapeUtils::IsScalar(f.shape())) return errors::InvalidArgument("file name must be scalar.");
-  *file = std::string(f.scalar<tstring>()().data());
-  return OkStatus();
-}
-
-class SaveToFileSystemOp : public OpKernel {
- public:
-  explicit SaveToFileSystemOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("dirpath_env", &dirpath_env_));
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("append_to_file", &append_));
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("buffer_size", &buffer_size_));
-  }
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    std::string dir, file;
-    OP_REQUIRES_OK(ctx, ResolvePath(ctx, dirpath_env_, &dir, &file));
-    OP_REQUIRES_OK(ctx, ctx->env()->RecursivelyCreateDir(dir));
-    OP_REQUIRES_OK(ctx, t->SaveToFile(ctx, io::JoinPath(dir, file), static_cast<size_t>(buffer_size_), append_));
-  }
-
- private:
-  std::string dirpath_env_;
-  bool append_ = false;
-  int64_t buffer_size_ = 1;
-};
-
-class LoadFromFileSystemOp : public OpKernel {
- public:
-  explicit LoadFromFileSystemOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("dirpath_env", &dirpath_env_));
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("load_entire_dir", &load_entire_dir_));
-    OP_REQUIRES_OK(ctx, ctx->GetAttr("buffer_size", &buffer_size_));
-  }
-  void Compute(OpKernelContext* ctx) override {
-    TFRA_TABLE_OR_RETURN(ctx, t);
-    std::string dir, file;
-    OP_REQUIRES_OK(ctx, ResolvePath(ctx, dirpath_env_, &dir, &file));
-    std::vector<std::string> prefixes;
-    if (load_entire_dir_) {   // every `<var>_mht_*` pair of the directory, each once (:1003-1019)
-      const size_t sep = file.rfind("_mht_");
-      std::vector<std::string> matches;
-      OP_REQUIRES_OK(ctx, ctx->env()->GetMatchingPaths(io::JoinPath(dir, file.substr(0, sep + 5)) + "*", &matches));
-      for (std::string& m : matches) m = m.substr(0, m.rfind('-'));   // drop the -keys / -values suffix
-      std::sort(matches.begin(), matches.end());
-      matches.erase(std::unique(matches.begin(), matches.end()), matches.end());
-      prefixes = matches;
-    } else {
-      prefixes.push_back(io::JoinPath(dir, file));
-    }
-    OP_REQUIRES_OK(ctx, t->LoadFromFiles(ctx, prefixes, static_cast<size_t>(buffer_size_)));
-  }
-
- private:
-  std::string dirpath_env_;
-  bool load_entire_dir_ = false;
-  int64_t buffer_size_ = 1;
-};
-
 // =========================================== kernel registrations ===========================================
 // K = int64 x V in {float, int8, int32, int64, half, bfloat16} on DEVICE_GPU (= the ROCm device string too), as
 // hkv_hashtable_op_gpu.cu.cc:1058-1138; Remove is registered once without type constraints (:809-811).
@@ -691,15 +252,15 @@ REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableRemove").Device(DEVICE_GPU), Remo
 
 #define TFRA_REGISTER_HKV(V)                                                                                            \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableOfTensors").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")     \
-                              .TypeConstraint<V>("value_dtype"), TableOfTensorsOp);                                     \
+                              .TypeConstraint<V>("value_dtype"), TableOfTensorsOp<false>);                                     \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableFind").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")          \
                               .TypeConstraint<V>("value_dtype"), FindOp);                                               \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableFindWithExists").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")\
                               .TypeConstraint<V>("value_dtype"), FindWithExistsOp);                                     \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableInsert").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")        \
-                              .TypeConstraint<V>("value_dtype"), InsertOp);                                             \
+                              .TypeConstraint<V>("value_dtype"), InsertOp<true>);                                             \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableAccum").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")         \
-                              .TypeConstraint<V>("value_dtype"), AccumOp);                                              \
+                              .TypeConstraint<V>("value_dtype"), AccumOp<true>);                                              \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableClear").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")         \
                               .TypeConstraint<V>("value_dtype"), ClearOp);                                              \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableSize").Device(DEVICE_GPU).TypeConstraint<int64_t>("key_dtype")          \
