@@ -546,14 +546,32 @@ def run_c2(args, torch, dist, de, dev, world, rank):
     for i in range(W):
       plain(base + i)
     elapsed_plain, _ = timed_steps(torch, dist, world, dev, K, lambda i: plain(base + W + i))
-  elif os.environ.get("TFRA_BENCH_ROUTE", "native") == "native":
+  route = None if single else os.environ.get("TFRA_BENCH_ROUTE", "native")
+  route_note = None
+  rs = None
+  if route == "native":
     # N > 1 (or the collectives forced on one GPU): the same prepared-ahead route as RoutedPrefetchStep below, issued from C
-    # (tfra_route_*: three calls per step, grouped ncclSend/ncclRecv on the driver's own RCCL communicators)
+    # (tfra_route_*: three calls per step, grouped ncclSend/ncclRecv on the driver's own RCCL communicators).  Should the
+    # driver not come up on some rank (its RCCL communicators are its own), every rank falls back to the Python-driven route.
     from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
-    rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B,
-                          threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
-    if dist.is_initialized() and rank == 0:
-      print("[bench] route: native C driver, world %d" % world, file=sys.stderr, flush=True)
+    err = None
+    try:
+      rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B,
+                            threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
+    except Exception as e:   # noqa: BLE001 — agreed on below
+      err = e
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+      if rs is not None:
+        rs.close()
+      rs, route = None, "prefetch"
+      route_note = "native route driver unavailable (%s): fell back to the Python-driven route" % (str(err)[:200] if err else "on another rank")
+    if rank == 0:
+      print("[bench] route: %s, world %d%s" % (route, world, "" if route_note is None else " — " + route_note), file=sys.stderr, flush=True)
+  if single:
+    pass
+  elif route == "native":
     ahead = int(os.environ.get("TFRA_ROUTE_AHEAD", "3"))   # batches whose ids are known before their step (input pipeline)
     for j in range(ahead):
       rs.feed(ids_all[j])
@@ -571,7 +589,7 @@ def run_c2(args, torch, dist, de, dev, world, rank):
       rs.lookup(); rs.apply(grads)
     torch.cuda.synchronize()
     rs.close()
-  elif os.environ.get("TFRA_BENCH_ROUTE") == "prefetch":
+  elif route == "prefetch":
     # N > 1 (or the collectives forced on one GPU): the id-only half of the route — distinct ids, owner-major order, count
     # exchange, id alltoall, both de-duplication plans — runs two batches ahead on a second stream (RoutedPrefetchStep);
     # per step: local find -> alltoall(rows) -> gather, gradient sums -> alltoall(grads) -> fused update at the owner
@@ -644,7 +662,7 @@ def run_c2(args, torch, dist, de, dev, world, rank):
           "new_key_ratio": new_ratio, "unique_ratio": round(uniq_ratio, 4), "unique_keys_per_batch": U,
           "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
           "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
-          "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
+          "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4), "route": route, "route_note": route_note,
           "drivers": {
               "value": ("tfra_table_step_prefetch: ONE C call per step = lookup + hot sums + fused Adam of batch i on the main "
                         "stream, CSR-by-key plan of batch i+1 on a second stream; one plan built per step inside the timed region")
@@ -653,7 +671,7 @@ def run_c2(args, torch, dist, de, dev, world, rank):
                             "batches ahead on its own streams; per step find -> alltoall(rows) -> gather, gradient sums -> "
                             "alltoall(grads) -> fused Adam at the owner",
                   "prefetch": "RoutedPrefetchStep (the same sequence driven from Python through torch.distributed)",
-              }.get(os.environ.get("TFRA_BENCH_ROUTE", "native"),
+              }.get(route,
                     "embedding_lookup + apply_gradients through the alltoall route (exact split sizes, no look-ahead)"),
               "value_plain_call": "tfra_table_find then tfra_table_apply_sparse (plan built inside the call): the reference's op "
                                   "sequence lookup -> optimizer apply, no look-ahead"},
