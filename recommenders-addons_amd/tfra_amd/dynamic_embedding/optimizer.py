@@ -251,7 +251,13 @@ class DynamicEmbeddingOptimizer:
     for grad, tw in grads_and_vars:
       if not isinstance(tw, TrainableWrapper):
         raise TypeError("expected the TrainableWrapper returned by embedding_lookup(..., return_trainable=True)")
-      self.apply_sparse(tw.params, tw.ids, grad, p)
+      plan = tw.take_plan() if (self.opt.kind is not None and not self.exact_order) else None
+      try:
+        self.apply_sparse(tw.params, tw.ids, grad, p, plan=plan)
+      finally:
+        if plan is not None:
+          from .variable import _release_plan
+          _release_plan(tw.params, plan)
 
   def _apply_generic(self, var, ids, grad):
     """The reference's write-back sequence for an arbitrary rule (`Generic`)."""

@@ -886,3 +886,43 @@ def test_sparse_segment_sum_reference_kats(env):
     de.device_ops.sparse_segment_combine(T(torch, np.arange(20, dtype=np.float32).reshape(10, 2)),
                                          torch.arange(6, dtype=torch.int32, device="cuda"),
                                          torch.arange(7, dtype=torch.int64, device="cuda"), None, "sum", 100)
+
+
+def test_write_back_plan_started_at_lookup_time(env):
+  """embedding_lookup(..., return_trainable=True, plan_writeback=True) + apply_gradients — the reference's API sequence —
+  builds the id-only half of the write-back on a second stream from lookup time on (the TrainableWrapper holds the ids):
+  same table, bit for bit, as lookup + one-call apply_sparse; plans go back to the Variable's pool, also when a wrapper
+  is dropped unapplied."""
+  torch, de = env
+  rng = np.random.default_rng(21)
+  opt = de.optimizers.Adam(1e-2)
+  kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
+  a = de.Variable(dim=32, name="plan_at_lookup_a", initializer=0.1, **kw)
+  b = de.Variable(dim=32, name="plan_at_lookup_b", initializer=0.1, **kw)
+  oa, ob = de.DynamicEmbeddingOptimizer(opt), de.DynamicEmbeddingOptimizer(de.optimizers.Adam(1e-2))
+  n = 20_000
+  for step in range(4):
+    ids = T(torch, (rng.zipf(1.2, size=n).astype(np.int64) % 30_000) * 7919 - 3).reshape(100, 200)
+    g = T(torch, (rng.standard_normal((n, 32)) * 0.01).astype(np.float32))
+    emb, tw = de.embedding_lookup(a, ids, return_trainable=True, plan_writeback=True)
+    assert tw.plan is not None and emb.shape == (100, 200, 32)
+    ref = b.lookup(ids.reshape(-1))
+    np.testing.assert_array_equal(emb.reshape(n, 32).cpu().numpy(), ref.cpu().numpy())
+    if step == 2:   # a lookup whose gradients never come: its plan returns to the pool with the wrapper
+      _, dropped = de.embedding_lookup(a, ids, return_trainable=True, plan_writeback=True)
+      assert dropped.plan is not None
+      del dropped
+    oa.apply_gradients([(g, tw)])
+    assert tw.plan is None
+    ob.apply_sparse(b, ids.reshape(-1), g)
+  pool = a._plan_pool
+  assert pool["made"] == 2 and len(pool["free"]) == 2
+  small, tws = de.embedding_lookup(a, ids.reshape(-1)[:100], return_trainable=True, plan_writeback=True)
+  assert tws.plan is None                      # below PLAN_AT_LOOKUP_MIN_IDS
+  _, plain_tw = de.embedding_lookup(a, ids, return_trainable=True)
+  assert plain_tw.plan is None and len(pool["free"]) == 2   # not asked for: nothing planned
+  ka, va = a.export(); kb, vb = b.export()
+  ia, ib = torch.argsort(ka), torch.argsort(kb)
+  assert torch.equal(ka[ia], kb[ib]) and torch.equal(va[ia], vb[ib])
+  for slot in ("m", "v"):
+    assert torch.equal(oa.get_slot(a, slot).lookup(ka[ia]), ob.get_slot(b, slot).lookup(kb[ib]))
