@@ -35,6 +35,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -958,7 +959,8 @@ __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// ASSIGN write-back, single pass with BUCKET OWNERSHIP (the normal path; the two kernels above are its remainder path).
+// ASSIGN write-back, single pass with BUCKET OWNERSHIP (the normal path; upsert_csr_kernel + upsert_evict_csr_kernel above
+// are what runs without owner tags).
 // Every bucket has an owner tag (one 32-bit word in a dense side array — NOT in the bucket's key line: an atomic and a
 // load issued together on the same 128-B line cost 41 us per 157 K instead of 11 us on separate lines,
 // scripts/mb/atomic_probe.hip).  Every key of the launch swaps the launch's generation into the tags of its two home
@@ -967,29 +969,33 @@ __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, cons
 // only writer of the launch that can touch them — every other key of the launch whose sequence includes one of them
 // fails that claim and leaves the table alone — so it resolves hit / free slot / minimum-score eviction with plain
 // loads and stores: no CAS, no LOCKED state, no score re-read, no publish ordering, and ONE dependent round trip (the
-// four lines and the two claims are in flight together) instead of the five of the locked protocol.  Keys that lose a
-// claim (two keys of one batch sharing a home bucket: ~(2U)^2/nb of them) or whose search cannot be decided from the
-// two home buckets (walk flags set) are marked `slow` and go through upsert_csr_kernel + upsert_evict_csr_kernel, which
-// run afterwards and look only at marked keys.
+// four lines and the two claims are in flight together) instead of the five of the locked protocol.
+//
+// LEFT-OVER keys: a key that loses a claim (two keys of one batch sharing a home bucket: ~(2U)^2 / (2 nb) of them, 16 of
+// 23 K / 185 of 78 K on 10^9 slots) or whose search cannot be decided from the two home buckets (walk flags) appends a
+// self-contained ITEM (key, value position, input score, reason) to the launch's list.  Round 2 = the same ownership pass
+// over the items with the NEXT generation — the winners of round 1 are done, so nearly every item now owns both buckets —
+// then a third round, then whatever is left (and every key that has to walk) goes through the locked protocol
+// (locked_upsert_kv).  Rounds 2.. are run by ONE workgroup (block barriers between the rounds):
+//   * finish inside (default on big tables): every block of upsert_own_kernel takes a ticket when its stores have been
+//     acknowledged; the block that draws the last ticket knows that every other block is done and runs the rounds — no
+//     second kernel, no co-residency requirement, nobody waits.  What it reads was written by blocks on other XCDs, so
+//     every table store of the pass is write-through (sc0 sc1) and the finishing block reads with agent-scope loads;
+//   * upsert_finish_kernel: the same rounds as a one-block kernel (TFRA_OWN_FINISH=kernel);
+//   * many left-overs expected (a small table): upsert_rest_kernel, a full grid of the locked protocol.
+// Round 2 used to be the locked protocol for ~180 keys in a kernel of its own: ~10 dependent round trips + a kernel
+// boundary = 12 us of the 43-us write-back.
+
 // One left-over key with the locked protocol for every kind of write: locate or claim the key's slot, LOCK it (CAS key
 // -> LOCKED: a concurrent evictor of this pass may have taken it, then start over), or lock a victim (evict_and_lock);
 // write row and score write-through, publish the key.  With every writer of the pass holding its slot locked, an assign
 // can no longer race with the eviction of the same slot, which is what the two separate kernels (assign / claim, then
 // evict) are for when they handle a whole batch.
 template <int G>
-__device__ __forceinline__ void locked_upsert_one(const TableView& v, const unsigned char* __restrict__ vals,
-                                                  const u64* __restrict__ scores, const CsrKeys& ks, const AuxInitPod& ai,
-                                                  const ScoreP& sp, unsigned g, int sub, int gshift, int& fresh, int& failed) {
+__device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsigned char* __restrict__ vals, i64 key, unsigned last,
+                                                 u64 in_score, const AuxInitPod& ai, const ScoreP& sp, int sub, int gshift,
+                                                 int& fresh, int& failed) {
   const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
-  const i64 key = ks.dkeys[g];
-  bool hot;
-  const unsigned w = load_record(ks, g, sub, hot);
-  const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
-  unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3));
-  if (hot) last = ks.hent[last];
-  last &= E_POS;
-  const u64 in_one = scores ? scores[last] : 1;
-  const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
   const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score;
   i64 row = -1;
   u64 word = 0;
@@ -1055,14 +1061,43 @@ __device__ __forceinline__ void locked_upsert_one(const TableView& v, const unsi
   publish_key(v, word, key, sub);
 }
 
-struct OwnCtrs;
-// The keys the ownership pass leaves over (its list; the flags when the list overflowed) when that pass does not take them
-// itself (small tables, where they are most of the batch): ONE pass of locked_upsert_one.
+// the same for key g of a plan: key, last position and input score come from its record
+template <int G>
+__device__ __forceinline__ void locked_upsert_one(const TableView& v, const unsigned char* __restrict__ vals,
+                                                  const u64* __restrict__ scores, const CsrKeys& ks, const AuxInitPod& ai,
+                                                  const ScoreP& sp, unsigned g, int sub, int gshift, int& fresh, int& failed) {
+  const i64 key = ks.dkeys[g];
+  bool hot;
+  const unsigned w = load_record(ks, g, sub, hot);
+  const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
+  unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3));
+  if (hot) last = ks.hent[last];
+  last &= E_POS;
+  const u64 in_one = scores ? scores[last] : 1;
+  const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+  locked_upsert_kv<G>(v, vals, key, last, in_score, ai, sp, sub, gshift, fresh, failed);
+}
+
+// A left-over key of the ownership pass, self-contained: rounds 2.. need nothing of the plan.
+struct OwnItem {          // 32 B, written as two 16-B write-through stores
+  i64 key;
+  unsigned last;          // batch position of the key's value row
+  unsigned g;             // index of the key in the launch (its dflag byte)
+  u64 ins;                // input score
+  unsigned flags, pad;
+};
+constexpr unsigned IT_WALK = 1u;   // the search cannot be decided from the two home buckets: locked protocol (it walks)
+// Counters of one use by the ownership write-back (two sets alternate, the last kernel / block of use k zeroes the set of
+// use k+1: nothing of use k-1 is still running by stream order).
+struct OwnCtrs { unsigned n_a, done, spare[2]; };
+
+// The keys the ownership pass leaves over when many are expected (small tables, where they are most of the batch): ONE
+// full-grid pass of the locked protocol over the list (the flags when the list overflowed).
 template <int G>
 __global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const unsigned char* __restrict__ vals,
                                                           const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
                                                           ScoreP sp, const uint8_t* __restrict__ dflag,
-                                                          const unsigned* slow_ctr, const unsigned* __restrict__ slow_list,
+                                                          const unsigned* slow_ctr, const OwnItem* __restrict__ items,
                                                           unsigned* zero4) {
   const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
   if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
@@ -1071,7 +1106,7 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const uns
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
   for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
-    const unsigned g = it.listed ? slow_list[i] : i;
+    const unsigned g = it.listed ? items[i].g : i;
     if (dflag[g] != 4) continue;
     locked_upsert_one<G>(v, vals, scores, ks, ai, sp, g, sub, gshift, fresh, failed);
   }
@@ -1089,29 +1124,73 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const uns
 // (the scalar results reach the group by shuffle).  Instruction issue, not HBM, bounds these kernels: with everything
 // computed per group the kernel was 4100 instructions per 16 keys and took 41 us for 78 K keys.
 // SIMPLE: the common shape — rows without optimizer slots, LRU scores, no caller scores — with everything else compiled out.
-// One batch of 16 keys of one wave (own_batch16).
+// Where the keys of a launch come from:
+//   SRC_PLAN    the unique keys of a de-duplication plan (value row = the key's LAST occurrence in the batch)
+//   SRC_DIRECT  a caller's array of UNIQUE keys, value row i belongs to key i (tfra_table_insert_or_assign with
+//               TFRA_FLAG_UNIQUE_KEYS: the reference's Insert op, hkv_hashtable_op_gpu.cu.cc:253-290)
+//   SRC_ITEMS   the left-over items of an earlier round (rounds 2.. of the finishing workgroup; agent-scope loads)
+enum { SRC_PLAN = 0, SRC_DIRECT = 1, SRC_ITEMS = 2 };
+
 struct OwnArgs {
   TableView v;
   const unsigned char* vals;
   const u64* scores;
-  CsrKeys ks;
+  CsrKeys ks;              // SRC_PLAN
+  const i64* keys;         // SRC_DIRECT
+  unsigned nkeys;          // SRC_DIRECT
   AuxInitPod ai;
   ScoreP sp;
-  uint8_t* dflag;
+  uint8_t* dflag;          // one byte per key of the launch: 4 = left over
   unsigned* tags;
-  bool with_scores, spec, lru, lru_like;
+  OwnItem* items;          // [item_cap] left-over list of the launch
+  unsigned item_cap;
 };
+// (OwnArgs stays a read-only kernel argument: a private, modified copy would live in scratch memory — its aux_init
+// pattern is indexed dynamically — and every field access of the hot loop would become a scratch load.)
+struct OwnFlags { bool with_scores, spec, lru, lru_like; };
 
-template <int G, bool SIMPLE>
-__device__ __forceinline__ void own_batch16(const OwnArgs& a, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
-                                            unsigned* __restrict__ slow_list, unsigned list_cap, int lane, int& fresh) {
+template <bool SIMPLE>
+__device__ __forceinline__ OwnFlags own_setup(const OwnArgs& a) {
+  OwnFlags fl;
+  fl.with_scores = SIMPLE || has_scores(a.v);
+  const bool dense = a.sp.bounded > 1 || (a.sp.bounded == 1 && *a.v.dense_flag);
+  fl.spec = fl.with_scores && dense;   // an eviction is likely: the score lines travel with the key lines
+  fl.lru = SIMPLE || a.sp.strategy == TFRA_EVICT_LRU;
+  fl.lru_like = fl.lru || a.sp.strategy == TFRA_EVICT_EPOCHLRU;
+  return fl;
+}
+
+__device__ __forceinline__ u64 load_u64_agent(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One batch of 16 keys of one wave.  gj = the lane's key: index into the plan's dense keys / the caller's key array / the
+// item list (clamped to a valid index; `valid` says whether the lane's key is real).
+//   SRC_PLAN / SRC_DIRECT: left-over keys are appended to a.items through *slow_ctr;
+//   SRC_ITEMS: state[] (LDS, one byte per item of the finishing workgroup's chunk, index gj - state_base) becomes
+//              0 done / 1 lost a claim again / 2 has to walk.
+template <int G, bool SIMPLE, int SRC>
+__device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
+                                            unsigned char* state, unsigned state_base, int lane, int& fresh) {
   constexpr int U = 4;
+  const u64* const scores = SIMPLE ? nullptr : a.scores;
+  constexpr bool COH = SRC == SRC_ITEMS;   // rounds 2..: the lines may have been written by this kernel's other blocks
   const TableView& v = a.v;
   const CsrKeys& ks = a.ks;
   const int sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
   // ---- one lane per key ------------------------------------------------------------------------------------
-  const i64 kreg = ks.dkeys[gj];
-  const unsigned kmreg = ks.keymap[gj];
+  i64 kreg;
+  unsigned kmreg = 0, lastreg = gj, greg = gj;
+  u64 insreg = 1;
+  if (SRC == SRC_PLAN) { kreg = ks.dkeys[gj]; kmreg = ks.keymap[gj]; }
+  else if (SRC == SRC_DIRECT) kreg = a.keys[gj];
+  else {
+    const OwnItem* it = a.items + gj;
+    kreg = (i64)load_u64_agent(&it->key);
+    const u64 lg = load_u64_agent(&it->last);
+    insreg = load_u64_agent(&it->ins);
+    lastreg = (unsigned)lg; greg = (unsigned)(lg >> 32);
+  }
   u64 hreg;
   const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
   const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
@@ -1122,53 +1201,68 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, unsigned gj, bool 
   }
   // ---- one group per key: the lines of 4 keys in flight --------------------------------------------------
   i64 key[U], kk[U][2], sc[U][2];
-  unsigned b0[U], b1[U], gk[U];
+  unsigned b0[U], b1[U], gk[U], gi[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = u * 4 + grp;
     key[u] = shfl_i64(kreg, j);
     b0[u] = (unsigned)__shfl((int)b0reg, j);
     b1[u] = (unsigned)__shfl((int)b1reg, j);
-    gk[u] = (unsigned)__shfl((int)gj, j);
-    // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
-    kk[u][0] = key_line(v, b0[u])[sub];
-    kk[u][1] = key_line(v, b1[u])[sub];
-    sc[u][0] = a.spec ? (i64)score_line(v, b0[u])[sub] : 0;
-    sc[u][1] = a.spec ? (i64)score_line(v, b1[u])[sub] : 0;
+    gk[u] = (unsigned)__shfl((int)greg, j);
+    gi[u] = SRC == SRC_ITEMS ? (unsigned)__shfl((int)gj, j) : 0u;   // (shuffles stay outside divergent code)
+    if (!COH) {
+      // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
+      kk[u][0] = key_line(v, b0[u])[sub];
+      kk[u][1] = key_line(v, b1[u])[sub];
+      sc[u][0] = fl.spec ? (i64)score_line(v, b0[u])[sub] : 0;
+      sc[u][1] = fl.spec ? (i64)score_line(v, b1[u])[sub] : 0;
+    } else {
+      kk[u][0] = load_key_coherent(key_line(v, b0[u]) + sub);
+      kk[u][1] = load_key_coherent(key_line(v, b1[u]) + sub);
+      sc[u][0] = fl.spec ? (i64)load_u64_agent(score_line(v, b0[u]) + sub) : 0;
+      sc[u][1] = fl.spec ? (i64)load_u64_agent(score_line(v, b1[u]) + sub) : 0;
+    }
   }
   // ---- per key again, while the lines travel: count and last position from the plan record, input score ---
-  const bool hot = (kmreg & KM_MANY) != 0;
-  const unsigned* rec = (hot ? ks.hrec : ks.crec) + (size_t)(kmreg & ~KM_MANY) * REC_WORDS;
-  const uint2 cl = *reinterpret_cast<const uint2*>(rec + 2);   // (count, last position of a key with few occurrences)
-  const unsigned cnt = cl.x;
-  unsigned lastreg = cl.y;
-  if (hot) lastreg = ks.hent[rec[5]];                          // many: where it is stored
-  lastreg &= E_POS;
-  const u64 in_one = a.scores ? a.scores[lastreg] : 1;
-  const u64 insreg = a.sp.strategy == TFRA_EVICT_LFU ? (a.scores ? in_one : (u64)cnt) : in_one;
-  const unsigned lostreg = (c0 == gen || c1 == gen || is_reserved_key(kreg)) ? 1u : 0u;   // (group 0's lanes)
+  if (SRC == SRC_PLAN) {
+    const bool hot = (kmreg & KM_MANY) != 0;
+    const unsigned* rec = (hot ? ks.hrec : ks.crec) + (size_t)(kmreg & ~KM_MANY) * REC_WORDS;
+    const uint2 cl = *reinterpret_cast<const uint2*>(rec + 2);   // (count, last position of a key with few occurrences)
+    const unsigned cnt = cl.x;
+    lastreg = cl.y;
+    if (hot) lastreg = ks.hent[rec[5]];                          // many: where it is stored
+    lastreg &= E_POS;
+    const u64 in_one = scores ? scores[lastreg] : 1;
+    insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+  } else if (SRC == SRC_DIRECT) {
+    insreg = scores ? scores[lastreg] : 1;
+  }
+  // why a key is left over: 1 lost a claim, 2 has to walk (sentinel keys live in the side rows: the general path)
+  const unsigned lostreg = is_reserved_key(kreg) ? 2u : ((c0 == gen || c1 == gen) ? 1u : 0u);   // (group 0's lanes)
   keep_live(kk[0][0], kk[1][0], kk[2][0], kk[3][0]);
   keep_live(kk[0][1], kk[1][1], kk[2][1], kk[3][1]);
-  if (a.spec) {
+  if (fl.spec) {
     keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
     keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
   }
-  const u64 now = a.lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
+  const u64 now = fl.lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
   u64 word[U], in_s[U];
   unsigned last[U];
-  int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry, -1 left over
+  int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry
+  int why[U];   // 0 handled, 1 lost a claim, 2 has to walk
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = u * 4 + grp;
     last[u] = (unsigned)__shfl((int)lastreg, j);
     in_s[u] = 1;
-    if (!a.lru_like) in_s[u] = ((u64)(unsigned)__shfl((int)(insreg >> 32), j) << 32) | (unsigned)__shfl((int)insreg, j);
-    bool slow = __shfl((int)lostreg, j) != 0;   // lane j of group 0 made the claims
+    if (!fl.lru_like)   // (LRU-type scores ignore the input score)
+      in_s[u] = ((u64)(unsigned)__shfl((int)(insreg >> 32), j) << 32) | (unsigned)__shfl((int)insreg, j);
+    why[u] = __shfl((int)lostreg, j);   // lane j of group 0 made the claims
     const bool on = __shfl((int)valid, j) != 0;
     act[u] = 0;
     word[u] = 0;
-    if (!on) continue;
-    if (!slow) {
+    if (!on) { why[u] = 0; continue; }
+    if (!why[u]) {
       const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
       const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
       const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
@@ -1178,44 +1272,53 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, unsigned gj, bool 
       bool flag_b0 = false;   // the key goes to b1 although b0 never overflowed before
       if (hit0) { word[u] = (u64)b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
       else if (hit1) { word[u] = (u64)b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
-      else if (ovf0 && ovf1) slow = true;   // the key may live further along: walk
+      else if (ovf0 && ovf1) why[u] = 2;   // the key may live further along: walk
       else if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
       else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
-      else if (a.spec && !ovf1) {
+      else if (fl.spec && !ovf1) {
         // both home buckets full, nothing further along: replace the minimum-score entry of the 30 slots
         u64 best_score, best_word;
         i64 best_key;
         select_victim_merged(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
         const u64 cmp = a.sp.strategy == TFRA_EVICT_EPOCHLFU ? ((a.sp.epoch << 32) | in_s[u]) : in_s[u];
-        if (a.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
+        if (fl.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
           word[u] = best_word;
           act[u] = 3;
           flag_b0 = (best_word >> 4) == b1[u];
         }
-      } else slow = true;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
+      } else why[u] = 2;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
       if (flag_b0 && !ovf0 && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
     }
-    if (sub == 0) a.dflag[gk[u]] = slow ? 4 : 0;
-    if (slow) act[u] = -1;
+    if (SRC != SRC_ITEMS) {
+      // agent-scope byte: read by the finishing block (list overflow) or by the next kernel
+      if (sub == 0) __hip_atomic_store(a.dflag + gk[u], (uint8_t)(why[u] ? 4 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (sub == 0) {
+      state[gi[u] - state_base] = (unsigned char)why[u];
+      if (!why[u]) __hip_atomic_store(a.dflag + gk[u], (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     fresh += (act[u] == 2 && sub == 0);
   }
-  {   // left-over keys of the wave -> the list: one atomic add for all of them
+  if (SRC != SRC_ITEMS) {   // left-over keys of the wave -> the list: one atomic add for all of them
     u64 sm[U];
     unsigned nslow = 0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { sm[u] = __ballot(act[u] < 0 && sub == 0); nslow += (unsigned)__popcll(sm[u]); }
+    for (int u = 0; u < U; ++u) { sm[u] = __ballot(why[u] != 0 && sub == 0); nslow += (unsigned)__popcll(sm[u]); }
     if (nslow) {
       unsigned at = 0;
       if (lane == 0) at = atomicAdd(slow_ctr, nslow);
       at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (act[u] < 0 && sub == 0) {
-          const unsigned pos = at + (unsigned)__popcll(sm[u] & ((1ULL << lane) - 1));
-          if (pos < list_cap) slow_list[pos] = gk[u];
+        if (why[u] != 0 && sub < 2) {
+          const unsigned pos = at + (unsigned)__popcll(sm[u] & ((1ULL << gshift) - 1));
+          if (pos < a.item_cap) {
+            uint4 w;
+            if (sub == 0) w = make_uint4((unsigned)(u64)key[u], (unsigned)((u64)key[u] >> 32), last[u], gk[u]);
+            else w = make_uint4((unsigned)in_s[u], (unsigned)(in_s[u] >> 32), why[u] == 2 ? IT_WALK : 0u, 0u);
+            store_wt16(reinterpret_cast<unsigned char*>(a.items + pos) + sub * 16, w);
+          }
         }
         at += (unsigned)__popcll(sm[u]);
-        if (act[u] < 0) act[u] = 0;
       }
     }
   }
@@ -1253,54 +1356,126 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, unsigned gj, bool 
               __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % a.ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
+      // owned bucket: no CAS; write-through, a later round of this kernel may read the line from another XCD
+      if (sub == 0) store_wt8(key_word(v, word[u]), (u64)key[u]);
     }
-    if (!a.with_scores) continue;
-    if (a.lru) { if (sub == 0) *score_word(v, word[u]) = now; }
+    if (!fl.with_scores) continue;
+    if (fl.lru) { if (sub == 0) store_wt8(score_word(v, word[u]), now); }
     else if (act[u] == 3 && a.sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) store_wt8(score_word(v, word[u]), in_s[u]); }   // the slot starts a new life
     else update_score<true>(v, (i64)((word[u] >> 4) * SLOTS + (word[u] & 15)), act[u] >= 2, a.sp.strategy, in_s[u], a.sp.epoch, sub);
   }
 }
 
-// Counters of one use of a plan by the ownership write-back (two sets alternate, the kernel of use k zeroes the set of
-// use k+1 at its start: nothing of use k-1 is still running by stream order).
-struct OwnCtrs { unsigned n_a, spare[3]; };
-
-// (Tried and removed: taking the left-over keys in a second ownership round INSIDE this kernel — co-resident persistent
-// grid, the blocks holding a share of the list wait for all blocks to finish round 1 — instead of a remainder kernel.
-// It saves a boundary and was still slower, 82 vs 48 us at 10^9 slots: fewer, longer-lived blocks hide less latency
-// than the hardware's own block scheduling, and the second round's code doubles the kernel's registers.)
-template <int G, bool SIMPLE>
-__global__ __launch_bounds__(256) void upsert_own_kernel(TableView v, const unsigned char* __restrict__ vals,
-                                                         const u64* __restrict__ scores_in, CsrKeys ks, AuxInitPod ai,
-                                                         ScoreP sp, uint8_t* __restrict__ dflag, OwnCtrs* ctr,
-                                                         unsigned* __restrict__ slow_list, unsigned list_cap, unsigned own_gen, unsigned* __restrict__ tags,
-                                                         unsigned* progress, unsigned progress_val) {
-  const int lane = threadIdx.x & 63;
-  const unsigned total = ks.d_counts[0] + ks.d_counts[1];
-  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+// Rounds 2.. by ONE workgroup (see the head of this section).  Items are taken in chunks of FIN_CHUNK (their state lives
+// in LDS): up to two more ownership rounds with the generations gen0+1, gen0+2 — all of a round's writes are acknowledged
+// and the workgroup has met before the next round reads — then the locked protocol for what is left.  If the list
+// overflowed, the flags of ALL keys are scanned afterwards (locked protocol; slow, and only on a table too small for
+// this path: the host sends those to upsert_rest_kernel).
+constexpr unsigned FIN_CHUNK = 1024;
+template <int G, bool SIMPLE, int SRC>
+__device__ __forceinline__ void own_finish(const OwnArgs& a, const OwnFlags fl, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned gen0, unsigned total,
+                                           unsigned char* s_state, unsigned* s_flag) {
+  const u64* const scores = SIMPLE ? nullptr : a.scores;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const unsigned counted = __hip_atomic_load(&ctr->n_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned n_items = min(counted, a.item_cap);
   int fresh = 0, failed = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
-    if (ks.d_counts[5]) atomicAdd(v.err_count, ks.d_counts[5]);
+  for (unsigned cb = 0; cb < n_items; cb += FIN_CHUNK) {
+    const unsigned m = min(FIN_CHUNK, n_items - cb);
+    for (unsigned i = threadIdx.x; i < m; i += blockDim.x)
+      s_state[i] = (load_u64_agent(&a.items[cb + i].flags) & IT_WALK) ? 2 : 1;
+    __syncthreads();
+    for (unsigned round = 1; round <= 2; ++round) {
+      if (threadIdx.x == 0) *s_flag = 0;
+      __syncthreads();
+      bool any = false;
+      for (unsigned base = wave * 16; base < m; base += nwaves * 16) {
+        const unsigned i = base + (unsigned)(lane & 15);
+        const bool valid = i < m && s_state[min(i, m - 1)] == 1;
+        if (!__ballot(valid)) continue;
+        any = true;
+        own_batch16<G, SIMPLE, SRC_ITEMS>(a, fl, cb + min(i, m - 1), valid, gen0 + round, nullptr, s_state, cb, lane, fresh);
+      }
+      if (any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this round's stores are in memory before the next round reads
+      __syncthreads();
+      for (unsigned i = threadIdx.x; i < m; i += blockDim.x) if (s_state[i] == 1) *s_flag = 1;
+      __syncthreads();
+      const unsigned pending = *s_flag;
+      __syncthreads();
+      if (!pending) break;
+    }
+    // what is left: lost twice more, or has to walk — the locked protocol, one key per group
+    for (unsigned i = threadIdx.x >> 4; i < m; i += blockDim.x >> 4) {
+      if (!s_state[i]) continue;
+      const OwnItem* it = a.items + cb + i;
+      const i64 key = (i64)load_u64_agent(&it->key);
+      const u64 lg = load_u64_agent(&it->last);
+      const u64 ins = load_u64_agent(&it->ins);
+      locked_upsert_kv<G>(a.v, a.vals, key, (unsigned)lg, ins, a.ai, a.sp, sub, gshift, fresh, failed);
+      if (sub == 0) __hip_atomic_store(a.dflag + (unsigned)(lg >> 32), (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
   }
-  OwnArgs a;
-  a.v = v; a.vals = vals; a.scores = SIMPLE ? nullptr : scores_in; a.ks = ks; a.ai = ai; a.sp = sp; a.dflag = dflag; a.tags = tags;
-  a.with_scores = SIMPLE || has_scores(v);
-  const bool dense = sp.bounded > 1 || (sp.bounded == 1 && *v.dense_flag);
-  a.spec = a.with_scores && dense;   // an eviction is likely: the score lines travel with the key lines
-  a.lru = SIMPLE || sp.strategy == TFRA_EVICT_LRU;
-  a.lru_like = a.lru || sp.strategy == TFRA_EVICT_EPOCHLRU;
-  for (unsigned wbase = wave * 16; wbase < total; wbase += nwaves * 16) {
-    const unsigned i = wbase + (unsigned)(lane & 15);
-    own_batch16<G, SIMPLE>(a, min(i, total - 1), i < total, own_gen, &ctr->n_a, slow_list, list_cap, lane, fresh);
+  if (counted > a.item_cap) {   // the list is incomplete: every key still flagged
+    for (unsigned g = threadIdx.x >> 4; g < total; g += blockDim.x >> 4) {
+      if (__hip_atomic_load(a.dflag + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 4) continue;
+      if (SRC == SRC_PLAN) locked_upsert_one<G>(a.v, a.vals, scores, a.ks, a.ai, a.sp, g, sub, gshift, fresh, failed);
+      else locked_upsert_kv<G>(a.v, a.vals, a.keys[g], g, scores ? scores[g] : 1, a.ai, a.sp, sub, gshift, fresh, failed);
+    }
   }
+  if (threadIdx.x < 4) reinterpret_cast<unsigned*>(next_ctr)[threadIdx.x] = 0;   // arm the next use's counters
   for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
   if (lane == 0) {
-    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
-    if (failed) atomicAdd(v.err_count, (unsigned)failed);
+    if (fresh) size_add(a.v, wave, fresh);
+    if (failed) atomicAdd(a.v.err_count, (unsigned)failed);
   }
+}
+
+// (Tried and removed in round 2: taking the left-over keys in a second ownership round inside this kernel with a
+// co-resident persistent grid whose blocks WAIT for round 1 to finish — 82 vs 48 us at 10^9 slots: fewer, longer-lived
+// blocks hide less latency than the hardware's own block scheduling.  The ticket below waits for nobody.)
+// finish: 0 = a later kernel takes the left-over keys, 1 = the block that draws the last ticket does.
+template <int G, bool SIMPLE, int SRC, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned own_gen, int finish,
+                                                        unsigned* progress, unsigned progress_val) {
+  __shared__ unsigned char s_state[FIN_CHUNK];
+  __shared__ unsigned s_flag;
+  const int lane = threadIdx.x & 63;
+  const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int fresh = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
+    if (SRC == SRC_PLAN && a.ks.d_counts[5]) atomicAdd(a.v.err_count, a.ks.d_counts[5]);
+  }
+  const OwnFlags fl = own_setup<SIMPLE>(a);
+  for (unsigned wbase = wave * 16; wbase < total; wbase += nwaves * 16) {
+    const unsigned i = wbase + (unsigned)(lane & 15);
+    own_batch16<G, SIMPLE, SRC>(a, fl, min(i, total - 1), i < total, own_gen, &ctr->n_a, nullptr, 0, lane, fresh);
+  }
+  for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
+  if (lane == 0 && fresh) size_add(a.v, wave, fresh);
+  if (!finish) return;
+  // ticket: every store of this block has been acknowledged by memory (they are write-through) before it is drawn
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&ctr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_flag != gridDim.x - 1) return;
+  __syncthreads();   // (s_flag is reused by own_finish)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  own_finish<G, SIMPLE, SRC>(a, fl, ctr, next_ctr, own_gen, total, s_state, &s_flag);
+}
+
+// the rounds 2.. as a kernel of their own: one workgroup
+template <int G, bool SIMPLE, int SRC, int NT>
+__global__ __launch_bounds__(NT) void upsert_finish_kernel(const OwnArgs a, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned own_gen) {
+  __shared__ unsigned char s_state[FIN_CHUNK];
+  __shared__ unsigned s_flag;
+  const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  own_finish<G, SIMPLE, SRC>(a, own_setup<SIMPLE>(a), ctr, next_ctr, own_gen, total, s_state, &s_flag);
 }
 
 }  // namespace
@@ -1326,7 +1501,7 @@ struct tfra_sparse_plan {
   unsigned* binmap = nullptr;
   unsigned* d_counts = nullptr;
   uint8_t* dflag = nullptr;
-  unsigned* slow_list = nullptr;   // [SLOW_CAP] keys the ownership pass of a write-back left to the general path
+  OwnItem* slow_items = nullptr;   // [SLOW_CAP] left-over keys of the ownership pass of a write-back (self-contained items)
   unsigned* any_deferred = nullptr;   // = use_gen of the last write-back that deferred a key to its eviction phase
   mutable unsigned use_gen = 0;
   mutable unsigned ups_uses = 0;   // upsert_planned uses: parity selects the left-over counter (SlowIter)
@@ -1389,7 +1564,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
                  + al(nrec_c * REC_WORDS * 4) + al(nrec_h * REC_WORDS * 4)      // key records
                  + al(nbin * SEG * 4) + al(nbin * 32 * 4)                       // bins + run outputs
                  + al(npad * 4) + al(npad * 8) + al(nbin * 4)                   // keymap, dense keys, binmap
-                 + al(npad) + al((size_t)SLOW_CAP * 4)                          // deferred flags, left-over key list
+                 + al(npad) + al((size_t)SLOW_CAP * sizeof(OwnItem))            // deferred flags, left-over item list
                  + al(npart * 4)                                                // partial row -> destination (route helpers)
                  + al(npart * (size_t)dim * 4);                                 // partial rows
   if (pl->bytes < bytes) {
@@ -1427,7 +1602,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   pl->dkeys = (i64*)w; w += al(npad * 8);
   pl->binmap = (unsigned*)w; w += al(nbin * 4);
   pl->dflag = (uint8_t*)w; w += al(npad);
-  pl->slow_list = (unsigned*)w; w += al((size_t)SLOW_CAP * 4);
+  pl->slow_items = (OwnItem*)w; w += al((size_t)SLOW_CAP * sizeof(OwnItem));
   pl->any_deferred = pl->d_counts + 8;
   pl->prow_dest = (int*)w; w += al(npart * 4);
   pl->partial = (float*)w;
@@ -1538,6 +1713,77 @@ extern "C" int tfra_table_apply_planned(tfra_table_t* tp, const tfra_opt_params*
   return apply_planned_impl(tp, p, pl, grads, param_default_row, stream, nullptr, 0);
 }
 
+// ---- launch of the ownership write-back (plan keys or a caller's unique keys) --------------------------------
+// How the left-over keys are taken (TFRA_OWN_FINISH, read once): "inside" (default) the last block of upsert_own_kernel,
+// "kernel" a one-block kernel behind it; a table on which many are expected always gets the full-grid locked pass.
+enum { FIN_REST = 0, FIN_KERNEL = 1, FIN_INSIDE = 2 };
+static int own_finish_pref() {
+  static const int pref = [] {
+    const char* e = getenv("TFRA_OWN_FINISH");
+    if (e && !strcmp(e, "kernel")) return (int)FIN_KERNEL;
+    if (e && !strcmp(e, "rest")) return (int)FIN_REST;
+    return (int)FIN_INSIDE;
+  }();
+  return pref;
+}
+static int own_block_threads() {   // TFRA_OWN_NT: threads per block of the 16-B-granule kernels (256 / 512 / 1024)
+  static const int nt = [] {
+    const char* e = getenv("TFRA_OWN_NT");
+    const int v = e ? atoi(e) : 512;
+    return v == 256 || v == 1024 ? v : 512;
+  }();
+  return nt;
+}
+
+template <int G, bool SIMPLE, int SRC, int NT>
+static void launch_own_nt(hipStream_t s, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og, int fin,
+                          unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
+  constexpr unsigned KPB = NT / 64 * 16;   // keys per block and pass
+  const unsigned blocks = (unsigned)std::max<size_t>(1, (nkeys + KPB - 1) / KPB);
+  upsert_own_kernel<G, SIMPLE, SRC, NT><<<blocks, NT, 0, s>>>(a, ctr, next_ctr, og, fin == FIN_INSIDE ? 1 : 0, progress, progress_val);
+  if (fin == FIN_KERNEL) upsert_finish_kernel<G, SIMPLE, SRC, (G == 16 ? 1024 : 256)><<<1, (G == 16 ? 1024 : 256), 0, s>>>(a, ctr, next_ctr, og);
+}
+
+template <int G, bool SIMPLE, int SRC>
+static void launch_own_g(hipStream_t s, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og, int fin,
+                         unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
+  if (G == 16) {
+    switch (own_block_threads()) {
+      case 256: launch_own_nt<G, SIMPLE, SRC, 256>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+      case 1024: launch_own_nt<G, SIMPLE, SRC, (G == 16 ? 1024 : 256)>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+      default: launch_own_nt<G, SIMPLE, SRC, (G == 16 ? 512 : 256)>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+    }
+  } else {
+    launch_own_nt<G, SIMPLE, SRC, 256>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val);
+  }
+}
+
+// granule g of the value rows; `simple`: rows without slots, LRU, no caller scores
+template <int SRC>
+static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og,
+                       int fin, unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
+  switch (g) {
+    case 16:
+      if (simple) launch_own_g<16, true, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val);
+      else launch_own_g<16, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val);
+      break;
+    case 8: launch_own_g<8, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+    case 4: launch_own_g<4, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+    case 2: launch_own_g<2, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+    default: launch_own_g<1, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+  }
+}
+
+// Expected left-over keys of an ownership pass over `nkeys` keys: two keys sharing a home bucket, (2 n)^2 / (2 nb).
+static double expect_leftover(double nkeys, double nb) { return 2.0 * nkeys * nkeys / nb; }
+constexpr double FINISH_MAX_EXPECTED = 512.0;   // more than that: a full grid of the locked protocol, not one workgroup
+
+static unsigned next_own_gen(Table* t) {   // a launch uses og (round 1), og+1, og+2 (rounds of the finishing workgroup)
+  t->own_gen += 4;
+  if (t->own_gen < 4) t->own_gen = 4;      // wrapped (tags start at 0; a stale equal tag only sends a key to the next round)
+  return t->own_gen;
+}
+
 static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, const void* values, const uint64_t* scores,
                                tfra_stream_t stream, unsigned* progress, unsigned progress_val) {
   // caller holds t->mu
@@ -1565,48 +1811,104 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   const u64* sc = (const u64*)scores;
   const unsigned gen = ++pl->use_gen;
   unsigned* tags = t->ensure_own_tags(s);    // nullptr (allocation failed): every key takes the general two-kernel path
-  if (++t->own_gen == 0) t->own_gen = 1;     // bucket-owner tag of this launch (tags start at 0)
-  const unsigned og = t->own_gen;
-  const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
-  OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
-  OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
-  // Left-over keys of the ownership pass: two keys of one batch sharing a home bucket, ~2 U^2 / nb of them.  Few (a big
-  // table): the remainder kernel walks their list with a handful of blocks.  Many (a small table): full grid.  Without
-  // tags every key takes the general two-kernel path.
-  const double nkeys = (double)key_blocks * 16.0;   // unique keys of the plan when its counts have arrived, else the id count
-  const double expect_slow = 2.0 * nkeys * nkeys / (double)t->cur.nb;
-  const unsigned rem_blocks = expect_slow < 2048.0 ? 32u : key_blocks;
-  const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !sc;
-  const unsigned own_blocks = (key_blocks + 3) / 4;
-#define TFRA_OWN(GG, SS)                                                                                                      \
-  upsert_own_kernel<GG, SS><<<own_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, ctr, pl->slow_list,     \
-                                                       SLOW_CAP, og, tags, progress, progress_val)
+  if (tags) {
+    const unsigned og = next_own_gen(t);
+    const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
+    OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
+    OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
+    // Left-over keys of the ownership pass.  Few (a big table): one workgroup runs two more ownership rounds over their
+    // list.  Many (a small table): a full grid of the locked protocol.
+    const double nkeys = (double)key_blocks * 16.0;   // unique keys of the plan when its counts have arrived, else the id count
+    const double expect_slow = expect_leftover(nkeys, (double)t->cur.nb);
+    const int fin = expect_slow < FINISH_MAX_EXPECTED ? own_finish_pref() : FIN_REST;
+    const unsigned rem_blocks = expect_slow < 2048.0 ? 32u : key_blocks;
+    const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !sc;
+    OwnArgs a{};
+    a.v = v; a.vals = vals; a.scores = sc; a.ks = keys_of(pl); a.keys = nullptr; a.nkeys = 0; a.ai = t->aux; a.sp = sp;
+    a.dflag = pl->dflag; a.tags = tags; a.items = pl->slow_items; a.item_cap = SLOW_CAP;
+    launch_own<SRC_PLAN>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, fin, rem_blocks, progress, progress_val);
+    if (fin == FIN_REST) {
+#define TFRA_REST(GG) upsert_rest_kernel<GG><<<rem_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, &ctr->n_a, \
+                                                                       pl->slow_items, reinterpret_cast<unsigned*>(next_ctr))
+      switch (g) {
+        case 16: TFRA_REST(16); break;
+        case 8: TFRA_REST(8); break;
+        case 4: TFRA_REST(4); break;
+        case 2: TFRA_REST(2); break;
+        default: TFRA_REST(1); break;
+      }
+#undef TFRA_REST
+    }
+  } else {
 #define TFRA_UPS(GG)                                                                                                          \
-  if (tags) {                                                                                                                 \
-    if (GG == 16 && simple) TFRA_OWN(16, true);                                                                               \
-    else TFRA_OWN(GG, false);                                                                                                 \
-    upsert_rest_kernel<GG><<<rem_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, &ctr->n_a,              \
-                                                      pl->slow_list, reinterpret_cast<unsigned*>(next_ctr));                 \
-  } else {                                                                                                                    \
     upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,   \
-                                                     nullptr, pl->slow_list, nullptr);                                       \
+                                                     nullptr, nullptr, nullptr);                                             \
     if (sp.bounded)                                                                                                           \
       upsert_evict_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,                  \
-                                                             pl->any_deferred, gen, nullptr, pl->slow_list, nullptr);        \
-  }
-  switch (g) {
-    case 16: TFRA_UPS(16); break;
-    case 8: TFRA_UPS(8); break;
-    case 4: TFRA_UPS(4); break;
-    case 2: TFRA_UPS(2); break;
-    default: TFRA_UPS(1); break;
-  }
-#undef TFRA_OWN
+                                                             pl->any_deferred, gen, nullptr, nullptr, nullptr);
+    switch (g) {
+      case 16: TFRA_UPS(16); break;
+      case 8: TFRA_UPS(8); break;
+      case 4: TFRA_UPS(4); break;
+      case 2: TFRA_UPS(2); break;
+      default: TFRA_UPS(1); break;
+    }
 #undef TFRA_UPS
+  }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");
   step_epoch_public(t);
   return TFRA_OK;
 }
+
+// tfra_table_insert_or_assign with TFRA_FLAG_UNIQUE_KEYS (the reference's Insert op hands HKV unique keys,
+// hkv_hashtable_op_gpu.cu.cc:253-290 -> lookup_table_op_hkv.h:522-537): the same single pass with bucket ownership, fed
+// with the caller's key array — value row i belongs to key i, no plan.  *taken = false: not for this call (no owner tags,
+// or so many keys for the table's size that most of them would collide on a home bucket: a bulk load) — the caller runs
+// the locked two-phase kernels.  Caller holds t->mu and has called prepare_insert.
+namespace tfra {
+int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken) {
+  *taken = false;
+  if (n == 0 || n > (1u << 24)) return TFRA_OK;
+  if (expect_leftover((double)n, (double)t->cur.nb) >= FINISH_MAX_EXPECTED) return TFRA_OK;
+  // the table's own scratch of this path: 2 counter sets | item list | one flag byte per key
+  const size_t head = 256 + (size_t)SLOW_CAP * sizeof(OwnItem);
+  const size_t need = head + ((n + 255) / 256) * 256;
+  if (t->capture_safe && (t->own_ws_bytes < need || !t->own_tags || t->own_tags_nb != t->cur.nb)) return TFRA_OK;   // no allocation while capturing
+  unsigned* tags = t->ensure_own_tags(s);
+  if (!tags) return TFRA_OK;
+  if (t->own_ws_bytes < need) {
+    if (t->own_ws) { if (hipStreamSynchronize(s) != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: sync"); t->dfree(t->own_ws, s); t->own_ws = nullptr; t->own_ws_bytes = 0; }
+    const size_t want = head + std::max<size_t>(((n + 255) / 256) * 256, (size_t)1 << 18);
+    t->own_ws = t->dalloc(want, s);
+    if (!t->own_ws) { g_last_error.clear(); return TFRA_OK; }   // no scratch: the locked kernels need none
+    if (hipMemsetAsync(t->own_ws, 0, 256, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: memset");
+    t->own_ws_bytes = want;
+    t->own_ws_uses = 0;
+  }
+  uint8_t* bounded_now;
+  int rc = t->bounded_flags(1, s, &bounded_now);
+  if (rc) return rc;
+  const ScoreP sp{t->opts.strategy, t->global_epoch, bounded_now ? (t->dense ? 2 : 1) : 0};
+  size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)values | 16;
+  int g = (int)(x & (~x + 1));
+  if (g > 16) g = 16;
+  const unsigned og = next_own_gen(t);
+  const unsigned par = t->own_ws_uses++ & 1u;
+  OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(t->own_ws) + par;
+  OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(t->own_ws) + (par ^ 1u);
+  const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !scores;
+  int fin = own_finish_pref();
+  if (fin == FIN_REST) fin = FIN_KERNEL;   // (the full-grid locked pass reads plan records)
+  OwnArgs a{};
+  a.v = t->view_of(t->cur); a.vals = (const unsigned char*)values; a.scores = scores; a.keys = keys; a.nkeys = (unsigned)n;
+  a.ai = t->aux; a.sp = sp; a.dflag = (uint8_t*)t->own_ws + head; a.tags = tags;
+  a.items = reinterpret_cast<OwnItem*>((unsigned char*)t->own_ws + 256); a.item_cap = SLOW_CAP;
+  launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, fin, 0, nullptr, 0);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: launch failed");
+  *taken = true;
+  return TFRA_OK;
+}
+}  // namespace tfra
 
 extern "C" int tfra_table_upsert_planned(tfra_table_t* tp, const tfra_sparse_plan_t* pl, const void* values,
                                          const uint64_t* scores, tfra_stream_t stream) {

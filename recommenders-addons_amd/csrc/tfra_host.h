@@ -55,6 +55,9 @@ struct Table {
   unsigned* own_tags = nullptr;  // [nb] bucket-owner tags (upsert_own_kernel), allocated on first use
   u64 own_tags_nb = 0;
   unsigned own_gen = 0;      // bucket-owner tag of the last ownership-based write-back (upsert_own_kernel)
+  void* own_ws = nullptr;    // scratch of the ownership pass over a caller's unique keys (own_upsert_unique): counters | items | flags
+  size_t own_ws_bytes = 0;
+  unsigned own_ws_uses = 0;
   unsigned apply_P = 0;      // bucket count the cursor area at the head of `scratch` is armed for (0 = not armed)
   AuxInitPod aux{};
   // host bookkeeping
@@ -97,6 +100,8 @@ struct Table {
 };
 
 void destroy_own_plan(Table* t);   // tfra_csr.hip
+// insert_or_assign of UNIQUE keys as one ownership pass (tfra_csr.hip); *taken = false: not applicable, run the locked kernels
+int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken);
 void destroy_workspace_plan(void* plan);   // tfra_csr.hip
 void step_epoch_public(Table* t);  // tfra_optim.hip
 

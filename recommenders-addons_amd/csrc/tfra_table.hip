@@ -1235,6 +1235,19 @@ static int insert_impl(Table* t, hipStream_t s, int field, size_t n, const int64
   if (bounded && !(flags & TFRA_FLAG_UNIQUE_KEYS))
     return set_error(TFRA_ERR_UNSUPPORTED, "insert: a bounded (Hkv) table at max_capacity needs TFRA_FLAG_UNIQUE_KEYS "
                                            "(HKV's unique-keys contract) so that eviction is well defined");
+  if ((flags & TFRA_FLAG_UNIQUE_KEYS) && field == 0) {
+    // the single pass with bucket ownership whenever the batch is small for the table: no locks, no CAS
+    bool taken = false;
+    rc = own_upsert_unique(t, s, n, k, vals, sc, &taken);
+    if (rc) return rc;
+    if (taken) {
+      if (strat == TFRA_EVICT_EPOCHLRU || strat == TFRA_EVICT_EPOCHLFU) {
+        t->curr_step += 1;
+        if (t->opts.step_per_epoch > 0 && t->curr_step > t->opts.step_per_epoch) { t->global_epoch += 1; t->curr_step = 1; }
+      }
+      return TFRA_OK;
+    }
+  }
   if (flags & TFRA_FLAG_UNIQUE_KEYS) {
     uint8_t* deferred = nullptr;
     if (bounded) {
@@ -1388,7 +1401,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   destroy_own_plan(t);
   t->free_storage(t->cur, s);
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
-  t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s); t->dfree(t->own_tags, s);
+  t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s); t->dfree(t->own_tags, s); t->dfree(t->own_ws, s);
   if (t->progress_host) (void)hipHostFree(t->progress_host);
   if (t->h_scalar) (void)hipHostFree(t->h_scalar);
   if (t->chain_event) (void)hipEventDestroy(t->chain_event);
