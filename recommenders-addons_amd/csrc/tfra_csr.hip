@@ -972,19 +972,22 @@ __global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, cons
 // four lines and the two claims are in flight together) instead of the five of the locked protocol.
 //
 // LEFT-OVER keys: a key that loses a claim (two keys of one batch sharing a home bucket: ~(2U)^2 / (2 nb) of them, 16 of
-// 23 K / 185 of 78 K on 10^9 slots) or whose search cannot be decided from the two home buckets (walk flags) appends a
-// self-contained ITEM (key, value position, input score, reason) to the launch's list.  Round 2 = the same ownership pass
-// over the items with the NEXT generation — the winners of round 1 are done, so nearly every item now owns both buckets —
-// then a third round, then whatever is left (and every key that has to walk) goes through the locked protocol
-// (locked_upsert_kv).  Rounds 2.. are run by ONE workgroup (block barriers between the rounds):
-//   * finish inside (default on big tables): every block of upsert_own_kernel takes a ticket when its stores have been
-//     acknowledged; the block that draws the last ticket knows that every other block is done and runs the rounds — no
-//     second kernel, no co-residency requirement, nobody waits.  What it reads was written by blocks on other XCDs, so
-//     every table store of the pass is write-through (sc0 sc1) and the finishing block reads with agent-scope loads;
-//   * upsert_finish_kernel: the same rounds as a one-block kernel (TFRA_OWN_FINISH=kernel);
-//   * many left-overs expected (a small table): upsert_rest_kernel, a full grid of the locked protocol.
-// Round 2 used to be the locked protocol for ~180 keys in a kernel of its own: ~10 dependent round trips + a kernel
-// boundary = 12 us of the 43-us write-back.
+// 23 K / 185 of 78 K on 10^9 slots) or that cannot be placed within its two home buckets appends a self-contained ITEM
+// (key, value position, input score) to the launch's list; upsert_rest_kernel takes the items afterwards with the locked
+// protocol.  A key that MAY live beyond its home buckets (both overflow flags set, ~0.1 % of the buckets of a table filled
+// to capacity) is looked for with reads in the main pass and claims the bucket it is found in.
+//
+// Round 3 measurements on the 10^9-slot table (scripts/mb_own.py, mb_sweep.py; rocprofv3 per-kernel times):
+//   * the pass costs 13 us + 0.23 us per 1000 keys: 3.0 us launch + key load, 5.5 us until the four lines AND the two
+//     claims are back (the lines alone 3.5 us — every access is a TLB miss on 273 GB), 4 us of dependent ALU / cross-lane
+//     work for ONE wave's 16 keys, 0.5 us value rows, 1 us stores;
+//   * the claims are ~5 us of 32 (78 K keys), their footprint does not matter (tags folded into 8 MB: same time);
+//   * tried and dropped: the left-over keys in two more OWNERSHIP rounds — by the last block of the pass (ticket) or by a
+//     one-block kernel behind it — 14-19 us against 10-12 us for 32 blocks of the locked protocol (one workgroup is one
+//     dependent chain per round, and the code of the rounds costs the pass registers); claim-after-look with shared /
+//     exclusive claim words in the score lines (an atomic on a line that has just been read is still a fabric
+//     read-modify-write, and it now sits behind the lines instead of beside them): 35 / 38 us against 30 / 24;
+//     the value row prefetched with the lines (direct keys): 42 us against 31 (16 more registers per lane, spills).
 
 // One left-over key with the locked protocol for every kind of write: locate or claim the key's slot, LOCK it (CAS key
 // -> LOCKED: a concurrent evictor of this pass may have taken it, then start over), or lock a victim (evict_and_lock);
@@ -1078,58 +1081,23 @@ __device__ __forceinline__ void locked_upsert_one(const TableView& v, const unsi
   locked_upsert_kv<G>(v, vals, key, last, in_score, ai, sp, sub, gshift, fresh, failed);
 }
 
-// A left-over key of the ownership pass, self-contained: rounds 2.. need nothing of the plan.
-struct OwnItem {          // 32 B, written as two 16-B write-through stores
+// A left-over key of the ownership pass, self-contained: the remainder pass needs nothing of the plan.
+struct OwnItem {          // 32 B, written as two 16-B stores
   i64 key;
   unsigned last;          // batch position of the key's value row
   unsigned g;             // index of the key in the launch (its dflag byte)
   u64 ins;                // input score
   unsigned flags, pad;
 };
-constexpr unsigned IT_WALK = 1u;   // the search cannot be decided from the two home buckets: locked protocol (it walks)
-// Counters of one use by the ownership write-back (two sets alternate, the last kernel / block of use k zeroes the set of
+// Counters of one use by the ownership write-back (two sets alternate, the last kernel of use k zeroes the set of
 // use k+1: nothing of use k-1 is still running by stream order).
-struct OwnCtrs { unsigned n_a, done, spare[2]; };
+struct OwnCtrs { unsigned n_a, spare[3]; };
 
-// The keys the ownership pass leaves over when many are expected (small tables, where they are most of the batch): ONE
-// full-grid pass of the locked protocol over the list (the flags when the list overflowed).
-template <int G>
-__global__ __launch_bounds__(256) void upsert_rest_kernel(TableView v, const unsigned char* __restrict__ vals,
-                                                          const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
-                                                          ScoreP sp, const uint8_t* __restrict__ dflag,
-                                                          const unsigned* slow_ctr, const OwnItem* __restrict__ items,
-                                                          unsigned* zero4) {
-  const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
-  if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
-  if (it.n == 0) return;
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
-  int fresh = 0, failed = 0;
-  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
-    const unsigned g = it.listed ? items[i].g : i;
-    if (dflag[g] != 4) continue;
-    locked_upsert_one<G>(v, vals, scores, ks, ai, sp, g, sub, gshift, fresh, failed);
-  }
-  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
-  if (lane == 0) {
-    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
-    if (failed) atomicAdd(v.err_count, (unsigned)failed);
-  }
-}
-
-// Shape: 16 keys per wave and iteration.  What is scalar per key — the key word, its hash, the two ownership claims,
-// the plan record (count, last position), the input score — is done ONE LANE PER KEY (lane j of every group holds
-// key j; group 0 issues the claims): one instruction stream for 16 keys.  What needs a whole line — the four bucket
-// lines, the ballots, the victim choice, the row copy — is done one 16-lane group per key, 4 keys per group in flight
-// (the scalar results reach the group by shuffle).  Instruction issue, not HBM, bounds these kernels: with everything
-// computed per group the kernel was 4100 instructions per 16 keys and took 41 us for 78 K keys.
-// SIMPLE: the common shape — rows without optimizer slots, LRU scores, no caller scores — with everything else compiled out.
 // Where the keys of a launch come from:
 //   SRC_PLAN    the unique keys of a de-duplication plan (value row = the key's LAST occurrence in the batch)
 //   SRC_DIRECT  a caller's array of UNIQUE keys, value row i belongs to key i (tfra_table_insert_or_assign with
 //               TFRA_FLAG_UNIQUE_KEYS: the reference's Insert op, hkv_hashtable_op_gpu.cu.cc:253-290)
-//   SRC_ITEMS   the left-over items of an earlier round (rounds 2.. of the finishing workgroup; agent-scope loads)
-enum { SRC_PLAN = 0, SRC_DIRECT = 1, SRC_ITEMS = 2 };
+enum { SRC_PLAN = 0, SRC_DIRECT = 1 };
 
 struct OwnArgs {
   TableView v;
@@ -1140,7 +1108,8 @@ struct OwnArgs {
   unsigned nkeys;          // SRC_DIRECT
   AuxInitPod ai;
   ScoreP sp;
-  uint8_t* dflag;          // one byte per key of the launch: 4 = left over
+  uint8_t* dflag;          // one byte per key of the launch: 4 = left over.  All zero between launches: only left-over keys
+                           // are flagged, and whoever takes a left-over key clears its flag
   unsigned* tags;
   OwnItem* items;          // [item_cap] left-over list of the launch
   unsigned item_cap;
@@ -1160,68 +1129,124 @@ __device__ __forceinline__ OwnFlags own_setup(const OwnArgs& a) {
   return fl;
 }
 
-__device__ __forceinline__ u64 load_u64_agent(const void* p) {
-  return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The keys the ownership pass leaves over: 32 blocks (a full grid on a small table, where they are most of the batch) of
+// the locked protocol over the item list; the flags of ALL keys when the list overflowed.
+template <int G, int SRC>
+__global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const unsigned* slow_ctr, unsigned* zero4) {
+  const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  const unsigned counted = *slow_ctr;
+  if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
+  if (counted == 0) return;
+  const bool listed = counted <= a.item_cap;
+  const unsigned n = listed ? counted : total;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
+  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  int fresh = 0, failed = 0;
+  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < n; i += ngroups) {
+    if (listed) {
+      const uint4 w0 = reinterpret_cast<const uint4*>(a.items + i)[0];
+      const uint2 w1 = reinterpret_cast<const uint2*>(a.items + i)[2];
+      const i64 key = (i64)(((u64)w0.y << 32) | w0.x);
+      locked_upsert_kv<G>(a.v, a.vals, key, w0.z, ((u64)w1.y << 32) | w1.x, a.ai, a.sp, sub, gshift, fresh, failed);
+      if (sub == 0) a.dflag[w0.w] = 0;
+    } else {
+      if (a.dflag[i] != 4) continue;
+      if (SRC == SRC_PLAN) locked_upsert_one<G>(a.v, a.vals, a.scores, a.ks, a.ai, a.sp, i, sub, gshift, fresh, failed);
+      else locked_upsert_kv<G>(a.v, a.vals, a.keys[i], i, a.scores ? a.scores[i] : 1, a.ai, a.sp, sub, gshift, fresh, failed);
+      if (sub == 0) a.dflag[i] = 0;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
+  if (lane == 0) {
+    if (fresh) size_add(a.v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (failed) atomicAdd(a.v.err_count, (unsigned)failed);
+  }
 }
 
-// One batch of 16 keys of one wave.  gj = the lane's key: index into the plan's dense keys / the caller's key array / the
-// item list (clamped to a valid index; `valid` says whether the lane's key is real).
-//   SRC_PLAN / SRC_DIRECT: left-over keys are appended to a.items through *slow_ctr;
-//   SRC_ITEMS: state[] (LDS, one byte per item of the finishing workgroup's chunk, index gj - state_base) becomes
-//              0 done / 1 lost a claim again / 2 has to walk.
+// 16-lane minimum of (score, index) pairs with DPP row rotations (row_ror 8, 4, 2, 1: every lane ends up with the row's
+// minimum; ~8 cycles per move instead of an LDS round trip per __shfl_xor — the four dependent rounds of the victim choice
+// were a fifth of the 4 us a wave spends deciding)
+__device__ __forceinline__ unsigned dpp_ror(unsigned x, int n) {
+  switch (n) {
+    case 8: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);
+    case 4: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false);
+    case 2: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false);
+    default: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false);
+  }
+}
+// Victim choice among the 30 slots of (b0, b1), as select_victim_merged (tfra_device.h): minimum score, the lower index
+// (b0's slots before b1's) on ties, EMPTY counts as score 0, LOCKED slots are not candidates.
+__device__ __forceinline__ void select_victim_dpp(u64 b0, u64 b1, const i64 (&kk2)[2], const i64 (&sc2)[2], int sub, int gshift,
+                                                  u64& best_score, u64& best_word) {
+  u64 s0 = (u64)sc2[0], s1 = (u64)sc2[1];
+  if (kk2[0] == EMPTY_KEY) s0 = 0;
+  if (kk2[1] == EMPTY_KEY) s1 = 0;
+  if (sub >= SLOTS || kk2[0] == LOCKED_KEY) s0 = ~0ULL;
+  if (sub >= SLOTS || kk2[1] == LOCKED_KEY) s1 = ~0ULL;
+  u64 my = s0;
+  unsigned idx = (unsigned)sub;
+  if (s1 < s0) { my = s1; idx = 16u + (unsigned)sub; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const u64 os = ((u64)dpp_ror((unsigned)(my >> 32), o) << 32) | dpp_ror((unsigned)my, o);
+    const unsigned oi = dpp_ror(idx, o);
+    if (os < my || (os == my && oi < idx)) { my = os; idx = oi; }
+  }
+  best_score = my;
+  best_word = (idx >= 16u ? b1 : b0) * 16 + (idx & 15u);
+}
+
+// One batch of 16 keys of one wave.  What is scalar per key — the key word, its hash, the two ownership claims, the plan
+// record (count, last position), the input score — is done ONE LANE PER KEY (lane j of every group holds key j; group 0
+// issues the claims): one instruction stream for 16 keys.  What needs a whole line — the four bucket lines, the ballots,
+// the victim choice, the row copy — is done one 16-lane group per key, 4 keys per group in flight (the scalar results
+// reach the group by shuffle).  SIMPLE: the common shape — rows without optimizer slots, LRU scores, no caller scores —
+// with everything else compiled out.
+// ORDER (round 3, from the phase timings above): the clock is read first (s_memrealtime is slow); every cross-lane
+// broadcast is issued before the first use of any; the claims are issued BEHIND the line loads and consumed LAST — memory
+// returns in order, so a claim issued first would hold back the lines, and consumed first it would stall the decisions,
+// which do not need it.
+// gj = the lane's key: index into the plan's dense keys / the caller's key array (clamped to a valid index; `valid` says
+// whether the lane's key is real).
 template <int G, bool SIMPLE, int SRC>
 __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
-                                            unsigned char* state, unsigned state_base, int lane, int& fresh) {
+                                            int lane, int& fresh) {
   constexpr int U = 4;
   const u64* const scores = SIMPLE ? nullptr : a.scores;
-  constexpr bool COH = SRC == SRC_ITEMS;   // rounds 2..: the lines may have been written by this kernel's other blocks
   const TableView& v = a.v;
   const CsrKeys& ks = a.ks;
   const int sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  const u64 now = fl.lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
   // ---- one lane per key ------------------------------------------------------------------------------------
   i64 kreg;
-  unsigned kmreg = 0, lastreg = gj, greg = gj;
+  unsigned kmreg = 0, lastreg = gj;
   u64 insreg = 1;
   if (SRC == SRC_PLAN) { kreg = ks.dkeys[gj]; kmreg = ks.keymap[gj]; }
-  else if (SRC == SRC_DIRECT) kreg = a.keys[gj];
-  else {
-    const OwnItem* it = a.items + gj;
-    kreg = (i64)load_u64_agent(&it->key);
-    const u64 lg = load_u64_agent(&it->last);
-    insreg = load_u64_agent(&it->ins);
-    lastreg = (unsigned)lg; greg = (unsigned)(lg >> 32);
-  }
+  else kreg = a.keys[gj];
   u64 hreg;
   const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
   const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
-  unsigned c0 = 0, c1 = 0;
-  if (grp == 0 && valid) {   // (a clamped duplicate must not claim: it would lock out the real key)
-    c0 = atomicExch(a.tags + b0reg, gen);
-    c1 = atomicExch(a.tags + b1reg, gen);
-  }
-  // ---- one group per key: the lines of 4 keys in flight --------------------------------------------------
+  const bool reserved = is_reserved_key(kreg);   // sentinel keys live in the side rows: the general path
+  // ---- one group per key: every broadcast first, then the lines of 4 keys in flight -------------------------
   i64 key[U], kk[U][2], sc[U][2];
-  unsigned b0[U], b1[U], gk[U], gi[U];
+  unsigned b0[U], b1[U], gk[U];
+  bool on[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = u * 4 + grp;
     key[u] = shfl_i64(kreg, j);
     b0[u] = (unsigned)__shfl((int)b0reg, j);
     b1[u] = (unsigned)__shfl((int)b1reg, j);
-    gk[u] = (unsigned)__shfl((int)greg, j);
-    gi[u] = SRC == SRC_ITEMS ? (unsigned)__shfl((int)gj, j) : 0u;   // (shuffles stay outside divergent code)
-    if (!COH) {
-      // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
-      kk[u][0] = key_line(v, b0[u])[sub];
-      kk[u][1] = key_line(v, b1[u])[sub];
-      sc[u][0] = fl.spec ? (i64)score_line(v, b0[u])[sub] : 0;
-      sc[u][1] = fl.spec ? (i64)score_line(v, b1[u])[sub] : 0;
-    } else {
-      kk[u][0] = load_key_coherent(key_line(v, b0[u]) + sub);
-      kk[u][1] = load_key_coherent(key_line(v, b1[u]) + sub);
-      sc[u][0] = fl.spec ? (i64)load_u64_agent(score_line(v, b0[u]) + sub) : 0;
-      sc[u][1] = fl.spec ? (i64)load_u64_agent(score_line(v, b1[u]) + sub) : 0;
-    }
+    gk[u] = (unsigned)__shfl((int)gj, j);
+    on[u] = __shfl((int)(valid && !reserved), j) != 0;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
+    kk[u][0] = key_line(v, b0[u])[sub];
+    kk[u][1] = key_line(v, b1[u])[sub];
+    sc[u][0] = fl.spec ? (i64)score_line(v, b0[u])[sub] : 0;
+    sc[u][1] = fl.spec ? (i64)score_line(v, b1[u])[sub] : 0;
   }
   // ---- per key again, while the lines travel: count and last position from the plan record, input score ---
   if (SRC == SRC_PLAN) {
@@ -1234,71 +1259,96 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
     lastreg &= E_POS;
     const u64 in_one = scores ? scores[lastreg] : 1;
     insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-  } else if (SRC == SRC_DIRECT) {
+  } else {
     insreg = scores ? scores[lastreg] : 1;
   }
-  // why a key is left over: 1 lost a claim, 2 has to walk (sentinel keys live in the side rows: the general path)
-  const unsigned lostreg = is_reserved_key(kreg) ? 2u : ((c0 == gen || c1 == gen) ? 1u : 0u);   // (group 0's lanes)
+  // the claims, behind the loads in program order (a clamped duplicate must not claim: it would lock out the real key)
+  unsigned c0 = 0, c1 = 0;
+  if (grp == 0 && valid && !reserved) {
+    c0 = atomicExch(a.tags + b0reg, gen);
+    c1 = atomicExch(a.tags + b1reg, gen);
+  }
   keep_live(kk[0][0], kk[1][0], kk[2][0], kk[3][0]);
   keep_live(kk[0][1], kk[1][1], kk[2][1], kk[3][1]);
   if (fl.spec) {
     keep_live(sc[0][0], sc[1][0], sc[2][0], sc[3][0]);
     keep_live(sc[0][1], sc[1][1], sc[2][1], sc[3][1]);
   }
-  const u64 now = fl.lru_like ? (u64)wall_clock64() : 0;   // one clock read for the 16 keys (LRU scores tie within a wave)
+  // ---- what each key would do, from its lines alone (the claims are still travelling) -----------------------
   u64 word[U], in_s[U];
-  unsigned last[U];
   int act[U];   // 0 nothing to write, 1 assign (hit), 2 new key in a free slot, 3 new key over an evicted entry
-  int why[U];   // 0 handled, 1 lost a claim, 2 has to walk
+  int why[U];   // 0 handled, 1 lost a claim, 2 cannot be placed within the home buckets: the locked protocol
+  bool flag_b0[U];   // the key goes to b1 although b0 never overflowed before: finds must go on to b1
+  unsigned bxc[U];   // bucket beyond the home buckets the key was found in (it must be claimed too); ~0: none
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    in_s[u] = 1;
+    if (!fl.lru_like) in_s[u] = (u64)shfl_i64((i64)insreg, u * 4 + grp);   // (LRU-type scores ignore the input score)
+    act[u] = 0; why[u] = 0; word[u] = 0; flag_b0[u] = false; bxc[u] = ~0u;
+    if (!on[u]) continue;
+    const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
+    const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
+    const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
+    const unsigned emp1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == EMPTY_KEY) >> gshift) & 0x7fffu;
+    const bool ovf0 = ((__ballot(sub == 15 && ((u64)kk[u][0] & META_OVF0)) >> gshift) & 0xffffu) != 0;
+    const bool ovf1 = ((__ballot(sub == 15 && ((u64)kk[u][1] & META_OVF1)) >> gshift) & 0xffffu) != 0;
+    if (hit0) { word[u] = (u64)b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
+    else if (hit1) { word[u] = (u64)b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
+    else {
+      bool absent = !(ovf0 && ovf1);   // the flags end the search at b0 / b1
+      if (!absent) {
+        // The key may live further along (placed while the table still walked): follow the flags with READS.  Found in
+        // bucket bx: it claims bx too — every key that could evict from bx has bx as a home bucket and claimed it at its
+        // start, so the exchange tells who goes first.
+        unsigned bx = b1[u];
+#pragma unroll 1
+        for (int stepn = 0; stepn < 8 && !absent && !act[u] && !why[u]; ++stepn) {
+          bx = bx + 1 == (unsigned)v.nb ? 0u : bx + 1;
+          const i64 kx = load_key_coherent(key_line(v, bx) + sub);
+          const unsigned hitx = (unsigned)(__ballot(sub < SLOTS && kx == key[u]) >> gshift) & 0x7fffu;
+          if (hitx) { word[u] = (u64)bx * 16 + (__ffs(hitx) - 1); act[u] = 1; if (bx != b0[u] && bx != b1[u]) bxc[u] = bx; }
+          else if (!((__ballot(sub == 15 && ((u64)kx & META_OVF1)) >> gshift) & 0xffffu)) absent = true;
+          else if (stepn == 7) why[u] = 2;   // a long chain (an unbounded table): the general path
+        }
+      }
+      if (absent) {   // not in the table
+        if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // first empty slot in probe order
+        else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0[u] = !ovf0; }
+        else if (fl.spec) {
+          // both home buckets full on a table that no longer walks: replace the minimum-score entry of the 30 slots
+          u64 best_score, best_word;
+          select_victim_dpp(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word);
+          const u64 cmp = a.sp.strategy == TFRA_EVICT_EPOCHLFU ? ((a.sp.epoch << 32) | in_s[u]) : in_s[u];
+          if (fl.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
+            word[u] = best_word;
+            act[u] = 3;
+            flag_b0[u] = !ovf0 && (best_word >> 4) == b1[u];
+          }
+        } else why[u] = 2;   // a table that still walks (not at capacity / unbounded): placed further along by the general path
+      }
+    }
+  }
+  // ---- now the claims -------------------------------------------------------------------------------------------
+  const unsigned lostreg = reserved ? 2u : ((c0 == gen || c1 == gen) ? 1u : 0u);   // (group 0's lanes)
+  unsigned last[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = u * 4 + grp;
     last[u] = (unsigned)__shfl((int)lastreg, j);
-    in_s[u] = 1;
-    if (!fl.lru_like)   // (LRU-type scores ignore the input score)
-      in_s[u] = ((u64)(unsigned)__shfl((int)(insreg >> 32), j) << 32) | (unsigned)__shfl((int)insreg, j);
-    why[u] = __shfl((int)lostreg, j);   // lane j of group 0 made the claims
-    const bool on = __shfl((int)valid, j) != 0;
-    act[u] = 0;
-    word[u] = 0;
-    if (!on) { why[u] = 0; continue; }
-    if (!why[u]) {
-      const unsigned hit0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == key[u]) >> gshift) & 0x7fffu;
-      const unsigned hit1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == key[u]) >> gshift) & 0x7fffu;
-      const unsigned emp0 = (unsigned)(__ballot(sub < SLOTS && kk[u][0] == EMPTY_KEY) >> gshift) & 0x7fffu;
-      const unsigned emp1 = (unsigned)(__ballot(sub < SLOTS && kk[u][1] == EMPTY_KEY) >> gshift) & 0x7fffu;
-      const bool ovf0 = ((__ballot(sub == 15 && ((u64)kk[u][0] & META_OVF0)) >> gshift) & 0xffffu) != 0;
-      const bool ovf1 = ((__ballot(sub == 15 && ((u64)kk[u][1] & META_OVF1)) >> gshift) & 0xffffu) != 0;
-      bool flag_b0 = false;   // the key goes to b1 although b0 never overflowed before
-      if (hit0) { word[u] = (u64)b0[u] * 16 + (__ffs(hit0) - 1); act[u] = 1; }
-      else if (hit1) { word[u] = (u64)b1[u] * 16 + (__ffs(hit1) - 1); act[u] = 1; }
-      else if (ovf0 && ovf1) why[u] = 2;   // the key may live further along: walk
-      else if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // not in the table: first empty slot in probe order
-      else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0 = true; }
-      else if (fl.spec && !ovf1) {
-        // both home buckets full, nothing further along: replace the minimum-score entry of the 30 slots
-        u64 best_score, best_word;
-        i64 best_key;
-        select_victim_merged(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word, best_key);
-        const u64 cmp = a.sp.strategy == TFRA_EVICT_EPOCHLFU ? ((a.sp.epoch << 32) | in_s[u]) : in_s[u];
-        if (fl.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
-          word[u] = best_word;
-          act[u] = 3;
-          flag_b0 = (best_word >> 4) == b1[u];
-        }
-      } else why[u] = 2;   // a table that still walks (not at capacity / unbounded), or a flagged b1: the general path
-      if (flag_b0 && !ovf0 && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
+    const int lost = __shfl((int)lostreg, j);   // lane j of group 0 made the claims
+    const bool real = __shfl((int)valid, j) != 0;
+    if (lost) { act[u] = 0; why[u] = lost; }
+    if (bxc[u] != ~0u && act[u]) {   // (rare) found beyond its home buckets: that bucket's claim
+      unsigned cx = 0;
+      if (sub == 0) cx = atomicExch(a.tags + bxc[u], gen) == gen ? 1u : 0u;
+      if (__shfl((int)cx, gshift)) { act[u] = 0; why[u] = 1; }
     }
-    if (SRC != SRC_ITEMS) {
-      // agent-scope byte: read by the finishing block (list overflow) or by the next kernel
-      if (sub == 0) __hip_atomic_store(a.dflag + gk[u], (uint8_t)(why[u] ? 4 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (sub == 0) {
-      state[gi[u] - state_base] = (unsigned char)why[u];
-      if (!why[u]) __hip_atomic_store(a.dflag + gk[u], (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (!real) { act[u] = 0; why[u] = 0; }
+    if (act[u] && flag_b0[u] && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
+    if (sub == 0 && why[u]) a.dflag[gk[u]] = 4;
     fresh += (act[u] == 2 && sub == 0);
   }
-  if (SRC != SRC_ITEMS) {   // left-over keys of the wave -> the list: one atomic add for all of them
+  {   // left-over keys of the wave -> the list: one atomic add for all of them
     u64 sm[U];
     unsigned nslow = 0;
 #pragma unroll
@@ -1314,8 +1364,8 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
           if (pos < a.item_cap) {
             uint4 w;
             if (sub == 0) w = make_uint4((unsigned)(u64)key[u], (unsigned)((u64)key[u] >> 32), last[u], gk[u]);
-            else w = make_uint4((unsigned)in_s[u], (unsigned)(in_s[u] >> 32), why[u] == 2 ? IT_WALK : 0u, 0u);
-            store_wt16(reinterpret_cast<unsigned char*>(a.items + pos) + sub * 16, w);
+            else w = make_uint4((unsigned)in_s[u], (unsigned)(in_s[u] >> 32), 0u, 0u);
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.items + pos) + sub * 16) = w;
           }
         }
         at += (unsigned)__popcll(sm[u]);
@@ -1356,91 +1406,18 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
               __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % a.ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      // owned bucket: no CAS; write-through, a later round of this kernel may read the line from another XCD
-      if (sub == 0) store_wt8(key_word(v, word[u]), (u64)key[u]);
+      if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
     }
     if (!fl.with_scores) continue;
-    if (fl.lru) { if (sub == 0) store_wt8(score_word(v, word[u]), now); }
+    if (fl.lru) { if (sub == 0) *score_word(v, word[u]) = now; }
     else if (act[u] == 3 && a.sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) store_wt8(score_word(v, word[u]), in_s[u]); }   // the slot starts a new life
     else update_score<true>(v, (i64)((word[u] >> 4) * SLOTS + (word[u] & 15)), act[u] >= 2, a.sp.strategy, in_s[u], a.sp.epoch, sub);
   }
 }
 
-// Rounds 2.. by ONE workgroup (see the head of this section).  Items are taken in chunks of FIN_CHUNK (their state lives
-// in LDS): up to two more ownership rounds with the generations gen0+1, gen0+2 — all of a round's writes are acknowledged
-// and the workgroup has met before the next round reads — then the locked protocol for what is left.  If the list
-// overflowed, the flags of ALL keys are scanned afterwards (locked protocol; slow, and only on a table too small for
-// this path: the host sends those to upsert_rest_kernel).
-constexpr unsigned FIN_CHUNK = 1024;
 template <int G, bool SIMPLE, int SRC>
-__device__ __forceinline__ void own_finish(const OwnArgs& a, const OwnFlags fl, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned gen0, unsigned total,
-                                           unsigned char* s_state, unsigned* s_flag) {
-  const u64* const scores = SIMPLE ? nullptr : a.scores;
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const unsigned counted = __hip_atomic_load(&ctr->n_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned n_items = min(counted, a.item_cap);
-  int fresh = 0, failed = 0;
-  for (unsigned cb = 0; cb < n_items; cb += FIN_CHUNK) {
-    const unsigned m = min(FIN_CHUNK, n_items - cb);
-    for (unsigned i = threadIdx.x; i < m; i += blockDim.x)
-      s_state[i] = (load_u64_agent(&a.items[cb + i].flags) & IT_WALK) ? 2 : 1;
-    __syncthreads();
-    for (unsigned round = 1; round <= 2; ++round) {
-      if (threadIdx.x == 0) *s_flag = 0;
-      __syncthreads();
-      bool any = false;
-      for (unsigned base = wave * 16; base < m; base += nwaves * 16) {
-        const unsigned i = base + (unsigned)(lane & 15);
-        const bool valid = i < m && s_state[min(i, m - 1)] == 1;
-        if (!__ballot(valid)) continue;
-        any = true;
-        own_batch16<G, SIMPLE, SRC_ITEMS>(a, fl, cb + min(i, m - 1), valid, gen0 + round, nullptr, s_state, cb, lane, fresh);
-      }
-      if (any) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this round's stores are in memory before the next round reads
-      __syncthreads();
-      for (unsigned i = threadIdx.x; i < m; i += blockDim.x) if (s_state[i] == 1) *s_flag = 1;
-      __syncthreads();
-      const unsigned pending = *s_flag;
-      __syncthreads();
-      if (!pending) break;
-    }
-    // what is left: lost twice more, or has to walk — the locked protocol, one key per group
-    for (unsigned i = threadIdx.x >> 4; i < m; i += blockDim.x >> 4) {
-      if (!s_state[i]) continue;
-      const OwnItem* it = a.items + cb + i;
-      const i64 key = (i64)load_u64_agent(&it->key);
-      const u64 lg = load_u64_agent(&it->last);
-      const u64 ins = load_u64_agent(&it->ins);
-      locked_upsert_kv<G>(a.v, a.vals, key, (unsigned)lg, ins, a.ai, a.sp, sub, gshift, fresh, failed);
-      if (sub == 0) __hip_atomic_store(a.dflag + (unsigned)(lg >> 32), (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-  }
-  if (counted > a.item_cap) {   // the list is incomplete: every key still flagged
-    for (unsigned g = threadIdx.x >> 4; g < total; g += blockDim.x >> 4) {
-      if (__hip_atomic_load(a.dflag + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 4) continue;
-      if (SRC == SRC_PLAN) locked_upsert_one<G>(a.v, a.vals, scores, a.ks, a.ai, a.sp, g, sub, gshift, fresh, failed);
-      else locked_upsert_kv<G>(a.v, a.vals, a.keys[g], g, scores ? scores[g] : 1, a.ai, a.sp, sub, gshift, fresh, failed);
-    }
-  }
-  if (threadIdx.x < 4) reinterpret_cast<unsigned*>(next_ctr)[threadIdx.x] = 0;   // arm the next use's counters
-  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
-  if (lane == 0) {
-    if (fresh) size_add(a.v, wave, fresh);
-    if (failed) atomicAdd(a.v.err_count, (unsigned)failed);
-  }
-}
-
-// (Tried and removed in round 2: taking the left-over keys in a second ownership round inside this kernel with a
-// co-resident persistent grid whose blocks WAIT for round 1 to finish — 82 vs 48 us at 10^9 slots: fewer, longer-lived
-// blocks hide less latency than the hardware's own block scheduling.  The ticket below waits for nobody.)
-// finish: 0 = a later kernel takes the left-over keys, 1 = the block that draws the last ticket does.
-template <int G, bool SIMPLE, int SRC, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned own_gen, int finish,
-                                                        unsigned* progress, unsigned progress_val) {
-  __shared__ unsigned char s_state[FIN_CHUNK];
-  __shared__ unsigned s_flag;
+__global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, unsigned own_gen, unsigned* progress,
+                                                         unsigned progress_val) {
   const int lane = threadIdx.x & 63;
   const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1453,29 +1430,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void up
   const OwnFlags fl = own_setup<SIMPLE>(a);
   for (unsigned wbase = wave * 16; wbase < total; wbase += nwaves * 16) {
     const unsigned i = wbase + (unsigned)(lane & 15);
-    own_batch16<G, SIMPLE, SRC>(a, fl, min(i, total - 1), i < total, own_gen, &ctr->n_a, nullptr, 0, lane, fresh);
+    own_batch16<G, SIMPLE, SRC>(a, fl, min(i, total - 1), i < total, own_gen, &ctr->n_a, lane, fresh);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(a.v, wave, fresh);
-  if (!finish) return;
-  // ticket: every store of this block has been acknowledged by memory (they are write-through) before it is drawn
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&ctr->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (s_flag != gridDim.x - 1) return;
-  __syncthreads();   // (s_flag is reused by own_finish)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  own_finish<G, SIMPLE, SRC>(a, fl, ctr, next_ctr, own_gen, total, s_state, &s_flag);
-}
-
-// the rounds 2.. as a kernel of their own: one workgroup
-template <int G, bool SIMPLE, int SRC, int NT>
-__global__ __launch_bounds__(NT) void upsert_finish_kernel(const OwnArgs a, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned own_gen) {
-  __shared__ unsigned char s_state[FIN_CHUNK];
-  __shared__ unsigned s_flag;
-  const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
-  own_finish<G, SIMPLE, SRC>(a, own_setup<SIMPLE>(a), ctr, next_ctr, own_gen, total, s_state, &s_flag);
 }
 
 }  // namespace
@@ -1501,6 +1459,7 @@ struct tfra_sparse_plan {
   unsigned* binmap = nullptr;
   unsigned* d_counts = nullptr;
   uint8_t* dflag = nullptr;
+  size_t dflag_len = 0;
   OwnItem* slow_items = nullptr;   // [SLOW_CAP] left-over keys of the ownership pass of a write-back (self-contained items)
   unsigned* any_deferred = nullptr;   // = use_gen of the last write-back that deferred a key to its eviction phase
   mutable unsigned use_gen = 0;
@@ -1576,6 +1535,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
     if (e != hipSuccess) { pl->buf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
     pl->bytes = bytes;
     pl->armed = false;
+    pl->dflag = nullptr;
   }
   unsigned char* w = (unsigned char*)pl->buf;
   pl->cursors = (unsigned*)w; w += head;
@@ -1601,6 +1561,10 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   pl->keymap = (unsigned*)w; w += al(npad * 4);
   pl->dkeys = (i64*)w; w += al(npad * 8);
   pl->binmap = (unsigned*)w; w += al(nbin * 4);
+  if (pl->dflag != (uint8_t*)w || pl->dflag_len != npad) {   // the left-over flags are all zero between launches (upsert_own_kernel)
+    if (hipMemsetAsync(w, 0, al(npad), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+    pl->dflag_len = npad;
+  }
   pl->dflag = (uint8_t*)w; w += al(npad);
   pl->slow_items = (OwnItem*)w; w += al((size_t)SLOW_CAP * sizeof(OwnItem));
   pl->any_deferred = pl->d_counts + 8;
@@ -1714,74 +1678,29 @@ extern "C" int tfra_table_apply_planned(tfra_table_t* tp, const tfra_opt_params*
 }
 
 // ---- launch of the ownership write-back (plan keys or a caller's unique keys) --------------------------------
-// How the left-over keys are taken (TFRA_OWN_FINISH, read once): "inside" (default) the last block of upsert_own_kernel,
-// "kernel" a one-block kernel behind it; a table on which many are expected always gets the full-grid locked pass.
-enum { FIN_REST = 0, FIN_KERNEL = 1, FIN_INSIDE = 2 };
-static int own_finish_pref() {
-  static const int pref = [] {
-    const char* e = getenv("TFRA_OWN_FINISH");
-    if (e && !strcmp(e, "kernel")) return (int)FIN_KERNEL;
-    if (e && !strcmp(e, "rest")) return (int)FIN_REST;
-    return (int)FIN_INSIDE;
-  }();
-  return pref;
-}
-static int own_block_threads() {   // TFRA_OWN_NT: threads per block of the 16-B-granule kernels (256 / 512 / 1024)
-  static const int nt = [] {
-    const char* e = getenv("TFRA_OWN_NT");
-    const int v = e ? atoi(e) : 512;
-    return v == 256 || v == 1024 ? v : 512;
-  }();
-  return nt;
-}
-
-template <int G, bool SIMPLE, int SRC, int NT>
-static void launch_own_nt(hipStream_t s, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og, int fin,
-                          unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
-  constexpr unsigned KPB = NT / 64 * 16;   // keys per block and pass
-  const unsigned blocks = (unsigned)std::max<size_t>(1, (nkeys + KPB - 1) / KPB);
-  upsert_own_kernel<G, SIMPLE, SRC, NT><<<blocks, NT, 0, s>>>(a, ctr, next_ctr, og, fin == FIN_INSIDE ? 1 : 0, progress, progress_val);
-  if (fin == FIN_KERNEL) upsert_finish_kernel<G, SIMPLE, SRC, (G == 16 ? 1024 : 256)><<<1, (G == 16 ? 1024 : 256), 0, s>>>(a, ctr, next_ctr, og);
-}
-
-template <int G, bool SIMPLE, int SRC>
-static void launch_own_g(hipStream_t s, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og, int fin,
-                         unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
-  if (G == 16) {
-    switch (own_block_threads()) {
-      case 256: launch_own_nt<G, SIMPLE, SRC, 256>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
-      case 1024: launch_own_nt<G, SIMPLE, SRC, (G == 16 ? 1024 : 256)>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
-      default: launch_own_nt<G, SIMPLE, SRC, (G == 16 ? 512 : 256)>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
-    }
-  } else {
-    launch_own_nt<G, SIMPLE, SRC, 256>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val);
-  }
-}
-
-// granule g of the value rows; `simple`: rows without slots, LRU, no caller scores
 template <int SRC>
 static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og,
-                       int fin, unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
+                       unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
+  const unsigned blocks = (unsigned)std::max<size_t>(1, (nkeys + 63) / 64);   // 4 waves x 16 keys per block and pass
+#define TFRA_OWN(GG, SS)                                                                                   \
+  upsert_own_kernel<GG, SS, SRC><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val);               \
+  upsert_rest_kernel<GG, SRC><<<rest_blocks, 256, 0, s>>>(a, &ctr->n_a, reinterpret_cast<unsigned*>(next_ctr))
   switch (g) {
-    case 16:
-      if (simple) launch_own_g<16, true, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val);
-      else launch_own_g<16, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val);
-      break;
-    case 8: launch_own_g<8, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
-    case 4: launch_own_g<4, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
-    case 2: launch_own_g<2, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
-    default: launch_own_g<1, false, SRC>(s, a, nkeys, ctr, next_ctr, og, fin, rest_blocks, progress, progress_val); break;
+    case 16: if (simple) { TFRA_OWN(16, true); } else { TFRA_OWN(16, false); } break;
+    case 8: TFRA_OWN(8, false); break;
+    case 4: TFRA_OWN(4, false); break;
+    case 2: TFRA_OWN(2, false); break;
+    default: TFRA_OWN(1, false); break;
   }
+#undef TFRA_OWN
 }
 
 // Expected left-over keys of an ownership pass over `nkeys` keys: two keys sharing a home bucket, (2 n)^2 / (2 nb).
 static double expect_leftover(double nkeys, double nb) { return 2.0 * nkeys * nkeys / nb; }
-constexpr double FINISH_MAX_EXPECTED = 512.0;   // more than that: a full grid of the locked protocol, not one workgroup
 
-static unsigned next_own_gen(Table* t) {   // a launch uses og (round 1), og+1, og+2 (rounds of the finishing workgroup)
-  t->own_gen += 4;
-  if (t->own_gen < 4) t->own_gen = 4;      // wrapped (tags start at 0; a stale equal tag only sends a key to the next round)
-  return t->own_gen;
+static unsigned next_own_gen(Table* t) {
+  if (++t->own_gen == 0) t->own_gen = 1;     // bucket-owner tag of this launch (tags start at 0; a stale equal tag after a wrap only
+  return t->own_gen;                         // sends a key to the remainder pass)
 }
 
 static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, const void* values, const uint64_t* scores,
@@ -1816,29 +1735,15 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
     const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
     OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
     OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
-    // Left-over keys of the ownership pass.  Few (a big table): one workgroup runs two more ownership rounds over their
-    // list.  Many (a small table): a full grid of the locked protocol.
+    // Left-over keys of the ownership pass.  Few (a big table): the remainder kernel walks their list with a handful of
+    // blocks.  Many (a small table): full grid.
     const double nkeys = (double)key_blocks * 16.0;   // unique keys of the plan when its counts have arrived, else the id count
-    const double expect_slow = expect_leftover(nkeys, (double)t->cur.nb);
-    const int fin = expect_slow < FINISH_MAX_EXPECTED ? own_finish_pref() : FIN_REST;
-    const unsigned rem_blocks = expect_slow < 2048.0 ? 32u : key_blocks;
+    const unsigned rem_blocks = expect_leftover(nkeys, (double)t->cur.nb) < 2048.0 ? 32u : key_blocks;
     const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !sc;
     OwnArgs a{};
     a.v = v; a.vals = vals; a.scores = sc; a.ks = keys_of(pl); a.keys = nullptr; a.nkeys = 0; a.ai = t->aux; a.sp = sp;
     a.dflag = pl->dflag; a.tags = tags; a.items = pl->slow_items; a.item_cap = SLOW_CAP;
-    launch_own<SRC_PLAN>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, fin, rem_blocks, progress, progress_val);
-    if (fin == FIN_REST) {
-#define TFRA_REST(GG) upsert_rest_kernel<GG><<<rem_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, &ctr->n_a, \
-                                                                       pl->slow_items, reinterpret_cast<unsigned*>(next_ctr))
-      switch (g) {
-        case 16: TFRA_REST(16); break;
-        case 8: TFRA_REST(8); break;
-        case 4: TFRA_REST(4); break;
-        case 2: TFRA_REST(2); break;
-        default: TFRA_REST(1); break;
-      }
-#undef TFRA_REST
-    }
+    launch_own<SRC_PLAN>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, rem_blocks, progress, progress_val);
   } else {
 #define TFRA_UPS(GG)                                                                                                          \
     upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,   \
@@ -1869,7 +1774,8 @@ namespace tfra {
 int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken) {
   *taken = false;
   if (n == 0 || n > (1u << 24)) return TFRA_OK;
-  if (expect_leftover((double)n, (double)t->cur.nb) >= FINISH_MAX_EXPECTED) return TFRA_OK;
+  const double expect = expect_leftover((double)n, (double)t->cur.nb);
+  if (expect >= 2048.0) return TFRA_OK;   // most keys would collide on a home bucket (a bulk load): the locked kernels
   // the table's own scratch of this path: 2 counter sets | item list | one flag byte per key
   const size_t head = 256 + (size_t)SLOW_CAP * sizeof(OwnItem);
   const size_t need = head + ((n + 255) / 256) * 256;
@@ -1881,7 +1787,7 @@ int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const 
     const size_t want = head + std::max<size_t>(((n + 255) / 256) * 256, (size_t)1 << 18);
     t->own_ws = t->dalloc(want, s);
     if (!t->own_ws) { g_last_error.clear(); return TFRA_OK; }   // no scratch: the locked kernels need none
-    if (hipMemsetAsync(t->own_ws, 0, 256, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: memset");
+    if (hipMemsetAsync(t->own_ws, 0, want, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: memset");   // counters and flags start at zero
     t->own_ws_bytes = want;
     t->own_ws_uses = 0;
   }
@@ -1897,13 +1803,11 @@ int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const 
   OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(t->own_ws) + par;
   OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(t->own_ws) + (par ^ 1u);
   const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !scores;
-  int fin = own_finish_pref();
-  if (fin == FIN_REST) fin = FIN_KERNEL;   // (the full-grid locked pass reads plan records)
   OwnArgs a{};
   a.v = t->view_of(t->cur); a.vals = (const unsigned char*)values; a.scores = scores; a.keys = keys; a.nkeys = (unsigned)n;
   a.ai = t->aux; a.sp = sp; a.dflag = (uint8_t*)t->own_ws + head; a.tags = tags;
   a.items = reinterpret_cast<OwnItem*>((unsigned char*)t->own_ws + 256); a.item_cap = SLOW_CAP;
-  launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, fin, 0, nullptr, 0);
+  launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, 32u, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: launch failed");
   *taken = true;
   return TFRA_OK;
