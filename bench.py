@@ -1,28 +1,39 @@
 """bench.py — dynamic-embedding hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|m1b] [--slots S] [--keys N_KEYS] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config m1b|c3|c2|c4|c5] [--slots S] [--keys N_KEYS] [--batch B]
 
 One "step" = one pass of the hot path over one batch of synthetic ids.  Configurations (BASELINE.json `configs`):
 
-  c3  (default at N=1: the largest single-GPU configuration, configs[2])
-      bounded (Hkv, LRU) table with 10^9 slots, dim=128 fp16 rows (256 B, the same row bytes as the metric's dim=64
-      fp32), pre-filled to capacity; every batch of B=131072 ids is 50 % Zipf-1.2 over the resident ranks and 50 %
-      never-seen ranks (monotone counter), so the timed region carries inserts AND score-based eviction:
+  m1b (default at N=1: the configuration BASELINE.json's `metric` is quoted on) dim=64 fp32, a 10^9-slot bounded (Hkv, LRU)
+      table pre-filled to capacity, batch B=131072 of Zipf-1.2 ids over the 10^9 ranks:
           lookup(B ids, misses get the default row)  ->  insert_or_assign(B ids, B rows; repeats: last one wins)
       If 10^9 slots do not allocate, the largest slot count that does is used and named in config.workload.
+  c3  configs[2]: the same table shape with dim=128 fp16 rows (256 B, the same row bytes) and 50 % never-seen ids per
+      batch (monotone counter): the timed region carries inserts AND score-based eviction.
   c2  configs[1]: growing table, 100 M resident keys, dim=64 fp32 rows [p|m|v], Zipf-1.2 batch, `--new-key-ratio`
       (default 0.1) of every batch are never-seen keys:
-          lookup(B) -> gradients [B,64] -> duplicate ids summed -> fused sparse Adam on the unique keys (= the
-          write-back/insert of the batch's keys)
-      Run as a secondary measurement of the default invocation (key "secondary") and as the per-GPU workload of N>1.
-  m1b the metric's own wording on one GPU: dim=64 fp32, 10^9 slots, Zipf-1.2 ids: lookup(B) -> insert_or_assign(B).
+          lookup(B) -> gradients [B,64] -> duplicate ids summed -> fused sparse Adam on the unique keys
+  c4  configs[3], the per-GPU workload of EVERY `--gpus N` run with N > 1 (and of `--config c4 --gpus 1`): N shards of
+      5*10^8 keys each, hash-sharded by the reference's default partitioner, dim=64 fp32, per-GPU batch B drawn from the
+      GLOBAL Zipf-1.2 over the N*5*10^8 keys, ids / rows / gradients routed by tfra_route_* (RCCL alltoall over xGMI; at
+      N=1 the same driver without a transport):  routed lookup(B) -> routed fused SGD write-back of the batch's keys.
+  c5  configs[4] on one GPU (26 tables, fused FTRL), not part of the default invocation.
+  The default invocation at N=1 prints m1b as the top-level line and c3 / c2 / c4 under "secondary".
 
 `value` = ids looked up AND written back per second (lookup+insert pairs/s), whole job, with the step driven by ONE
 C call per step that also builds the de-duplication plan of batch i+1 on a second HIP stream (the ids of a batch are
-known one batch ahead, as an input pipeline provides them); `value_plain_call` = the same step as the reference's op
-sequence issues it (Find op, then Insert / optimizer op; no look-ahead).  Inputs (id batches, values, gradients) are
-resident in HBM before the timed region.  N>1: one process per GPU, tables sharded by key hash, ids/rows/grads
-routed with alltoall over RCCL (weak scaling: per-GPU keys and batch fixed).  Prints ONE JSON line on rank 0.
+known one batch ahead, as an input pipeline provides them).  Next to it, without any look-ahead:
+  `value_plain_call`  tfra_table_find + tfra_table_upsert_sparse — the second call is a fused extra that de-duplicates
+                      on the device inside the call (NOT an op of the reference's surface);
+  `value_op_surface`  exactly what the TF shim (tf_ops/mi355x_table_ops.h) issues per step: tfra_table_find (B ids) ->
+                      tfra_unique + ONE host read of the count (tf.unique's output shape) ->
+                      tfra_table_insert_or_assign(unique keys, TFRA_FLAG_UNIQUE_KEYS);
+  `value_op_surface_table_ops_only` the same two table ops with the unique keys prepared beforehand.
+Timing: after W warm-up steps, R = 5 back-to-back windows of exactly K steps each, every window bracketed by
+barrier + torch.cuda.synchronize() (max over ranks); `value` / `ms_per_step` are the MEDIAN window, min / max are in
+config.timing.  Inputs (id batches, values, gradients) are generated on the device and resident in HBM before the timed
+region; an untimed verification pass checks the table against the values written (config.verified).
+N>1: one process per GPU.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -110,96 +121,176 @@ def mixed_batches(rng, nbatch, batch, n_resident, new_ratio, fresh_start):
   return ranks, fresh_start + nbatch * n_new
 
 
+def zipf_bounded_torch(torch, gen, size, n, dev, s=ZIPF_S):
+  """zipf_bounded on the device (float64, the same rejection-inversion): a timed region of R x K steps needs hundreds of
+  batches, one numpy draw of that many samples would take longer than the benchmark."""
+  one_s = 1.0 - s
+  h_int = lambda x: (torch.pow(x, one_s) - 1.0) / one_s
+  h_int_inv = lambda y: torch.pow(1.0 + y * one_s, 1.0 / one_s)
+  h = lambda x: torch.pow(x, -s)
+  f64 = lambda v: torch.tensor(v, dtype=torch.float64, device=dev)
+  hx1 = h_int(f64(1.5)) - 1.0
+  hn = h_int(f64(n + 0.5))
+  sc = 2.0 - h_int_inv(h_int(f64(2.5)) - h(f64(2.0)))
+  out = torch.empty(size, dtype=torch.int64, device=dev)
+  todo = torch.arange(size, device=dev)
+  while todo.numel():
+    u = hn + torch.rand(todo.numel(), generator=gen, device=dev, dtype=torch.float64) * (hx1 - hn)
+    x = h_int_inv(u)
+    k = torch.clamp(torch.floor(x + 0.5), 1, n)
+    ok = (k - x <= sc) | (u >= h_int(k + 0.5) - h(k))
+    out[todo[ok]] = k[ok].to(torch.int64)
+    todo = todo[~ok]
+  return out
+
+
+class IdFactory:
+  """Batches of ids on the device: Zipf-1.2 over the ranks 1..n_resident, `new_ratio` of the positions (evenly interleaved)
+  replaced by never-seen ranks from a monotone counter; rank -> key by the bijective scramble."""
+
+  def __init__(self, torch, dev, batch, n_resident, new_ratio, fresh_start, seed):
+    self.torch, self.dev, self.B, self.n, self.ratio = torch, dev, batch, n_resident, new_ratio
+    self.fresh = fresh_start
+    self.gen = torch.Generator(device=dev).manual_seed(seed)
+    self.n_new = int(round(batch * new_ratio))
+    self.pos = (torch.arange(self.n_new, device=dev, dtype=torch.float64) * (batch / max(1, self.n_new))).to(torch.int64)
+
+  def ranks(self, nbatch):
+    t = self.torch
+    out = []
+    for lo in range(0, nbatch, 64):   # bounded scratch: 64 batches per draw
+      m = min(64, nbatch - lo)
+      r = zipf_bounded_torch(t, self.gen, m * self.B, self.n, self.dev).reshape(m, self.B)
+      if self.n_new:
+        fresh = self.fresh + t.arange(m * self.n_new, device=self.dev, dtype=t.int64).reshape(m, self.n_new)
+        r[:, self.pos] = fresh
+        self.fresh += m * self.n_new
+      out.append(r)
+    return t.cat(out) if len(out) > 1 else out[0]
+
+  def keys(self, nbatch):
+    return keys_of_ranks_torch(self.torch, self.ranks(nbatch))
+
+
 # ------------------------------------------------------------------ CPU baseline (reference engine)
-def cpu_baseline(batch, budget_s=20.0):
-  """The reference's CPU table — lib/cuckoo/cuckoohash_map.hh compiled in place (oracle/_ref) behind a restatement of
-  TableWrapperOptimized + the LaunchTensors* launchers (K/cuckoo_hashtable_op.cc:39-182: static split of the keys over
-  a persistent intra-op pool) — timed on this box's host cores: per op (find / insert_or_assign / insert_or_accum),
-  for the full lookup + write-back step, with the table pre-sized (init_size = N) and at the reference default
-  (init_size = 8192, growth included), over a sweep of pool sizes.  dim 64 fp32 rows (256 B; the reference engine's
-  half type needs Eigen, absent here).  A bounded sample: N = 4 M keys, ~20 s of CPU work in total."""
+def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg):
+  """Child process (no torch): builds the reference's CPU table with n_keys resident keys and times the ops on it.  Every rate
+  is the MEDIAN of 3 repeats of a fixed number of batches; the pool size is fixed."""
   import oracle
-  kind = "reference" if oracle.available("reference") else "port"
-  cores = os.cpu_count() or 1
-  sweep = sorted(set(t for t in (8, 32, 64, cores) if t <= cores)) if kind == "reference" else [1]
-  dim, n_keys = 64, 4_000_000
+  dim = 64
   rng = np.random.default_rng(SEED)
   batches = [keys_of_ranks(zipf_bounded(rng, batch, n_keys)) for _ in range(8)]
   uniq = [np.unique(b) for b in batches]
+  umean = float(np.mean([u.size for u in uniq]))
   vals = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
   zero = np.zeros(dim, np.float32)
-  t_begin = time.perf_counter()
 
-  def fill(init_size, threads):
+  def fill(init_size):
+    t0 = time.perf_counter()
     t = oracle.CpuTable(dim, np.float32, kind=kind, init_size=init_size, threads=threads)
+    t_create = time.perf_counter() - t0
     t0 = time.perf_counter()
     for lo in range(1, n_keys + 1, 500_000):
       k = keys_of_ranks(np.arange(lo, min(n_keys, lo + 499_999) + 1, dtype=np.int64))
       t.insert(k, np.broadcast_to(vals[:1], (k.size, dim)))
-    return t, time.perf_counter() - t0
+    return t, t_create, time.perf_counter() - t0
 
-  def rate(fn, units, min_s=0.4):
+  def rate(fn, units, iters=16, repeats=3):
     fn(0)
-    n, t0 = 0, time.perf_counter()
-    while True:
-      fn(n + 1)
-      n += 1
-      dt = time.perf_counter() - t0
-      if dt >= min_s or n >= 64:
-        return units * n / dt
+    out = []
+    for r in range(repeats):
+      t0 = time.perf_counter()
+      for i in range(iters):
+        fn(i)
+      out.append(units * iters / (time.perf_counter() - t0))
+    return sorted(out)[len(out) // 2]
 
-  per_threads = {}
-  best = None
-  for th in sweep:
-    if time.perf_counter() - t_begin > budget_s * 0.7:
-      break
-    tab, fill_s = fill(n_keys, th)
-    ops = {
-        "find_ops_per_s": rate(lambda i: tab.find(batches[i % 8], zero), batch),
-        # what embedding_lookup issues: unique first (PY/dynamic_embedding_ops.py:99), Find on the distinct ids
-        "find_unique_ids_ops_per_s": rate(lambda i: tab.find(uniq[i % 8], zero), float(np.mean([u.size for u in uniq]))),
-        "insert_or_assign_ops_per_s": rate(lambda i: tab.insert(uniq[i % 8], vals[:uniq[i % 8].size]), float(np.mean([u.size for u in uniq]))),
-        "insert_or_accum_ops_per_s": rate(lambda i: tab.accum(uniq[i % 8], vals[:uniq[i % 8].size], np.ones(uniq[i % 8].size, bool)),
-                                          float(np.mean([u.size for u in uniq]))),
-        # the step as the reference issues it: unique (not timed here, see dedup_ids_per_s), Find(distinct ids),
-        # Insert(distinct ids, their rows); counted in batch ids (pairs) per second
-        "step_pairs_per_s": rate(lambda i: (tab.find(uniq[i % 8], zero), tab.insert(uniq[i % 8], vals[:uniq[i % 8].size])), batch),
-        "prefill_keys_per_s_init_size_N": n_keys / fill_s,
-    }
-    per_threads[th] = {k: round(v) for k, v in ops.items()}
-    if best is None or ops["step_pairs_per_s"] > best[1]["step_pairs_per_s"]:
-      best = (th, ops)
-    del tab
-  th, ops = best
-  t0 = time.perf_counter()
-  for b in batches:
-    np.unique(b, return_inverse=True)
-  dedup_rate = len(batches) * batch / (time.perf_counter() - t0)
-  # growth included: the reference default init_size = 8192 (K/cuckoo_hashtable_op.cc:199-207), same fill
+  tab, create_s, fill_s = fill(n_keys)
+  ops = {
+      "find_ops_per_s": rate(lambda i: tab.find(batches[i % 8], zero), batch),
+      # what embedding_lookup issues: unique first (PY/dynamic_embedding_ops.py:99), Find on the distinct ids
+      "find_unique_ids_ops_per_s": rate(lambda i: tab.find(uniq[i % 8], zero), umean),
+      "insert_or_assign_ops_per_s": rate(lambda i: tab.insert(uniq[i % 8], vals[:uniq[i % 8].size]), umean),
+      "insert_or_accum_ops_per_s": rate(lambda i: tab.accum(uniq[i % 8], vals[:uniq[i % 8].size], np.ones(uniq[i % 8].size, bool)), umean),
+      # the step as the reference issues it: unique (timed apart, see dedup), Find(distinct ids), Insert(distinct ids, their rows);
+      # counted in batch ids (pairs) per second
+      "step_pairs_per_s": rate(lambda i: (tab.find(uniq[i % 8], zero), tab.insert(uniq[i % 8], vals[:uniq[i % 8].size])), batch),
+      "prefill_keys_per_s_init_size_N": n_keys / fill_s,
+  }
+  del tab
+  ded = []
+  for r in range(3):
+    t0 = time.perf_counter()
+    for b in batches:
+      np.unique(b, return_inverse=True)
+    ded.append(len(batches) * batch / (time.perf_counter() - t0))
   grow_rate = None
-  if time.perf_counter() - t_begin < budget_s:
-    tab, fill_s = fill(8192, th)
+  if growth_leg:   # growth included: the reference default init_size = 8192 (K/cuckoo_hashtable_op.cc:199-207), same fill
+    tab, _, fill_s = fill(8192)
     grow_rate = n_keys / fill_s
     del tab
-  if kind == "reference":
-    try:
-      oracle._load("reference")  # pools are process-wide; nothing else to release
-    except Exception:
-      pass
+  conn.send({"ops": ops, "dedup_rate": sorted(ded)[1], "grow_rate": grow_rate, "create_s": create_s, "unique_per_batch": umean})
+  conn.close()
+
+
+def cpu_baseline(batch):
+  """The reference's CPU table — lib/cuckoo/cuckoohash_map.hh compiled in place (oracle/_ref) behind a restatement of
+  TableWrapperOptimized + the LaunchTensors* launchers (K/cuckoo_hashtable_op.cc:39-182: static split of the keys over
+  a persistent intra-op pool) — timed on this box's host cores: per op (find / insert_or_assign / insert_or_accum) and
+  for the full lookup + write-back step, table pre-sized (init_size = N) and at the reference default (init_size = 8192,
+  growth included).  dim 64 fp32 rows (256 B).  N = the largest rung of (64 M, 16 M, 4 M) resident keys whose table this
+  box builds within the time box (SURVEY §8d asks for the largest N the RAM holds; the constructor of a pre-sized libcuckoo
+  table touches every bucket on one thread, so the time box, not the RAM, is what binds); each rung runs in a child process
+  that is killed when it overruns.  Fixed pool size, every rate the median of 3 repeats."""
+  import multiprocessing as mp
+  import oracle
+  kind = "reference" if oracle.available("reference") else "port"
+  cores = os.cpu_count() or 1
+  threads = min(cores, 128) if kind == "reference" else 1
+  try:
+    ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+  except (ValueError, OSError):
+    ram = 0
+  rungs = [n for n in (64_000_000, 16_000_000, 4_000_000) if n == 4_000_000 or (ram > 3 * n * 330 and cores >= (32 if n > 16_000_000 else 8))]
+  t_begin = time.perf_counter()
+  got, tried = None, []
+  ctx = mp.get_context("spawn")
+  for n_keys in rungs:
+    last = n_keys == rungs[-1]
+    parent, child = ctx.Pipe(duplex=False)
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, n_keys, threads, kind, last or n_keys <= 16_000_000))
+    pr.start()
+    child.close()
+    box = 90.0 if last else 30.0
+    if parent.poll(box):
+      try:
+        got = parent.recv()
+      except EOFError:
+        got = None
+    pr.join(timeout=1.0)
+    if pr.is_alive():
+      pr.kill()   # the exact process started above
+      pr.join()
+    tried.append({"keys": n_keys, "finished": got is not None, "seconds": round(time.perf_counter() - t_begin, 1)})
+    if got is not None:
+      break
+  if got is None:
+    return {"value": None, "unit": "lookup+insert pairs/s", "cores": threads, "kind": kind, "sample": "no rung finished: %s" % tried}
+  ops, dedup_rate = got["ops"], got["dedup_rate"]
   # the whole CPU step = de-duplicate the batch (tf.unique in the reference, single-threaded; numpy's stands in) +
   # Find + Insert on the distinct ids
   step_incl_dedup = 1.0 / (1.0 / dedup_rate + 1.0 / ops["step_pairs_per_s"])
   return {
-      "value": step_incl_dedup, "unit": "lookup+insert pairs/s", "cores": th, "kind": kind,
+      "value": step_incl_dedup, "unit": "lookup+insert pairs/s", "cores": threads, "kind": kind,
       "table_ops_only_pairs_per_s": round(ops["step_pairs_per_s"]),
       "dedup_ids_per_s_numpy_unique_1_core": round(dedup_rate),
-      "sample": "per batch of %d Zipf-1.2 ids: unique + Find(distinct ids) + Insert(distinct ids) on a %d-key table, dim 64 fp32, init_size = N; "
-                "best of pool sizes %s (host has %d cores); %.0f s of CPU work" % (batch, n_keys, list(per_threads), cores,
-                                                                                  time.perf_counter() - t_begin),
+      "resident_keys": n_keys, "host_cores": cores, "host_ram_bytes": ram, "rungs_tried": tried,
+      "sample": "per batch of %d Zipf-1.2 ids: unique + Find(distinct ids) + Insert(distinct ids) on a %d-key table (dim 64 fp32, "
+                "init_size = N, created in %.1f s), %d-thread pool (host has %d cores), median of 3 x 16 batches; %.0f s of CPU work"
+                % (batch, n_keys, got["create_s"], threads, cores, time.perf_counter() - t_begin),
       "per_op": {k: round(v) for k, v in ops.items()},
-      "per_op_per_core": {k: round(v / th) for k, v in ops.items()},
-      "prefill_keys_per_s_init_size_8192_growth_included": round(grow_rate) if grow_rate else None,
-      "by_pool_size": per_threads,
+      "per_op_per_core": {k: round(v / threads) for k, v in ops.items()},
+      "prefill_keys_per_s_init_size_8192_growth_included": round(got["grow_rate"]) if got["grow_rate"] else None,
   }
 
 
@@ -241,25 +332,44 @@ def raw_calls(torch, dev):
   return r
 
 
-def timed_steps(torch, dist, world, dev, K, step):
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for i in range(K):
-    step(i)
-  host_s = time.perf_counter() - t0
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-  return elapsed, host_s
+WINDOWS = 5
+
+
+def timed_windows(torch, dist, world, dev, K, step, first=0, windows=WINDOWS):
+  """`windows` back-to-back windows of exactly K steps (step(first + w*K + i)), each bracketed by barrier +
+  torch.cuda.synchronize() on both sides, the max over ranks taken per window.  Returns (per-window seconds, host seconds of
+  the median window's enqueue loop).  The first window's first steps still run into cold caches / an idle clock: the median
+  window is what the line reports, so that a driver run with --steps 20 and a builder run with --steps 200 agree."""
+  secs, hosts = [], []
+  for w in range(windows):
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+      step(first + w * K + i)
+    host_s = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+      t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      elapsed = float(t.item())
+    secs.append(elapsed)
+    hosts.append(host_s)
+  order = sorted(range(windows), key=lambda i: secs[i])
+  med = order[windows // 2]
+  return secs, secs[med], hosts[med]
+
+
+def timing_note(secs, K):
+  return {"windows": len(secs), "steps_per_window": K, "reported": "median window",
+          "ms_per_step_min": round(min(secs) / K * 1e3, 5), "ms_per_step_max": round(max(secs) / K * 1e3, 5),
+          "ms_per_step_by_window": [round(x / K * 1e3, 5) for x in secs]}
 
 
 def profile_summary():
@@ -315,10 +425,20 @@ def measure_growth(torch, de, dev, dim, dtype, slots):
     return {"error": str(e)[:200]}
 
 
+def last_occurrence_rows(torch, ids, values):
+  """rows a lookup of `ids` must return after insert_or_assign(ids, values) with repeats: the row of each id's LAST position"""
+  uk, inv = torch.unique(ids, return_inverse=True)
+  lp = torch.zeros(uk.numel(), dtype=torch.long, device=ids.device)
+  lp.scatter_reduce_(0, inv, torch.arange(ids.numel(), device=ids.device), reduce="amax", include_self=False)
+  return values[lp][inv]
+
+
 def run_bounded(args, torch, de, dev, cfg):
-  """cfg 'c3': dim 128 fp16, 50 % never-seen ids;  'm1b': dim 64 fp32, `--new-key-ratio` (default 0) never-seen ids."""
+  """cfg 'm1b': dim 64 fp32, `--new-key-ratio` (default 0) never-seen ids;  'c3': dim 128 fp16, 50 % never-seen ids."""
+  import ctypes
   from tfra_amd import _capi
   from tfra_amd.dynamic_embedding.table_ops import _ptr, _stream
+  from tfra_amd.dynamic_embedding.device_ops import _workspace
   B, K, W = args.batch, args.steps, args.warmup
   dim, dtype = (128, torch.float16) if cfg == "c3" else (64, torch.float32)
   new_ratio = 0.5 if cfg == "c3" else (args.new_key_ratio if args.new_key_ratio is not None else 0.0)
@@ -345,72 +465,142 @@ def run_bounded(args, torch, de, dev, cfg):
   resident = int(table.size().item())
   t_fill = time.perf_counter() - t0
   del vals_fill
-  capacity = table._table.capacity()
-
-  rng = np.random.default_rng(SEED + 7)
-  nb = 2 * (K + W) + 16
-  ranks, fresh_end = mixed_batches(rng, nb, B, n_res, new_ratio, n_res + 1)
-  ids_all = torch.from_numpy(keys_of_ranks(ranks.reshape(-1)).reshape(nb, B)).to(dev)
-  uniq_ratio = float(np.mean([np.unique(ranks[i]).size / B for i in range(4)]))
+  tbl = table._table
+  capacity = tbl.capacity()
+  lib = _capi.lib()
+  st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  idf = IdFactory(torch, dev, B, n_res, new_ratio, n_res + 1, SEED + 7)
   values = (torch.randn((B, dim), generator=gen, device=dev) * 0.01).to(dtype)
+  nsteps = W + WINDOWS * K
+  verified = {}
   tm = Timer(torch)
 
   # ---- driver 1: one C call per step, plan of batch i+1 on the second stream ---------------------------
-  ps = de.PrefetchAssignStep(table).prime(ids_all[0])
+  ids = idf.keys(nsteps + 1)
+  uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
+  ps = de.PrefetchAssignStep(table).prime(ids[0])
   for i in range(W):
-    ps.step(values, ids_all[i + 1])
-  elapsed, host_s = timed_steps(torch, None, 1, dev, K, lambda i: ps.step(values, ids_all[W + i + 1]))
+    ps.step(values, ids[i + 1])
+  secs, med, host_s = timed_windows(torch, None, 1, dev, K, lambda i: ps.step(values, ids[i + 1]), first=W)
   size_after = int(table.size().item())
-  # ---- driver 2: the reference's op sequence, no look-ahead: Find, then Insert (repeats resolved on the device) ----
-  base = K + W + 2
-  tbl = table._table
+  last = ids[nsteps - 1]
+  got, ex = table.lookup(last, return_exists=True)
+  verified["look_ahead_driver_last_batch"] = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, last, values)))
+  del ps, ids, got, ex
+
+  # ---- driver 2: no look-ahead, two calls: Find, then the fused extra that de-duplicates inside the call --------------
+  ids = idf.keys(nsteps)
 
   def plain(i):
-    tbl.find(ids_all[base + i])
-    tbl.upsert_sparse(ids_all[base + i], values)
+    tbl.find(ids[i])
+    tbl.upsert_sparse(ids[i], values)
 
   for i in range(W):
     plain(i)
-  base += W
-  elapsed_plain, _ = timed_steps(torch, None, 1, dev, K, plain)
+  secs_plain, med_plain, _ = timed_windows(torch, None, 1, dev, K, plain, first=W)
+  last = ids[nsteps - 1]
+  got, ex = table.lookup(last, return_exists=True)
+  verified["plain_call_last_batch"] = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, last, values)))
+  del ids, got, ex
 
-  # ---- per-kernel timings (HIP events on the launching stream), fresh batches each launch ----------------------
-  spare = 2 * (K + W) + 2
-  rc = raw_calls(torch, dev)
+  # ---- driver 3: the reference's op surface as the TF shim issues it (tf_ops/mi355x_table_ops.h) -------------------
+  #   Find op      -> tfra_table_find(B ids)
+  #   tf.unique    -> tfra_unique + ONE host read of the count (the output shape of tf.unique is data dependent)
+  #   Insert op    -> tfra_table_insert_or_assign(unique keys, rows, TFRA_FLAG_UNIQUE_KEYS)
+  ids = idf.keys(nsteps)
   out_buf = torch.empty((B, dim), dtype=dtype, device=dev)
   dflt_row = tbl._default_value
-  # lookups of FRESH batches (half never-seen ids, like the step's), none of them written back in between
-  finds = [rc.find(tbl._h, ids_all[spare + 8 + j], out_buf, dflt_row) for j in range(6)]
-  find_us = tm.us(lambda i: finds[i % 6](), reps=24, warm=3)
+  ubuf = torch.empty(B, dtype=torch.int64, device=dev)
+  ibuf = torch.empty(B, dtype=torch.int32, device=dev)
+  cbuf = torch.zeros((), dtype=torch.int64, device=dev)
+  ws = _workspace(dev)
+  finds = [(tbl._h, B, P(ids[i]), P(out_buf), None, P(dflt_row), 0, st) for i in range(nsteps)]
+  uniqs = [(ws, B, P(ids[i]), P(ubuf), P(ibuf), P(cbuf), st) for i in range(nsteps)]
+  last_u = [0]
+
+  def op_surface(i):
+    _capi.check(lib.tfra_table_find(*finds[i]))
+    _capi.check(lib.tfra_unique(*uniqs[i]))
+    u = int(cbuf.item())
+    last_u[0] = u
+    _capi.check(lib.tfra_table_insert_or_assign(tbl._h, u, P(ubuf), P(values), None, 1, st))
+
+  for i in range(W):
+    op_surface(i)
+  secs_ops, med_ops, _ = timed_windows(torch, None, 1, dev, K, op_surface, first=W)
+  u = last_u[0]
+  got, ex = table.lookup(ubuf[:u], return_exists=True)
+  verified["op_surface_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:u]))
+  # the two table ops alone, the unique keys prepared beforehand
+  uq = [torch.unique(ids[i]) for i in range(nsteps)]
+  ins = [(tbl._h, uq[i].numel(), P(uq[i]), P(values), None, 1, st) for i in range(nsteps)]
+
+  def table_ops_only(i):
+    _capi.check(lib.tfra_table_find(*finds[i]))
+    _capi.check(lib.tfra_table_insert_or_assign(*ins[i]))
+
+  for i in range(W):
+    table_ops_only(i)
+  secs_tops, med_tops, _ = timed_windows(torch, None, 1, dev, K, table_ops_only, first=W)
+  got, ex = table.lookup(uq[nsteps - 1], return_exists=True)
+  verified["op_surface_table_ops_only_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:uq[nsteps - 1].numel()]))
+  del got, ex
+
+  # ---- per-kernel timings (HIP events on the launching stream), fresh batches each launch ----------------------
+  rc = raw_calls(torch, dev)
+  kids = idf.keys(30)
+  fk = [rc.find(tbl._h, kids[j], out_buf, dflt_row) for j in range(6)]
+  find_us = tm.us(lambda i: fk[i % 6](), reps=24, warm=3)
   plans = [de.table_ops.SparsePlan(dev, 0) for _ in range(8)]
   for j, pl in enumerate(plans):
-    pl.build(ids_all[spare + j], sync=False)
+    pl.build(kids[6 + j], sync=False)
   torch.cuda.synchronize()
   counts = plans[0].read()[0]
   U = counts["many"] + counts["few"]
   ups = [rc.upsert_planned(tbl._h, plans[j], values) for j in range(8)]
-  upsert_us = tm.us(lambda i: ups[i](), reps=6, warm=2)       # every launch inserts its own never-seen keys
-  builds = [rc.plan_build(plans[j], ids_all[spare + j], 0) for j in range(8)]
+  upsert_us = tm.us(lambda i: ups[i](), reps=6, warm=2)       # every launch writes its own batch
+  builds = [rc.plan_build(plans[j], kids[6 + j], 0) for j in range(8)]
   plan_us = tm.us(lambda i: builds[i % 8](), reps=24, warm=3)
-  # export: one window of 16 Mi slots per launch, a different window each time; a full sweep = capacity / window launches
-  win = min(16 << 20, capacity)
-  kbuf = torch.empty(win, dtype=torch.int64, device=dev)
-  vbuf = torch.empty((win, dim), dtype=dtype, device=dev)
-  cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-  nwin = max(1, capacity // win)
+  uqk = [torch.unique(kids[14 + j]) for j in range(8)]
+  insk = [(lambda a=(tbl._h, uqk[j].numel(), P(uqk[j]), P(values), None, 1, st): _capi.check(lib.tfra_table_insert_or_assign(*a))) for j in range(8)]
+  insert_unique_us = tm.us(lambda i: insk[i](), reps=6, warm=2)
+  unique_us = tm.us(lambda i: _capi.check(lib.tfra_unique(*uniqs[i % nsteps])), reps=24, warm=3)
+  export = None
+  if cfg == "c3":
+    # export: one window of 16 Mi slots per launch, a different window each time; a full sweep = capacity / window launches
+    win = min(16 << 20, capacity)
+    kbuf = torch.empty(win, dtype=torch.int64, device=dev)
+    vbuf = torch.empty((win, dim), dtype=dtype, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    nwin = max(1, capacity // win)
 
-  def export_window(i):
-    cnt.zero_()
-    _capi.call("tfra_table_export_batch", tbl._h, win, (i % nwin) * win, _ptr(cnt), _ptr(kbuf), _ptr(vbuf), None, _stream(dev))
+    def export_window(i):
+      cnt.zero_()
+      _capi.call("tfra_table_export_batch", tbl._h, win, (i % nwin) * win, _ptr(cnt), _ptr(kbuf), _ptr(vbuf), None, _stream(dev))
 
-  export_us = tm.us(export_window, reps=6, warm=1)
-  live = int(cnt.item())
-  export_bytes = (win // 15 + 1) * (4096 if Rb == 256 else 256 + 15 * Rb) + live * (8 + Rb)
-  sweep_s = export_us * 1e-6 * (capacity / win)
-  del kbuf, vbuf
+    export_us = tm.us(export_window, reps=6, warm=1)
+    live = int(cnt.item())
+    export_bytes = (win // 15 + 1) * (4096 if Rb == 256 else 256 + 15 * Rb) + live * (8 + Rb)
+    sweep_s = export_us * 1e-6 * (capacity / win)
+    del kbuf, vbuf
+    export = {"window_slots": win, "live_keys_in_last_window": live, "avg_launch_us": export_us,
+              "achieved_GBps": export_bytes / export_us / 1e3, "full_sweep_s": sweep_s,
+              "pairs_per_s_with_a_full_export_sweep_every_1000_steps": B * 1000 / (1000 * med / K + sweep_s),
+              "note": "export_batch(n, offset) windows over the slot range (K/lookup_impl/lookup_table_op_hkv.h:548-594); BASELINE's "
+                      "'export every 1000 steps' is NOT inside the timed region (%d steps): the sweep is timed alone and folded in "
+                      "arithmetically" % (WINDOWS * K)}
+  # ---- untimed verification of the table itself (SURVEY §8c properties that do not depend on the size) ---------------
+  tbl.check_errors()
+  census = {k: int(v) for k, v in tbl.slot_census().items()}
+  size_end = int(table.size().item())
+  verified.update({"check_errors_clean": True, "size_le_capacity": size_end <= capacity, "no_locked_slot": census["locked"] == 0,
+                   "size_matches_live_slots": abs(size_end - census["live"]) <= 2, "size_at_end": size_end})
+  bad = [k for k, v in verified.items() if v is False]
+  assert not bad, "bench verification failed: %s" % bad
 
-  ms = elapsed / K * 1e3
-  value = B * K / elapsed
+  ms = med / K * 1e3
+  value = B * K / med
   lookup_bytes = B * (8 + 2 * Rb)                      # key + row read + row written out
   upsert_bytes = U * (8 + Rb + Rb + 8)                 # per unique key: key, value row read, row written, key stored
   step_bytes = lookup_bytes + upsert_bytes
@@ -420,12 +610,17 @@ def run_bounded(args, torch, de, dev, cfg):
           "avg_launch_us": find_us, "algorithmic_bytes_per_launch": lookup_bytes,
           "achieved_GBps": lookup_bytes / find_us / 1e3, "frac": lookup_bytes / find_us / 1e3 / HBM_PEAK_GBS,
           "traffic": traffic_of(prof, cfg, "find_kernel")},
-      "upsert_own_kernel<16,SIMPLE> + upsert_rest_kernel<16> (single pass with bucket ownership: assign / claim / score-based eviction; then the few keys that lost a claim)": {
+      "upsert_own_kernel<16,SIMPLE,PLAN> + upsert_rest_kernel<16,PLAN> (write-back of a plan's unique keys: single pass with bucket ownership, then the few keys that lost a claim)": {
           "avg_launch_us": upsert_us, "algorithmic_bytes_per_launch": upsert_bytes, "unique_keys": U,
           "achieved_GBps": upsert_bytes / upsert_us / 1e3, "frac": upsert_bytes / upsert_us / 1e3 / HBM_PEAK_GBS,
           "traffic": (traffic_of(prof, cfg, "upsert_own_kernel") or 0) + (traffic_of(prof, cfg, "upsert_rest_kernel") or 0) or None},
+      "upsert_own_kernel<16,SIMPLE,DIRECT> + upsert_rest_kernel<16,DIRECT> (tfra_table_insert_or_assign of unique keys: the reference's Insert op)": {
+          "avg_launch_us": insert_unique_us, "algorithmic_bytes_per_launch": upsert_bytes, "unique_keys": U,
+          "achieved_GBps": upsert_bytes / insert_unique_us / 1e3, "frac": upsert_bytes / insert_unique_us / 1e3 / HBM_PEAK_GBS, "traffic": None},
   }
-  dom = max(kernels, key=lambda k: kernels[k]["avg_launch_us"])
+  on_step = list(kernels)[:2]   # the kernels of the `value` step
+  dom = max(on_step, key=lambda k: kernels[k]["avg_launch_us"])
+  cfg_name = "2" if cfg == "c3" else "metric (dim 64 fp32, 1 B keys, Zipf-1.2)"
   res = {
       "metric": "embedding lookup+insert pairs/s (%s, %d-slot bounded table, %d %% never-seen ids per batch: lookup + "
                 "insert_or_assign with score-based eviction)" % ("dim=128 fp16" if cfg == "c3" else "dim=64 fp32", capacity,
@@ -433,277 +628,277 @@ def run_bounded(args, torch, de, dev, cfg):
       "value": value, "unit": "pairs/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "f32",
       "data": "synthetic",
-      "value_plain_call": B * K / elapsed_plain, "ms_per_step_plain_call": elapsed_plain / K * 1e3,
+      "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
+      "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
+      "value_op_surface_table_ops_only": B * K / med_tops, "ms_per_step_op_surface_table_ops_only": med_tops / K * 1e3,
       "config": {
           "workload": "BASELINE configs[%s]: bounded Hkv (LRU) table, %d slots (%.1f GB in HBM: key line + score line + 15 rows per "
                       "4 KiB bucket block), pre-filled with %d unique keys -> %d resident, %s rows, batch=%d = %d %% Zipf-1.2 over "
-                      "the resident ranks + %d %% never-seen ranks; step = lookup(B) + insert_or_assign(B, last occurrence "
-                      "wins) with eviction" % ("2" if cfg == "c3" else "metric (dim 64, 1 B keys)", capacity,
-                                               capacity / 15 * (256 + 15 * Rb) / 1e9, n_res, resident,
-                                               "dim=128 fp16" if cfg == "c3" else "dim=64 fp32", B, round(100 * (1 - new_ratio)),
-                                               round(100 * new_ratio)),
+                      "the %d ranks + %d %% never-seen ranks; step = lookup(B) + insert_or_assign(B, last occurrence "
+                      "wins) with eviction%s" % (cfg_name, capacity, capacity / 15 * (256 + 15 * Rb) / 1e9, n_res, resident,
+                                                  "dim=128 fp16" if cfg == "c3" else "dim=64 fp32", B, round(100 * (1 - new_ratio)), n_res,
+                                                  round(100 * new_ratio),
+                                                  "; the export sweep of configs[2] ('every 1000 steps') is outside the timed region, see config.export" if cfg == "c3" else ""),
           "slots": capacity, "requested_slots": want, "alloc_failures": failures, "growth_in_place": growth,
           "resident_after_prefill": resident,
           "resident_after_timed_steps": size_after, "new_key_ratio": new_ratio, "global_batch": B,
           "unique_ratio": round(uniq_ratio, 4), "unique_keys_per_batch": U, "prefill_s": round(t_fill, 2),
           "table_ops_per_s": 2 * value, "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
+          "timing": {"value": timing_note(secs, K), "value_plain_call": timing_note(secs_plain, K),
+                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_table_ops_only": timing_note(secs_tops, K)},
+          "verified": verified,
           "drivers": {
               "value": "tfra_table_step_prefetch_assign: ONE C call per step = lookup + insert_or_assign of batch i on the main "
-                       "stream, de-duplication plan (CSR by key) of batch i+1 on a second stream; one plan built per step "
-                       "inside the timed region",
-              "value_plain_call": "tfra_table_find then tfra_table_upsert_sparse (plan built inside the call): the reference's "
-                                  "op sequence Find -> Insert without look-ahead"},
-          "plan_build_us_alone": plan_us,
-          "export": {"window_slots": win, "live_keys_in_last_window": live, "avg_launch_us": export_us,
-                     "achieved_GBps": export_bytes / export_us / 1e3, "full_sweep_s": sweep_s,
-                     "pairs_per_s_with_a_full_export_sweep_every_1000_steps": B * 1000 / (1000 * elapsed / K + sweep_s),
-                     "note": "export_batch(n, offset) windows over the slot range (K/lookup_impl/lookup_table_op_hkv.h:548-594); "
-                             "BASELINE's 'export every 1000 steps' falls outside a %d-step timed region, so the sweep is timed "
-                             "separately and folded in arithmetically" % K},
+                       "stream, de-duplication plan of batch i+1 on a second stream (needs the ids one batch ahead); one plan built "
+                       "per step inside the timed region",
+              "value_plain_call": "tfra_table_find then tfra_table_upsert_sparse, no look-ahead; upsert_sparse is a fused extra (plan "
+                                  "built inside the call, repeats resolved on the device), not an op of the reference's surface",
+              "value_op_surface": "per step exactly the calls of tf_ops/mi355x_table_ops.h: tfra_table_find (B ids) -> tfra_unique + "
+                                  "one host read of the count (tf.unique's output shape) -> tfra_table_insert_or_assign(unique keys, "
+                                  "TFRA_FLAG_UNIQUE_KEYS)",
+              "value_op_surface_table_ops_only": "tfra_table_find (B ids) -> tfra_table_insert_or_assign(unique keys prepared beforehand)"},
+          "plan_build_us_alone": plan_us, "tfra_unique_us_alone": unique_us,
+          "export": export,
       },
       "roofline": {
           "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
           "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_launch_us"],
           "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-          "step_frac_plain_call": step_bytes / (elapsed_plain / K) / 1e9 / HBM_PEAK_GBS,
+          "step_frac_plain_call": step_bytes / (med_plain / K) / 1e9 / HBM_PEAK_GBS,
+          "step_frac_op_surface": step_bytes / (med_ops / K) / 1e9 / HBM_PEAK_GBS,
           "step_algorithmic_bytes": step_bytes,
           "step_bytes_definition": "B*(8+2*Rb) for the lookup + U*(16+2*Rb) for the write-back of the U unique keys (SURVEY §8d)",
           "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "kernels": kernels,
-          "timing": "HIP events on the launching stream around 4-40 launches, a different batch each; instruction issue and "
-                    "dependent memory round trips, not bytes, bound the write-back kernels (DESIGN.md §5: SQ counters in "
-                    "profiles/r02_summary.json)",
+          "timing": "HIP events on the launching stream around 6-24 launches, a different batch each; latency (TLB-missing round "
+                    "trips on a 273-GB table) and cross-lane work, not bytes, bound the write-back kernels (DESIGN.md §5)",
       },
   }
-  del ps, plans, table, tbl
+  del plans, table, tbl, uq, ins, finds
   import gc
   gc.collect()
   torch.cuda.empty_cache()
   return res
 
 
-# ------------------------------------------------------------------ c2: growing table, sparse Adam
-def run_c2(args, torch, dist, de, dev, world, rank):
+# ------------------------------------------------------------------ c2 / c4: growing table behind de.Variable, fused optimizer
+def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
+  """cfg 'c2' (configs[1], one GPU): 100 M keys, rows [p|m|v], 10 % never-seen ids, lookup + fused sparse Adam; look-ahead
+  driver and plain calls.
+  cfg 'c4' (configs[3], ANY number of GPUs, also 1): `--c4-keys` (5*10^8) keys PER GPU, hash-sharded by the reference's
+  default partitioner over `world` shards, rows without optimizer slots (fused SGD: 5*10^8 rows [p|m|v] would not fit
+  one GPU), per-GPU batch from the GLOBAL Zipf-1.2 over world*5*10^8 ranks, the whole step driven by tfra_route_* — at
+  world 1 the same driver without a transport (device copies instead of alltoalls)."""
   from tfra_amd.dynamic_embedding.distributed import AllToAllEmbedding
   DIM = 64
   B, K, W = args.batch, args.steps, args.warmup
-  n_local = args.keys
+  c4 = cfg == "c4"
+  n_local = args.c4_keys if c4 else args.keys
   n_total = n_local * world
-  new_ratio = args.new_key_ratio if args.new_key_ratio is not None else 0.1
-  if world > 1:
-    new_ratio = 0.0
+  new_ratio = 0.0 if c4 else (args.new_key_ratio if args.new_key_ratio is not None else 0.1)
+  nsteps = W + WINDOWS * K
 
-  opt = de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
+  opt = de.optimizers.SGD(0.05) if c4 else de.optimizers.Adam(1e-3, 0.9, 0.999, 1e-8)
   deo = de.DynamicEmbeddingOptimizer(opt)
   # init_size: the resident keys plus room for the never-seen ids of every batch of the run (warm-up and both drivers), so
   # that the table does not grow inside a timed region (it grows as soon as its true size passes max_load_factor)
-  headroom = int(2.2 * (K + W + 8) * B * max(new_ratio, 0.0)) + (1 << 20)
+  headroom = int(2.2 * (nsteps + 8) * B * max(new_ratio, 0.0)) + (1 << 20)
   var = de.Variable(dim=DIM, devices=[str(dev)], name="bench_rank%d" % rank, initializer=0.0, init_size=int(n_local * 1.05) + headroom,
                     **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
   force_a2a = os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist.is_initialized()
-  emb = (AllToAllEmbedding(var, partition_mode=0, dedup=os.environ.get("TFRA_BENCH_DEDUP", "1") == "1",
-                           force_collectives=force_a2a) if (world > 1 or force_a2a) else None)
   table = var.tables[0]
   gen = torch.Generator(device=dev).manual_seed(SEED + rank)
   chunk = 4_000_000
   t_fill = time.perf_counter()
+  fill_vals = torch.randn((chunk, DIM), generator=gen, device=dev) * 0.01
   for lo in range(1, n_total + 1, chunk):
     r = torch.arange(lo, min(n_total, lo + chunk - 1) + 1, dtype=torch.int64, device=dev)
     k = keys_of_ranks_torch(torch, r)
     if world > 1:
-      k = k[((k & 0x7FFFFFFF) % world) == rank]
-    table._table.upsert(k, torch.randn((k.numel(), DIM), generator=gen, device=dev) * 0.01, unique_keys=True)
+      k = k[((k & 0x7FFFFFFF) % world) == rank]   # default_partition_fn (PY/dynamic_embedding_variable.py:165-197)
+    table._table.upsert(k, fill_vals[:k.numel()], unique_keys=True)
+  del fill_vals
   resident = int(table.size().item())
   t_fill = time.perf_counter() - t_fill
 
-  rng = np.random.default_rng(SEED + 1000 * rank)
-  nb = 2 * (K + W) + 8
-  ranks, _ = mixed_batches(rng, nb, B, n_total, new_ratio, n_total + 1 + rank * (1 << 40))
-  ids_all = torch.from_numpy(keys_of_ranks(ranks.reshape(-1)).reshape(nb, B)).to(dev)
-  uniq_ratio = float(np.mean([np.unique(ranks[i]).size / B for i in range(4)]))
+  idf = IdFactory(torch, dev, B, n_total, new_ratio, n_total + 1 + rank * (1 << 40), SEED + 1000 * rank + 1)
   grads = torch.randn((B, DIM), generator=gen, device=dev) * 0.01
   tm = Timer(torch)
-  single = world == 1 and emb is None
-
-  def plain(i):
-    ids = ids_all[i]
-    if emb is None:
-      out = var.lookup(ids)
-      deo.apply_sparse(var, ids, grads)
-    else:
-      out = emb.lookup(ids)
-      emb.apply_gradients(deo, grads)
-    return out
-
-  elapsed_plain = None
+  single = not c4 and world == 1
+  secs_plain = med_plain = None
+  route, route_note, rs = None, None, None
   if single:
-    prefetch = de.PrefetchStep(var, deo).prime(ids_all[0])
+    ids = idf.keys(nsteps + 1)
+    uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
+    prefetch = de.PrefetchStep(var, deo).prime(ids[0])
     for i in range(W):
-      prefetch.step(grads, ids_all[i + 1])
-    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: prefetch.step(grads, ids_all[W + i + 1]))
-    base = K + W + 2
+      prefetch.step(grads, ids[i + 1])
+    secs, med, host_s = timed_windows(torch, dist, world, dev, K, lambda i: prefetch.step(grads, ids[i + 1]), first=W)
+    del prefetch
+    ids = idf.keys(nsteps)
+
+    def plain(i):
+      var.lookup(ids[i])
+      deo.apply_sparse(var, ids[i], grads)
+
     for i in range(W):
-      plain(base + i)
-    elapsed_plain, _ = timed_steps(torch, dist, world, dev, K, lambda i: plain(base + W + i))
-  route = None if single else os.environ.get("TFRA_BENCH_ROUTE", "native")
-  route_note = None
-  rs = None
-  if route == "native":
-    # N > 1 (or the collectives forced on one GPU): the same prepared-ahead route as RoutedPrefetchStep below, issued from C
-    # (tfra_route_*: three calls per step, grouped ncclSend/ncclRecv on the driver's own RCCL communicators).  Should the
-    # driver not come up on some rank (its RCCL communicators are its own), every rank falls back to the Python-driven route.
-    from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
-    err = None
-    try:
-      rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B,
-                            threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
-    except Exception as e:   # noqa: BLE001 — agreed on below
-      err = e
-    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
-      if rs is not None:
-        rs.close()
-      rs, route = None, "prefetch"
-      route_note = "native route driver unavailable (%s): fell back to the Python-driven route" % (str(err)[:200] if err else "on another rank")
-    if rank == 0:
-      print("[bench] route: %s, world %d%s" % (route, world, "" if route_note is None else " — " + route_note), file=sys.stderr, flush=True)
-  if single:
-    pass
-  elif route == "native":
+      plain(i)
+    secs_plain, med_plain, _ = timed_windows(torch, dist, world, dev, K, plain, first=W)
+  else:
+    # N >= 1 through the route: the id-only half — distinct ids, owner-major order, count exchange, id alltoall, both
+    # de-duplication plans — runs up to three batches ahead on the driver's own streams (tfra_route_*: three C calls per step,
+    # grouped ncclSend/ncclRecv on its own RCCL communicators); per step: find -> alltoall(rows) -> gather, gradient sums ->
+    # alltoall(grads) -> fused update at the owner.  Should the C driver not come up on some rank, every rank falls back to the
+    # same sequence driven from Python (RoutedPrefetchStep); recorded in config.route.
+    from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep, RoutedPrefetchStep
+    route = os.environ.get("TFRA_BENCH_ROUTE", "native")
     ahead = int(os.environ.get("TFRA_ROUTE_AHEAD", "3"))   # batches whose ids are known before their step (input pipeline)
+    ids = idf.keys(nsteps + ahead + 1)
+    uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
+    if route == "native":
+      err = None
+      try:
+        rs = NativeRoutedStep(var, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B,
+                              threaded=os.environ.get("TFRA_ROUTE_THREAD", "1") != "0")
+      except Exception as e:   # noqa: BLE001 — agreed on below
+        err = e
+      if dist.is_initialized():
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        agreed = int(ok.item()) == 1
+      else:
+        agreed = err is None
+      if not agreed:
+        if rs is not None:
+          rs.close()
+        rs, route = None, "prefetch"
+        route_note = "native route driver unavailable (%s): fell back to the Python-driven route" % (str(err)[:200] if err else "on another rank")
+      if rank == 0:
+        print("[bench] route: %s, world %d%s" % (route, world, "" if route_note is None else " — " + route_note), file=sys.stderr, flush=True)
+    if route != "native":
+      if not dist.is_initialized():
+        raise RuntimeError("the Python-driven route needs torch.distributed (run under torch.distributed.run)")
+      rs = RoutedPrefetchStep(var, deo, partition_mode=0, force_collectives=force_a2a)
+      ahead = 2
     for j in range(ahead):
-      rs.feed(ids_all[j])
+      rs.feed(ids[j])
 
     def routed(i):
       out = rs.lookup()
       rs.apply(grads)
-      rs.feed(ids_all[i + ahead])
+      rs.feed(ids[i + ahead])
       return out
 
     for i in range(W):
       routed(i)
-    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: routed(W + i))
+    secs, med, host_s = timed_windows(torch, dist, world, dev, K, routed, first=W)
     for _ in range(ahead):   # drain the batches fed ahead
       rs.lookup(); rs.apply(grads)
     torch.cuda.synchronize()
-    rs.close()
-  elif route == "prefetch":
-    # N > 1 (or the collectives forced on one GPU): the id-only half of the route — distinct ids, owner-major order, count
-    # exchange, id alltoall, both de-duplication plans — runs two batches ahead on a second stream (RoutedPrefetchStep);
-    # per step: local find -> alltoall(rows) -> gather, gradient sums -> alltoall(grads) -> fused update at the owner
-    from tfra_amd.dynamic_embedding.distributed import RoutedPrefetchStep
-    rs = RoutedPrefetchStep(var, deo, partition_mode=0, force_collectives=force_a2a)
-    rs.feed(ids_all[0]); rs.feed(ids_all[1])
-
-    def routed(i):
-      out = rs.lookup()
-      rs.apply(grads)
-      rs.feed(ids_all[i + 2])
-      return out
-
-    for i in range(W):
-      routed(i)
-    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: routed(W + i))
-    while rs.fed:   # drain the batches fed ahead
-      rs.lookup(); rs.apply(grads)
-  else:
-    for i in range(W):
-      plain(i)
-    elapsed, host_s = timed_steps(torch, dist, world, dev, K, lambda i: plain(W + i))
+    if hasattr(rs, "close"):
+      rs.close()
   size_after = int(table.size().item())
+  table._table.check_errors()
 
   # ---- per-kernel timings, each phase alone -----------------------------------------------------------------
   rc = raw_calls(torch, dev)
   h = table._table._h
   out_buf = torch.empty((B, DIM), dtype=torch.float32, device=dev)
   dflt_row = table._default_value
-  finds = [rc.find(h, ids_all[(W + j) % (K + W)], out_buf, dflt_row) for j in range(K + W)]
-  find_us = tm.us(lambda i: finds[i % len(finds)]())
+  kids = idf.keys(16)
+  finds = [rc.find(h, kids[j], out_buf, dflt_row) for j in range(8)]
+  find_us = tm.us(lambda i: finds[i % 8]())
   find_b2b_us = tm.us(lambda i: finds[0]())
   find_bytes = B * (8 + 2 * DIM * 4)
   p = opt.params(1)
   dflt = table._default_value.to(torch.float32)
-  spare = 2 * (K + W) + 2
   grad_half_us = plan_us = None
-  U = int(np.unique(ranks[spare]).size)
+  U = int(torch.unique(kids[8]).numel())
   if de.DynamicEmbeddingOptimizer.can_plan(var, B):
     plans = [de.table_ops.SparsePlan(dev, DIM) for _ in range(6)]
     for j, pl in enumerate(plans):
-      pl.build(ids_all[spare + j], sync=False)
+      pl.build(kids[8 + j], sync=False)
     torch.cuda.synchronize()
     counts = plans[0].read()[0]
     U = counts["many"] + counts["few"]
     halves = [rc.apply_planned(h, p, plans[j], grads, dflt) for j in range(6)]
     grad_half_us = tm.us(lambda i: halves[i % 6](), reps=30)
-    builds = [rc.plan_build(plans[j], ids_all[spare + j], DIM) for j in range(6)]
+    builds = [rc.plan_build(plans[j], kids[8 + j], DIM) for j in range(6)]
     plan_us = tm.us(lambda i: builds[i % 6](), reps=30)
-  wb_bytes = B * (8 + DIM * 4) + U * (8 + 7 * DIM * 4)   # ids + gradient rows once, fused Adam on the unique keys
-  uniq = torch.from_numpy(keys_of_ranks(np.unique(ranks[spare]))).to(dev)
+  nslot = 0 if c4 else 2
+  per_key = 8 + (2 + 2 * nslot + 1) * DIM * 4          # key + gradient + (1+S) rows read and written
+  wb_bytes = B * (8 + DIM * 4) + U * per_key           # ids + gradient rows once, fused update on the unique keys
+  uniq = torch.unique(kids[14])
   gsum = torch.randn((uniq.numel(), DIM), generator=gen, device=dev) * 0.01
   apply_one = rc.apply_optimizer(h, p, uniq, gsum, dflt)
   apply_us = tm.us(lambda i: apply_one(), reps=30)
-  apply_bytes = int(uniq.numel()) * (8 + 7 * DIM * 4)
+  apply_bytes = int(uniq.numel()) * per_key
   prof = profile_summary()
 
-  ms = elapsed / K * 1e3
-  value = world * B * K / elapsed
+  ms = med / K * 1e3
+  value = world * B * K / med
   step_bytes = find_bytes + wb_bytes
+  oname = "SGD" if c4 else "Adam"
   res = {
-      "metric": "embedding lookup+insert pairs/s (dim=64 fp32, Zipf-1.2, lookup + sparse-Adam write-back)",
+      "metric": "embedding lookup+insert pairs/s (dim=64 fp32, Zipf-1.2, lookup + fused sparse-%s write-back%s)"
+                % (oname, ", %d-GPU hash-sharded table, ids/rows/grads routed" % world if c4 else ""),
       "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms,
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
       "config": {
-          "workload": "BASELINE configs[1]: %d resident keys/GPU (%d total), dim=64 fp32 rows [p|m|v], Zipf-1.2 batch=%d/GPU with "
-                      "%d %% never-seen keys per batch, lookup + dedup + fused sparse Adam (insert/write-back)"
-                      % (resident, n_total, B, round(100 * new_ratio)),
+          "workload": ("BASELINE configs[3]: %d shard(s) x %d resident keys (%d total, owner = default_partition_fn), dim=64 fp32 rows, "
+                       "per-GPU batch=%d from the GLOBAL Zipf-1.2 over all keys, routed lookup + routed fused SGD write-back"
+                       % (world, resident, n_total, B)) if c4 else
+                      ("BASELINE configs[1]: %d resident keys, dim=64 fp32 rows [p|m|v], Zipf-1.2 batch=%d with %d %% never-seen keys per "
+                       "batch, lookup + dedup + fused sparse Adam (insert/write-back)" % (resident, B, round(100 * new_ratio))),
           "global_batch": B * world, "keys_per_gpu": resident, "keys_per_gpu_after_timed_steps": size_after,
           "new_key_ratio": new_ratio, "unique_ratio": round(uniq_ratio, 4), "unique_keys_per_batch": U,
-          "parallelism": "key-hash sharded x%d, RCCL alltoall" % world if world > 1 else "single GPU",
+          "parallelism": ("key-hash sharded x%d, RCCL alltoall" % world) if world > 1 else ("single GPU through the route driver (no transport)" if c4 else "single GPU"),
+          "multi_rank_rccl_note": None if not c4 else "no RCCL communicator with more than one rank has been formed on the builder's side (one GPU per box): "
+                                                      "the N>1 numbers are the driver's to measure; nothing is projected here",
           "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
           "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4), "route": route, "route_note": route_note,
+          "timing": {"value": timing_note(secs, K)},
           "drivers": {
               "value": ("tfra_table_step_prefetch: ONE C call per step = lookup + hot sums + fused Adam of batch i on the main "
                         "stream, CSR-by-key plan of batch i+1 on a second stream; one plan built per step inside the timed region")
               if single else {
-                  "native": "tfra_route_* (C driver, grouped ncclSend/ncclRecv): id-only half of the alltoall route up to three "
-                            "batches ahead on its own streams; per step find -> alltoall(rows) -> gather, gradient sums -> "
-                            "alltoall(grads) -> fused Adam at the owner",
-                  "prefetch": "RoutedPrefetchStep (the same sequence driven from Python through torch.distributed)",
-              }.get(route,
-                    "embedding_lookup + apply_gradients through the alltoall route (exact split sizes, no look-ahead)"),
+                  "native": "tfra_route_* (C driver; grouped ncclSend/ncclRecv at world > 1, device copies at world 1): id-only half of "
+                            "the alltoall route up to three batches ahead on its own streams; per step find -> alltoall(rows) -> gather, "
+                            "gradient sums -> alltoall(grads) -> fused update at the owner",
+                  "prefetch": "RoutedPrefetchStep (the same sequence driven from Python through torch.distributed)"}.get(route),
               "value_plain_call": "tfra_table_find then tfra_table_apply_sparse (plan built inside the call): the reference's op "
-                                  "sequence lookup -> optimizer apply, no look-ahead"},
+                                  "sequence lookup -> optimizer apply, no look-ahead" if single else None},
       },
       "roofline": {
           "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",
           "achieved": find_bytes / find_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "frac": find_bytes / find_us / 1e3 / HBM_PEAK_GBS, "traffic": traffic_of(prof, "c2", "find_kernel"),
+          "frac": find_bytes / find_us / 1e3 / HBM_PEAK_GBS, "traffic": traffic_of(prof, cfg, "find_kernel"),
           "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
           "avg_launch_us_same_batch_back_to_back": find_b2b_us,
-          "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if single else None,
+          "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
           "step_algorithmic_bytes": step_bytes,
-          "step_bytes_definition": "B*(8+2*Rb) lookup + B*(8+Rb) ids and gradient rows + U*(8+7*Rb) fused Adam on the U unique keys",
-          "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if single else None,
+          "step_bytes_definition": "B*(8+2*Rb) lookup + B*(8+Rb) ids and gradient rows + U*(8+(3+2S)*Rb) fused update on the U unique keys (S optimizer slots)",
+          "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
           "timing": "HIP events on the launching stream around 30-50 launches, a different batch each",
           "kernels": {
-              "hot_sums_kernel + apply_csr_kernel<ADAM> (gradient half: duplicate sums + fused Adam)": {
+              "hot_sums_kernel + apply_csr_kernel<%s> (gradient half: duplicate sums + fused update)" % oname.upper(): {
                   "avg_launch_us": grad_half_us, "algorithmic_bytes_per_launch": wb_bytes, "unique_keys": U,
                   "achieved_GBps": wb_bytes / grad_half_us / 1e3 if grad_half_us else None,
                   "frac": wb_bytes / grad_half_us / 1e3 / HBM_PEAK_GBS if grad_half_us else None,
-                  "traffic": (traffic_of(prof, "c2", "hot_sums_kernel") or 0) + (traffic_of(prof, "c2", "apply_csr_kernel") or 0) or None},
+                  "traffic": (traffic_of(prof, cfg, "hot_sums_kernel") or 0) + (traffic_of(prof, cfg, "apply_csr_kernel") or 0) or None},
               "csr_tile_kernel + csr_bucket_kernel + csr_scatter_kernel (id-only plan, second stream)": {"avg_launch_us": plan_us},
-              "apply_kernel<ADAM> alone on pre-summed unique keys": {
+              "apply_kernel<%s> alone on pre-summed unique keys" % oname.upper(): {
                   "avg_launch_us": apply_us, "algorithmic_bytes_per_launch": apply_bytes,
                   "achieved_GBps": apply_bytes / apply_us / 1e3, "frac": apply_bytes / apply_us / 1e3 / HBM_PEAK_GBS},
           },
       },
   }
-  if elapsed_plain is not None:
-    res["value_plain_call"] = B * K / elapsed_plain
-    res["ms_per_step_plain_call"] = elapsed_plain / K * 1e3
-    res["roofline"]["step_frac_plain_call"] = step_bytes / (elapsed_plain / K) / 1e9 / HBM_PEAK_GBS
+  if med_plain is not None:
+    res["value_plain_call"] = B * K / med_plain
+    res["ms_per_step_plain_call"] = med_plain / K * 1e3
+    res["roofline"]["step_frac_plain_call"] = step_bytes / (med_plain / K) / 1e9 / HBM_PEAK_GBS
+    res["config"]["timing"]["value_plain_call"] = timing_note(secs_plain, K)
   del var, table, deo
   import gc
   gc.collect()
@@ -806,14 +1001,15 @@ def main():
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--c5-streams", type=int, default=4)
   ap.add_argument("--c5-workers", type=int, default=1)
-  ap.add_argument("--config", choices=["c3", "c2", "m1b", "c5"], default=None,
-                  help="default: c3 on one GPU (largest single-GPU configuration), c2 per GPU for N>1")
-  ap.add_argument("--slots", type=int, default=1_000_000_000, help="c3 / m1b: slots of the bounded table")
-  ap.add_argument("--keys", type=int, default=100_000_000, help="c2: resident keys PER GPU")
+  ap.add_argument("--config", choices=["m1b", "c3", "c2", "c4", "c5"], default=None,
+                  help="default: m1b on one GPU (the metric's own configuration; c3 / c2 / c4 as secondary), c4 per GPU for N>1")
+  ap.add_argument("--slots", type=int, default=1_000_000_000, help="m1b / c3: slots of the bounded table")
+  ap.add_argument("--keys", type=int, default=100_000_000, help="c2: resident keys")
+  ap.add_argument("--c4-keys", type=int, default=500_000_000, help="c4: resident keys PER GPU")
   ap.add_argument("--batch", type=int, default=131072, help="ids per GPU per step")
   ap.add_argument("--new-key-ratio", type=float, default=None, help="c2 / m1b: share of never-seen keys per batch")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--no-secondary", action="store_true", help="skip the secondary c2 / m1b measurements of the default invocation")
+  ap.add_argument("--no-secondary", action="store_true", help="skip the secondary c3 / c2 / c4 measurements of the default invocation")
   args = ap.parse_args()
 
   import torch
@@ -835,20 +1031,31 @@ def main():
       dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
   dev = torch.device("cuda", local_rank)
   torch.cuda.set_device(dev)
-  cfg = args.config or ("c3" if (world == 1 and not dist.is_initialized()) else "c2")
+  cfg = args.config or ("m1b" if (world == 1 and not dist.is_initialized()) else "c4")
   if cfg in ("c3", "m1b"):
     assert world == 1, "%s is a single-GPU configuration" % cfg
     res = run_bounded(args, torch, de, dev, cfg)
-    if not args.no_secondary and cfg == "c3":
-      keep = ("metric", "value", "value_plain_call", "ms_per_step", "ms_per_step_plain_call", "config", "roofline")
-      m1b = run_bounded(args, torch, de, dev, "m1b")   # the metric's own wording: dim 64 fp32, 10^9 slots, Zipf-1.2 ids
-      sec = run_c2(args, torch, dist, de, dev, 1, 0)
-      res["secondary"] = {"m1b": {k: m1b[k] for k in keep if k in m1b}, "c2": {k: sec[k] for k in keep if k in sec}}
+    if not args.no_secondary and args.config is None:
+      keep = ("metric", "value", "value_plain_call", "value_op_surface", "value_op_surface_table_ops_only", "ms_per_step",
+              "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
+      sec = {}
+      for name, fn in (("c3", lambda: run_bounded(args, torch, de, dev, "c3")),       # configs[2]
+                       ("c2", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c2")),   # configs[1]
+                       ("c4", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c4"))):  # configs[3] at N=1: the first point of the N-GPU curve
+        try:
+          r = fn()
+          sec[name] = {k: r[k] for k in keep if k in r}
+        except Exception as e:   # noqa: BLE001 — a secondary measurement must not lose the line
+          sec[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+      res["secondary"] = sec
   elif cfg == "c5":
     assert world == 1, "c5 here is the one-GPU form of configs[4]"
     res = run_c5(args, torch, de, dev)
+  elif cfg == "c2":
+    assert world == 1, "c2 is a single-GPU configuration (N > 1 runs configs[3]: --config c4)"
+    res = run_sharded(args, torch, dist, de, dev, 1, 0, "c2")
   else:
-    res = run_c2(args, torch, dist, de, dev, world, rank)
+    res = run_sharded(args, torch, dist, de, dev, world, rank, "c4")
   if rank == 0:
     if not args.no_cpu_baseline:
       res["cpu_baseline"] = cpu_baseline(args.batch)

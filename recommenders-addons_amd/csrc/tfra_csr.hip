@@ -498,39 +498,50 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
     const unsigned sh = shard_of(s_bpre, gid);
     binmap[gid] = sh * out.br + (gid - s_bpre[sh]);
   }
-  if (blockIdx.x == 0) {
-    for (unsigned i = threadIdx.x; i <= P; i += NTA) cursors[(size_t)i * CSTRIDE] = 0;   // bucket cursors + overflow count
-    if (threadIdx.x == 0) {
-      const unsigned e = cursors[(size_t)(P + 1) * CSTRIDE];
-      cursors[(size_t)(P + 1) * CSTRIDE] = 0;
-      const unsigned v[6] = {nhot, ncold, 0u, nbins, 0u, e};
-      for (int k = 0; k < 6; ++k) d_counts[k] = v[k];
-      *reinterpret_cast<i64*>(d_counts + 32) = (i64)nhot + (i64)ncold;   // tfra_plan_partition: the count as tfra_partition reads it
-      if (host_counts) {
-        for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
   // (a)
   const size_t base = (size_t)blockIdx.x * TILE;
   const int L = (int)tile_len[blockIdx.x];
   const int q = threadIdx.x;
-  if (q >= L) return;
-  const unsigned te = tile_entries[base + q];
-  const unsigned m = te >> 9, position = (unsigned)base + (te & 511u);
-  const unsigned rank = (unsigned)q - run_start[base + m];
-  const uint4 r = drec[base + m];
-  if (r.w == 0xffffffffu) {
-    const unsigned idx = r.x + rank, rb = idx & ~(REC_WORDS - 1);   // a record is 16 words, positions in words 4..11
-    out.crec[idx] = position;
-    if ((idx & (REC_WORDS - 1)) - 3 == out.crec[rb + 2]) out.crec[rb + 3] = position;   // the key's last occurrence
-    return;
+  if (q < L) {
+    const unsigned te = tile_entries[base + q];
+    const unsigned m = te >> 9, position = (unsigned)base + (te & 511u);
+    const unsigned rank = (unsigned)q - run_start[base + m];
+    const uint4 r = drec[base + m];
+    if (r.w == 0xffffffffu) {
+      const unsigned idx = r.x + rank, rb = idx & ~(REC_WORDS - 1);   // a record is 16 words, positions in words 4..11
+      out.crec[idx] = position;
+      if ((idx & (REC_WORDS - 1)) - 3 == out.crec[rb + 2]) out.crec[rb + 3] = position;   // the key's last occurrence
+    } else if (r.w != 0xfffffffeu) {
+      const unsigned e = r.x + rank, nfull = r.w;
+      if (e < nfull * SEG) out.hent[(size_t)r.y + e] = position | ((e & (SEG - 1)) == 0 ? E_HEAD : 0u);
+      else out.hent[(size_t)r.z + (e - nfull * SEG)] = position | (e == nfull * SEG ? E_HEAD : 0u);
+    }
   }
-  if (r.w == 0xfffffffeu) return;
-  const unsigned e = r.x + rank, nfull = r.w;
-  if (e < nfull * SEG) out.hent[(size_t)r.y + e] = position | ((e & (SEG - 1)) == 0 ? E_HEAD : 0u);
-  else out.hent[(size_t)r.z + (e - nfull * SEG)] = position | (e == nfull * SEG ? E_HEAD : 0u);
+  // (c) by the block that finishes LAST (a ticket per block, behind an agent-scope release of the block's stores): the step
+  // driver launches the other half on another stream as soon as the pinned generation shows this build — published by the
+  // first block, as until round 2, the readers could overtake the scatter blocks still running.
+  __shared__ unsigned s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = __hip_atomic_fetch_add(d_counts + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (unsigned i = threadIdx.x; i <= P; i += NTA) cursors[(size_t)i * CSTRIDE] = 0;   // bucket cursors + overflow count
+  if (threadIdx.x == 0) {
+    const unsigned e = cursors[(size_t)(P + 1) * CSTRIDE];
+    cursors[(size_t)(P + 1) * CSTRIDE] = 0;
+    const unsigned v[6] = {nhot, ncold, 0u, nbins, 0u, e};
+    for (int k = 0; k < 6; ++k) __hip_atomic_store(d_counts + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<u64*>(d_counts + 32), (u64)nhot + (u64)ncold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tfra_plan_partition: the count as tfra_partition reads it
+    __hip_atomic_store(d_counts + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next build's tickets
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (host_counts) {
+      for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -604,6 +615,10 @@ struct CsrKeys {
   const unsigned* crec; const unsigned* hrec;
   const unsigned* hent;
   const unsigned* d_counts;
+  // SET plan (assign-only, see setplan_kernel): dense distinct keys, their slots, (last position + 1, occurrences) per slot
+  const i64* ukeys;
+  const unsigned* uslot;
+  const uint2* gpc;
 };
 
 // one coalesced 64-B load per key group: lane i holds word i of the key's record
@@ -811,156 +826,11 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
   }
 }
 
-// The keys upsert_own_kernel leaves to the general path are few (tens to hundreds per batch on a big table): it appends
-// them to a list — one atomic add per wave that has any — so that the two remainder kernels run with a handful of blocks
-// instead of scanning every key of the batch (11 us each for a scan of 78 K flags).  Two counters alternate between
-// the uses of a plan: use k counts in ctr[k & 1], and the last kernel of use k zeroes ctr[(k + 1) & 1], which nothing of
-// use k reads, for use k + 1 (stream order makes that safe; no extra launch, no CAS loop).  A count above SLOW_CAP
-// means the list is incomplete and the remainder kernels scan the flags instead.
-constexpr unsigned SLOW_CAP = 8192;
-struct SlowIter {
-  unsigned n;      // iterations: list entries, or every key of the plan (scan)
-  bool listed;
-  __device__ SlowIter(const unsigned* slow_ctr, unsigned total) {
-    if (!slow_ctr) { n = total; listed = false; return; }   // no ownership pass ran: every key
-    const unsigned cnt = *slow_ctr;
-    listed = cnt <= SLOW_CAP;
-    n = listed ? cnt : total;
-  }
-};
+constexpr unsigned SLOW_CAP = 8192;   // items of the left-over list of an ownership pass (more: the flags of all keys are scanned)
 
 // ---------------------------------------------------------------------------------------------
-// ASSIGN write-back: row of the key's LAST occurrence in the batch -> the table (insert_or_assign with repeats,
-// "last one wins").  scores: optional per-position in_score (the last occurrence's is used; LFU without scores adds
-// the occurrence count).  One 16-lane group per unique key; both home-bucket lines are in flight together on a table
-// running near capacity.  (A 4-keys-per-group variant like find_kernel's was measured SLOWER here — 110 us vs 66 us for
-// 78 K keys at 10^9 slots: the probe logic is branchy, the four groups of a wave run it in lockstep, and every key
-// of a group that has to claim a slot or walk its chain stalls the other fifteen keys of the wave.)
-// On a bounded table at max_capacity the keys that find neither themselves nor a free slot are flagged in `dflag`
-// for upsert_evict_csr_kernel.
-template <int G>
-__global__ __launch_bounds__(256) void upsert_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
-                                                         const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
-                                                         ScoreP sp, uint8_t* __restrict__ dflag, unsigned* any_deferred,
-                                                         unsigned use_gen, const unsigned* slow_ctr,
-                                                         const unsigned* __restrict__ slow_list, unsigned* zero_ctr) {
-  // slow_ctr != nullptr: remainder path of upsert_own_kernel, only the keys it marked (dflag == 4) — from its list,
-  // or by scanning the flags when the list overflowed
-  const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
-  if (zero_ctr && blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0;   // last kernel of this use: arm the next use's counter
-  if (it.n == 0) return;
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
-  int fresh = 0, failed = 0;
-  const bool pf1 = sp.bounded > 1;
-  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
-    const unsigned g = it.listed ? slow_list[i] : i;
-    if (slow_ctr && dflag[g] != 4) continue;
-    const i64 key = ks.dkeys[g];
-    u64 h;
-    const u64 b0 = bucket0(key, v.nb, h);
-    // plain loads for the FIRST look (like find_kernel): everything written before this launch is visible, and what other
-    // groups of this launch change concurrently — slot claims, overflow flags — is caught by the CAS / re-done with
-    // coherent loads in locate_or_claim_from (keys are unique per call, nothing is evicted or erased in this kernel)
-    i64 k0 = key_line(v, b0)[sub];
-    i64 k1 = key_line(v, pf1 ? bucket1(h, b0, v.nb) : b0)[sub];
-    bool hot;
-    const unsigned w = load_record(ks, g, sub, hot);
-    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
-    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3 + (int)min(max(cnt, 1u), 8u)));   // few: the last position itself
-    if (hot) last = ks.hent[last];                                                                     // many: where it is stored
-    last &= E_POS;
-    const u64 in_one = scores ? scores[last] : 1;
-    const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-    bool is_new = false;
-    const i64 row = locate_or_claim_from(v, key, h, b0, k0, sub, gshift, is_new, sp.bounded, pf1 ? &k1 : nullptr);
-    if (sp.bounded && sub == 0) {
-      dflag[g] = row == NEED_EVICT;
-      if (row == NEED_EVICT) *any_deferred = use_gen;   // plain store, every writer writes the same value
-    }
-    if (row < 0) { failed += (sub == 0 && row != NEED_EVICT); continue; }
-    fresh += (is_new && sub == 0);
-    unsigned char* pr = row_ptr(v, row);
-    copy_bytes16<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
-    if (is_new && v.n_fields > 1) {   // slot fields of a brand-new row start at aux_init
-      for (unsigned f = 1; f < v.n_fields; ++f) {
-        const unsigned pat = ai.pattern[(f - 1) & 3];
-        unsigned char* q = pr + f * v.field_bytes;
-        if ((v.field_bytes & 3) == 0)
-          for (unsigned off = sub * 4; off < v.field_bytes; off += 64) *reinterpret_cast<unsigned*>(q + off) = pat;
-        else
-          for (unsigned off = sub; off < v.field_bytes; off += 16) q[off] = (unsigned char)(pat >> (8 * (off % ai.elem_bytes)));
-      }
-    }
-    update_score(v, row, is_new, sp.strategy, in_score, sp.epoch, sub);
-  }
-  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
-  if (lane == 0) {
-    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
-    if (failed) atomicAdd(v.err_count, (unsigned)failed);
-  }
-}
-
-// Phase 2 of the ASSIGN write-back, one key per 16-lane group: the keys flagged in `dflag` replace the minimum-score
-// entry of their two home buckets (key + score lines of both buckets in flight together, evict_and_lock).
-template <int G>
-__global__ __launch_bounds__(256) void upsert_evict_csr_kernel(TableView v, const unsigned char* __restrict__ vals,
-                                                               const u64* __restrict__ scores, CsrKeys ks, AuxInitPod ai,
-                                                               ScoreP sp, const uint8_t* __restrict__ dflag,
-                                                               const unsigned* any_deferred, unsigned use_gen,
-                                                               const unsigned* slow_ctr, const unsigned* __restrict__ slow_list,
-                                                               unsigned* zero_ctr) {
-  if (zero_ctr && blockIdx.x == 0 && threadIdx.x == 0) *zero_ctr = 0;   // last kernel of this use: arm the next use's counter
-  if (*any_deferred != use_gen) return;   // phase 1 of this use deferred nothing: the usual case below capacity
-  const SlowIter it(slow_ctr, ks.d_counts[0] + ks.d_counts[1]);
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
-  int fresh = 0, failed = 0;
-  const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
-  for (unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 4); i < it.n; i += ngroups) {
-    const unsigned g = it.listed ? slow_list[i] : i;
-    if (dflag[g] != 1) continue;
-    const i64 key = ks.dkeys[g];
-    bool hot;
-    const unsigned w = load_record(ks, g, sub, hot);
-    const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
-    unsigned last = (unsigned)__shfl((int)w, gshift + (hot ? 5 : 3 + (int)min(max(cnt, 1u), 8u)));
-    if (hot) last = ks.hent[last];
-    last &= E_POS;
-    const u64 in_one = scores ? scores[last] : 1;
-    const u64 in_score = sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
-    u64 word = 0;
-    bool claimed_empty = false;
-    const i64 row = evict_and_lock(v, key, sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score, lru_like,
-                                   sub, gshift, &word, claimed_empty);
-    if (row < 0) { failed += (sub == 0 && row == -3); continue; }   // -1: not admitted (score below every resident one)
-    fresh += (claimed_empty && sub == 0);
-    unsigned char* pr = row_ptr(v, row);
-    copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
-    for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of the new row start at aux_init
-      const unsigned pat = ai.pattern[(f - 1) & 3];
-      unsigned char* q = pr + f * v.field_bytes;
-      if ((v.field_bytes & 3) == 0)
-        for (unsigned off = sub * 4; off < v.field_bytes; off += 64)
-          __hip_atomic_store(reinterpret_cast<unsigned*>(q + off), pat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        for (unsigned off = sub; off < v.field_bytes; off += 16)
-          __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (sub == 0) store_wt8(score_word(v, word), 0);   // the slot starts a new life
-    update_score<true>(v, row, true, sp.strategy, in_score, sp.epoch, sub);
-    publish_key(v, word, key, sub);
-  }
-  for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
-  if (lane == 0) {
-    if (fresh) size_add(v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
-    if (failed) atomicAdd(v.err_count, (unsigned)failed);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ASSIGN write-back, single pass with BUCKET OWNERSHIP (the normal path; upsert_csr_kernel + upsert_evict_csr_kernel above
-// are what runs without owner tags).
+// ASSIGN write-back, single pass with BUCKET OWNERSHIP (without owner tags — TFRA_OPTION_NO_OWNER_TAGS — every key takes the
+// locked protocol of upsert_rest_kernel).
 // Every bucket has an owner tag (one 32-bit word in a dense side array — NOT in the bucket's key line: an atomic and a
 // load issued together on the same 128-B line cost 41 us per 157 K instead of 11 us on separate lines,
 // scripts/mb/atomic_probe.hip).  Every key of the launch swaps the launch's generation into the tags of its two home
@@ -1097,7 +967,8 @@ struct OwnCtrs { unsigned n_a, spare[3]; };
 //   SRC_PLAN    the unique keys of a de-duplication plan (value row = the key's LAST occurrence in the batch)
 //   SRC_DIRECT  a caller's array of UNIQUE keys, value row i belongs to key i (tfra_table_insert_or_assign with
 //               TFRA_FLAG_UNIQUE_KEYS: the reference's Insert op, hkv_hashtable_op_gpu.cu.cc:253-290)
-enum { SRC_PLAN = 0, SRC_DIRECT = 1 };
+//   SRC_SET     the distinct keys of a SET plan (assign-only: last position and count per key, no positions list)
+enum { SRC_PLAN = 0, SRC_DIRECT = 1, SRC_SET = 2 };
 
 struct OwnArgs {
   TableView v;
@@ -1133,11 +1004,12 @@ __device__ __forceinline__ OwnFlags own_setup(const OwnArgs& a) {
 // the locked protocol over the item list; the flags of ALL keys when the list overflowed.
 template <int G, int SRC>
 __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const unsigned* slow_ctr, unsigned* zero4) {
-  const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
-  const unsigned counted = *slow_ctr;
-  if (blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
+  // slow_ctr == nullptr: there was no ownership pass (no owner tags): EVERY key of the launch, with the locked protocol
+  const unsigned total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  const unsigned counted = slow_ctr ? *slow_ctr : total;
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
   if (counted == 0) return;
-  const bool listed = counted <= a.item_cap;
+  const bool listed = slow_ctr && counted <= a.item_cap;
   const unsigned n = listed ? counted : total;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
@@ -1150,10 +1022,15 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
       locked_upsert_kv<G>(a.v, a.vals, key, w0.z, ((u64)w1.y << 32) | w1.x, a.ai, a.sp, sub, gshift, fresh, failed);
       if (sub == 0) a.dflag[w0.w] = 0;
     } else {
-      if (a.dflag[i] != 4) continue;
+      if (slow_ctr && a.dflag[i] != 4) continue;
       if (SRC == SRC_PLAN) locked_upsert_one<G>(a.v, a.vals, a.scores, a.ks, a.ai, a.sp, i, sub, gshift, fresh, failed);
-      else locked_upsert_kv<G>(a.v, a.vals, a.keys[i], i, a.scores ? a.scores[i] : 1, a.ai, a.sp, sub, gshift, fresh, failed);
-      if (sub == 0) a.dflag[i] = 0;
+      else if (SRC == SRC_SET) {
+        const uint2 pc = a.ks.gpc[a.ks.uslot[i]];
+        const u64 in_one = a.scores ? a.scores[pc.x - 1] : 1;
+        locked_upsert_kv<G>(a.v, a.vals, a.ks.ukeys[i], pc.x - 1, a.sp.strategy == TFRA_EVICT_LFU ? (a.scores ? in_one : (u64)pc.y) : in_one,
+                            a.ai, a.sp, sub, gshift, fresh, failed);
+      } else locked_upsert_kv<G>(a.v, a.vals, a.keys[i], i, a.scores ? a.scores[i] : 1, a.ai, a.sp, sub, gshift, fresh, failed);
+      if (slow_ctr && sub == 0) a.dflag[i] = 0;
     }
   }
   for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
@@ -1222,6 +1099,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   unsigned kmreg = 0, lastreg = gj;
   u64 insreg = 1;
   if (SRC == SRC_PLAN) { kreg = ks.dkeys[gj]; kmreg = ks.keymap[gj]; }
+  else if (SRC == SRC_SET) { kreg = ks.ukeys[gj]; kmreg = ks.uslot[gj]; }
   else kreg = a.keys[gj];
   u64 hreg;
   const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
@@ -1259,6 +1137,11 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
     lastreg &= E_POS;
     const u64 in_one = scores ? scores[lastreg] : 1;
     insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
+  } else if (SRC == SRC_SET) {
+    const uint2 pc = ks.gpc[kmreg];   // (last position + 1, occurrences) of the key's slot in the plan's table
+    lastreg = pc.x - 1;
+    const u64 in_one = scores ? scores[lastreg] : 1;
+    insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)pc.y) : in_one;
   } else {
     insreg = scores ? scores[lastreg] : 1;
   }
@@ -1419,7 +1302,7 @@ template <int G, bool SIMPLE, int SRC>
 __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, unsigned own_gen, unsigned* progress,
                                                          unsigned progress_val) {
   const int lane = threadIdx.x & 63;
-  const unsigned total = SRC == SRC_PLAN ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  const unsigned total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int fresh = 0;
@@ -1434,6 +1317,136 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(a.v, wave, fresh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SET plan: the id-only half of an ASSIGN write-back (tfra_sparse_plan_build with dim 0) in ONE kernel.
+// An assign needs, per distinct id, the position of its LAST occurrence (and how often it occurred: LFU scores) — not the
+// CSR of all positions the gradient sums need.  The CSR plan's three kernels take 29 us for 131 072 ids and six of the
+// step's nine kernel launches; the step driver that builds it one batch ahead was bound by the host's launch rate
+// (52 us per step of host time for 39 us of kernels on the main stream).
+//   phase A  one block per 1024 ids: equal ids meet in an LDS hash table (compare-and-swap on the key word, atomic max on
+//            position + 1, atomic add on the count);
+//   phase B  every distinct id of the block goes into a global open-addressing table of >= 2 n slots (compare-and-swap on
+//            the key, atomic max / add on (position + 1, count)): its slot is the same for every block.  The block whose
+//            swap installed the key appends (key, slot) to the dense list of distinct keys — one counter add per block;
+//   phase C  the plan keeps TWO such tables and alternates: while build k fills one, it empties the slots build k-1 used in
+//            the other (its dense list says which) — no memset, no extra launch;
+//   the block that draws the last ticket publishes the counts (device copy for the write-back, pinned copy for the step
+//   driver: every other block's list entries were stored write-through and acknowledged before its ticket).
+// The two sentinel key values have slots of their own behind the table (no hashing: EMPTY_KEY is the free-slot marker).
+constexpr int SP_NT = 1024;
+constexpr unsigned SP_LDS = 2048;
+struct SetTab {   // one of the plan's two tables
+  i64* gkey;        // [m2 + 2]   EMPTY_KEY = free (the two sentinel slots: EMPTY_KEY = free, else taken)
+  uint2* gpc;       // [m2 + 2]   (last position + 1, occurrences)
+  i64* ukeys;       // [n] dense list: the distinct keys, in no particular order
+  unsigned* uslot;  // [n] their slots
+  unsigned* count;  // number of distinct keys (zero before its build)
+};
+
+__global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
+                                                        unsigned* d_counts, unsigned* host_counts, unsigned gen) {
+  __shared__ i64 s_key[SP_LDS];
+  __shared__ unsigned s_pos[SP_LDS + 2], s_cnt[SP_LDS + 2];
+  __shared__ unsigned s_n, s_base, s_last;
+  const unsigned tid = threadIdx.x;
+  const unsigned n_old = *old.count;   // (read before anybody can zero it: the last block does, at its very end)
+  for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; s_cnt[i] = 0; }
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  // ---- A: equal ids of the block meet in LDS ---------------------------------------------------------------
+  const size_t gid = (size_t)blockIdx.x * SP_NT + tid;
+  if (gid < n) {
+    const i64 id = ids[gid];
+    unsigned slot;
+    if (is_reserved_key(id)) slot = SP_LDS + (unsigned)reserved_index(id);
+    else {
+      slot = (unsigned)(fmix64((u64)id) >> 41) & (SP_LDS - 1);
+      for (;;) {
+        const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&s_key[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)id);
+        if (was == EMPTY_KEY || was == id) break;
+        slot = (slot + 1) & (SP_LDS - 1);
+      }
+    }
+    atomicMax(&s_pos[slot], (unsigned)gid + 1u);
+    atomicAdd(&s_cnt[slot], 1u);
+  }
+  __syncthreads();
+  // ---- B: the block's distinct ids into the global table --------------------------------------------------
+  i64 mykey[2];
+  unsigned myslot[2], myidx[2];
+  bool mine[2] = {false, false};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned s = tid + (unsigned)r * SP_NT;   // 2048 hash slots; the two sentinel slots ride with threads 0 and 1 below
+    i64 key = s_key[s];
+    unsigned p1 = s_pos[s], c = s_cnt[s];
+    bool have = p1 != 0;
+    unsigned sl = 0;
+    if (have) {
+      sl = (unsigned)(fmix64((u64)key) >> 20) & (m2 - 1);
+      for (;;) {
+        const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + sl), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (was == EMPTY_KEY) { mine[r] = true; break; }
+        if (was == key) break;
+        sl = (sl + 1) & (m2 - 1);
+      }
+      atomicMax(&cur.gpc[sl].x, p1);
+      atomicAdd(&cur.gpc[sl].y, c);
+    }
+    mykey[r] = key; myslot[r] = sl;
+    myidx[r] = mine[r] ? atomicAdd(&s_n, 1u) : 0u;
+  }
+  if (tid < 2 && s_pos[SP_LDS + tid] != 0) {   // a sentinel key value occurred in this block
+    const unsigned sl = m2 + tid;
+    const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + sl), (unsigned long long)EMPTY_KEY, 1ULL);
+    atomicMax(&cur.gpc[sl].x, s_pos[SP_LDS + tid]);
+    atomicAdd(&cur.gpc[sl].y, s_cnt[SP_LDS + tid]);
+    if (was == EMPTY_KEY) {
+      const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
+      store_wt8(cur.ukeys + at, (u64)(EMPTY_KEY + (i64)tid));
+      __hip_atomic_store(cur.uslot + at, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) s_base = s_n ? atomicAdd(cur.count, s_n) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (!mine[r]) continue;
+    store_wt8(cur.ukeys + s_base + myidx[r], (u64)mykey[r]);
+    __hip_atomic_store(cur.uslot + s_base + myidx[r], myslot[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- C: empty the slots the previous build used in the OTHER table ------------------------------------------
+  for (size_t i = gid; i < n_old; i += (size_t)gridDim.x * SP_NT) {
+    const unsigned sl = old.uslot[i];
+    old.gkey[sl] = EMPTY_KEY;
+    old.gpc[sl] = make_uint2(0u, 0u);
+  }
+  // ---- the last block publishes --------------------------------------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's list entries are in memory
+  __syncthreads();
+  if (tid == 0) s_last = __hip_atomic_fetch_add(d_counts + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last || tid != 0) return;
+  const unsigned U = __hip_atomic_load(cur.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // agent-scope stores (write-through): the step driver launches the write-back as soon as the pinned flag below shows this
+  // build — that kernel may start on another XCD before this one has ended
+  const unsigned v[6] = {0u, U, 0u, 0u, 0u, 0u};
+  for (int k = 0; k < 6; ++k) __hip_atomic_store(d_counts + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<u64*>(d_counts + 32), (u64)U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(d_counts + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket counter of the next build
+  __hip_atomic_store(old.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the other table is empty again: its next build counts from zero
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (host_counts) {
+    for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ void fill_i64_kernel(i64* p, size_t n, i64 v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
 }  // namespace
@@ -1463,7 +1476,7 @@ struct tfra_sparse_plan {
   OwnItem* slow_items = nullptr;   // [SLOW_CAP] left-over keys of the ownership pass of a write-back (self-contained items)
   unsigned* any_deferred = nullptr;   // = use_gen of the last write-back that deferred a key to its eviction phase
   mutable unsigned use_gen = 0;
-  mutable unsigned ups_uses = 0;   // upsert_planned uses: parity selects the left-over counter (SlowIter)
+  mutable unsigned ups_uses = 0;   // upsert_planned uses: parity selects the left-over counter set
   float* partial = nullptr;
   int* prow_dest = nullptr;        // [partial rows] scratch of tfra_plan_positions_to
   bool armed = false;              // cursors/counters are zero (re-armed by the last kernel of the previous build)
@@ -1471,6 +1484,16 @@ struct tfra_sparse_plan {
   unsigned gen = 0;                // generation of the last enqueued build
   bool ev_recorded = false;        // the last build ran on a side stream (tfra_table_step_prefetch)
   unsigned last_used_step = 0;     // last step whose write-back read this plan
+  // SET plan (dim 0): its own buffer; two tables alternate (setplan_kernel)
+  int kind = 0;                    // 0 CSR, 1 SET
+  void* setbuf = nullptr;
+  size_t set_cap = 0;              // ids the set buffer was sized for
+  unsigned set_m2 = 0;
+  SetTab set_tab[2]{};
+  unsigned set_parity = 0;         // table of the last build
+  unsigned* set_counts = nullptr;  // the d_counts block of the set buffer
+  uint8_t* set_dflag = nullptr;
+  OwnItem* set_items = nullptr;
 };
 
 extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
@@ -1485,12 +1508,57 @@ extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
 extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
   if (!pl) return TFRA_OK;
   if (pl->buf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->buf); }
+  if (pl->setbuf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->setbuf); }
   if (pl->host_counts) (void)hipHostFree(pl->host_counts);
   delete pl;
   return TFRA_OK;
 }
 
 static size_t plan_smem_bytes(unsigned cm) { return (size_t)cm * 36 + (size_t)TABW * 4; }
+
+// The SET plan of a batch (dim 0): see setplan_kernel.
+static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hipStream_t s) {
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  if (pl->set_cap < n) {
+    if (pl->setbuf) {
+      if (hipDeviceSynchronize() != hipSuccess || hipFree(pl->setbuf) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: free");
+      pl->setbuf = nullptr; pl->set_cap = 0;
+    }
+    const size_t cap = std::max<size_t>(n, 4096);
+    unsigned m2 = 4096;
+    while ((size_t)m2 < 2 * cap) m2 <<= 1;
+    const size_t tab = al(((size_t)m2 + 2) * 8) * 2 + al(cap * 8) + al(cap * 4);   // gkey, gpc, ukeys, uslot
+    const size_t bytes = 512 + al(cap) + al((size_t)SLOW_CAP * sizeof(OwnItem)) + 2 * tab;
+    hipError_t e = hipMalloc(&pl->setbuf, bytes);
+    if (e != hipSuccess) { pl->setbuf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
+    if (hipMemsetAsync(pl->setbuf, 0, bytes, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+    unsigned char* w = (unsigned char*)pl->setbuf;
+    pl->set_counts = (unsigned*)w; w += 512;          // [0..5] counts [6] ticket [8] any_deferred [12..19] OwnCtrs x2 [20,21] list counts [32] i64 count
+    pl->set_dflag = (uint8_t*)w; w += al(cap);
+    pl->set_items = (OwnItem*)w; w += al((size_t)SLOW_CAP * sizeof(OwnItem));
+    for (int p = 0; p < 2; ++p) {
+      SetTab& tb = pl->set_tab[p];
+      tb.gkey = (i64*)w; w += al(((size_t)m2 + 2) * 8);
+      tb.gpc = (uint2*)w; w += al(((size_t)m2 + 2) * 8);
+      tb.ukeys = (i64*)w; w += al(cap * 8);
+      tb.uslot = (unsigned*)w; w += al(cap * 4);
+      tb.count = pl->set_counts + 20 + p;
+      fill_i64_kernel<<<256, 256, 0, s>>>(tb.gkey, (size_t)m2 + 2, EMPTY_KEY);
+    }
+    pl->set_cap = cap; pl->set_m2 = m2; pl->set_parity = 1;
+  }
+  const unsigned p = pl->set_parity ^ 1u;
+  pl->gen += 1;
+  const unsigned blocks = (unsigned)((n + SP_NT - 1) / SP_NT);
+  setplan_kernel<<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, pl->set_tab[p], pl->set_tab[p ^ 1u], pl->set_counts,
+                                          pl->host_counts, pl->gen);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
+  pl->set_parity = p;
+  pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
+  pl->n = n; pl->dim = 0; pl->kind = 1;
+  return TFRA_OK;
+}
 
 extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const int64_t* ids, int dim, tfra_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1499,6 +1567,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
   pl->n = 0;
   if (n == 0) return TFRA_OK;
   if (!ids) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null ids");
+  if (dim == 0) return setplan_build(pl, n, ids, s);   // assign-only: the last position and the count of every distinct id
   if (dim < 0 || dim % 4 != 0 || dim > 64 * MAXCH)
     return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: needs dim % 4 == 0 and dim <= 256 (dim 0: assign-only plan)");
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
@@ -1587,7 +1656,7 @@ extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const in
                                                            pl->dkeys, pl->binmap, pl->cursors, P, pl->d_counts, pl->host_counts, pl->gen);
   pl->armed = true;
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
-  pl->n = n; pl->npad = npad; pl->ntiles = ntiles; pl->P = P; pl->cm = cm; pl->dim = dim;
+  pl->n = n; pl->npad = npad; pl->ntiles = ntiles; pl->P = P; pl->cm = cm; pl->dim = dim; pl->kind = 0;
   return TFRA_OK;
 }
 
@@ -1607,7 +1676,11 @@ static void plan_grids(const tfra_sparse_plan* pl, unsigned* key_blocks, unsigne
 }
 
 static CsrKeys keys_of(const tfra_sparse_plan* pl) {
-  return CsrKeys{pl->keymap, pl->dkeys, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts};
+  if (pl->kind == 1) {
+    const SetTab& tb = pl->set_tab[pl->set_parity];
+    return CsrKeys{nullptr, nullptr, nullptr, nullptr, nullptr, pl->d_counts, tb.ukeys, tb.uslot, tb.gpc};
+  }
+  return CsrKeys{pl->keymap, pl->dkeys, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts, nullptr, nullptr, nullptr};
 }
 
 template <int KIND>
@@ -1682,9 +1755,14 @@ template <int SRC>
 static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og,
                        unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
   const unsigned blocks = (unsigned)std::max<size_t>(1, (nkeys + 63) / 64);   // 4 waves x 16 keys per block and pass
-#define TFRA_OWN(GG, SS)                                                                                   \
-  upsert_own_kernel<GG, SS, SRC><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val);               \
-  upsert_rest_kernel<GG, SRC><<<rest_blocks, 256, 0, s>>>(a, &ctr->n_a, reinterpret_cast<unsigned*>(next_ctr))
+  // a.tags == nullptr (TFRA_OPTION_NO_OWNER_TAGS, or the tags did not allocate): the locked protocol for every key
+#define TFRA_OWN(GG, SS)                                                                                      \
+  if (a.tags) {                                                                                               \
+    upsert_own_kernel<GG, SS, SRC><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val);                \
+    upsert_rest_kernel<GG, SRC><<<rest_blocks, 256, 0, s>>>(a, &ctr->n_a, reinterpret_cast<unsigned*>(next_ctr)); \
+  } else {                                                                                                    \
+    upsert_rest_kernel<GG, SRC><<<(unsigned)std::max<size_t>(1, (nkeys + 15) / 16), 256, 0, s>>>(a, nullptr, nullptr); \
+  }
   switch (g) {
     case 16: if (simple) { TFRA_OWN(16, true); } else { TFRA_OWN(16, false); } break;
     case 8: TFRA_OWN(8, false); break;
@@ -1729,9 +1807,10 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   const unsigned char* vals = (const unsigned char*)values;
   const u64* sc = (const u64*)scores;
   const unsigned gen = ++pl->use_gen;
-  unsigned* tags = t->ensure_own_tags(s);    // nullptr (allocation failed): every key takes the general two-kernel path
-  if (tags) {
-    const unsigned og = next_own_gen(t);
+  unsigned* tags = t->ensure_own_tags(s);    // nullptr (no owner tags): every key takes the locked protocol
+  (void)gen;
+  {
+    const unsigned og = tags ? next_own_gen(t) : 0;
     const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
     OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
     OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
@@ -1743,22 +1822,8 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
     OwnArgs a{};
     a.v = v; a.vals = vals; a.scores = sc; a.ks = keys_of(pl); a.keys = nullptr; a.nkeys = 0; a.ai = t->aux; a.sp = sp;
     a.dflag = pl->dflag; a.tags = tags; a.items = pl->slow_items; a.item_cap = SLOW_CAP;
-    launch_own<SRC_PLAN>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, rem_blocks, progress, progress_val);
-  } else {
-#define TFRA_UPS(GG)                                                                                                          \
-    upsert_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag, pl->any_deferred, gen,   \
-                                                     nullptr, nullptr, nullptr);                                             \
-    if (sp.bounded)                                                                                                           \
-      upsert_evict_csr_kernel<GG><<<key_blocks, 256, 0, s>>>(v, vals, sc, keys_of(pl), t->aux, sp, pl->dflag,                  \
-                                                             pl->any_deferred, gen, nullptr, nullptr, nullptr);
-    switch (g) {
-      case 16: TFRA_UPS(16); break;
-      case 8: TFRA_UPS(8); break;
-      case 4: TFRA_UPS(4); break;
-      case 2: TFRA_UPS(2); break;
-      default: TFRA_UPS(1); break;
-    }
-#undef TFRA_UPS
+    if (pl->kind == 1) launch_own<SRC_SET>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, rem_blocks, progress, progress_val);
+    else launch_own<SRC_PLAN>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, rem_blocks, progress, progress_val);
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");
   step_epoch_public(t);
@@ -1833,6 +1898,19 @@ extern "C" int tfra_sparse_plan_read(const tfra_sparse_plan_t* pl, uint32_t* cou
     return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
   const unsigned nhot = counts[0], ncold = counts[1], nbins = counts[3];
   if (!keys) return TFRA_OK;
+  if (pl->kind == 1) {   // SET plan: distinct keys and their occurrence counts; it keeps no positions list
+    if (positions) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_read: an assign-only plan keeps the last position of a key, not the list of its positions");
+    if ((size_t)ncold > cap) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: buffers too small");
+    const SetTab& tb = pl->set_tab[pl->set_parity];
+    std::vector<unsigned> sl(ncold);
+    std::vector<uint2> pc((size_t)pl->set_m2 + 2);
+    if ((ncold && hipMemcpyAsync(keys, tb.ukeys, (size_t)ncold * 8, hipMemcpyDeviceToHost, s) != hipSuccess) ||
+        (ncold && hipMemcpyAsync(sl.data(), tb.uslot, (size_t)ncold * 4, hipMemcpyDeviceToHost, s) != hipSuccess) ||
+        hipMemcpyAsync(pc.data(), tb.gpc, pc.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
+    for (unsigned i = 0; i < ncold; ++i) cnt[i] = pc[sl[i]].y;
+    return TFRA_OK;
+  }
   if ((size_t)nhot + ncold > cap) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: buffers too small");
   const CsrOut& o = pl->out;
   const size_t nrec_c = (size_t)NSH * o.cr, nrec_h = (size_t)NSH * o.hr, nbin = (size_t)NSH * o.br;
@@ -2073,6 +2151,7 @@ extern "C" int tfra_plan_reduce_to(const tfra_sparse_plan_t* pl, const float* gr
                                    tfra_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!pl) return set_error(TFRA_ERR_INVALID, "plan_reduce_to: null plan");
+  if (pl->kind == 1) return set_error(TFRA_ERR_UNSUPPORTED, "plan_reduce_to: needs a plan built with the table's dim");
   if (pl->n == 0) return TFRA_OK;
   if (!grads || !dest || !rows_out) return set_error(TFRA_ERR_INVALID, "plan_reduce_to: null buffer");
   const int dim = pl->dim;
@@ -2145,6 +2224,7 @@ __global__ __launch_bounds__(NTA) void plan_dest_bins_kernel(const unsigned* __r
 extern "C" int tfra_plan_partition(const tfra_sparse_plan_t* pl, tfra_workspace_t* ws, int num_shards, int mode,
                                    int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream) {
   if (!pl || pl->n == 0) return set_error(TFRA_ERR_INVALID, "plan_partition: no built plan");
+  if (pl->kind == 1) return set_error(TFRA_ERR_UNSUPPORTED, "plan_partition: needs a plan built with the table's dim (an assign-only plan keeps no positions)");
   return tfra_partition(ws, pl->n, reinterpret_cast<const int64_t*>(pl->d_counts + 32), (const int64_t*)pl->dkeys, num_shards, mode,
                         keys_out, perm_out, d_counts, stream);
 }
@@ -2152,6 +2232,7 @@ extern "C" int tfra_plan_partition(const tfra_sparse_plan_t* pl, tfra_workspace_
 extern "C" int tfra_plan_positions_to(const tfra_sparse_plan_t* pl, const int32_t* perm, int32_t* dest_out, tfra_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!pl || pl->n == 0) return set_error(TFRA_ERR_INVALID, "plan_positions_to: no built plan");
+  if (pl->kind == 1) return set_error(TFRA_ERR_UNSUPPORTED, "plan_positions_to: needs a plan built with the table's dim (an assign-only plan keeps no positions)");
   if (!perm || !dest_out) return set_error(TFRA_ERR_INVALID, "plan_positions_to: null buffer");
   { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != pl->device) { if (hipSetDevice(pl->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "plan_positions_to: hipSetDevice"); } }
   unsigned key_blocks, bin_blocks;

@@ -543,8 +543,9 @@ class MultiTablePrefetchStep:
     return self
 
   def step(self, grads_list, next_ids_list=None):
-    """grads_list[i]: [n_i, dim_i] float32 gradients of table i's staged batch; next_ids_list[i]: its next batch (complete
-    in memory: the streams of this driver do not wait for the caller's stream) or None at the end."""
+    """grads_list[i]: [n_i, dim_i] float32 gradients of table i's staged batch; next_ids_list[i]: its next batch or None at the
+    end.  Ordered against the caller's current stream both ways (inputs produced there are waited for, the returned rows are
+    safe to consume there)."""
     cur, nxt_slot = self.cur, (self.cur + 1) % self.NPLANS
     p = self.deo.begin_step()
     outs, keep = [], [p]
@@ -573,7 +574,27 @@ class MultiTablePrefetchStep:
       self.ids[i][nxt_slot] = nxt
       outs.append(out)
       keep.append(g)
+    # The tables run on this driver's own streams.  What the caller produced on ITS stream — the gradients of backward, the
+    # float32 / contiguous copies made above, the next ids — must be complete before any of them reads it, and what they
+    # produce (the looked-up rows) before the caller's stream consumes it: one event each way, and the caching allocator is
+    # told which streams use the buffers (it would otherwise hand `out` / `g` to someone else as soon as the caller drops them).
+    caller = torch.cuda.current_stream(self.dev)
+    ready = torch.cuda.Event()
+    ready.record(caller)
+    for st in self.main + self.side:
+      st.wait_event(ready)
+    for i in range(len(self.vars)):
+      ms, ss = self.main[i % len(self.main)], self.side[i % len(self.side)]
+      outs[i].record_stream(ms)
+      keep[1 + i].record_stream(ms)
+      if self.ids[i][nxt_slot] is not None:
+        self.ids[i][nxt_slot].record_stream(ss)
+        self.ids[i][nxt_slot].record_stream(ms)
     _capi.call("tfra_multi_step_prefetch", len(self.vars), ctypes.cast(self.descs, ctypes.c_void_p), self.workers)
+    for st in self.main:
+      done = torch.cuda.Event()
+      done.record(st)
+      caller.wait_event(done)   # `outs` are safe to use on the caller's stream
     self._keep = keep   # buffers of the step in flight stay alive until the next call
     self.cur = nxt_slot
     return outs
@@ -604,6 +625,7 @@ class PrefetchAssignStep:
     self.default = self.table._default_value
     self.side = torch.cuda.Stream(device=self.dev)
     self.cur = 0
+    self._main = None
 
   def prime(self, ids):
     ids = torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
@@ -612,31 +634,41 @@ class PrefetchAssignStep:
     return self
 
   def step(self, values, next_ids=None, scores=None, lookup=True, next_ids_ready=True):
-    """next_ids_ready: see PrefetchStep.step."""
-    from .table_ops import _ptr
+    """next_ids_ready: see PrefetchStep.step.  (The host side of a step is kept short — cached function pointer and stream
+    handles, no per-call name lookups: with six kernel launches behind it this call IS the step time once the kernels are
+    faster than the host can launch them.)"""
     cur = self.cur
     nxt_slot = (cur + 1) % self.NPLANS
     ids = self.ids[cur]
     n = ids.numel()
-    values = values.reshape(n, self.table.dim)
-    if values.dtype != self.table.value_dtype or not values.is_contiguous():
-      values = values.to(self.table.value_dtype).contiguous()
-    out = torch.empty((n, self.table.dim), dtype=self.table.value_dtype, device=self.dev) if lookup else None
+    dim, vdt, dev = self.table.dim, self.table.value_dtype, self.dev
+    if values.dtype != vdt or not values.is_contiguous() or values.dim() != 2:
+      values = values.reshape(n, dim).to(vdt).contiguous()
+    out = torch.empty((n, dim), dtype=vdt, device=dev) if lookup else None
     nxt = None
-    main = torch.cuda.current_stream(self.dev)
+    if self._main is None:
+      main = torch.cuda.current_stream(dev)
+      self._main, self._main_h, self._side_h = main, ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(self.side.cuda_stream)
+      self._fn = _capi.lib().tfra_table_step_prefetch_assign
+      self._default_p = ctypes.c_void_p(self.default.data_ptr())
+    elif torch.cuda.current_stream(dev) != self._main:
+      main = torch.cuda.current_stream(dev)
+      self._main, self._main_h = main, ctypes.c_void_p(main.cuda_stream)
     if next_ids is not None:
       nxt = next_ids
-      if not (torch.is_tensor(nxt) and nxt.dtype == torch.int64 and nxt.dim() == 1 and nxt.is_contiguous() and
-              nxt.device == self.dev):
-        nxt = torch.as_tensor(next_ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+      if not (torch.is_tensor(nxt) and nxt.dtype == torch.int64 and nxt.dim() == 1 and nxt.is_contiguous() and nxt.device == dev):
+        nxt = torch.as_tensor(next_ids, device=dev).reshape(-1).to(torch.int64).contiguous()
       nxt.record_stream(self.side)
       self.ids[nxt_slot] = nxt
       if not next_ids_ready:
-        self.side.wait_stream(main)
+        self.side.wait_stream(self._main)
+    sp = None
     if scores is not None:
-      scores = scores.to(self.dev, torch.int64).contiguous()
-    _capi.call("tfra_table_step_prefetch_assign", self.table._h, self.plans[cur]._h, _ptr(ids), _ptr(out), _ptr(self.default),
-               _ptr(values), _ptr(scores), self.plans[nxt_slot]._h if nxt is not None else None, _ptr(nxt),
-               0 if nxt is None else nxt.numel(), ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(self.side.cuda_stream))
+      scores = scores.to(dev, torch.int64).contiguous()
+      sp = ctypes.c_void_p(scores.data_ptr())
+    _capi.check(self._fn(self.table._h, self.plans[cur]._h, ctypes.c_void_p(ids.data_ptr()),
+                         ctypes.c_void_p(out.data_ptr()) if lookup else None, self._default_p, ctypes.c_void_p(values.data_ptr()), sp,
+                         self.plans[nxt_slot]._h if nxt is not None else None, ctypes.c_void_p(nxt.data_ptr()) if nxt is not None else None,
+                         0 if nxt is None else nxt.numel(), self._main_h, self._side_h))
     self.cur = nxt_slot
     return out

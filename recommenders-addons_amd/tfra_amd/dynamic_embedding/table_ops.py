@@ -419,9 +419,9 @@ class SparsePlan:
     u = counts[0] + counts[1]
     keys = np.empty(u, np.int64)
     cnt = np.empty(u, np.uint32)
-    pos = np.empty(self.n, np.uint32)
+    pos = np.empty(self.n, np.uint32) if self._dim else None   # an assign-only plan (dim 0) keeps the last position of a key only
     _capi.call("tfra_sparse_plan_read", self._h, counts, keys.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p),
-               pos.ctypes.data_as(ctypes.c_void_p), u, _stream(self._device))
+               pos.ctypes.data_as(ctypes.c_void_p) if pos is not None else None, u, _stream(self._device))
     names = ("many", "few", "partials", "bins", "few_entries", "errors")
     return dict(zip(names, list(counts))), keys, cnt, pos
 

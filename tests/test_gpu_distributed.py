@@ -146,7 +146,7 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   env = dict(os.environ, TFRA_BENCH_BACKEND="gloo", TFRA_BENCH_ROUTE=route, HSA_ENABLE_IPC_MODE_LEGACY="0")
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(29990 + (route == "native")), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-         "--keys", "300000", "--batch", "8192", "--no-cpu-baseline"]
+         "--c4-keys", "300000", "--batch", "8192", "--no-cpu-baseline"]
   p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
   assert p.returncode == 0, p.stderr[-3000:]
   lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -155,3 +155,6 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
   assert d["config"]["global_batch"] == 2 * 8192
   assert "roofline" in d and d["unit"] == "pairs/s"
+  # every N runs ONE per-GPU workload, BASELINE configs[3] (hash-sharded, per-GPU batch from the global Zipf, routed)
+  assert d["config"]["workload"].startswith("BASELINE configs[3]") and d["config"]["route"] == route
+  assert d["config"]["timing"]["value"]["windows"] == 5 and d["config"]["timing"]["value"]["steps_per_window"] == 6

@@ -182,3 +182,98 @@ def test_c3_1e8_slots_bench_path_properties(env, cap):
   m = int(cnt.item())
   assert m > 2_000_000 and kbuf[:m].unique().numel() == m
   assert torch.equal(vbuf[:50_000], row_of(torch, kbuf[:50_000], dim, torch.float16))
+
+
+def test_metric_config_1e9_slots_benchmarked_paths(env):
+  """BASELINE.json's metric configuration at its FULL size — a 10^9-slot bounded LRU table, dim 64 fp32 (273 GB of the
+  288 GB) — through the three paths bench.py times: the look-ahead step driver (tfra_table_step_prefetch_assign), the plain
+  calls (find + upsert_sparse) and the reference's op surface (find -> unique -> insert_or_assign with unique keys, the
+  ownership pass fed directly).  Rows are a closed form of (key, version), so every lookup is checkable on the device:
+  size <= capacity; a resident key returns its own row bit-exactly; never-seen ids miss before their write-back and hit
+  after it; repeats: the LAST occurrence wins; no slot stays locked; check_errors is clean; exported keys are unique."""
+  torch, de = env
+  from bench import keys_of_ranks_torch, IdFactory
+  dim, B, cap = 64, 131072, 1_000_000_000
+  try:
+    t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                        evict_strategy=de.HkvEvictStrategy.LRU, name="m1b_full")
+  except Exception as e:   # a box with less free HBM than the benchmark needs
+    pytest.skip("10^9 slots do not allocate here: %s" % str(e)[:120])
+  tbl = t._table
+  capacity = tbl.capacity()
+  for lo in range(1, cap + 1, 4_000_000):
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(cap, lo + 3_999_999) + 1, dtype=torch.int64, device="cuda"))
+    tbl.upsert(k, row_of(torch, k, dim), unique_keys=True)
+  n0 = int(t.size().item())
+  assert 0.9 * cap < n0 <= capacity
+
+  def versioned(keys, ver):   # the row a key gets when it is written in step `ver`
+    return row_of(torch, keys * 31 + ver, dim)
+
+  # resident keys return the row of their pre-fill (those the pre-fill's own evictions removed miss)
+  idf = IdFactory(torch, torch.device("cuda", 0), B, cap, 0.25, cap + 1, 1234)   # 25 % never-seen ids per batch
+  ids = idf.keys(1)[0]
+  out, ex = t.lookup(ids, return_exists=True)
+  assert torch.equal(out[ex], row_of(torch, ids, dim)[ex])
+  assert not bool(ex[idf.pos].any())            # the never-seen quarter of the batch misses
+  # (the pre-fill's own evictions took the OLDEST entries = the lowest ranks = the hottest ids of the Zipf stream: a good part
+  # of the remaining positions misses too until the first steps have written those ids back)
+  assert float(ex.float().mean()) > 0.2
+  written = {}   # key tensor -> version, for a final spot check
+
+  # (1) look-ahead driver: 6 steps, values differ per step AND per position (repeats: the last one wins)
+  batches = idf.keys(7)
+  ps = de.PrefetchAssignStep(t).prime(batches[0])
+  for s in range(6):
+    b = batches[s]
+    pos = torch.arange(B, device="cuda")
+    vals = versioned(b, 100 + s) + (pos[:, None] % 7).to(torch.float32)     # position-dependent: tells WHICH occurrence was kept
+    fresh = b[~t.lookup(b, return_exists=True)[1]]
+    ps.step(vals, batches[s + 1])
+    got, ex = t.lookup(b, return_exists=True)
+    assert bool(ex.all())                                                   # written back (never-seen ids included)
+    uk, inv = torch.unique(b, return_inverse=True)
+    lp = torch.zeros(uk.numel(), dtype=torch.long, device="cuda")
+    lp.scatter_reduce_(0, inv, pos, reduce="amax", include_self=False)
+    assert torch.equal(got, vals[lp][inv])
+    assert fresh.numel() > B // 8
+    assert int(t.size().item()) <= capacity
+  del ps
+  # (2) plain calls
+  for s in range(4):
+    b = idf.keys(1)[0]
+    vals = versioned(b, 200 + s)
+    out, ex = t.lookup(b, return_exists=True)
+    tbl.upsert_sparse(b, vals)
+    got, ex2 = t.lookup(b, return_exists=True)
+    assert bool(ex2.all()) and torch.equal(got, vals)
+  # (3) op surface: unique keys straight into insert_or_assign (TFRA_FLAG_UNIQUE_KEYS)
+  for s in range(4):
+    b = idf.keys(1)[0]
+    u, _, _ = de.device_ops.unique(b)
+    vals = versioned(u, 300 + s)
+    miss_before = ~t.lookup(u, return_exists=True)[1]
+    tbl.upsert(u, vals, unique_keys=True)
+    got, ex2 = t.lookup(u, return_exists=True)
+    assert bool(ex2.all()) and torch.equal(got, vals)
+    assert int(miss_before.sum().item()) > u.numel() // 8                    # never-seen ids did miss before
+    written[s] = (u[:4096].clone(), vals[:4096].clone())
+  for s, (k, v) in written.items():
+    if s == 3:   # the last call's keys are still there (earlier ones may have been overwritten by later batches' hot ids)
+      got, ex = t.lookup(k, return_exists=True)
+      assert bool(ex.all()) and torch.equal(got, v)
+  c = tbl.slot_census()
+  assert c["locked"] == 0 and c["live"] == int(t.size().item()) <= capacity
+  tbl.check_errors()
+  kbuf = torch.empty(2_000_000, dtype=torch.int64, device="cuda")
+  vbuf = torch.empty((2_000_000, dim), dtype=torch.float32, device="cuda")
+  cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+  from tfra_amd import _capi
+  from tfra_amd.dynamic_embedding.table_ops import _ptr, _stream
+  _capi.call("tfra_table_export_batch", tbl._h, 1_500_000, capacity // 3, _ptr(cnt), _ptr(kbuf), _ptr(vbuf), None, _stream(tbl.device))
+  m = int(cnt.item())
+  assert m > 1_000_000 and kbuf[:m].unique().numel() == m
+  del t, tbl, kbuf, vbuf
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
