@@ -25,7 +25,8 @@ namespace {
 
 // 16 lanes per key; lane `sub` owns elements sub*4..sub*4+3 (+64 per step): float4 everywhere
 // when dim % 4 == 0 (VEC4), scalar otherwise.
-template <int KIND, bool VEC4>
+// ST: storage type of the rows (tfra_dtype F32 / F16 / BF16); VEC4 only with float rows.
+template <int KIND, bool VEC4, int ST = TFRA_F32>
 __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
                                                     const float* __restrict__ grads,
                                                     const float* __restrict__ defaults, int full, int dim,
@@ -78,23 +79,30 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
           if (S >= 2) store_wt16(pr + 2 * dim + c, *reinterpret_cast<uint4*>(&s2));
         }
       } else {
+        typedef typename Stored<ST>::T V;
+        V* sr = reinterpret_cast<V*>(row_ptr(v, row));
         for (int c = sub; c < dim; c += 16) {
           float p, s1 = aux0, s2 = aux1;
           if (is_new) {
             p = df[c];
           } else {
-            p = pr[c];
-            if (S >= 1) s1 = pr[dim + c];
-            if (S >= 2) s2 = pr[2 * dim + c];
+            p = load_stored<ST>(sr + c);
+            if (S >= 1) s1 = load_stored<ST>(sr + dim + c);
+            if (S >= 2) s2 = load_stored<ST>(sr + 2 * dim + c);
           }
           apply_one<KIND>(o, gr[c], p, s1, s2);
-          pr[c] = p;
-          if (S >= 1) pr[dim + c] = s1;
-          if (S >= 2) pr[2 * dim + c] = s2;
+          sr[c] = to_stored<ST>(p);
+          if (S >= 1) sr[dim + c] = to_stored<ST>(s1);
+          if (S >= 2) sr[2 * dim + c] = to_stored<ST>(s2);
+        }
+        // aux fields the optimizer does not own (table created with more slots than it uses)
+        if (is_new && (int)v.n_fields - 1 > S) {
+          for (int f = S + 1; f < (int)v.n_fields; ++f)
+            for (int c = sub; c < dim; c += 16) sr[f * dim + c] = to_stored<ST>(f == 1 ? aux0 : aux1);
         }
       }
       // aux fields the optimizer does not own (table created with more slots than it uses)
-      if (is_new && (int)v.n_fields - 1 > S) {
+      if (VEC4 && is_new && (int)v.n_fields - 1 > S) {
         for (int f = S + 1; f < (int)v.n_fields; ++f)
           for (int c = sub; c < dim; c += 16) pr[f * dim + c] = (f == 1 ? aux0 : aux1);
       }
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void apply_kernel(TableView v, OptP o, size_t 
 // minimum-score entry of its two home buckets and starts from the default row / initial slot values —
 // what find (miss -> default) + dense apply + upsert (evicting) give in the reference
 // (PY/dynamic_embedding_optimizer.py:165-204 on an HkvHashTable, lookup_table_op_hkv.h:522-537).
-template <int KIND>
+template <int KIND, int ST = TFRA_F32>
 __global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, size_t n, const i64* __restrict__ keys,
                                                           const float* __restrict__ grads,
                                                           const float* __restrict__ defaults, int full, int dim,
@@ -135,11 +143,12 @@ __global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, s
     bool claimed_empty;
     i64 row = evict_and_lock(v, key, in_score, lru_like, sub, gshift, &word, claimed_empty);
     if (row >= 0) {
-      float* pr = reinterpret_cast<float*>(row_ptr(v, row));
+      typedef typename Stored<ST>::T V;
+      V* pr = reinterpret_cast<V*>(row_ptr(v, row));
       const float* gr = grads + g * (size_t)dim;
       const float* df = defaults + (full ? g * (size_t)dim : 0);
       // write-through stores: the row is in memory before the key is published (publish_key)
-      auto st = [](float* q, float x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      auto st = [](V* q, float x) { __hip_atomic_store(q, to_stored<ST>(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
       for (int c = sub; c < dim; c += 16) {
         float p = df[c], s1 = aux0, s2 = aux1;
         apply_one<KIND>(o, gr[c], p, s1, s2);
@@ -165,8 +174,18 @@ __global__ __launch_bounds__(256) void apply_evict_kernel(TableView v, OptP o, s
 }
 
 template <int KIND>
-void launch_apply(bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
+void launch_apply(int dt, bool vec4, dim3 grid, hipStream_t s, TableView v, OptP o, size_t n, const i64* k, const float* g,
                   const float* d, int full, int dim, float a0, float a1, const i64* dn, ScoreP sp, uint8_t* deferred) {
+  if (dt == TFRA_F16) {
+    apply_kernel<KIND, false, TFRA_F16><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
+    if (deferred) apply_evict_kernel<KIND, TFRA_F16><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
+    return;
+  }
+  if (dt == TFRA_BF16) {
+    apply_kernel<KIND, false, TFRA_BF16><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
+    if (deferred) apply_evict_kernel<KIND, TFRA_BF16><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
+    return;
+  }
   if (vec4) apply_kernel<KIND, true><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
   else apply_kernel<KIND, false><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
   if (deferred) apply_evict_kernel<KIND><<<grid, 256, 0, s>>>(v, o, n, k, g, d, full, dim, a0, a1, dn, sp, deferred);
@@ -199,7 +218,9 @@ extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_param
   if (rc) return rc;
   if (n == 0) return TFRA_OK;
   if (!keys || !grads || !param_defaults) return set_error(TFRA_ERR_INVALID, "apply_optimizer: null buffer");
-  if (t->opts.value_dtype != TFRA_F32) return set_error(TFRA_ERR_UNSUPPORTED, "apply_optimizer: value_dtype must be float32");
+  const int dt = t->opts.value_dtype;
+  if (dt != TFRA_F32 && dt != TFRA_F16 && dt != TFRA_BF16)
+    return set_error(TFRA_ERR_UNSUPPORTED, "apply_optimizer: value_dtype must be float32, float16 or bfloat16 (gradients and defaults are float32)");
   int need = p->kind == TFRA_OPT_SGD ? 0 : (p->kind == TFRA_OPT_ADAGRAD ? 1 : 2);
   if (p->kind < 0 || p->kind > TFRA_OPT_FTRL) return set_error(TFRA_ERR_INVALID, "apply_optimizer: unknown kind");
   if (t->opts.aux_fields < need)
@@ -220,10 +241,10 @@ extern "C" int tfra_table_apply_optimizer(tfra_table_t* tp, const tfra_opt_param
   if (rc) return rc;
   const ScoreP sp{t->opts.strategy, t->global_epoch, deferred ? (t->dense ? 2 : 1) : 0};
   switch (p->kind) {
-    case TFRA_OPT_SGD: launch_apply<TFRA_OPT_SGD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
-    case TFRA_OPT_ADAM: launch_apply<TFRA_OPT_ADAM>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
-    case TFRA_OPT_ADAGRAD: launch_apply<TFRA_OPT_ADAGRAD>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
-    default: launch_apply<TFRA_OPT_FTRL>(vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    case TFRA_OPT_SGD: launch_apply<TFRA_OPT_SGD>(dt, vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    case TFRA_OPT_ADAM: launch_apply<TFRA_OPT_ADAM>(dt, vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    case TFRA_OPT_ADAGRAD: launch_apply<TFRA_OPT_ADAGRAD>(dt, vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
+    default: launch_apply<TFRA_OPT_FTRL>(dt, vec4, grid, s, v, o, n, k, grads, d, default_is_full, dim, a0, a1, (const i64*)d_n, sp, deferred); break;
   }
   step_epoch(t);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "apply_optimizer: launch failed");

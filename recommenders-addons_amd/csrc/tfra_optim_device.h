@@ -3,6 +3,7 @@
 // operation order as oracle/optimizers.py; compile with -ffp-contract=off.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include "../../include/tfra_mi355x.h"
 
@@ -40,6 +41,24 @@ __device__ __forceinline__ void apply_one(const OptP& o, float g, float& p, floa
     p = (fabsf(s2) > o.l1) ? (sgnf(s2) * o.l1 - s2) / q : 0.f;
     s1 = a_new;
   }
+}
+
+// Rows of half / bfloat16 tables (GPU value types of the reference: hkv_hashtable_op_gpu.cu.cc:1133-1138) through the fused
+// optimizers: the rule is evaluated in fp32 on the up-cast row and slots, the results are rounded to the storage type once,
+// to nearest even.  ST: 0 float, 1 half, 2 bfloat16 (tfra_dtype).
+template <int ST> struct Stored { typedef float T; };
+template <> struct Stored<TFRA_F16> { typedef __half T; };
+template <> struct Stored<TFRA_BF16> { typedef unsigned short T; };
+template <int ST> __device__ __forceinline__ float load_stored(const typename Stored<ST>::T* p) { return *p; }
+template <> __device__ __forceinline__ float load_stored<TFRA_F16>(const __half* p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float load_stored<TFRA_BF16>(const unsigned short* p) { return __uint_as_float((unsigned)*p << 16); }
+template <int ST> __device__ __forceinline__ typename Stored<ST>::T to_stored(float x) { return x; }
+template <> __device__ __forceinline__ __half to_stored<TFRA_F16>(float x) { return __float2half_rn(x); }
+template <> __device__ __forceinline__ unsigned short to_stored<TFRA_BF16>(float x) {
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
 }
 
 // score strategy of the table + its current epoch (update_score)

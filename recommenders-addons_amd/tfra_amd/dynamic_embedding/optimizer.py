@@ -322,15 +322,17 @@ class DynamicEmbeddingOptimizer:
       return
     if getattr(var, "restrict_policy", None) is not None:  # PY/embedding_weights.py:441-442
       var.restrict_policy.apply_update(ids)
-    if var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and not self.exact_order:
+    if (var.shard_num == 1 and not callable(var.initializer) and var.dim % 4 == 0 and var.dim <= 256 and not self.exact_order and
+        var.value_dtype == torch.float32):
       # whole backward half in two kernels (tile reduce + bucket apply): no host sync, deterministic.  (More than 2^18
       # ids: the library reduces chunk by chunk and applies every key once — tfra_csr.hip: apply_sparse_big.)
       t = var._tables[0]
       t._table.apply_sparse(p, ids, grad, t._default_value.to(torch.float32))
       return
     if var.dim % 4 == 0 and var.dim <= 256 and n <= (1 << 18) and not self.exact_order:
-      # sharded variables / callable initializers: the same parallel, order-fixed duplicate reduction
-      # (tile reduce + bucket merge), then one fused update per unique key and shard.  (unique +
+      # sharded variables / callable initializers / half and bfloat16 rows: the same parallel, order-fixed duplicate reduction
+      # (tile reduce + bucket merge, float32 sums), then one fused update per unique key and shard — on a half / bfloat16
+      # table the rule runs in float32 on the up-cast row and slots and the results are rounded to the storage type once.  (unique +
       # segment_sum walks a segment sequentially: 9 ms for a Zipf batch whose hottest id repeats 24 000 times.)
       uniq_buf, gsum, cnt = device_ops.reduce_by_key(ids, grad)
     else:

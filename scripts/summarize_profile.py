@@ -15,15 +15,23 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["find_kernel", "upsert_own_kernel", "upsert_rest_kernel", "upsert_csr_kernel", "upsert_evict_csr_kernel", "insert_unique_kernel",
+KERNELS = ["find_kernel", "upsert_own_kernel", "upsert_rest_kernel", "setplan_kernel", "insert_unique_kernel",
            "insert_evict_kernel", "export_kernel", "csr_tile_kernel", "csr_bucket_kernel", "csr_scatter_kernel", "hot_sums_kernel",
            "apply_csr_kernel", "apply_kernel", "density_kernel"]
-COMMANDS = {"c3": "python bench.py --config c3 --no-secondary --no-cpu-baseline", "c2": "python bench.py --config c2 --no-secondary --no-cpu-baseline"}
+COMMANDS = {w: "python bench.py --config %s --no-secondary --no-cpu-baseline" % w for w in ("m1b", "c3", "c2")}
+SRC_NAMES = {"0": "plan", "1": "direct", "2": "set"}   # upsert_own_kernel<G, SIMPLE, SRC> / upsert_rest_kernel<G, SRC>: where the keys come from
 
 
 def short(name):
   m = re.search(r"(\w+_kernel)\b", name)
-  return m.group(1) if m and m.group(1) in KERNELS else None
+  if not m or m.group(1) not in KERNELS:
+    return None
+  k = m.group(1)
+  if k in ("upsert_own_kernel", "upsert_rest_kernel"):
+    a = re.search(r"%s<([^>]*)>" % k, name)
+    if a:
+      k += "[%s]" % SRC_NAMES.get(a.group(1).split(",")[-1].strip(), "?")
+  return k
 
 
 def counter_avg(path, names):
@@ -80,13 +88,13 @@ def workload(src, tag, w, out_dir):
                           "wait_any_frac": round(s.get("SQ_WAIT_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), 3),
                           "issue_stall_frac": round(s.get("SQ_WAIT_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), 3),
                           "active_frac": round(s.get("SQ_ACTIVE_INST_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1), 3)}
-  return {"command": "rocprofv3 --kernel-trace --stats -- %s --steps 100 --warmup 10  (+ separate --pmc passes FETCH_SIZE / WRITE_SIZE / "
-                     "TCC_HIT_sum TCC_MISS_sum / SQ_*, --steps 20 --warmup 5)" % COMMANDS[w],
+  return {"command": "rocprofv3 --kernel-trace --stats -- %s --steps 40 --warmup 10 (5 windows)  (+ separate --pmc passes FETCH_SIZE / WRITE_SIZE / "
+                     "TCC_HIT_sum TCC_MISS_sum / SQ_*, --steps 10 --warmup 5)" % COMMANDS[w],
           "kernels": kernels}
 
 
 def main():
-  tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+  tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
   src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
   out_dir = os.path.join(ROOT, "profiles")
   os.makedirs(out_dir, exist_ok=True)
@@ -95,7 +103,7 @@ def main():
                      "Kernel averages mix the timed steps with the per-kernel timing loops of bench.py (same kernels, same shapes) and, for "
                      "insert_unique_kernel / insert_evict_kernel, are the 4 M-key pre-fill launches.  sq_per_wave: SQ_* counters per wave "
                      "(wave_quad_cycles in 4-cycle units; wait_any = parked on s_waitcnt, issue_stall = dependency / pipe stalls)."}
-  for w in ("c3", "c2"):
+  for w in ("m1b", "c3", "c2"):
     r = workload(src, tag, w, out_dir)
     if r:
       summary["workloads"][w] = r

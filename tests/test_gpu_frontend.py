@@ -926,3 +926,55 @@ def test_write_back_plan_started_at_lookup_time(env):
   assert torch.equal(ka[ia], kb[ib]) and torch.equal(va[ia], vb[ib])
   for slot in ("m", "v"):
     assert torch.equal(oa.get_slot(a, slot).lookup(ka[ia]), ob.get_slot(b, slot).lookup(kb[ib]))
+
+
+@pytest.mark.parametrize("vdtype", ["float16", "bfloat16"])
+@pytest.mark.parametrize("kind", ["sgd", "adam", "adagrad", "ftrl"])
+def test_fused_optimizers_on_half_tables(env, kind, vdtype):
+  """configs[2]-shaped training (half rows) no longer falls back to optimizers.Generic: the fused kernels take float16 /
+  bfloat16 tables (GPU value types of the reference: hkv_hashtable_op_gpu.cu.cc:1133-1138) — float32 math on the up-cast
+  row and slots, ONE rounding to the storage type.  Checked against the NumPy rule (oracle/optimizers.py) applied to the
+  up-cast rows: at most 1 ulp of the storage type (the float32 results of kernel and NumPy differ by <= 1e-6 relative, which
+  moves a rounding only when the value sits on a tie)."""
+  torch, de = env
+  from oracle import optimizers as oopt
+  dt = getattr(torch, vdtype)
+  dim, n_keys, B = 32, 500, 4096
+  opt = {"sgd": de.optimizers.SGD(0.1), "adam": de.optimizers.Adam(0.01, 0.9, 0.999, 1e-7),
+         "adagrad": de.optimizers.Adagrad(0.05, 0.1), "ftrl": de.optimizers.Ftrl(0.05, -0.5, 0.1, 1e-3, 1e-3)}[kind]
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  var = de.Variable(dim=dim, name="half_%s_%s" % (kind, vdtype), value_dtype=dt, initializer=0.25, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  rng = np.random.default_rng(3)
+
+  def cast(x):   # float32 -> storage type -> float32, round to nearest even like the kernel
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dt).to(torch.float32).numpy()
+
+  ulp = 2.0 ** -10 if vdtype == "float16" else 2.0 ** -7
+  init_acc = 0.1
+  state = {}   # key -> [p, s1, s2] float32 arrays holding storage-representable values
+  for step in range(1, 5):
+    ids = rng.integers(0, n_keys, size=B).astype(np.int64)
+    g = (rng.standard_normal((B, dim)) * 0.1).astype(np.float32)
+    deo.apply_sparse(var, torch.from_numpy(ids).cuda(), torch.from_numpy(g).cuda())
+    uniq, gsum, _ = oopt.segment_sum_by_key(ids, g)
+    for k, gs in zip(uniq.tolist(), gsum):
+      # a new row starts from the float32 default / initial slot values (not from their rounded images)
+      p, s1, s2 = state.get(k, [np.full(dim, 0.25, np.float32), np.full(dim, init_acc if kind in ("adagrad", "ftrl") else 0.0, np.float32),
+                                np.zeros(dim, np.float32)])
+      if kind == "sgd":
+        p = oopt.sgd(p, gs, 0.1)
+      elif kind == "adam":
+        p, s1, s2 = oopt.adam(p, s1, s2, gs, 0.01, 0.9, 0.999, 1e-7, step)
+      elif kind == "adagrad":
+        p, s1 = oopt.adagrad(p, s1, gs, 0.05)
+      else:
+        p, s1, s2 = oopt.ftrl(p, s1, s2, gs, 0.05, 1e-3, 1e-3)
+      state[k] = [cast(p), cast(s1), cast(s2)]
+  keys = np.array(sorted(state), np.int64)
+  got = var.lookup(torch.from_numpy(keys).cuda()).to(torch.float32).cpu().numpy()
+  want = np.stack([state[k][0] for k in keys.tolist()])
+  # the duplicate sums of the fused path use a fixed tree, the oracle the sequential order: gradient sums differ by ~1e-7
+  # relative, so after four steps a value may sit one storage ulp apart (two where a rounding tie flipped twice)
+  err = np.abs(got - want) / np.maximum(np.abs(want), 2.0 ** -14)
+  assert float(np.quantile(err, 0.999)) <= 2 * ulp and float(err.max()) <= 4 * ulp, (float(err.max()), ulp)
+  assert var.size() == keys.size
