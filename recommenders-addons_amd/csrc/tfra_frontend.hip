@@ -200,6 +200,146 @@ __global__ void unq_idx_kernel(size_t n, const int* __restrict__ slot_of, const 
   if (i < n) idx_out[i] = hrank[slot_of[i]];
 }
 
+// ---- tfra_unique in three launches (n <= 2^20) ------------------------------------------------------------------
+// The six launches above (fill, insert, count, scan, scatter, idx) cost 34 us for 131 072 ids, most of it launch latency.
+//   unq2_insert   as unq_insert_kernel, into one of TWO persistent sets; the thread whose compare-and-swap installed a
+//                 key appends its slot to the set's used list, and the slots the OTHER set used in the previous call are
+//                 emptied on the way (no fill kernel);
+//   unq2_scatter  per tile of 1024 ids: first-occurrence flags, tile count published with the call's generation, the
+//                 tile's offset = sum of the earlier tiles' counts (they are read as they appear: the tiles of a call are
+//                 co-resident, <= 1024 blocks), then the scatter of unq_scatter_kernel; the last tile writes the total;
+//   unq_idx_kernel.
+struct UnqSet {
+  i64* hkeys;       // [cap + 1]
+  int* hfirst;      // [cap + 1]
+  int* hrank;       // [cap + 1]
+  unsigned* used;   // [nmax] slots taken by the set's last call
+  unsigned* nused;  // their number (zero before its call)
+};
+
+__global__ __launch_bounds__(UNQ_INS) void unq2_insert_kernel(size_t n, const i64* __restrict__ ids, UnqSet cur, UnqSet old, int* slot_of,
+                                                              size_t cap) {
+  __shared__ i64 l_id[UNQ_INS];
+  __shared__ unsigned l_own[UNQ_LCAP];
+  __shared__ int l_first[UNQ_LCAP];
+  __shared__ int l_slot[UNQ_LCAP];
+  __shared__ unsigned s_n, s_base;
+  const int t = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * UNQ_INS + t;
+  const unsigned n_old = *old.nused;
+  const bool ok = i < n;
+  const i64 id = ok ? ids[i] : 0;
+  l_id[t] = id;
+  for (unsigned q = t; q < UNQ_LCAP; q += UNQ_INS) { l_own[q] = 0; l_first[q] = 0x7fffffff; }
+  if (t == 0) s_n = 0;
+  __syncthreads();
+  unsigned h = 0;
+  if (ok) {
+    h = (unsigned)(fmix64((u64)id) >> 20) & (UNQ_LCAP - 1);
+    for (;;) {
+      unsigned o = l_own[h];
+      if (o == 0) {
+        o = atomicCAS(&l_own[h], 0u, (unsigned)t + 1u);
+        if (o == 0) break;
+      }
+      if (l_id[o - 1] == id) break;
+      h = (h + 1) & (UNQ_LCAP - 1);
+    }
+    atomicMin(&l_first[h], t);
+  }
+  __syncthreads();
+  bool mine = false;
+  unsigned myslot = 0, myidx = 0;
+  if (ok && l_first[h] == t) {  // first position of its id in this block
+    size_t sl;
+    if (id == EMPTY_KEY) {
+      sl = cap;  // side slot for the sentinel value itself
+      mine = atomicMin(&cur.hfirst[sl], (int)i) == 0x7fffffff;
+    } else {
+      sl = fmix64((u64)id) & (cap - 1);
+      for (;;) {
+        const i64 was = (i64)atomicCAS((u64*)&cur.hkeys[sl], (u64)EMPTY_KEY, (u64)id);
+        if (was == EMPTY_KEY) { mine = true; break; }
+        if (was == id) break;
+        sl = (sl + 1) & (cap - 1);
+      }
+      atomicMin(&cur.hfirst[sl], (int)i);
+    }
+    l_slot[h] = (int)sl;
+    myslot = (unsigned)sl;
+    if (mine) myidx = atomicAdd(&s_n, 1u);
+  }
+  __syncthreads();
+  if (ok) slot_of[i] = l_slot[h];
+  if (t == 0) s_base = s_n ? atomicAdd(cur.nused, s_n) : 0u;
+  __syncthreads();
+  if (mine) cur.used[s_base + myidx] = myslot;
+  // the other set: empty the slots its last call used
+  for (size_t k = (size_t)blockIdx.x * UNQ_INS + t; k < n_old; k += (size_t)gridDim.x * UNQ_INS) {
+    const unsigned sl = old.used[k];
+    old.hkeys[sl] = EMPTY_KEY;
+    old.hfirst[sl] = 0x7fffffff;
+  }
+}
+
+__global__ __launch_bounds__(256) void unq2_scatter_kernel(size_t n, const i64* __restrict__ ids, UnqSet cur, UnqSet old,
+                                                           const int* __restrict__ slot_of, unsigned long long* agg, unsigned gen,
+                                                           i64* unique_out, i64* total_out) {
+  __shared__ int wsum[4];
+  __shared__ int s_off;
+  const size_t base = (size_t)blockIdx.x * UNQ_TILE + threadIdx.x * UNQ_ITEMS;
+  int flag[UNQ_ITEMS], c = 0;
+#pragma unroll
+  for (int k = 0; k < UNQ_ITEMS; ++k) {
+    const size_t i = base + k;
+    flag[k] = (i < n) && cur.hfirst[slot_of[i]] == (int)i;
+    c += flag[k];
+  }
+  // exclusive scan of c over the block in thread order (= input order)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int woff = 0;
+  for (int k = 0; k < w; ++k) woff += wsum[k];
+  const int tile_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (threadIdx.x == 0)   // publish this tile's count under the call's generation
+    __hip_atomic_store(agg + blockIdx.x, ((unsigned long long)gen << 32) | (unsigned)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // offset = counts of the earlier tiles, read as they appear (wave 0: 64 tiles per sweep)
+  if (w == 0) {
+    int sum = 0;
+    for (unsigned j0 = 0; j0 < blockIdx.x; j0 += 64) {
+      const unsigned j = j0 + (unsigned)lane;
+      if (j < blockIdx.x) {
+        unsigned long long v;
+        do { v = __hip_atomic_load(agg + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(v >> 32) != gen);
+        sum += (int)(unsigned)v;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) s_off = sum;
+  }
+  __syncthreads();
+  int pos = s_off + woff + incl - c;
+#pragma unroll
+  for (int k = 0; k < UNQ_ITEMS; ++k) {
+    if (flag[k]) {
+      const size_t i = base + k;
+      unique_out[pos] = ids[i];
+      cur.hrank[slot_of[i]] = pos;
+      ++pos;
+    }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (total_out) *total_out = (i64)(s_off + tile_total);
+    *old.nused = 0;   // the other set is empty again (unq2_insert_kernel of this call emptied it): its next call counts from zero
+  }
+}
+
 // ------------------------------------ row gather / scatter ------------------------------------
 template <int G, bool SCATTER>
 __global__ __launch_bounds__(256) void move_rows_kernel(size_t n, unsigned row_bytes, const unsigned char* __restrict__ in,
@@ -432,6 +572,54 @@ __global__ __launch_bounds__(256) void part_scatter_kernel(size_t n, const i64* 
 
 }  // namespace
 
+// tfra_unique for n <= 2^20 ids: three launches over two persistent, self-emptying sets (see unq2_insert_kernel)
+static int unique_fast(tfra_workspace* ws, size_t n, const i64* ids, i64* unique_out, int32_t* idx_out, i64* d_num_unique, hipStream_t s) {
+  const size_t tiles = (n + UNQ_TILE - 1) / UNQ_TILE;
+  if (ws->unq_nmax < n) {
+    if (ws->unq_buf) {
+      if (hipStreamSynchronize(s) != hipSuccess || hipFree(ws->unq_buf) != hipSuccess) return set_error(TFRA_ERR_HIP, "unique: free failed");
+      ws->unq_buf = nullptr; ws->unq_nmax = 0;
+    }
+    const size_t nmax = std::max<size_t>(n, 4096);
+    size_t cap = 1024;
+    while (cap < 2 * nmax) cap <<= 1;
+    const size_t per = align_up((cap + 1) * 8) + 2 * align_up((cap + 1) * 4) + align_up(nmax * 4);
+    const size_t bytes = 256 + 2 * per + align_up(nmax * 4) + align_up(((nmax + UNQ_TILE - 1) / UNQ_TILE) * 8);
+    hipError_t e = hipMalloc(&ws->unq_buf, bytes);
+    if (e != hipSuccess) { ws->unq_buf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "unique: hipMalloc failed"); }
+    HIP_TRY(hipMemsetAsync(ws->unq_buf, 0, bytes, s));
+    ws->unq_cap = cap; ws->unq_nmax = nmax; ws->unq_parity = 1; ws->unq_gen = 0;
+    unsigned char* w = (unsigned char*)ws->unq_buf + 256;
+    for (int p = 0; p < 2; ++p) {   // both sets start empty
+      unq_fill_kernel<<<(unsigned)std::min<size_t>(2048, (cap + 256) / 256), 256, 0, s>>>((i64*)w, (int*)(w + align_up((cap + 1) * 8)), cap + 1);
+      w += per;
+    }
+  }
+  const size_t cap = ws->unq_cap, nmax = ws->unq_nmax;
+  const size_t per = align_up((cap + 1) * 8) + 2 * align_up((cap + 1) * 4) + align_up(nmax * 4);
+  auto set_of = [&](unsigned p) {
+    unsigned char* w = (unsigned char*)ws->unq_buf + 256 + (size_t)p * per;
+    UnqSet u;
+    u.hkeys = (i64*)w; w += align_up((cap + 1) * 8);
+    u.hfirst = (int*)w; w += align_up((cap + 1) * 4);
+    u.hrank = (int*)w; w += align_up((cap + 1) * 4);
+    u.used = (unsigned*)w;
+    u.nused = (unsigned*)ws->unq_buf + p;
+    return u;
+  };
+  const unsigned p = ws->unq_parity ^ 1u;
+  const UnqSet cur = set_of(p), old = set_of(p ^ 1u);
+  int* slot_of = (int*)((unsigned char*)ws->unq_buf + 256 + 2 * per);
+  unsigned long long* agg = (unsigned long long*)((unsigned char*)slot_of + align_up(nmax * 4));
+  if (++ws->unq_gen == 0) ws->unq_gen = 1;   // (tile counts of an earlier call carry another generation)
+  unq2_insert_kernel<<<(unsigned)((n + UNQ_INS - 1) / UNQ_INS), UNQ_INS, 0, s>>>(n, ids, cur, old, slot_of, cap);
+  unq2_scatter_kernel<<<(unsigned)tiles, 256, 0, s>>>(n, ids, cur, old, slot_of, agg, ws->unq_gen, unique_out, d_num_unique);
+  unq_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, slot_of, cur.hrank, idx_out);
+  HIP_TRY(hipGetLastError());
+  ws->unq_parity = p;
+  return TFRA_OK;
+}
+
 extern "C" {
 
 int tfra_workspace_create(int device, tfra_workspace_t** out) {
@@ -447,6 +635,7 @@ int tfra_workspace_destroy(tfra_workspace_t* ws) {
   if (!ws) return TFRA_OK;
   (void)hipSetDevice(ws->device);
   if (ws->buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->buf); }
+  if (ws->unq_buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->unq_buf); }
   tfra::destroy_workspace_plan(ws->plan);
   delete ws;
   return TFRA_OK;
@@ -460,6 +649,7 @@ int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* uni
   if (n == 0) { HIP_TRY(hipMemsetAsync(d_num_unique, 0, sizeof(int64_t), s)); return TFRA_OK; }
   if (!ids || !unique_out || !idx_out) return set_error(TFRA_ERR_INVALID, "unique: null buffer");
   if (n >= (1ULL << 30)) return set_error(TFRA_ERR_INVALID, "unique: more than 2^30 ids per call");
+  if (n <= ((size_t)1 << 20)) return unique_fast(ws, n, (const i64*)ids, (i64*)unique_out, idx_out, (i64*)d_num_unique, s);
   size_t cap = 1024;
   while (cap < 2 * n) cap <<= 1;
   size_t tiles = (n + UNQ_TILE - 1) / UNQ_TILE;

@@ -113,6 +113,10 @@ struct tfra_workspace {
   void* buf = nullptr;
   size_t bytes = 0;
   void* plan = nullptr;   // tfra_sparse_plan of tfra_reduce_by_key
+  // tfra_unique (up to 2^20 ids): two persistent hash sets that alternate and empty each other (no fill kernel per call)
+  void* unq_buf = nullptr;
+  size_t unq_cap = 0, unq_nmax = 0;
+  unsigned unq_parity = 0, unq_gen = 0;
   int ensure(size_t need, hipStream_t s) {
     if (need <= bytes) return TFRA_OK;
     if (buf) {
