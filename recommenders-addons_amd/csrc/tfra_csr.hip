@@ -517,29 +517,24 @@ __global__ __launch_bounds__(NTA) void csr_scatter_kernel(const unsigned* __rest
       else out.hent[(size_t)r.z + (e - nfull * SEG)] = position | (e == nfull * SEG ? E_HEAD : 0u);
     }
   }
-  // (c) by the block that finishes LAST (a ticket per block, behind an agent-scope release of the block's stores): the step
-  // driver launches the other half on another stream as soon as the pinned generation shows this build — published by the
-  // first block, as until round 2, the readers could overtake the scatter blocks still running.
-  __shared__ unsigned s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    s_last = __hip_atomic_fetch_add(d_counts + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  for (unsigned i = threadIdx.x; i <= P; i += NTA) cursors[(size_t)i * CSTRIDE] = 0;   // bucket cursors + overflow count
-  if (threadIdx.x == 0) {
-    const unsigned e = cursors[(size_t)(P + 1) * CSTRIDE];
-    cursors[(size_t)(P + 1) * CSTRIDE] = 0;
-    const unsigned v[6] = {nhot, ncold, 0u, nbins, 0u, e};
-    for (int k = 0; k < 6; ++k) __hip_atomic_store(d_counts + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<u64*>(d_counts + 32), (u64)nhot + (u64)ncold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tfra_plan_partition: the count as tfra_partition reads it
-    __hip_atomic_store(d_counts + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next build's tickets
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (host_counts) {
-      for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (c) block 0: counts for the kernels of the other half (device copy) and for the host's grid sizes (pinned copy), cursors
+  // re-armed for the next build, errors latched.  NOT a completion signal: other blocks are still scattering — whoever needs
+  // the finished plan on another stream waits for the build's event (tfra_table_step_prefetch: hipEventQuery on the host), or
+  // is ordered behind it by the stream.  (Round 2 treated the pinned generation as "plan complete" — ADVICE r2; a per-block
+  // release + ticket here cost the kernel 8 us, the event costs nothing on the critical path.)
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i <= P; i += NTA) cursors[(size_t)i * CSTRIDE] = 0;   // bucket cursors + overflow count
+    if (threadIdx.x == 0) {
+      const unsigned e = cursors[(size_t)(P + 1) * CSTRIDE];
+      cursors[(size_t)(P + 1) * CSTRIDE] = 0;
+      const unsigned v[6] = {nhot, ncold, 0u, nbins, 0u, e};
+      for (int k = 0; k < 6; ++k) d_counts[k] = v[k];
+      *reinterpret_cast<i64*>(d_counts + 32) = (i64)nhot + (i64)ncold;   // tfra_plan_partition: the count as tfra_partition reads it
+      if (host_counts) {
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -1484,6 +1479,7 @@ struct tfra_sparse_plan {
   unsigned gen = 0;                // generation of the last enqueued build
   bool ev_recorded = false;        // the last build ran on a side stream (tfra_table_step_prefetch)
   unsigned last_used_step = 0;     // last step whose write-back read this plan
+  hipEvent_t built_ev = nullptr;   // recorded behind a build on a side stream (tfra_table_step_prefetch): complete = the plan is in memory
   // SET plan (dim 0): its own buffer; two tables alternate (setplan_kernel)
   int kind = 0;                    // 0 CSR, 1 SET
   void* setbuf = nullptr;
@@ -1510,6 +1506,7 @@ extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
   if (pl->buf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->buf); }
   if (pl->setbuf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->setbuf); }
   if (pl->host_counts) (void)hipHostFree(pl->host_counts);
+  if (pl->built_ev) (void)hipEventDestroy(pl->built_ev);
   delete pl;
   return TFRA_OK;
 }
@@ -2040,14 +2037,20 @@ static int apply_sparse_big(Table* t, tfra_table_t* tp, tfra_sparse_plan* pl, co
     rc = tfra_gather_rows(T, (size_t)dim * sizeof(float), sums_cat, perm, sums_part, stream);
     if (rc) return cleanup(rc);
     size_t off = 0;
+    // ONE logical write-back: the epoch / step counters of the EPOCH* strategies advance once, not once per part (the
+    // reference counts one upsert per write-back, lookup_table_op_hkv.h:528-536).  (On a bounded table at max_capacity a
+    // later part may still evict keys an earlier part of the same batch inserted.)
+    t->epoch_hold = true;
     for (i64 c : counts) {
       if (c > 0) {
         rc = tfra_sparse_plan_build(pl, (size_t)c, (const int64_t*)keys_part + off, dim, stream);
         if (!rc) rc = apply_planned_impl(tp, p, pl, sums_part + off * (size_t)dim, param_default_row, stream, nullptr, 0);
-        if (rc) return cleanup(rc);
+        if (rc) { t->epoch_hold = false; return cleanup(rc); }
       }
       off += (size_t)c;
     }
+    t->epoch_hold = false;
+    step_epoch_public(t);
     return cleanup(TFRA_OK);
   }
   return cleanup(set_error(TFRA_ERR_UNSUPPORTED, "apply_sparse: could not split the batch into parts of 2^18 ids"));
@@ -2297,11 +2300,17 @@ static int step_prefetch_impl(tfra_table_t* tp, const tfra_opt_params* p, tfra_s
   if (plan_next) {
     rc = tfra_sparse_plan_build(plan_next, n_next, ids_next, p ? t->opts.dim : 0, side_stream);
     if (rc) return rc;
+    if (!plan_next->built_ev && hipEventCreateWithFlags(&plan_next->built_ev, hipEventDisableTiming) != hipSuccess) {
+      plan_next->built_ev = nullptr;
+      return set_error(TFRA_ERR_HIP, "step_prefetch: event");
+    }
+    if (hipEventRecord(plan_next->built_ev, ss) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: event record");
     plan_next->ev_recorded = true;   // built on the side stream: the join below applies
   }
   if (plan_cur->ev_recorded) {  // built on the side stream by an earlier call
-    const bool built = plan_cur->host_counts && (int)(*(volatile unsigned*)plan_cur->host_counts - plan_cur->gen) >= 0;
-    if (!built && hipStreamSynchronize(ss) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_prefetch: join");   // rare
+    // complete = every block of the build has ended and its stores are in memory (the pinned counts alone do not say that)
+    if (hipEventQuery(plan_cur->built_ev) != hipSuccess && hipEventSynchronize(plan_cur->built_ev) != hipSuccess)   // the wait: rare
+      return set_error(TFRA_ERR_HIP, "step_prefetch: join");
     plan_cur->ev_recorded = false;
   }
   plan_cur->last_used_step = step;

@@ -76,6 +76,7 @@ struct Table {
   bool no_owner_tags = false; // TFRA_OPTION_NO_OWNER_TAGS
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
+  bool epoch_hold = false;   // see step_epoch (tfra_optim.hip)
   int n_rehash = 0;
 
   void* dalloc(size_t bytes, hipStream_t s);

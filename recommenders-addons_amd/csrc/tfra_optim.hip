@@ -193,6 +193,7 @@ void launch_apply(int dt, bool vec4, dim3 grid, hipStream_t s, TableView v, OptP
 
 // one fused write-back counts as one upsert for the epoch strategies (lookup_table_op_hkv.h:528-536)
 void step_epoch(Table* t) {
+  if (t->epoch_hold) return;   // one logical write-back issued as several launches (apply_sparse_big): stepped once by the caller
   const int strat = t->opts.strategy;
   if (strat == TFRA_EVICT_EPOCHLRU || strat == TFRA_EVICT_EPOCHLFU) {
     t->curr_step += 1;

@@ -1046,8 +1046,23 @@ int Table::grow_in_place(u64 min_nb, hipStream_t s) {
   const size_t bstride = (size_t)hdr_bytes(opts) + (size_t)SLOTS * row_stride;
   const size_t side = (size_t)NUM_RESERVED * row_stride, new_bytes = nbn * bstride + side;
   if (nbn >= (1ULL << 32) - 1 || new_bytes > cur.va_bytes) return set_error(TFRA_ERR_UNSUPPORTED, "in-place growth: beyond the address range");
+  const size_t mapped_before = cur.mapped;
+  const size_t chunks_before = cur.chunks.size();
   int rc = vmm_map_more(&cur, new_bytes, device);
-  if (rc) return rc;   // out of memory: the caller keeps running denser
+  if (rc) {
+    // out of memory part-way: give back the chunks mapped so far (up to nearly the table's own size of HBM would otherwise sit
+    // behind the table unused, exactly when memory is short); the caller keeps running denser
+    while (cur.chunks.size() > chunks_before) {
+      const auto c = cur.chunks.back();
+      cur.mapped -= c.second;
+      (void)hipMemUnmap(cur.base + cur.mapped, c.second);
+      (void)hipMemRelease(c.first);
+      cur.chunks.pop_back();
+    }
+    cur.mapped = mapped_before;
+    (void)hipGetLastError();
+    return rc;
+  }
   Storage nw = cur;    // same range, new bucket count
   nw.nb = nbn;
   const TableView ov = view_of(cur), nv = view_of(nw);
@@ -1165,7 +1180,8 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
     u64 need = (u64)((double)(sz + n) / opts.max_load_factor / SLOTS) + 1;
     u64 tries[2] = {std::min(std::max(need, cur.nb * 2), max_nb), std::min(std::max(need, cur.nb + cur.nb / 4), max_nb)};
     rc = TFRA_ERR_OOM;
-    for (int i = 0; i < 2 && rc == TFRA_ERR_OOM; ++i) rc = grow(tries[i], s);
+    // (a table in a mapped address range grows by doublings only: the 1.25x retry would ask for the same doubling again)
+    for (int i = 0; i < (cur.vmm ? 1 : 2) && rc == TFRA_ERR_OOM; ++i) rc = grow(tries[i], s);
     if (rc == TFRA_ERR_OOM) {
       if ((double)(sz + n) > 0.98 * slots) return rc;  // cannot fit: report the allocation failure
       growth_blocked = true;                            // keep running denser instead

@@ -279,11 +279,36 @@ class Variable:
     import os
     import numpy as np
     own = self.name.replace("/", "_") + "_mht_"
-    files = sorted(f[:-len("-keys")] for f in os.listdir(dirpath) if f.endswith("-keys") and f.startswith(own))
+    listing = os.listdir(dirpath)
+    files = sorted(f[:-len("-keys")] for f in listing if f.endswith("-keys") and f.startswith(own))
     slots = self._slot_file_names(optimizer)
 
     def slot_files(base):
-      return sorted(f[:-len("-keys")] for f in os.listdir(dirpath) if f.endswith("-keys") and f.startswith(base + "_mht_"))
+      return sorted(f[:-len("-keys")] for f in listing if f.endswith("-keys") and f.startswith(base + "_mht_"))
+
+    # The slot files are named after the optimizer's slot variables when an optimizer is passed, `<param>_slot<f>` when not.
+    # Saving one way and restoring the other must not silently reset Adam's m / v or FTRL's accumulators: when the expected
+    # names are absent, the other scheme is looked for (`<param>_<Opt>_<slot>` files in the order of the slot fields), and a
+    # directory that holds state files of this variable which match neither is an error, not a skip.
+    if self.aux_fields:
+      prefix = self.name.replace("/", "_") + "_"
+      others = sorted({f[:f.index("_mht_")] for f in listing if f.endswith("-keys") and f.startswith(prefix) and "_mht_" in f and
+                       not f.startswith(own)})
+      missing = [f for f, base in slots.items() if not slot_files(base)]
+      if missing and others:
+        generic = [b for b in others if b.startswith(prefix + "slot")]
+        named = [b for b in others if b not in generic]
+        if optimizer is None and named and len(named) >= len(missing):
+          for f, base in zip(sorted(slots), sorted(named, key=lambda b: b)):   # (names sort like get_slot_variables does)
+            slots[f] = base
+        elif optimizer is not None and generic:
+          for f in missing:
+            if prefix + "slot%d" % f in generic:
+              slots[f] = prefix + "slot%d" % f
+        still = [f for f, base in slots.items() if not slot_files(base)]
+        if still:
+          raise ValueError("load_from_file_system: %r holds optimizer-state files %s of variable %r, but none matches slot field(s) %s "
+                           "(saved with another optimizer?); pass the optimizer the checkpoint was saved with" % (dirpath, others, self.name, still))
 
     same = all(self._make_name(i) in files for i in range(self.shard_num)) and len(files) == self.shard_num
     if same and proc_size == 1:
