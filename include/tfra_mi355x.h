@@ -107,7 +107,11 @@ int tfra_table_find(tfra_table_t* t, size_t n, const int64_t* keys, void* values
 
 /* -- insert_or_assign = TableWrapper::upsert (lookup_table_op_hkv.h:522-537); scores NULL or
  *    [n] (HkvHashTableInsert's `scores` input, empty tensor -> NULL).  Advances the epoch
- *    counter for EPOCH* strategies.  Oracle: LaunchTensorsInsert (cuckoo_hashtable_op.cc:111). */
+ *    counter for EPOCH* strategies.  Oracle: LaunchTensorsInsert (cuckoo_hashtable_op.cc:111).
+ *    With TFRA_FLAG_UNIQUE_KEYS (what the Insert op passes: HKV's contract) the call is ONE pass
+ *    with bucket ownership over the caller's keys (the kernels of tfra_table_upsert_planned, no
+ *    plan); a bulk load — so many keys for the table's size that most would collide on a home
+ *    bucket — and calls without the flag take the locked kernels.  Same results either way.     */
 int tfra_table_insert_or_assign(tfra_table_t* t, size_t n, const int64_t* keys, const void* values,
                                 const uint64_t* scores, uint32_t flags, tfra_stream_t stream);
 
@@ -194,7 +198,9 @@ int tfra_table_load_field(tfra_table_t* t, int field, const char* prefix, size_t
  * (PY/dynamic_embedding_optimizer.py:165-204) with one pass over rows laid out [p|slot..].
  * keys [n] UNIQUE (use tfra_segment_sum first), grads [n,dim] fp32.  Missing keys are inserted
  * with p = param_defaults (full [n,dim] or broadcast [dim], like find) and slots = aux_init.
- * Requires value_dtype F32 and aux_fields >= the optimizer's slot count.                     */
+ * Requires aux_fields >= the optimizer's slot count.  value_dtype F32, F16 or BF16 (tfra_table_apply_optimizer; gradients
+ * and defaults are float32 in every case: the rule runs in fp32 on the up-cast row and slots and the results are rounded
+ * to the storage type once); the planned / sparse forms below: F32.                           */
 typedef enum { TFRA_OPT_SGD = 0, TFRA_OPT_ADAM = 1, TFRA_OPT_ADAGRAD = 2, TFRA_OPT_FTRL = 3 } tfra_opt_kind;
 typedef struct {
   int32_t kind;     /* tfra_opt_kind */
@@ -239,7 +245,9 @@ int tfra_table_upsert_sparse(tfra_table_t* t, size_t n, const int64_t* ids, cons
  * tfra_table_upsert_planned do the rest when the gradients / values exist.  Results are bit-identical to the
  * one-call forms.  The caller orders build and use (event / same stream) and keeps `plan` untouched until the
  * work using it has finished; a plan can be rebuilt for the next batch afterwards (it owns its device buffers:
- * ~ (90 + dim/2) B per id + 12 MB).  dim: the table's dim (0 for a plan only used by upsert_planned).
+ * ~ (90 + dim/2) B per id + 12 MB).  dim: the table's dim, or 0 for a plan only used by upsert_planned: an
+ * assign needs the LAST position and the count of every distinct id, not the list of its positions, and such a
+ * plan is built by ONE kernel (LDS de-duplication per 1024 ids + a global hash set with atomic max; ~21 MB).
  * A plan object is not internally locked: one thread builds / consumes it at a time (different plans and
  * different tables are independent).                                                                  */
 typedef struct tfra_sparse_plan tfra_sparse_plan_t;
@@ -253,7 +261,8 @@ int tfra_table_upsert_planned(tfra_table_t* t, const tfra_sparse_plan_t* plan, c
 /* Introspection (tests, tools): counts[6] = {keys with > 8 occurrences, other keys, partial sums, 512-entry bins,
  * entries of the other keys, build errors}; when keys != NULL also the CSR itself, keys with > 8 occurrences first:
  * keys[i], cnt[i], and positions[] = the batch positions of key 0, of key 1, ... each ascending (cap = length of
- * keys/cnt, positions holds n).  Host buffers; synchronises `stream`. */
+ * keys/cnt, positions holds n).  A plan built with dim 0 keeps no positions list: counts = {0, distinct keys, 0, 0, 0, 0},
+ * keys / cnt in no particular order, positions must be NULL.  Host buffers; synchronises `stream`. */
 int tfra_sparse_plan_read(const tfra_sparse_plan_t* plan, uint32_t* counts, int64_t* keys, uint32_t* cnt,
                           uint32_t* positions, size_t cap, tfra_stream_t stream);
 
