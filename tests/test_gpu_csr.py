@@ -350,3 +350,62 @@ def test_upsert_sparse_more_ids_than_a_plan_holds(env):
   got = t.lookup(torch.from_numpy(uk).cuda()).cpu().numpy()
   np.testing.assert_array_equal(got[:, 0], np.array([last[int(k)] for k in uk], np.float32))
   assert np.all(got == got[:, :1])
+
+
+def test_set_plan_counts_last_positions_and_reuse(env):
+  """The assign-only plan (dim 0, setplan_kernel): distinct keys, occurrence counts and — through upsert_planned — the LAST
+  position of every id, over a sequence of builds of ONE plan object with very different sizes (its two tables alternate and
+  empty each other: a stale entry of an earlier build would show up as a wrong count or a phantom key), with the two sentinel
+  key values (they have slots of their own) and a hot id."""
+  torch, de, SparsePlan = env
+  dim = 8
+  t = de.CuckooHashTable(torch.int64, torch.float32, torch.zeros(dim), device="cuda:0", dim=dim, name="setplan")
+  plan = SparsePlan("cuda:0", 0)
+  rng = np.random.default_rng(11)
+  imin = np.iinfo(np.int64).min
+  expect = {}
+  for n in (1, 5, 3000, 70_000, 17, 262_144, 40_000, 2):
+    keys = (rng.zipf(1.25, size=n) % max(3, n // 3)).astype(np.int64) * 104729 - 3
+    if n >= 17:
+      keys[rng.integers(0, n, size=max(1, n // 50))] = imin          # EMPTY_KEY as an ordinary key
+      keys[rng.integers(0, n, size=max(1, n // 70))] = imin + 1      # LOCKED_KEY as an ordinary key
+      keys[: n // 5] = 42                                            # a hot id
+    ids = torch.from_numpy(keys).cuda()
+    plan.build(ids)
+    counts, pk, pc, ppos = plan.read()
+    uk, uc = np.unique(keys, return_counts=True)
+    assert counts["many"] == 0 and counts["few"] == uk.size and counts["errors"] == 0 and ppos is None
+    o = np.argsort(pk)
+    np.testing.assert_array_equal(pk[o], uk)
+    np.testing.assert_array_equal(pc[o], uc)
+    vals = torch.arange(n, device="cuda", dtype=torch.float32)[:, None].repeat(1, dim)   # row i = [i] * dim
+    t._table.upsert_planned(plan, vals)
+    last = {}
+    for i, k in enumerate(keys.tolist()):
+      last[k] = i
+    expect.update(last)
+    got = t.lookup(torch.from_numpy(uk).cuda())
+    want = torch.tensor([float(last[int(k)]) for k in uk], device="cuda")[:, None].repeat(1, dim)
+    assert torch.equal(got, want)
+  ek, ev = t.export()
+  assert ek.numel() == len(expect) == int(t.size().item())
+  t._table.check_errors()
+
+
+def test_unique_many_calls_one_workspace(env):
+  """tfra_unique keeps two persistent sets per workspace that empty each other: a sequence of calls with sizes going up and
+  down (incl. the sentinel value and a hot id) must each equal numpy's first-occurrence unique."""
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(13)
+  imin = np.iinfo(np.int64).min
+  for n in (7, 50_000, 3, 131_072, 1000, 600_000, 131_072, 1):
+    ids = (rng.zipf(1.2, size=n) % max(2, n // 2)).astype(np.int64) * 7919 - 11
+    if n > 100:
+      ids[rng.integers(0, n, size=n // 40)] = imin
+      ids[n // 3: n // 2] = 5
+    u, idx, cnt = de.device_ops.unique(torch.from_numpy(ids).cuda())
+    _, first = np.unique(ids, return_index=True)
+    want = ids[np.sort(first)]                       # distinct values in order of first occurrence (tf.unique)
+    assert int(cnt.item()) == want.size
+    np.testing.assert_array_equal(u.cpu().numpy(), want)
+    np.testing.assert_array_equal(want[idx.cpu().numpy()], ids)
