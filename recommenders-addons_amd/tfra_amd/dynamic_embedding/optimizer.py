@@ -625,7 +625,7 @@ class PrefetchAssignStep:
     self.plans = [SparsePlan(self.dev, 0) for _ in range(self.NPLANS)]
     self.ids = [None] * self.NPLANS
     self.default = self.table._default_value
-    self.side = torch.cuda.Stream(device=self.dev)
+    self.side = torch.cuda.Stream(device=self.dev)   # (a lower priority for it changes nothing: measured)
     self.cur = 0
     self._main = None
 
