@@ -623,41 +623,52 @@ __device__ __forceinline__ unsigned load_record(const CsrKeys& ks, unsigned g, i
   return (many ? ks.hrec : ks.crec)[(size_t)(km & ~KM_MANY) * REC_WORDS + sub];
 }
 
-// the <= 8 source rows of one batch of a key's sum: loads issued together, adds in order
+// The source rows of a key's sum, NB of them in flight: rows j0 .. j0+NB-1 of its list (clamped to the last one; loads issued
+// together, adds in list order).  A key with few occurrences lists their batch positions in words 4.. of its record (lane i
+// of the group holds word i: EVERY lane of the group must be here); a key with many lists consecutive rows of the partial
+// sums.  The addresses are formed here, from the record word, not kept in an array across the kernel: with 8 pointers and
+// 8 rows held per lane the update kernel needed 145 registers (3 waves per SIMD); this form needs 125 (Adam) / 109 (SGD).
 template <int NB>
-__device__ __forceinline__ void add_rows(float4& acc, const float* (&src)[8], int nsrc, int c) {
+__device__ __forceinline__ void add_rows(float4& acc, const float* __restrict__ grads, const float* __restrict__ partial, bool hot,
+                                         unsigned w, unsigned first, unsigned nsrc, unsigned j0, int dim, int c, int gshift) {
   float4 x[NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) x[j] = *reinterpret_cast<const float4*>(src[j] + c);
-  if (NB == 8) { keep_live(x[0], x[1], x[2], x[3]); keep_live(x[NB - 4], x[NB - 3], x[NB - 2], x[NB - 1]); }
-  else if (NB == 4) keep_live(x[0], x[1], x[2], x[3]);
+  for (int j = 0; j < NB; ++j) {
+    const unsigned jj = min(j0 + (unsigned)j, nsrc - 1);
+    const unsigned position = (unsigned)__shfl((int)w, gshift + 4 + (int)min(jj, 7u));
+    const float* q = hot ? partial + (size_t)(first + jj) * dim : grads + (size_t)position * dim;
+    x[j] = *reinterpret_cast<const float4*>(q + c);
+  }
+  if (NB == 4) keep_live(x[0], x[1], x[2], x[3]);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    if (j < nsrc) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+    if (j0 + (unsigned)j < nsrc) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
 }
 
-// partial rows 8.. of a key with many partials: contiguous rows, 8 in flight per batch, added in order
-__device__ __forceinline__ void add_partials_tail(float4& acc, const float* __restrict__ partial, unsigned first, unsigned nsrc,
-                                                  int dim, int c) {
-  for (unsigned j0 = 8; j0 < nsrc; j0 += 8) {
-    float4 x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4*>(partial + (size_t)(first + min(j0 + j, nsrc - 1)) * dim + c);
-    keep_live(x[0], x[1], x[2], x[3]); keep_live(x[4], x[5], x[6], x[7]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j0 + j < nsrc) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+// the whole sum of a key; wmax = the largest list length (capped at 8) among the wave's four keys: the trip count of the
+// common part is uniform across the wave, the few keys with more than 8 partial rows go on alone
+__device__ __forceinline__ float4 sum_rows(const float* __restrict__ grads, const float* __restrict__ partial, bool hot, unsigned w,
+                                           unsigned first, unsigned nsrc, unsigned wmax, int dim, int c, int gshift) {
+  float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wmax <= 1) add_rows<1>(gg, grads, partial, hot, w, first, nsrc, 0, dim, c, gshift);
+  else if (wmax <= 2) add_rows<2>(gg, grads, partial, hot, w, first, nsrc, 0, dim, c, gshift);
+  else {
+    add_rows<4>(gg, grads, partial, hot, w, first, nsrc, 0, dim, c, gshift);
+    if (wmax > 4) add_rows<4>(gg, grads, partial, hot, w, first, nsrc, 4, dim, c, gshift);
   }
+  for (unsigned j0 = 8; j0 < nsrc; j0 += 4) add_rows<4>(gg, grads, partial, hot, w, first, nsrc, j0, dim, c, gshift);
+  return gg;
 }
 
+// ---------------------------------------------------------------------------------------------
 // gradient half, kernel 2: one 16-lane group per unique key, hot keys first (their partial lists are the longest
 // chains of the kernel: started first, they finish inside the kernel's duration).
 // PHASE2: bounded (Hkv) table at max_capacity — the keys flagged in `dflag` (no free slot in phase 1; one byte per key:
 // a list appended through ONE atomic counter cost 4 ns per key, 260 us for a batch of new keys) replace the minimum-score
 // entry of their two home buckets and start from the default row / initial slot values, exactly like
 // apply_evict_kernel (tfra_optim.hip).
-// (Tried: amdgpu_waves_per_eu(4) — 145 -> 128 VGPRs with 7 spilled, 4 waves per SIMD instead of 3: gradient half 32.5 us
-// instead of 31.5, step 62.6 instead of 59.6 us.)
+// (Tried: amdgpu_waves_per_eu(4) on the 145-register form — 128 VGPRs with 7 spilled: gradient half 32.5 us instead of 31.5.
+// Without the pointer arrays — add_rows — it is 125 registers, 4 waves per SIMD, no spills: 28.7 us, step 57.2 instead of 59.9 us.)
 template <int KIND, bool PHASE2>
 __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int dim, const float* __restrict__ grads,
                                                         const float* __restrict__ partial, CsrKeys ks,
@@ -690,14 +701,7 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
     const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
     const unsigned first = (unsigned)__shfl((int)w, gshift + 3);             // keys with many occurrences: first partial row
     const unsigned nsrc = hot ? (unsigned)__shfl((int)w, gshift + 4) : cnt;
-    const float* src[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned jj = min((unsigned)j, nsrc - 1);
-      const unsigned position = (unsigned)__shfl((int)w, gshift + 4 + (int)min(jj, 7u));   // (few occurrences) word 4+j
-      src[j] = hot ? partial + (size_t)(first + jj) * dim : grads + (size_t)position * dim;
-    }
-    // wave-uniform batch width: 1 / 2 / 4 / 8 rows in flight (most keys of a Zipf batch occur once)
+    // wave-uniform batch width: 1 / 2 / 4 rows in flight (most keys of a Zipf batch occur once)
     unsigned wmax = min(nsrc, 8u);
     for (int o2 = 32; o2 >= 16; o2 >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o2));
     wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wmax);
@@ -724,16 +728,15 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
     }
     fresh += ((PHASE2 ? claimed_empty : is_new) && sub == 0);
     float* pr = reinterpret_cast<float*>(row_ptr(v, row));
-    for (int c = sub * 4; c < dim; c += 64) {
+    // (every lane of the group takes every trip — sum_rows reads the record words of the other lanes; a lane beyond the row
+    // works on column 0 and stores nothing)
+    for (int c0 = 0; c0 < dim; c0 += 64) {
+      const bool col = c0 + sub * 4 < dim;
+      const int c = col ? c0 + sub * 4 : 0;
       float4 p = *reinterpret_cast<const float4*>((is_new ? default_row : pr) + c);
       float4 s1 = *reinterpret_cast<const float4*>(pr + (S >= 1 ? dim : 0) + c);
       float4 s2 = *reinterpret_cast<const float4*>(pr + (S >= 2 ? 2 * dim : 0) + c);
-      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wmax <= 1) add_rows<1>(gg, src, (int)nsrc, c);
-      else if (wmax <= 2) add_rows<2>(gg, src, (int)nsrc, c);
-      else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
-      else add_rows<8>(gg, src, (int)nsrc, c);
-      if (nsrc > 8) add_partials_tail(gg, partial, first, nsrc, dim, c);   // the few keys with more than 8 partials
+      float4 gg = sum_rows(grads, partial, hot, w, first, nsrc, wmax, dim, c, gshift);
       float4 dummy = p;
       keep_live(dummy, p, s1, s2);
       if (is_new || S < 1) s1 = make_float4(aux0, aux0, aux0, aux0);
@@ -743,9 +746,11 @@ __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int
       apply_one<KIND>(o, gg.z, p.z, s1.z, s2.z);
       apply_one<KIND>(o, gg.w, p.w, s1.w, s2.w);
       // write-through: the rows leave L2 during the kernel, not at the boundary to the next one
-      store_wt16(pr + c, *reinterpret_cast<uint4*>(&p));
-      if (S >= 1) store_wt16(pr + dim + c, *reinterpret_cast<uint4*>(&s1));
-      if (S >= 2) store_wt16(pr + 2 * dim + c, *reinterpret_cast<uint4*>(&s2));
+      if (col) {
+        store_wt16(pr + c, *reinterpret_cast<uint4*>(&p));
+        if (S >= 1) store_wt16(pr + dim + c, *reinterpret_cast<uint4*>(&s1));
+        if (S >= 2) store_wt16(pr + 2 * dim + c, *reinterpret_cast<uint4*>(&s2));
+      }
     }
     // aux fields the optimizer does not own (table created with more slots than it uses)
     if (is_new && (int)v.n_fields - 1 > S) {
@@ -791,13 +796,6 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
     const unsigned cnt = (unsigned)__shfl((int)w, gshift + 2);
     const unsigned first = (unsigned)__shfl((int)w, gshift + 3);
     const unsigned nsrc = hot ? (unsigned)__shfl((int)w, gshift + 4) : cnt;
-    const float* src[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned jj = min((unsigned)j, nsrc - 1);
-      const unsigned position = (unsigned)__shfl((int)w, gshift + 4 + (int)min(jj, 7u));
-      src[j] = hot ? partial + (size_t)(first + jj) * dim : grads + (size_t)position * dim;
-    }
     unsigned wmax = min(nsrc, 8u);
     for (int o2 = 32; o2 >= 16; o2 >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o2));
     wmax = (unsigned)__builtin_amdgcn_readfirstlane((int)wmax);
@@ -808,14 +806,11 @@ __global__ __launch_bounds__(256) void gather_csr_kernel(int dim, const float* _
       if (hot) lastp = ks.hent[lastp];
       orow = (size_t)dest[lastp & E_POS];
     }
-    for (int c = sub * 4; c < dim; c += 64) {
-      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (wmax <= 1) add_rows<1>(gg, src, (int)nsrc, c);
-      else if (wmax <= 2) add_rows<2>(gg, src, (int)nsrc, c);
-      else if (wmax <= 4) add_rows<4>(gg, src, (int)nsrc, c);
-      else add_rows<8>(gg, src, (int)nsrc, c);
-      if (nsrc > 8) add_partials_tail(gg, partial, first, nsrc, dim, c);
-      *reinterpret_cast<float4*>(rows_out + orow * dim + c) = gg;
+    for (int c0 = 0; c0 < dim; c0 += 64) {   // (every lane takes every trip: see apply_csr_kernel)
+      const bool col = c0 + sub * 4 < dim;
+      const int c = col ? c0 + sub * 4 : 0;
+      const float4 gg = sum_rows(grads, partial, hot, w, first, nsrc, wmax, dim, c, gshift);
+      if (col) *reinterpret_cast<float4*>(rows_out + orow * dim + c) = gg;
     }
     if (keys_out && sub == 0) keys_out[g] = key;
   }
@@ -1302,7 +1297,10 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int fresh = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (progress) __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // see hot_sums_kernel
+    if (progress) {   // see hot_sums_kernel; [1]: the keys of this write-back — the host sizes the next one's grid from it
+      __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(progress + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (SRC == SRC_PLAN && a.ks.d_counts[5]) atomicAdd(a.v.err_count, a.ks.d_counts[5]);
   }
   const OwnFlags fl = own_setup<SIMPLE>(a);
@@ -1326,9 +1324,14 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
 //            the key, atomic max / add on (position + 1, count)): its slot is the same for every block.  The block whose
 //            swap installed the key appends (key, slot) to the dense list of distinct keys — one counter add per block;
 //   phase C  the plan keeps TWO such tables and alternates: while build k fills one, it empties the slots build k-1 used in
-//            the other (its dense list says which) — no memset, no extra launch;
-//   the block that draws the last ticket publishes the counts (device copy for the write-back, pinned copy for the step
-//   driver: every other block's list entries were stored write-through and acknowledged before its ticket).
+//            the other (its dense list says which) — no memset, no extra launch.
+// NO block finishes the build for the others (round 3: the kernel used to end with a ticket — wait for the block's stores,
+// draw, the last block reads the count and publishes it to device and pinned memory, resets the counters: four more
+// dependent round trips, 6 of the kernel's 17.8 us).  The count of distinct keys IS the append counter, read by the
+// consumer after the kernel; each table has two counter words and alternates between them from use to use — block 0 of a
+// build zeroes the word of the table's NEXT use (its last reader, the other table's build right after the use before,
+// is over by stream order).  The host sizes the consumer's grid from the count the previous write-back saw
+// (upsert_own_kernel publishes it), grid-stride covers a batch that has more.
 // The two sentinel key values have slots of their own behind the table (no hashing: EMPTY_KEY is the free-slot marker).
 constexpr int SP_NT = 1024;
 constexpr unsigned SP_LDS = 2048;
@@ -1337,17 +1340,20 @@ struct SetTab {   // one of the plan's two tables
   uint2* gpc;       // [m2 + 2]   (last position + 1, occurrences)
   i64* ukeys;       // [n] dense list: the distinct keys, in no particular order
   unsigned* uslot;  // [n] their slots
-  unsigned* count;  // number of distinct keys (zero before its build)
+  unsigned* count;  // number of distinct keys of the table's current use (zero before its build)
 };
 
+// COUNTS: also count the occurrences of every id (LFU scores without caller scores; tfra_sparse_plan_read)
+template <bool COUNTS>
 __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
-                                                        unsigned* d_counts, unsigned* host_counts, unsigned gen) {
+                                                        unsigned* next_use_count) {
   __shared__ i64 s_key[SP_LDS];
   __shared__ unsigned s_pos[SP_LDS + 2], s_cnt[SP_LDS + 2];
-  __shared__ unsigned s_n, s_base, s_last;
+  __shared__ unsigned s_n, s_base;
   const unsigned tid = threadIdx.x;
-  const unsigned n_old = *old.count;   // (read before anybody can zero it: the last block does, at its very end)
-  for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; s_cnt[i] = 0; }
+  const unsigned n_old = *old.count;
+  if (blockIdx.x == 0 && tid == 0) *next_use_count = 0;
+  for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS) s_cnt[i] = 0; }
   if (tid == 0) s_n = 0;
   __syncthreads();
   // ---- A: equal ids of the block meet in LDS ---------------------------------------------------------------
@@ -1365,78 +1371,63 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
       }
     }
     atomicMax(&s_pos[slot], (unsigned)gid + 1u);
-    atomicAdd(&s_cnt[slot], 1u);
+    if (COUNTS) atomicAdd(&s_cnt[slot], 1u);
   }
   __syncthreads();
-  // ---- B: the block's distinct ids into the global table --------------------------------------------------
+  // ---- B: the block's distinct ids into the global table: the first probes of both of a thread's keys travel together ----
   i64 mykey[2];
-  unsigned myslot[2], myidx[2];
-  bool mine[2] = {false, false};
+  unsigned myslot[2], myidx[2], p1[2], cn[2];
+  bool have[2], mine[2] = {false, false};
+  i64 was[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const unsigned s = tid + (unsigned)r * SP_NT;   // 2048 hash slots; the two sentinel slots ride with threads 0 and 1 below
-    i64 key = s_key[s];
-    unsigned p1 = s_pos[s], c = s_cnt[s];
-    bool have = p1 != 0;
-    unsigned sl = 0;
-    if (have) {
-      sl = (unsigned)(fmix64((u64)key) >> 20) & (m2 - 1);
+    mykey[r] = s_key[s];
+    p1[r] = s_pos[s]; cn[r] = COUNTS ? s_cnt[s] : 0u;
+    have[r] = p1[r] != 0;
+    myslot[r] = (unsigned)(fmix64((u64)mykey[r]) >> 20) & (m2 - 1);
+    was[r] = 0;
+    if (have[r]) was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + myslot[r]), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (have[r]) {
       for (;;) {
-        const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + sl), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-        if (was == EMPTY_KEY) { mine[r] = true; break; }
-        if (was == key) break;
-        sl = (sl + 1) & (m2 - 1);
+        if (was[r] == EMPTY_KEY) { mine[r] = true; break; }
+        if (was[r] == mykey[r]) break;
+        myslot[r] = (myslot[r] + 1) & (m2 - 1);
+        was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + myslot[r]), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
       }
-      atomicMax(&cur.gpc[sl].x, p1);
-      atomicAdd(&cur.gpc[sl].y, c);
+      atomicMax(&cur.gpc[myslot[r]].x, p1[r]);
+      if (COUNTS) atomicAdd(&cur.gpc[myslot[r]].y, cn[r]);
     }
-    mykey[r] = key; myslot[r] = sl;
     myidx[r] = mine[r] ? atomicAdd(&s_n, 1u) : 0u;
   }
   if (tid < 2 && s_pos[SP_LDS + tid] != 0) {   // a sentinel key value occurred in this block
     const unsigned sl = m2 + tid;
-    const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + sl), (unsigned long long)EMPTY_KEY, 1ULL);
+    const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + sl), (unsigned long long)EMPTY_KEY, 1ULL);
     atomicMax(&cur.gpc[sl].x, s_pos[SP_LDS + tid]);
-    atomicAdd(&cur.gpc[sl].y, s_cnt[SP_LDS + tid]);
-    if (was == EMPTY_KEY) {
+    if (COUNTS) atomicAdd(&cur.gpc[sl].y, s_cnt[SP_LDS + tid]);
+    if (w == EMPTY_KEY) {
       const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
-      store_wt8(cur.ukeys + at, (u64)(EMPTY_KEY + (i64)tid));
-      __hip_atomic_store(cur.uslot + at, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cur.ukeys[at] = EMPTY_KEY + (i64)tid;
+      cur.uslot[at] = sl;
     }
   }
   __syncthreads();
   if (tid == 0) s_base = s_n ? atomicAdd(cur.count, s_n) : 0u;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    if (!mine[r]) continue;
-    store_wt8(cur.ukeys + s_base + myidx[r], (u64)mykey[r]);
-    __hip_atomic_store(cur.uslot + s_base + myidx[r], myslot[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // ---- C: empty the slots the previous build used in the OTHER table ------------------------------------------
+  // ---- C: empty the slots the previous build used in the OTHER table (while the counter add travels) -------------------
   for (size_t i = gid; i < n_old; i += (size_t)gridDim.x * SP_NT) {
     const unsigned sl = old.uslot[i];
     old.gkey[sl] = EMPTY_KEY;
     old.gpc[sl] = make_uint2(0u, 0u);
   }
-  // ---- the last block publishes --------------------------------------------------------------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's list entries are in memory
   __syncthreads();
-  if (tid == 0) s_last = __hip_atomic_fetch_add(d_counts + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last || tid != 0) return;
-  const unsigned U = __hip_atomic_load(cur.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // agent-scope stores (write-through): the step driver launches the write-back as soon as the pinned flag below shows this
-  // build — that kernel may start on another XCD before this one has ended
-  const unsigned v[6] = {0u, U, 0u, 0u, 0u, 0u};
-  for (int k = 0; k < 6; ++k) __hip_atomic_store(d_counts + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<u64*>(d_counts + 32), (u64)U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(d_counts + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket counter of the next build
-  __hip_atomic_store(old.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the other table is empty again: its next build counts from zero
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (host_counts) {
-    for (int k = 0; k < 6; ++k) __hip_atomic_store(host_counts + 1 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_counts, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (!mine[r]) continue;
+    cur.ukeys[s_base + myidx[r]] = mykey[r];
+    cur.uslot[s_base + myidx[r]] = myslot[r];
   }
 }
 
@@ -1487,7 +1478,11 @@ struct tfra_sparse_plan {
   unsigned set_m2 = 0;
   SetTab set_tab[2]{};
   unsigned set_parity = 0;         // table of the last build
-  unsigned* set_counts = nullptr;  // the d_counts block of the set buffer
+  unsigned* set_counts = nullptr;  // the d_counts block of the set buffer: [8] any_deferred [12..19] OwnCtrs x2; [64 + 8 (2 p + use & 1) ..]
+                                   // the key counts of table p's uses ({0, distinct keys, 0, 0, 0, 0}: what CsrKeys::d_counts shows)
+  unsigned set_use[2] = {0, 0};    // uses of each table so far
+  bool built_counts = true;        // the last build counted occurrences
+  bool want_counts = true;         // count the occurrences of every id too (off: LRU-type tables, tfra_table_step_prefetch_assign)
   uint8_t* set_dflag = nullptr;
   OwnItem* set_items = nullptr;
 };
@@ -1540,17 +1535,24 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
       tb.gpc = (uint2*)w; w += al(((size_t)m2 + 2) * 8);
       tb.ukeys = (i64*)w; w += al(cap * 8);
       tb.uslot = (unsigned*)w; w += al(cap * 4);
-      tb.count = pl->set_counts + 20 + p;
+      tb.count = nullptr;   // set per build: the table's two counter words alternate
       fill_i64_kernel<<<256, 256, 0, s>>>(tb.gkey, (size_t)m2 + 2, EMPTY_KEY);
     }
-    pl->set_cap = cap; pl->set_m2 = m2; pl->set_parity = 1;
+    pl->set_cap = cap; pl->set_m2 = m2; pl->set_parity = 1; pl->set_use[0] = pl->set_use[1] = 0;
   }
   const unsigned p = pl->set_parity ^ 1u;
   pl->gen += 1;
   const unsigned blocks = (unsigned)((n + SP_NT - 1) / SP_NT);
-  setplan_kernel<<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, pl->set_tab[p], pl->set_tab[p ^ 1u], pl->set_counts,
-                                          pl->host_counts, pl->gen);
+  auto count_word = [&](unsigned tab, unsigned use) { return pl->set_counts + 64 + 8 * (2 * tab + (use & 1u)) + 1; };
+  const unsigned use = ++pl->set_use[p];
+  SetTab cur = pl->set_tab[p], old = pl->set_tab[p ^ 1u];
+  cur.count = count_word(p, use);
+  old.count = count_word(p ^ 1u, pl->set_use[p ^ 1u]);   // (never used yet: a zero word)
+  pl->set_tab[p].count = cur.count;
+  if (pl->want_counts) setplan_kernel<true><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
+  else setplan_kernel<false><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
+  pl->built_counts = pl->want_counts;
   pl->set_parity = p;
   pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
   pl->n = n; pl->dim = 0; pl->kind = 1;
@@ -1675,7 +1677,7 @@ static void plan_grids(const tfra_sparse_plan* pl, unsigned* key_blocks, unsigne
 static CsrKeys keys_of(const tfra_sparse_plan* pl) {
   if (pl->kind == 1) {
     const SetTab& tb = pl->set_tab[pl->set_parity];
-    return CsrKeys{nullptr, nullptr, nullptr, nullptr, nullptr, pl->d_counts, tb.ukeys, tb.uslot, tb.gpc};
+    return CsrKeys{nullptr, nullptr, nullptr, nullptr, nullptr, tb.count - 1, tb.ukeys, tb.uslot, tb.gpc};
   }
   return CsrKeys{pl->keymap, pl->dkeys, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts, nullptr, nullptr, nullptr};
 }
@@ -1793,6 +1795,12 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   if (rc) return rc;
   unsigned key_blocks, bin_blocks;
   plan_grids(pl, &key_blocks, &bin_blocks);
+  if (pl->kind == 1 && progress) {
+    // an assign-only plan does not tell the host how many distinct keys it found; the step driver's batches resemble each
+    // other: the count the last write-back that has started saw, plus a quarter (a batch with more: grid-stride)
+    const unsigned seen = reinterpret_cast<volatile unsigned*>(progress)[1];
+    if (seen) key_blocks = (unsigned)std::max<size_t>(1, (std::min<size_t>(pl->n, (size_t)seen + seen / 4 + 1024) * 16 + 255) / 256);
+  }
   uint8_t* bounded_now;
   rc = t->bounded_flags(1, s, &bounded_now);
   if (rc) return rc;
@@ -1891,7 +1899,7 @@ extern "C" int tfra_sparse_plan_read(const tfra_sparse_plan_t* pl, uint32_t* cou
   hipStream_t s = (hipStream_t)stream;
   if (!pl || !counts) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: null argument");
   if (pl->n == 0) { for (int i = 0; i < 6; ++i) counts[i] = 0; return TFRA_OK; }
-  if (hipMemcpyAsync(counts, pl->d_counts, 6 * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+  if (hipMemcpyAsync(counts, keys_of(pl).d_counts, 6 * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
     return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
   const unsigned nhot = counts[0], ncold = counts[1], nbins = counts[3];
   if (!keys) return TFRA_OK;
@@ -2096,6 +2104,7 @@ extern "C" int tfra_table_upsert_sparse(tfra_table_t* tp, size_t n, const int64_
   // "the last occurrence wins" across chunks too
   for (size_t off = 0; off < n; off += MAX_IDS) {
     const size_t m = std::min<size_t>(MAX_IDS, n - off);
+    pl->want_counts = t->opts.strategy == TFRA_EVICT_LFU && !scores;   // what uses a key's occurrence count (own_batch16)
     rc = tfra_sparse_plan_build(pl, m, ids + off, 0, stream);
     if (rc) return rc;
     rc = upsert_planned_impl(tp, pl, (const unsigned char*)values + off * (size_t)t->field_bytes, scores ? scores + off : nullptr, stream,
@@ -2277,7 +2286,7 @@ static int step_prefetch_impl(tfra_table_t* tp, const tfra_opt_params* p, tfra_s
   int rc = TFRA_OK;
   if (!t->progress_host) {
     if (hipHostMalloc((void**)&t->progress_host, 64, hipHostMallocDefault) != hipSuccess) { t->progress_host = nullptr; return set_error(TFRA_ERR_OOM, "step_prefetch: hipHostMalloc"); }
-    *t->progress_host = 0;
+    t->progress_host[0] = 0; t->progress_host[1] = 0;
   }
   const unsigned step = ++t->step_gen;
   if (plan_next) {
@@ -2298,6 +2307,7 @@ static int step_prefetch_impl(tfra_table_t* tp, const tfra_opt_params* p, tfra_s
     if (rc) return rc;
   }
   if (plan_next) {
+    if (!p) plan_next->want_counts = t->opts.strategy == TFRA_EVICT_LFU && !scores;   // (the next step's call passes scores or not like this one)
     rc = tfra_sparse_plan_build(plan_next, n_next, ids_next, p ? t->opts.dim : 0, side_stream);
     if (rc) return rc;
     if (!plan_next->built_ev && hipEventCreateWithFlags(&plan_next->built_ev, hipEventDisableTiming) != hipSuccess) {
