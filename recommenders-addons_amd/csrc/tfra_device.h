@@ -166,7 +166,10 @@ __device__ __forceinline__ void keep_live(unsigned char&, unsigned char&, unsign
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt16(void* p, uint4 v) {
   v4u_t x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+  // s_nop 1: a store of more than 64 bits reads its data registers after issue — a VALU write to them needs two wait states
+  // behind it, and the compiler's hazard recogniser does not look into inline assembly (a loop that recomputed the stored
+  // float4 right after the store wrote the NEXT iteration's values: the partial sums of rows wider than 64 floats)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 
 // ---- find: continue a probe whose first line `k` (bucket b) is already in registers --------
