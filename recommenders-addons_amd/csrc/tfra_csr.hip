@@ -24,8 +24,26 @@
 //     hot_sums_kernel    one block per bin: 32 groups x 16 rows in flight, ordered add -> one partial row per run
 //     apply_csr_kernel   one 16-lane group per unique key (hot keys first): gathers its <= 8 gradient rows or
 //                        its partial rows IN ORDER, sums, locates/claims the table row, applies the optimizer.
-//   ASSIGN (tfra_table_upsert_planned): upsert_csr_kernel — one group per unique key copies the row of the
-//     key's LAST occurrence (no sums, any value dtype).
+//   ASSIGN (tfra_table_upsert_planned): upsert_own_kernel (one pass with bucket ownership) + upsert_rest_kernel (the few
+//     keys that pass leaves over) copy the row of every key's LAST occurrence (no sums, any value dtype); the assign-only
+//     plan (setplan_kernel, dim 0) is one kernel: distinct ids with their last position.
+//
+// Round 3, tried and dropped (measured on the 10^9-slot table, B = 131 072 Zipf-1.2; each is in the git history as one
+// experiment, none in the code):
+//   * the remainder pass deferred to the table's next call and taken into the lookup's kernel (its first 32 blocks run the
+//     list, every block waits for them when the list is not empty): a lookup kernel that holds the remainder's code needs
+//     81 registers instead of 57 (6 instead of 8 waves per SIMD, or spills on the remainder's path), an agent-scope acquire
+//     per waiting block is an L2 invalidate each (60 us per launch), 2000 blocks polling one word take 300 us, and while the
+//     blocks wait they hold every wave slot, so the plan kernel of the second stream cannot run beside them: 48-51 us per
+//     step against 47; only a sequence whose lists are always empty gained (34 -> 28 us);
+//   * keys that lost a claim handled inside the pass (found keys lock their own slot, evictions take their victim by
+//     compare-and-swap): correct, 45 % of the lists become empty, but the remainder kernel costs the same 8 us with one item
+//     as with sixteen, and the swaps cost the pass 1.5-3 us on batches that evict;
+//   * the assign-only plan partitioned by KEY (every block reads all ids and keeps its hash range: no global hash table, no
+//     device-scope atomics): one CU streams 1 MB of ids in >= 7 us — 73 us as written, ~13 us at best, against 16 us;
+//   * the hot sums as the leading blocks of their consumer kernel (keys with partial rows wait for them): the bin part has
+//     to acknowledge its write-through rows before it may count itself done and shares the consumer's registers — 22 us
+//     instead of 12 inside a step, and the keys that need it cannot start before it ends: 37-45 us against 38.
 //
 // Summation tree of a key = f(its occurrence count) only: [16 consecutive occurrences, ascending batch position,
 // sequential] -> [the 32 groups of a bin, sequential] -> [the key's partials, sequential]; keys with <= 8
