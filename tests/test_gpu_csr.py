@@ -409,3 +409,34 @@ def test_unique_many_calls_one_workspace(env):
     assert int(cnt.item()) == want.size
     np.testing.assert_array_equal(u.cpu().numpy(), want)
     np.testing.assert_array_equal(want[idx.cpu().numpy()], ids)
+
+
+@pytest.mark.parametrize("owner_tags", [True, False])
+@pytest.mark.parametrize("driver", ["upsert_sparse", "step"])
+def test_sparse_write_back_lfu_scores_are_occurrence_counts(env, driver, owner_tags):
+  """An LFU table's score of a key = how often it was written (lookup_table_op_hkv.h:454-475, kLfu: score += 1 per upsert
+  of the key; a batch with repeats counts every occurrence).  The assign-only plan counts occurrences only for tables that
+  read them (LFU without caller scores) — here they must arrive — and the write-back adds them to the key's score."""
+  torch, de, SparsePlan = env
+  dim, cap = 8, 1 << 16
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LFU, name="lfu_counts_%s_%d" % (driver, owner_tags))
+  t._table.set_owner_tags(owner_tags)
+  rng = np.random.default_rng(17)
+  total = {}
+  batches = [(rng.zipf(1.3, size=20_000) % 3000).astype(np.int64) * 11 + 5 for _ in range(4)]
+  if driver == "step":
+    ps = de.PrefetchAssignStep(t).prime(torch.from_numpy(batches[0]).cuda())
+  for i, ids in enumerate(batches):
+    vals = torch.full((ids.size, dim), float(i + 1), device="cuda")
+    if driver == "step":
+      ps.step(vals, torch.from_numpy(batches[i + 1]).cuda() if i + 1 < len(batches) else None, lookup=False)
+    else:
+      t._table.upsert_sparse(torch.from_numpy(ids).cuda(), vals)
+    for k, c in zip(*np.unique(ids, return_counts=True)):
+      total[int(k)] = total.get(int(k), 0) + int(c)
+  ek, es = t.export_keys_and_scores(1 << 20)
+  ek, es = ek.cpu().numpy(), es.cpu().numpy()
+  assert ek.size == len(total) == int(t.size().item())
+  np.testing.assert_array_equal(es[np.argsort(ek)], np.array([total[k] for k in sorted(total)], np.uint64).astype(es.dtype))
+  t._table.check_errors()
