@@ -1109,12 +1109,12 @@ __device__ __forceinline__ void select_victim_dpp(u64 b0, u64 b1, const i64 (&kk
 template <int U, typename T>
 __device__ __forceinline__ void keep_live_u(T (&x)[U]) {
   if (U == 4) keep_live(x[0], x[1], x[2], x[3]);
-  else keep_live(x[0], x[1], x[0], x[1]);
+  else keep_live(x[0], x[U - 1], x[0], x[U - 1]);
 }
 template <int U, typename T>
 __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
   if (U == 4) keep_live(x[0][k], x[1][k], x[2][k], x[3][k]);
-  else keep_live(x[0][k], x[1][k], x[0][k], x[1][k]);
+  else keep_live(x[0][k], x[U - 1][k], x[0][k], x[U - 1][k]);
 }
 
 // One batch of 16 keys of one wave.  What is scalar per key — the key word, its hash, the two ownership claims, the plan
@@ -1815,7 +1815,8 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
                        unsigned rest_blocks, unsigned* progress, unsigned progress_val) {
   // 4 waves x 16 keys per block and pass; up to a batch's worth of keys 8 keys per wave instead (own_batch16: U): twice the
   // waves, half the dependent work in each, 86 instead of 118 registers.  Measured on the 10^9-slot table: 22.7 K keys
-  // 13.1 -> 11.3 us (the step 42.5 -> 41.1), 78 K keys the same kernel time alone and the step 64.0 -> 60.7 us
+  // 13.1 -> 11.3 us (the step 42.5 -> 41.1), 78 K keys the same kernel time alone and the step 64.0 -> 60.7 us; 4 keys per
+  // wave: nothing more on 22.7 K keys (40.8 us), 64.6 us on 78 K
   const bool half = g == 16 && nkeys <= 131072;
   const unsigned blocks = (unsigned)std::max<size_t>(1, half ? (nkeys + 31) / 32 : (nkeys + 63) / 64);
   // a.tags == nullptr (TFRA_OPTION_NO_OWNER_TAGS, or the tags did not allocate): the locked protocol for every key
