@@ -30,7 +30,9 @@ def short(name):
   if k in ("upsert_own_kernel", "upsert_rest_kernel"):
     a = re.search(r"%s<([^>]*)>" % k, name)
     if a:
-      k += "[%s]" % SRC_NAMES.get(a.group(1).split(",")[-1].strip(), "?")
+      args = [x.strip() for x in a.group(1).split(",")]
+      src = args[2] if k == "upsert_own_kernel" and len(args) > 2 else args[1] if len(args) > 1 else "?"   # <G, SIMPLE, SRC, U> / <G, SRC>
+      k += "[%s]" % SRC_NAMES.get(src, "?")
   return k
 
 
