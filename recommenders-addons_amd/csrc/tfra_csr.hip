@@ -1542,7 +1542,8 @@ struct tfra_sparse_plan {
                                    // the key counts of table p's uses ({0, distinct keys, 0, 0, 0, 0}: what CsrKeys::d_counts shows)
   unsigned set_use[2] = {0, 0};    // uses of each table so far
   bool built_counts = true;        // the last build counted occurrences
-  bool want_counts = true;         // count the occurrences of every id too (off: LRU-type tables, tfra_table_step_prefetch_assign)
+  bool skip_counts_once = false;   // the NEXT build need not count occurrences (set by the table's own drivers for tables whose
+                                   // scores do not read them; a build through the public entry point always counts)
   uint8_t* set_dflag = nullptr;
   OwnItem* set_items = nullptr;
 };
@@ -1609,10 +1610,12 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
   cur.count = count_word(p, use);
   old.count = count_word(p ^ 1u, pl->set_use[p ^ 1u]);   // (never used yet: a zero word)
   pl->set_tab[p].count = cur.count;
-  if (pl->want_counts) setplan_kernel<true><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
+  const bool counts = !pl->skip_counts_once;
+  pl->skip_counts_once = false;
+  if (counts) setplan_kernel<true><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
   else setplan_kernel<false><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
-  pl->built_counts = pl->want_counts;
+  pl->built_counts = counts;
   pl->set_parity = p;
   pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
   pl->n = n; pl->dim = 0; pl->kind = 1;
@@ -1859,6 +1862,8 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   if (pl->n == 0) return TFRA_OK;
   if (!values) return set_error(TFRA_ERR_INVALID, "upsert_planned: null values");
   if (t->opts.device != pl->device && t->opts.device >= 0) return set_error(TFRA_ERR_INVALID, "upsert_planned: plan and table live on different devices");
+  if (pl->kind == 1 && !pl->built_counts && t->opts.strategy == TFRA_EVICT_LFU && !scores)
+    return set_error(TFRA_ERR_INVALID, "upsert_planned: this plan was built without occurrence counts (by a step driver of a table whose scores do not read them); an LFU table without caller scores needs them");
   rc = t->prepare_insert(pl->n, s);
   if (rc) return rc;
   unsigned key_blocks, bin_blocks;
@@ -2172,7 +2177,7 @@ extern "C" int tfra_table_upsert_sparse(tfra_table_t* tp, size_t n, const int64_
   // "the last occurrence wins" across chunks too
   for (size_t off = 0; off < n; off += MAX_IDS) {
     const size_t m = std::min<size_t>(MAX_IDS, n - off);
-    pl->want_counts = t->opts.strategy == TFRA_EVICT_LFU && !scores;   // what uses a key's occurrence count (own_batch16)
+    pl->skip_counts_once = !(t->opts.strategy == TFRA_EVICT_LFU && !scores);   // what reads a key's occurrence count (own_batch16)
     rc = tfra_sparse_plan_build(pl, m, ids + off, 0, stream);
     if (rc) return rc;
     rc = upsert_planned_impl(tp, pl, (const unsigned char*)values + off * (size_t)t->field_bytes, scores ? scores + off : nullptr, stream,
@@ -2375,7 +2380,7 @@ static int step_prefetch_impl(tfra_table_t* tp, const tfra_opt_params* p, tfra_s
     if (rc) return rc;
   }
   if (plan_next) {
-    if (!p) plan_next->want_counts = t->opts.strategy == TFRA_EVICT_LFU && !scores;   // (the next step's call passes scores or not like this one)
+    if (!p) plan_next->skip_counts_once = !(t->opts.strategy == TFRA_EVICT_LFU && !scores);   // (the next step's call passes scores or not like this one)
     rc = tfra_sparse_plan_build(plan_next, n_next, ids_next, p ? t->opts.dim : 0, side_stream);
     if (rc) return rc;
     if (!plan_next->built_ev && hipEventCreateWithFlags(&plan_next->built_ev, hipEventDisableTiming) != hipSuccess) {
