@@ -554,22 +554,23 @@ def run_bounded(args, torch, de, dev, cfg):
 
   # ---- per-kernel timings (HIP events on the launching stream), fresh batches each launch ----------------------
   rc = raw_calls(torch, dev)
-  kids = idf.keys(30)
+  NP = 24                                     # write-back launches timed, every one on its own batch (6 were too few: +-10 %)
+  kids = idf.keys(6 + 2 * NP)
   fk = [rc.find(tbl._h, kids[j], out_buf, dflt_row) for j in range(6)]
   find_us = tm.us(lambda i: fk[i % 6](), reps=24, warm=3)
-  plans = [de.table_ops.SparsePlan(dev, 0) for _ in range(8)]
+  plans = [de.table_ops.SparsePlan(dev, 0) for _ in range(NP)]
   for j, pl in enumerate(plans):
     pl.build(kids[6 + j], sync=False)
   torch.cuda.synchronize()
   counts = plans[0].read()[0]
   U = counts["many"] + counts["few"]
-  ups = [rc.upsert_planned(tbl._h, plans[j], values) for j in range(8)]
-  upsert_us = tm.us(lambda i: ups[i](), reps=6, warm=2)       # every launch writes its own batch
+  ups = [rc.upsert_planned(tbl._h, plans[j], values) for j in range(NP)]
+  upsert_us = tm.us(lambda i: ups[i](), reps=NP - 4, warm=4)   # every launch writes its own batch
   builds = [rc.plan_build(plans[j], kids[6 + j], 0) for j in range(8)]
   plan_us = tm.us(lambda i: builds[i % 8](), reps=24, warm=3)
-  uqk = [torch.unique(kids[14 + j]) for j in range(8)]
-  insk = [(lambda a=(tbl._h, uqk[j].numel(), P(uqk[j]), P(values), None, 1, st): _capi.check(lib.tfra_table_insert_or_assign(*a))) for j in range(8)]
-  insert_unique_us = tm.us(lambda i: insk[i](), reps=6, warm=2)
+  uqk = [torch.unique(kids[6 + NP + j]) for j in range(NP)]
+  insk = [(lambda a=(tbl._h, uqk[j].numel(), P(uqk[j]), P(values), None, 1, st): _capi.check(lib.tfra_table_insert_or_assign(*a))) for j in range(NP)]
+  insert_unique_us = tm.us(lambda i: insk[i](), reps=NP - 4, warm=4)
   unique_us = tm.us(lambda i: _capi.check(lib.tfra_unique(*uniqs[i % nsteps])), reps=24, warm=3)
   export = None
   if cfg == "c3":
@@ -677,7 +678,7 @@ def run_bounded(args, torch, de, dev, cfg):
           "step_bytes_definition": "B*(8+2*Rb) for the lookup + U*(16+2*Rb) for the write-back of the U unique keys (SURVEY §8d)",
           "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "kernels": kernels,
-          "timing": "HIP events on the launching stream around 6-24 launches, a different batch each; latency (TLB-missing round "
+          "timing": "HIP events on the launching stream around 20-24 launches, a different batch each; latency (TLB-missing round "
                     "trips on a 273-GB table) and cross-lane work, not bytes, bound the write-back kernels (DESIGN.md §5)",
       },
   }
