@@ -262,7 +262,9 @@ class Variable:
     """Per-shard files `<name>_mht_<i>of<N>[_rank<r>_size<s>]-keys/-values`
     (PY/dynamic_embedding_variable.py:1009-1060) — and the same for every optimizer slot of the rows (the reference
     saves its slot variables as tables of their own; not saving them would silently reset Adam's m / v, Adagrad's and
-    FTRL's accumulators on restore)."""
+    FTRL's accumulators on restore).  The optimizer's step count (`DynamicEmbeddingOptimizer.iterations`, Adam's bias
+    correction) is the OPTIMIZER's state, not the variable's: the reference keeps it in the Keras optimizer's own
+    checkpoint, and so must the caller here (`deo.iterations` is a plain int)."""
     import os
     suffix = "_rank{}_size{}".format(proc_rank, proc_size) if proc_size > 1 else ""
     slots = self._slot_file_names(optimizer)
