@@ -404,6 +404,31 @@ def test_k13_fused_optimizer_matches_reference_sequence(env, name, dim, shards):
     np.testing.assert_allclose(got, exp, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("kat_i", range(4))
+@pytest.mark.parametrize("path", ["apply_gradients", "apply_optimizer"])
+def test_ftrl_tensorflow_known_answers(env, kat_i, path):
+  """The four FTRL known answers TensorFlow's own ftrl_test.py publishes (tests/test_optimizers_pinned.py::FTRL_KATS) through
+  the HIP kernels: fused planned write-back (apply_gradients) and tfra_table_apply_optimizer on pre-summed unique keys.
+  Two resident keys = TF's var0 / var1 (dim 2), constant gradients, lr 3.0, initial_accumulator_value 0.1."""
+  torch, de = env
+  from tests.test_optimizers_pinned import FTRL_KATS, FTRL_KAT_GRADS
+  name, v0, v1, l1, l2, steps, e0, e1 = FTRL_KATS[kat_i]
+  opt = de.optimizers.Ftrl(3.0, -0.5, 0.1, l1, l2)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  v = de.Variable(dim=2, name="ftrl_kat_%d_%s" % (kat_i, path), initializer=0.0, **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+  keys = torch.tensor([7, 11], dtype=torch.int64, device="cuda")
+  v.upsert(keys, torch.tensor([v0, v1], dtype=torch.float32, device="cuda"))
+  g = torch.tensor(FTRL_KAT_GRADS, dtype=torch.float32, device="cuda")
+  for _ in range(steps):
+    if path == "apply_gradients":
+      _, tw = de.embedding_lookup(v, keys, return_trainable=True)
+      deo.apply_gradients([(g, tw)])
+    else:
+      v.tables[0]._table.apply_optimizer(deo.begin_step(), keys, g, torch.zeros(2, device="cuda"))
+  got = v.lookup(keys).cpu().numpy()
+  np.testing.assert_allclose(got, np.array([e0, e1], np.float32), rtol=1e-5, atol=0)
+
+
 def test_generic_optimizer_custom_rule_and_errors(env):
   """optimizers.Generic with a user rule (here Adamax, T/dynamic_embedding_optimizer_test.py:313-319 lists it):
   same write-back sequence; a plan cannot be built for it; slot count is limited by the row layout."""

@@ -9,8 +9,10 @@ reference available here:
   ResourceApplyAdam (eps-hat)   == torch.optim.Adam with eps_torch(t) = eps_tf / sqrt(1 - beta2^t):
                                    torch: p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps_torch)
                                         = lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps_torch*sqrt(1-b2^t))   = TF's rule
-  ResourceApplyFtrl             no independent implementation in this image: stays pinned differentially
-                                (tests/test_gpu_frontend.py K13 and the oracle-vs-kernel tests).
+  ResourceApplyFtrl             == the known answers TensorFlow publishes in its own test-suite
+                                (tensorflow/python/training/ftrl_test.py: testFtrlwithoutRegularization[2], testFtrlWithL1,
+                                testFtrlWithL1_L2 — FTRL_KATS below; the HIP kernels run the same four in
+                                tests/test_gpu_frontend.py::test_ftrl_tensorflow_known_answers)
 Tolerance 2e-6 relative (+1e-7 absolute): both sides are fp32 with a different association of the same operations."""
 import math
 
@@ -104,7 +106,7 @@ def test_adam_lr_t_is_the_bias_corrected_step():
 
 
 def test_ftrl_closed_form_properties():
-  """No independent FTRL exists here; at least the closed form's fixed points hold: |z| <= l1 -> p = 0; l1 = l2 = 0 and
+  """Besides TensorFlow's known answers (FTRL_KATS below), the closed form's fixed points hold: |z| <= l1 -> p = 0; l1 = l2 = 0 and
   lr_power = -0.5 reduce the rule to p = -z * lr / sqrt(a) (per-coordinate adaptive step)."""
   rng = np.random.default_rng(5)
   p = rng.standard_normal((8, 4)).astype(np.float32)
@@ -116,3 +118,28 @@ def test_ftrl_closed_form_properties():
   p2, a2, z2 = O.ftrl(p, a, z, g, 0.05, l1=0.0, l2=0.0)
   np.testing.assert_allclose(p2, -z2 * np.float32(0.05) / np.sqrt(a2), rtol=1e-6)
   np.testing.assert_allclose(a2, a + g * g, rtol=1e-7)
+
+
+# TensorFlow's own known answers for FtrlOptimizer(3.0, initial_accumulator_value=0.1, l1, l2) — tensorflow/python/training/
+# ftrl_test.py (TF 2.16): two variables, constant gradients [0.1, 0.2] and [0.01, 0.02], `steps` applications.
+#   (name, var0, var1, l1, l2, steps, expected var0, expected var1)
+FTRL_KATS = [
+    ("testFtrlwithoutRegularization", [0.0, 0.0], [0.0, 0.0], 0.0, 0.0, 3, [-2.60260963, -4.29698515], [-0.28432083, -0.56694895]),
+    ("testFtrlwithoutRegularization2", [1.0, 2.0], [4.0, 3.0], 0.0, 0.0, 3, [-2.55607247, -3.98729396], [-0.28232238, -0.56096673]),
+    ("testFtrlWithL1", [1.0, 2.0], [4.0, 3.0], 0.001, 0.0, 10, [-7.66718769, -10.91273689], [-0.93460727, -1.86147261]),
+    ("testFtrlWithL1_L2", [1.0, 2.0], [4.0, 3.0], 0.001, 2.0, 10, [-0.24059935, -0.46829352], [-0.02406147, -0.04830509]),
+]
+FTRL_KAT_GRADS = ([0.1, 0.2], [0.01, 0.02])
+
+
+@pytest.mark.parametrize("kat", FTRL_KATS, ids=[k[0] for k in FTRL_KATS])
+def test_ftrl_matches_tensorflow_known_answers(kat):
+  """oracle.optimizers.ftrl against the numbers TensorFlow's ftrl_test.py pins (rtol 1e-5: TF's own assertAllCloseAccordingToType
+  bound for float32 is 1e-6 absolute on values of this size after rounding the literals to 8 digits)."""
+  _, v0, v1, l1, l2, steps, e0, e1 = kat
+  for p0, g, want in ((v0, FTRL_KAT_GRADS[0], e0), (v1, FTRL_KAT_GRADS[1], e1)):
+    p, a, z = np.array(p0, np.float32), np.full(2, 0.1, np.float32), np.zeros(2, np.float32)
+    g = np.array(g, np.float32)
+    for _ in range(steps):
+      p, a, z = O.ftrl(p, a, z, g, 3.0, l1, l2)
+    np.testing.assert_allclose(p, np.array(want, np.float32), rtol=1e-5, atol=0)
