@@ -1522,7 +1522,10 @@ struct tfra_sparse_plan {
   OwnItem* slow_items = nullptr;   // [SLOW_CAP] left-over keys of the ownership pass of a write-back (self-contained items)
   unsigned* any_deferred = nullptr;   // = use_gen of the last write-back that deferred a key to its eviction phase
   mutable unsigned use_gen = 0;
-  mutable unsigned ups_uses = 0;   // upsert_planned uses: parity selects the left-over counter set
+  mutable unsigned ups_uses[2] = {0, 0};   // upsert_planned uses of the CSR buffer / of the SET buffer: the parity selects the left-over
+                                           // counter set of THAT buffer (each buffer has its own two sets and its own flag bytes: a plan
+                                           // object rebuilt with dim > 0, then dim 0, then dim > 0 again must find its CSR buffer's sets
+                                           // where its last CSR use left them)
   float* partial = nullptr;
   int* prow_dest = nullptr;        // [partial rows] scratch of tfra_plan_positions_to
   bool armed = false;              // cursors/counters are zero (re-armed by the last kernel of the previous build)
@@ -1570,7 +1573,7 @@ extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
 static size_t plan_smem_bytes(unsigned cm) { return (size_t)cm * 36 + (size_t)TABW * 4; }
 
 // The SET plan of a batch (dim 0): see setplan_kernel.
-static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hipStream_t s) {
+static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hipStream_t s, bool counts) {
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   if (pl->set_cap < n) {
@@ -1610,8 +1613,6 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
   cur.count = count_word(p, use);
   old.count = count_word(p ^ 1u, pl->set_use[p ^ 1u]);   // (never used yet: a zero word)
   pl->set_tab[p].count = cur.count;
-  const bool counts = !pl->skip_counts_once;
-  pl->skip_counts_once = false;
   if (counts) setplan_kernel<true><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
   else setplan_kernel<false><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
@@ -1625,11 +1626,13 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
 extern "C" int tfra_sparse_plan_build(tfra_sparse_plan_t* pl, size_t n, const int64_t* ids, int dim, tfra_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!pl) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null plan");
+  const bool skip_counts = pl->skip_counts_once;   // consumed here on EVERY path (an empty batch or an error must not leak it into the next build)
+  pl->skip_counts_once = false;
   { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != pl->device) { if (hipSetDevice(pl->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: hipSetDevice"); } }
   pl->n = 0;
   if (n == 0) return TFRA_OK;
   if (!ids) return set_error(TFRA_ERR_INVALID, "sparse_plan_build: null ids");
-  if (dim == 0) return setplan_build(pl, n, ids, s);   // assign-only: the last position and the count of every distinct id
+  if (dim == 0) return setplan_build(pl, n, ids, s, !skip_counts);   // assign-only: the last position and the count of every distinct id
   if (dim < 0 || dim % 4 != 0 || dim > 64 * MAXCH)
     return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: needs dim % 4 == 0 and dim <= 256 (dim 0: assign-only plan)");
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
@@ -1889,7 +1892,7 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   (void)gen;
   {
     const unsigned og = tags ? next_own_gen(t) : 0;
-    const unsigned par = pl->ups_uses++ & 1u;   // (its own count: apply_planned uses of the plan do not touch the counters)
+    const unsigned par = pl->ups_uses[pl->kind == 1 ? 1 : 0]++ & 1u;   // (its own count per buffer: apply_planned uses of the plan do not touch the counters)
     OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
     OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
     // Left-over keys of the ownership pass.  Few (a big table): the remainder kernel walks their list with a handful of

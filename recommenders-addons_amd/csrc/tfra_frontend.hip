@@ -206,8 +206,10 @@ __global__ void unq_idx_kernel(size_t n, const int* __restrict__ slot_of, const 
 //                 key appends its slot to the set's used list, and the slots the OTHER set used in the previous call are
 //                 emptied on the way (no fill kernel);
 //   unq2_scatter  per tile of 1024 ids: first-occurrence flags, tile count published with the call's generation, the
-//                 tile's offset = sum of the earlier tiles' counts (they are read as they appear: the tiles of a call are
-//                 co-resident, <= 1024 blocks), then the scatter of unq_scatter_kernel; the last tile writes the total;
+//                 tile's offset = sum of the earlier tiles' counts, read as they appear (decoupled look-back: tile j only
+//                 waits for tiles < j, and the hardware dispatches the blocks of a grid in index order, so whatever a
+//                 waiting tile needs is already resident or finished — this does NOT rely on the whole grid being
+//                 co-resident, other streams may hold CUs), then the scatter of unq_scatter_kernel; the last tile writes the total;
 //   unq_idx_kernel.
 struct UnqSet {
   i64* hkeys;       // [cap + 1]
@@ -595,6 +597,15 @@ static int unique_fast(tfra_workspace* ws, size_t n, const i64* ids, i64* unique
       w += per;
     }
   }
+  // The two sets, their parity and generation are STATE of the workspace: calls must reach them in one order.  Same stream:
+  // stream order.  Another stream than the last call's: wait for that call (the Python layer keeps one workspace per stream,
+  // so this only triggers for callers of the C ABI that share a workspace across streams).
+  if (ws->unq_stream_set && ws->unq_stream != s) {
+    if (!ws->unq_ev) HIP_TRY(hipEventCreateWithFlags(&ws->unq_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ws->unq_ev, ws->unq_stream));
+    HIP_TRY(hipStreamWaitEvent(s, ws->unq_ev, 0));
+  }
+  ws->unq_stream = s; ws->unq_stream_set = true;
   const size_t cap = ws->unq_cap, nmax = ws->unq_nmax;
   const size_t per = align_up((cap + 1) * 8) + 2 * align_up((cap + 1) * 4) + align_up(nmax * 4);
   auto set_of = [&](unsigned p) {
@@ -636,6 +647,7 @@ int tfra_workspace_destroy(tfra_workspace_t* ws) {
   (void)hipSetDevice(ws->device);
   if (ws->buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->buf); }
   if (ws->unq_buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->unq_buf); }
+  if (ws->unq_ev) (void)hipEventDestroy(ws->unq_ev);
   tfra::destroy_workspace_plan(ws->plan);
   delete ws;
   return TFRA_OK;

@@ -118,6 +118,10 @@ struct tfra_workspace {
   void* unq_buf = nullptr;
   size_t unq_cap = 0, unq_nmax = 0;
   unsigned unq_parity = 0, unq_gen = 0;
+  // the sets persist from call to call: a call on ANOTHER stream than the previous one is ordered behind it by an event
+  hipStream_t unq_stream = nullptr;
+  bool unq_stream_set = false;
+  hipEvent_t unq_ev = nullptr;
   int ensure(size_t need, hipStream_t s) {
     if (need <= bytes) return TFRA_OK;
     if (buf) {

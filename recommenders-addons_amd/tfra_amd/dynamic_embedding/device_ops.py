@@ -11,7 +11,10 @@ _WS = {}
 
 
 def _workspace(device):
-  key = device.index
+  """One scratch workspace per (device, CURRENT STREAM): a workspace holds state that persists from call to call (tfra_unique's
+  two self-emptying hash sets, their parity and generation), so two streams must never share one — calls on different
+  streams are not ordered with each other."""
+  key = (device.index, _stream(device).value)
   if key not in _WS:
     h = ctypes.c_void_p()
     _capi.call("tfra_workspace_create", device.index, ctypes.byref(h))

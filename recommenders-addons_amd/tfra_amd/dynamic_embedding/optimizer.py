@@ -644,8 +644,8 @@ class PrefetchAssignStep:
     ids = self.ids[cur]
     n = ids.numel()
     dim, vdt, dev = self.table.dim, self.table.value_dtype, self.dev
-    if values.dtype != vdt or not values.is_contiguous() or values.dim() != 2:
-      values = values.reshape(n, dim).to(vdt).contiguous()
+    if values.dtype != vdt or not values.is_contiguous() or values.shape != (n, dim):
+      values = values.reshape(n, dim).to(vdt).contiguous()   # (raises on a size mismatch: the kernels index row `last` of [n, dim])
     out = torch.empty((n, dim), dtype=vdt, device=dev) if lookup else None
     nxt = None
     if self._main is None:

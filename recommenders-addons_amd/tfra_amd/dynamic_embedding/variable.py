@@ -290,27 +290,38 @@ class Variable:
 
     # The slot files are named after the optimizer's slot variables when an optimizer is passed, `<param>_slot<f>` when not.
     # Saving one way and restoring the other must not silently reset Adam's m / v or FTRL's accumulators: when the expected
-    # names are absent, the other scheme is looked for (`<param>_<Opt>_<slot>` files in the order of the slot fields), and a
-    # directory that holds state files of this variable which match neither is an error, not a skip.
+    # names are absent, the other scheme is looked for — by EXACT base name only (`<param>_<OptClass>_<slot>` for the known
+    # optimizer classes, mapped to the field by slot NAME; or `<param>_slot<f>`), never by prefix: a sibling variable
+    # `<param>_2` or `<param>_user` in the same directory is not this variable's state.  State files of this variable that
+    # match neither scheme completely are an error, not a skip.
     if self.aux_fields:
       prefix = self.name.replace("/", "_") + "_"
-      others = sorted({f[:f.index("_mht_")] for f in listing if f.endswith("-keys") and f.startswith(prefix) and "_mht_" in f and
-                       not f.startswith(own)})
+      siblings = {n.replace("/", "_") for n in _VARIABLES if n != self.name}
       missing = [f for f, base in slots.items() if not slot_files(base)]
-      if missing and others:
-        generic = [b for b in others if b.startswith(prefix + "slot")]
-        named = [b for b in others if b not in generic]
-        if optimizer is None and named and len(named) >= len(missing):
-          for f, base in zip(sorted(slots), sorted(named, key=lambda b: b)):   # (names sort like get_slot_variables does)
-            slots[f] = base
-        elif optimizer is not None and generic:
-          for f in missing:
-            if prefix + "slot%d" % f in generic:
-              slots[f] = prefix + "slot%d" % f
+      if missing:
+        generic = {f: prefix + "slot%d" % f for f in slots}
+        layouts = {cls: tuple(sl) for cls, sl in _known_slot_layouts().items() if len(sl) == self.aux_fields}
+        named = {cls: {i + 1: prefix + cls + "_" + sname for i, sname in enumerate(sl)} for cls, sl in layouts.items()}
+        named = {cls: m for cls, m in named.items() if not any(b in siblings for b in m.values())}
+        if optimizer is None:
+          complete = [cls for cls, m in named.items() if all(slot_files(b) for b in m.values())]
+          if len(complete) == 1 and len(missing) == len(slots):
+            slots = dict(named[complete[0]])
+        else:
+          if all(slot_files(generic[f]) for f in missing) and not any(generic[f] in siblings for f in missing):
+            for f in missing:
+              slots[f] = generic[f]
         still = [f for f, base in slots.items() if not slot_files(base)]
         if still:
-          raise ValueError("load_from_file_system: %r holds optimizer-state files %s of variable %r, but none matches slot field(s) %s "
-                           "(saved with another optimizer?); pass the optimizer the checkpoint was saved with" % (dirpath, others, self.name, still))
+          # is there ANY state file that can only be this variable's?  (exact bases of either scheme)
+          cands = set(generic.values())
+          for m in named.values():
+            cands.update(m.values())
+          found = sorted(b for b in cands if b not in siblings and slot_files(b))
+          if found:
+            raise ValueError("load_from_file_system: %r holds optimizer-state files %s of variable %r, but they do not cover slot "
+                             "field(s) %s (saved with another optimizer?); pass the optimizer the checkpoint was saved with"
+                             % (dirpath, found, self.name, still))
 
     same = all(self._make_name(i) in files for i in range(self.shard_num)) and len(files) == self.shard_num
     if same and proc_size == 1:
@@ -340,6 +351,18 @@ class Variable:
 
 
 _VARIABLES = {}
+
+
+def _known_slot_layouts():
+  """{optimizer class name: slot names in field order} of the optimizers this package ships (the `<opt>` and `<slot>` parts of
+  the reference's slot-variable names `<param>/<opt>/<slot>`, PY/dynamic_embedding_optimizer.py:870-904)."""
+  from . import optimizer as _o
+  out = {}
+  for cls in (_o.Adam, _o.Adagrad, _o.Ftrl, _o.Momentum, _o.RMSProp):
+    sl = cls.slots if cls.slots else cls().slots
+    if sl:
+      out[cls.__name__] = tuple(sl)
+  return out
 
 
 def get_variable(name, key_dtype=torch.int64, value_dtype=torch.float32, dim=1, devices=None,

@@ -85,6 +85,58 @@ def test_optimizer_slots_survive_save_and_load(env, tmp_path, shards_after):
   assert torch.equal(var.lookup(uk), var2.lookup(uk))
 
 
+def test_slot_file_fallback_matches_exact_names_only(env, tmp_path):
+  """Restoring WITHOUT the optimizer object finds `<param>_<Opt>_<slot>` files by exact name and maps them to the row
+  fields by slot NAME; sibling variables in the same directory (`emb_2`, `emb_user`: same prefix) are never taken for
+  this variable's state, and a checkpoint that has no slot files next to such a sibling loads without an error."""
+  torch, de = env
+  dim = 4
+  opt = de.optimizers.Adam(1e-2)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  kw = de.DynamicEmbeddingOptimizer.variable_kwargs(opt)
+  var = de.Variable(dim=dim, name="emb", initializer=0.25, devices=["cuda:0"], **kw)
+  sib = de.Variable(dim=dim, name="emb_2", initializer=0.5, devices=["cuda:0"])            # sorts before emb_Adam_m
+  sib2 = de.Variable(dim=dim, name="emb_user", initializer=0.5, devices=["cuda:0"])
+  ids = torch.arange(64, device="cuda")
+  g = torch.ones((64, dim), device="cuda")
+  for _ in range(2):
+    deo.apply_sparse(var, ids, g)
+  foreign = torch.arange(1000, 1100, device="cuda")
+  sib.upsert(foreign, torch.full((100, dim), 7.0, device="cuda"))
+  sib2.upsert(foreign, torch.full((100, dim), 9.0, device="cuda"))
+  var.save_to_file_system(str(tmp_path), optimizer=deo)
+  sib.save_to_file_system(str(tmp_path))
+  sib2.save_to_file_system(str(tmp_path))
+  want = [var.lookup(ids)] + [v.lookup(ids) for v in var.get_slot_variables(deo)]
+  var2 = de.Variable(dim=dim, name="emb", initializer=0.25, devices=["cuda:0"], **kw)
+  var2.load_from_file_system(str(tmp_path))                     # optimizer=None: the named files, by exact name
+  assert int(var2.size().item()) == 64                           # none of the siblings' keys came along
+  got = [var2.lookup(ids)] + [v.lookup(ids) for v in var2.get_slot_variables(deo)]
+  for a, b in zip(want, got):
+    assert torch.equal(a, b)
+  # a checkpoint saved WITHOUT slot files, siblings present: loads, slots start at their initial values
+  d2 = tmp_path / "noslots"
+  d2.mkdir()
+  plain = de.Variable(dim=dim, name="emb", initializer=0.25, devices=["cuda:0"])
+  plain.upsert(ids, want[0])
+  plain.save_to_file_system(str(d2))
+  sib.save_to_file_system(str(d2))
+  var3 = de.Variable(dim=dim, name="emb", initializer=0.25, devices=["cuda:0"], **kw)
+  var3.load_from_file_system(str(d2), optimizer=deo)
+  assert int(var3.size().item()) == 64 and torch.equal(var3.lookup(ids), want[0])
+  # state files of another optimizer (FTRL's accum / linear) do not cover Adam's fields: an error, not a silent reset
+  d3 = tmp_path / "other_opt"
+  d3.mkdir()
+  fo = de.optimizers.Ftrl(0.05)
+  fdeo = de.DynamicEmbeddingOptimizer(fo)
+  fvar = de.Variable(dim=dim, name="emb", initializer=0.25, devices=["cuda:0"], **de.DynamicEmbeddingOptimizer.variable_kwargs(fo))
+  fdeo.apply_sparse(fvar, ids, g)
+  fvar.save_to_file_system(str(d3), optimizer=fdeo)
+  var4 = de.Variable(dim=dim, name="emb", initializer=0.25, devices=["cuda:0"], **kw)
+  with pytest.raises(ValueError, match="optimizer-state files"):
+    var4.load_from_file_system(str(d3), optimizer=deo)
+
+
 def test_one_global_step_for_tables_sharing_an_optimizer(env):
   """begin_step(): N tables written with the parameters of ONE step advance `iterations` once (TF's apply_gradients)."""
   torch, de = env

@@ -392,6 +392,37 @@ def test_set_plan_counts_last_positions_and_reuse(env):
   t._table.check_errors()
 
 
+def test_one_plan_object_alternating_csr_and_set_builds(env):
+  """A plan object may be rebuilt with dim > 0 (CSR buffer) and dim 0 (SET buffer) in any order; each buffer keeps its own
+  pair of left-over counter sets and its own flag bytes, selected by that buffer's OWN use count.  With one shared count a
+  CSR use -> SET use -> CSR use found the CSR buffer's counter where the first launch left it (stale left-over list replayed
+  against new values).  Small table, many keys per bucket pair: every launch has left-over keys."""
+  torch, de, SparsePlan = env
+  dim = 4
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=4096, max_capacity=4096, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name="altplan")
+  universe = torch.arange(1, 1501, dtype=torch.int64, device="cuda") * 7919
+  t._table.upsert(universe, torch.zeros((universe.numel(), dim), device="cuda"), unique_keys=True)
+  plan = SparsePlan("cuda:0", dim)
+  rng = np.random.default_rng(3)
+  expect = {}
+  for step, pdim in enumerate([dim, 0, dim, dim, 0, 0, dim, 0, dim]):
+    n = int(rng.integers(500, 2000))
+    keys = universe.cpu().numpy()[rng.integers(0, universe.numel(), size=n)]
+    ids = torch.from_numpy(keys).cuda()
+    plan._dim = pdim          # (the C entry point takes the dim per build: the same object, the other buffer)
+    plan.build(ids)
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 10000.0 * step)[:, None].repeat(1, dim)
+    t._table.upsert_planned(plan, vals)
+    for i, k in enumerate(keys.tolist()):
+      expect[k] = float(i + 10000.0 * step)
+    uk = np.array(sorted(expect), np.int64)
+    got = t.lookup(torch.from_numpy(uk).cuda())
+    want = torch.tensor([expect[int(k)] for k in uk], device="cuda")[:, None].repeat(1, dim)
+    assert torch.equal(got, want), "step %d (plan dim %d)" % (step, pdim)
+  t._table.check_errors()
+
+
 def test_unique_many_calls_one_workspace(env):
   """tfra_unique keeps two persistent sets per workspace that empty each other: a sequence of calls with sizes going up and
   down (incl. the sentinel value and a hot id) must each equal numpy's first-occurrence unique."""
