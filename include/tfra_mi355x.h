@@ -315,6 +315,56 @@ typedef struct {
 } tfra_step_desc;
 int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n_workers);
 
+/* -- the overlapped step: lookup of batch i+1 in ONE launch with the write-back of batch i ------------------------------
+ * Replaces, for a training loop that alternates Find and Insert on one table, the pair of ops
+ *   HkvHashTableOfTensorsGpu::Find   (K/hkv_hashtable_op_gpu.cu.cc:182-213  -> lookup_table_op_hkv.h:719-756 get)
+ *   HkvHashTableOfTensorsGpu::Insert (K/hkv_hashtable_op_gpu.cu.cc:253-290  -> lookup_table_op_hkv.h:522-537 upsert)
+ * with results IDENTICAL to running them one after the other (Insert exclusive, Find shared: lookup i+1 sees update i).
+ * The driver defers the write-back of a batch to the NEXT call and runs it in the same kernel as that call's lookup; ids the
+ * two batches share are served from `values_prev` (the rows being written), everything else from the table; an entry the
+ * write-back would evict although this lookup looks for it is evicted after the lookup and the lookup's output corrected
+ * (csrc/tfra_step_impl.h).  Ids may repeat (the last occurrence wins).  Two launches per step on ONE stream, nothing
+ * waits on the host: steps can be enqueued any number ahead (tfra_table_steps_overlap) or captured into a graph.
+ *
+ *   tfra_table_step_overlap(d, n, ids, rows_out, exists_out, defaults, default_is_full, values_prev, scores_prev,
+ *                           n_next, ids_next, stream)
+ *     rows_out[n, dim] / exists_out[n] (optional) = Find(ids) with the default fill of tfra_table_find;
+ *     values_prev [n_prev, dim] = the rows to assign to the ids of the PREVIOUS call (NULL on the first call / after a
+ *       flush); they must stay unchanged until this call's work has run;
+ *     ids_next / n_next (optional) = the ids of the NEXT call, known one step ahead (an input pipeline): their
+ *       de-duplication plan is built inside this call's launch; without them the next call builds it in front of its step.
+ *   tfra_table_step_overlap_flush(d, values_prev, scores_prev, stream) writes the last batch back: call it before the table
+ *     is used through any other entry point.
+ * Tables or calls the overlap does not cover (not a bounded LRU table at capacity, caller scores, optimizer slots, rows
+ * that are not multiples of 16 bytes) run the same sequence one op after the other inside the same entry points. */
+typedef struct tfra_step_driver tfra_step_driver_t;
+int tfra_step_driver_create(tfra_table_t* t, tfra_step_driver_t** out);
+int tfra_step_driver_destroy(tfra_step_driver_t* d);
+int tfra_table_step_overlap(tfra_step_driver_t* d, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists_out,
+                            const void* defaults, int default_is_full, const void* values_prev, const uint64_t* scores_prev,
+                            size_t n_next, const int64_t* ids_next, tfra_stream_t stream);
+int tfra_table_step_overlap_flush(tfra_step_driver_t* d, const void* values_prev, const uint64_t* scores_prev, tfra_stream_t stream);
+/* `count` consecutive steps from ONE host call (the arguments of tfra_table_step_overlap per step). */
+typedef struct {
+  uint32_t struct_size;              /* = sizeof(tfra_overlap_step) */
+  int32_t default_is_full;
+  size_t n;
+  const int64_t* ids;
+  void* rows_out;
+  uint8_t* exists_out;
+  const void* defaults;
+  const void* values_prev;
+  const uint64_t* scores_prev;
+  size_t n_next;
+  const int64_t* ids_next;
+} tfra_overlap_step;
+int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_overlap_step* steps, tfra_stream_t stream);
+/* steps taken overlapped / one op after the other so far; whether a write-back is pending; device_counts[3] (optional,
+ * synchronises the device) = {evictions the pass deferred because the next lookup wanted the victim, victims the remainder
+ * pass noted, output rows it rewrote with the default row} */
+int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending,
+                           uint32_t* device_counts);
+
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 
 /* Scratch for unique/partition; grows on demand, reusable across calls on one stream. */

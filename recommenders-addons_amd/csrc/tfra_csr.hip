@@ -631,8 +631,34 @@ struct CsrKeys {
   // SET plan (assign-only, see setplan_kernel): dense distinct keys, their slots, (last position + 1, occurrences) per slot
   const i64* ukeys;
   const unsigned* uslot;
-  const uint2* gpc;
+  const struct SetEnt* sent;
 };
+// One slot of a SET plan's open-addressing table: 16 B, so that a probe is ONE load (the overlapped step's lookup probes the
+// previous batch's plan for every id, tfra_step.hip... see step_kernel)
+struct SetEnt { i64 key; unsigned pos1, cnt; };   // key (EMPTY_KEY = free) | last position + 1 | occurrences
+__device__ __forceinline__ uint2 set_pc(const SetEnt* e) { return *reinterpret_cast<const uint2*>(&e->pos1); }
+// A SET plan's table as something to PROBE (read-only): is this key one of the batch's ids, and where is its last occurrence?
+struct SetProbe { const SetEnt* ent; unsigned m2; };   // m2 entries (a power of two) + the two sentinel slots + padding
+__device__ __forceinline__ unsigned set_home(const SetProbe& p, i64 key, u64 h) {   // h = fmix64(key)
+  return is_reserved_key(key) ? p.m2 + (unsigned)reserved_index(key) : (unsigned)(h >> 20) & (p.m2 - 1);
+}
+// All 16 lanes of a key group: does the table hold `key`?  Lanes 0..3 look at four consecutive entries per round (linear
+// probing, slots are never freed during a build: a match anywhere is the key, an EMPTY entry before it ends the search).
+__device__ __forceinline__ bool set_contains_group(const SetProbe& p, i64 key, int sub, int gshift) {
+  const bool resv = is_reserved_key(key);
+  unsigned slot = set_home(p, key, fmix64((u64)key));
+  for (int round = 0; round < 4096; ++round) {
+    const unsigned e = resv ? slot + (unsigned)(sub & 3) : (slot + (unsigned)(sub & 3)) & (p.m2 - 1);
+    const i64 k = p.ent[e].key;
+    const bool match = resv ? ((sub & 3) == 0 && k != EMPTY_KEY) : k == key;
+    const unsigned mm = (unsigned)(__ballot(match && sub < 4) >> gshift) & 0xfu;
+    const unsigned em = (unsigned)(__ballot(k == EMPTY_KEY && sub < 4) >> gshift) & 0xfu;
+    if (mm) return true;
+    if (em || resv) return false;
+    slot += 4;
+  }
+  return true;   // (a chain this long does not exist: 2 n slots for n ids; say "present", the conservative answer)
+}
 
 // one coalesced 64-B load per key group: lane i holds word i of the key's record
 __device__ __forceinline__ unsigned load_record(const CsrKeys& ks, unsigned g, int sub, bool& many) {
@@ -878,7 +904,9 @@ constexpr unsigned SLOW_CAP = 8192;   // items of the left-over list of an owner
 template <int G>
 __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsigned char* __restrict__ vals, i64 key, unsigned last,
                                                  u64 in_score, const AuxInitPod& ai, const ScoreP& sp, int sub, int gshift,
-                                                 int& fresh, int& failed, bool hinted = false, unsigned hint_word = 0) {
+                                                 int& fresh, int& failed, bool hinted = false, unsigned hint_word = 0,
+                                                 i64* evicted_key = nullptr) {
+  // evicted_key (optional): set to the key this upsert replaced by eviction (untouched when it evicted nothing)
   const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
   const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score;
   i64 row = -1;
@@ -910,10 +938,12 @@ __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsig
     if (r == NEED_EVICT) {
       bool ce = false;
       u64 wd = 0;
-      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce, pre ? kk2 : nullptr, pre ? sc2 : nullptr);
+      i64 vk = EMPTY_KEY;
+      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce, pre ? kk2 : nullptr, pre ? sc2 : nullptr, &vk);
       if (r == -1) break;                        // not admitted (its score is below every resident one): dropped
       if (r == -3) { failed += (sub == 0); break; }
       row = r; word = wd; is_new = true; evicted = !ce;
+      if (evicted && evicted_key) *evicted_key = vk;
       fresh += (ce && sub == 0);
       break;
     }
@@ -1057,7 +1087,7 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
       if (slow_ctr && a.dflag[i] != 4) continue;
       if (SRC == SRC_PLAN) locked_upsert_one<G>(a.v, a.vals, a.scores, a.ks, a.ai, a.sp, i, sub, gshift, fresh, failed);
       else if (SRC == SRC_SET) {
-        const uint2 pc = a.ks.gpc[a.ks.uslot[i]];
+        const uint2 pc = set_pc(a.ks.sent + a.ks.uslot[i]);
         const u64 in_one = a.scores ? a.scores[pc.x - 1] : 1;
         locked_upsert_kv<G>(a.v, a.vals, a.ks.ukeys[i], pc.x - 1, a.sp.strategy == TFRA_EVICT_LFU ? (a.scores ? in_one : (u64)pc.y) : in_one,
                             a.ai, a.sp, sub, gshift, fresh, failed);
@@ -1132,9 +1162,12 @@ __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
 // U: keys per 16-lane group in flight (the wave's batch is 4 U keys: lanes 0 .. 4U-1 of every group hold them).  2 for up
 // to a batch's worth of keys (22.7 K keys are 1420 waves of 16 keys on 1024 SIMDs: the 4 us of dependent cross-lane work
 // per wave halve, the waves double and still fit in one round), 4 beyond.
-template <int G, bool SIMPLE, int SRC, int U>
+// CF (the overlapped step, step_kernel): the lookup of the NEXT batch runs beside this pass and reads the table rows of every key
+// that is not in this batch — an entry this pass is about to EVICT must not be one of them: `cf` = the next batch's plan; a victim
+// that is in it defers the new key to the remainder pass (which runs after that lookup and corrects its output).
+template <int G, bool SIMPLE, int SRC, int U, bool CF = false>
 __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
-                                            int lane, int& fresh) {
+                                            int lane, int& fresh, const SetProbe* cf = nullptr, unsigned* cf_stat = nullptr) {
   const u64* const scores = SIMPLE ? nullptr : a.scores;
   const TableView& v = a.v;
   const CsrKeys& ks = a.ks;
@@ -1184,7 +1217,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
     const u64 in_one = scores ? scores[lastreg] : 1;
     insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)cnt) : in_one;
   } else if (SRC == SRC_SET) {
-    const uint2 pc = ks.gpc[kmreg];   // (last position + 1, occurrences) of the key's slot in the plan's table
+    const uint2 pc = set_pc(ks.sent + kmreg);   // (last position + 1, occurrences) of the key's slot in the plan's table
     lastreg = pc.x - 1;
     const u64 in_one = scores ? scores[lastreg] : 1;
     insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)pc.y) : in_one;
@@ -1252,6 +1285,15 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
             word[u] = best_word;
             act[u] = 3;
             flag_b0[u] = !ovf0 && (best_word >> 4) == b1[u];
+            if (CF) {
+              const int vsrc = gshift + (int)(best_word & 15u);
+              const i64 ka = shfl_i64(kk[u][0], vsrc), kb = shfl_i64(kk[u][1], vsrc);
+              const i64 vk = (best_word >> 4) == (u64)b1[u] ? kb : ka;
+              if (vk != EMPTY_KEY && set_contains_group(*cf, vk, sub, gshift)) {   // the next lookup wants it: deferred
+                act[u] = 0; why[u] = 3;
+                if (cf_stat && sub == 0) atomicAdd(cf_stat, 1u);
+              }
+            }
           }
         } else why[u] = 2;   // a table that still walks (not at capacity / unbounded): placed further along by the general path
       }
@@ -1395,9 +1437,9 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
 // The two sentinel key values have slots of their own behind the table (no hashing: EMPTY_KEY is the free-slot marker).
 constexpr int SP_NT = 1024;
 constexpr unsigned SP_LDS = 2048;
+constexpr unsigned SET_PAD = 4;   // entries behind the two sentinel slots, never used: a probe reads 4 consecutive entries
 struct SetTab {   // one of the plan's two tables
-  i64* gkey;        // [m2 + 2]   EMPTY_KEY = free (the two sentinel slots: EMPTY_KEY = free, else taken)
-  uint2* gpc;       // [m2 + 2]   (last position + 1, occurrences)
+  SetEnt* ent;      // [m2 + 2 + SET_PAD]  key: EMPTY_KEY = free (the two sentinel slots [m2], [m2 + 1]: EMPTY_KEY = free, else taken)
   i64* ukeys;       // [n] dense list: the distinct keys, in no particular order
   unsigned* uslot;  // [n] their slots
   unsigned* count;  // number of distinct keys of the table's current use (zero before its build)
@@ -1447,7 +1489,7 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
     have[r] = p1[r] != 0;
     myslot[r] = (unsigned)(fmix64((u64)mykey[r]) >> 20) & (m2 - 1);
     was[r] = 0;
-    if (have[r]) was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + myslot[r]), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
+    if (have[r]) was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -1456,18 +1498,18 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
         if (was[r] == EMPTY_KEY) { mine[r] = true; break; }
         if (was[r] == mykey[r]) break;
         myslot[r] = (myslot[r] + 1) & (m2 - 1);
-        was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + myslot[r]), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
+        was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
       }
-      atomicMax(&cur.gpc[myslot[r]].x, p1[r]);
-      if (COUNTS) atomicAdd(&cur.gpc[myslot[r]].y, cn[r]);
+      atomicMax(&cur.ent[myslot[r]].pos1, p1[r]);
+      if (COUNTS) atomicAdd(&cur.ent[myslot[r]].cnt, cn[r]);
     }
     myidx[r] = mine[r] ? atomicAdd(&s_n, 1u) : 0u;
   }
   if (tid < 2 && s_pos[SP_LDS + tid] != 0) {   // a sentinel key value occurred in this block
     const unsigned sl = m2 + tid;
-    const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(cur.gkey + sl), (unsigned long long)EMPTY_KEY, 1ULL);
-    atomicMax(&cur.gpc[sl].x, s_pos[SP_LDS + tid]);
-    if (COUNTS) atomicAdd(&cur.gpc[sl].y, s_cnt[SP_LDS + tid]);
+    const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[sl].key), (unsigned long long)EMPTY_KEY, 1ULL);
+    atomicMax(&cur.ent[sl].pos1, s_pos[SP_LDS + tid]);
+    if (COUNTS) atomicAdd(&cur.ent[sl].cnt, s_cnt[SP_LDS + tid]);
     if (w == EMPTY_KEY) {
       const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
       cur.ukeys[at] = EMPTY_KEY + (i64)tid;
@@ -1479,8 +1521,7 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
   // ---- C: empty the slots the previous build used in the OTHER table (while the counter add travels) -------------------
   for (size_t i = gid; i < n_old; i += (size_t)gridDim.x * SP_NT) {
     const unsigned sl = old.uslot[i];
-    old.gkey[sl] = EMPTY_KEY;
-    old.gpc[sl] = make_uint2(0u, 0u);
+    *reinterpret_cast<uint4*>(old.ent + sl) = make_uint4(0u, 0x80000000u, 0u, 0u);   // {EMPTY_KEY, 0, 0}
   }
   __syncthreads();
 #pragma unroll
@@ -1491,6 +1532,14 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
   }
 }
 
+#define TFRA_STEP_DEVICE_PART
+#include "tfra_step_impl.h"
+#undef TFRA_STEP_DEVICE_PART
+
+__global__ void fill_setent_kernel(SetEnt* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0x80000000u, 0u, 0u);   // {EMPTY_KEY, 0, 0}
+}
 __global__ void fill_i64_kernel(i64* p, size_t n, i64 v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1572,8 +1621,10 @@ extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
 
 static size_t plan_smem_bytes(unsigned cm) { return (size_t)cm * 36 + (size_t)TABW * 4; }
 
-// The SET plan of a batch (dim 0): see setplan_kernel.
-static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hipStream_t s, bool counts) {
+// The SET plan of a batch (dim 0): see setplan_kernel.  setplan_prepare = everything but the launch (buffers, which of the two
+// tables, its counter words): the overlapped step builds the plan inside its own kernel (step_kernel's PLAN role).
+struct SetPlanLaunch { SetTab cur, old; unsigned* next_use_count; unsigned m2; unsigned blocks; };
+static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool counts, SetPlanLaunch* L) {
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   if (pl->set_cap < n) {
@@ -1584,7 +1635,7 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
     const size_t cap = std::max<size_t>(n, 4096);
     unsigned m2 = 4096;
     while ((size_t)m2 < 2 * cap) m2 <<= 1;
-    const size_t tab = al(((size_t)m2 + 2) * 8) * 2 + al(cap * 8) + al(cap * 4);   // gkey, gpc, ukeys, uslot
+    const size_t tab = al(((size_t)m2 + 2 + SET_PAD) * sizeof(SetEnt)) + al(cap * 8) + al(cap * 4);   // entries, ukeys, uslot
     const size_t bytes = 512 + al(cap) + al((size_t)SLOW_CAP * sizeof(OwnItem)) + 2 * tab;
     hipError_t e = hipMalloc(&pl->setbuf, bytes);
     if (e != hipSuccess) { pl->setbuf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
@@ -1595,12 +1646,11 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
     pl->set_items = (OwnItem*)w; w += al((size_t)SLOW_CAP * sizeof(OwnItem));
     for (int p = 0; p < 2; ++p) {
       SetTab& tb = pl->set_tab[p];
-      tb.gkey = (i64*)w; w += al(((size_t)m2 + 2) * 8);
-      tb.gpc = (uint2*)w; w += al(((size_t)m2 + 2) * 8);
+      tb.ent = (SetEnt*)w; w += al(((size_t)m2 + 2 + SET_PAD) * sizeof(SetEnt));
       tb.ukeys = (i64*)w; w += al(cap * 8);
       tb.uslot = (unsigned*)w; w += al(cap * 4);
       tb.count = nullptr;   // set per build: the table's two counter words alternate
-      fill_i64_kernel<<<256, 256, 0, s>>>(tb.gkey, (size_t)m2 + 2, EMPTY_KEY);
+      fill_setent_kernel<<<256, 256, 0, s>>>(tb.ent, (size_t)m2 + 2 + SET_PAD);
     }
     pl->set_cap = cap; pl->set_m2 = m2; pl->set_parity = 1; pl->set_use[0] = pl->set_use[1] = 0;
   }
@@ -1613,13 +1663,20 @@ static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hip
   cur.count = count_word(p, use);
   old.count = count_word(p ^ 1u, pl->set_use[p ^ 1u]);   // (never used yet: a zero word)
   pl->set_tab[p].count = cur.count;
-  if (counts) setplan_kernel<true><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
-  else setplan_kernel<false><<<blocks, SP_NT, 0, s>>>(n, (const i64*)ids, pl->set_m2, cur, old, count_word(p, use + 1));
-  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
+  L->cur = cur; L->old = old; L->next_use_count = count_word(p, use + 1); L->m2 = pl->set_m2; L->blocks = blocks;
   pl->built_counts = counts;
   pl->set_parity = p;
   pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
   pl->n = n; pl->dim = 0; pl->kind = 1;
+  return TFRA_OK;
+}
+static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hipStream_t s, bool counts) {
+  SetPlanLaunch L;
+  int rc = setplan_prepare(pl, n, s, counts, &L);
+  if (rc) return rc;
+  if (counts) setplan_kernel<true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count);
+  else setplan_kernel<false><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: launch failed");
   return TFRA_OK;
 }
 
@@ -1743,7 +1800,7 @@ static void plan_grids(const tfra_sparse_plan* pl, unsigned* key_blocks, unsigne
 static CsrKeys keys_of(const tfra_sparse_plan* pl) {
   if (pl->kind == 1) {
     const SetTab& tb = pl->set_tab[pl->set_parity];
-    return CsrKeys{nullptr, nullptr, nullptr, nullptr, nullptr, tb.count - 1, tb.ukeys, tb.uslot, tb.gpc};
+    return CsrKeys{nullptr, nullptr, nullptr, nullptr, nullptr, tb.count - 1, tb.ukeys, tb.uslot, tb.ent};
   }
   return CsrKeys{pl->keymap, pl->dkeys, pl->out.crec, pl->out.hrec, pl->out.hent, pl->d_counts, nullptr, nullptr, nullptr};
 }
@@ -1854,6 +1911,62 @@ static unsigned next_own_gen(Table* t) {
   return t->own_gen;                         // sends a key to the remainder pass)
 }
 
+// Host half of an ownership write-back of a plan's keys: everything but the launches (upsert_planned_impl launches the pair
+// upsert_own_kernel + upsert_rest_kernel, the overlapped step puts the pass into its step_kernel).
+struct OwnLaunch {
+  OwnArgs a;
+  OwnCtrs* ctr; OwnCtrs* next_ctr;
+  unsigned og;            // bucket-owner generation of this launch (0: no owner tags)
+  unsigned key_blocks;    // the plan's keys / 16, as far as the host knows them
+  unsigned rem_blocks;    // grid of the remainder pass
+  bool simple;
+  int g;                  // copy granule
+};
+static int own_prepare(Table* t, const tfra_sparse_plan_t* pl, const void* values, const uint64_t* scores, hipStream_t s,
+                       const unsigned* progress, OwnLaunch* L) {
+  // caller holds t->mu and has called t->enter(s)
+  if (!values) return set_error(TFRA_ERR_INVALID, "upsert_planned: null values");
+  if (t->opts.device != pl->device && t->opts.device >= 0) return set_error(TFRA_ERR_INVALID, "upsert_planned: plan and table live on different devices");
+  if (pl->kind == 1 && !pl->built_counts && t->opts.strategy == TFRA_EVICT_LFU && !scores)
+    return set_error(TFRA_ERR_INVALID, "upsert_planned: this plan was built without occurrence counts (by a step driver of a table whose scores do not read them); an LFU table without caller scores needs them");
+  int rc = t->prepare_insert(pl->n, s);
+  if (rc) return rc;
+  unsigned key_blocks, bin_blocks;
+  plan_grids(pl, &key_blocks, &bin_blocks);
+  if (pl->kind == 1 && progress) {
+    // an assign-only plan does not tell the host how many distinct keys it found; the step driver's batches resemble each
+    // other: the count the last write-back that has started saw, plus a quarter (a batch with more: grid-stride)
+    const unsigned seen = reinterpret_cast<const volatile unsigned*>(progress)[1];
+    if (seen) key_blocks = (unsigned)std::max<size_t>(1, (std::min<size_t>(pl->n, (size_t)seen + seen / 4 + 1024) * 16 + 255) / 256);
+  }
+  uint8_t* bounded_now;
+  rc = t->bounded_flags(1, s, &bounded_now);
+  if (rc) return rc;
+  const ScoreP sp{t->opts.strategy, t->global_epoch, bounded_now ? (t->dense ? 2 : 1) : 0};
+  size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)values | 16;
+  int g = (int)(x & (~x + 1));
+  if (g > 16) g = 16;
+  ++pl->use_gen;
+  unsigned* tags = t->ensure_own_tags(s);    // nullptr (no owner tags): every key takes the locked protocol
+  L->og = tags ? next_own_gen(t) : 0;
+  const unsigned par = pl->ups_uses[pl->kind == 1 ? 1 : 0]++ & 1u;   // (its own count per buffer: apply_planned uses of the plan do not touch the counters)
+  L->ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
+  L->next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
+  // Left-over keys of the ownership pass.  Few (a big table): the remainder kernel walks their list with a handful of
+  // blocks.  Many (a small table): full grid.
+  const double nkeys = (double)key_blocks * 16.0;   // unique keys of the plan when its counts have arrived, else the id count
+  L->rem_blocks = expect_leftover(nkeys, (double)t->cur.nb) < 2048.0 ? 32u : key_blocks;
+  L->key_blocks = key_blocks;
+  L->simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !scores;
+  L->g = g;
+  OwnArgs& a = L->a;
+  a = OwnArgs{};
+  a.v = t->view_of(t->cur); a.vals = (const unsigned char*)values; a.scores = (const u64*)scores; a.ks = keys_of(pl); a.keys = nullptr; a.nkeys = 0;
+  a.ai = t->aux; a.sp = sp;
+  a.dflag = pl->dflag; a.tags = tags; a.items = pl->slow_items; a.item_cap = SLOW_CAP;
+  return TFRA_OK;
+}
+
 static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, const void* values, const uint64_t* scores,
                                tfra_stream_t stream, unsigned* progress, unsigned progress_val) {
   // caller holds t->mu
@@ -1863,49 +1976,11 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
   int rc = t->enter(s);
   if (rc) return rc;
   if (pl->n == 0) return TFRA_OK;
-  if (!values) return set_error(TFRA_ERR_INVALID, "upsert_planned: null values");
-  if (t->opts.device != pl->device && t->opts.device >= 0) return set_error(TFRA_ERR_INVALID, "upsert_planned: plan and table live on different devices");
-  if (pl->kind == 1 && !pl->built_counts && t->opts.strategy == TFRA_EVICT_LFU && !scores)
-    return set_error(TFRA_ERR_INVALID, "upsert_planned: this plan was built without occurrence counts (by a step driver of a table whose scores do not read them); an LFU table without caller scores needs them");
-  rc = t->prepare_insert(pl->n, s);
+  OwnLaunch L;
+  rc = own_prepare(t, pl, values, scores, s, progress, &L);
   if (rc) return rc;
-  unsigned key_blocks, bin_blocks;
-  plan_grids(pl, &key_blocks, &bin_blocks);
-  if (pl->kind == 1 && progress) {
-    // an assign-only plan does not tell the host how many distinct keys it found; the step driver's batches resemble each
-    // other: the count the last write-back that has started saw, plus a quarter (a batch with more: grid-stride)
-    const unsigned seen = reinterpret_cast<volatile unsigned*>(progress)[1];
-    if (seen) key_blocks = (unsigned)std::max<size_t>(1, (std::min<size_t>(pl->n, (size_t)seen + seen / 4 + 1024) * 16 + 255) / 256);
-  }
-  uint8_t* bounded_now;
-  rc = t->bounded_flags(1, s, &bounded_now);
-  if (rc) return rc;
-  const ScoreP sp{t->opts.strategy, t->global_epoch, bounded_now ? (t->dense ? 2 : 1) : 0};
-  TableView v = t->view_of(t->cur);
-  size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)values | 16;
-  int g = (int)(x & (~x + 1));
-  if (g > 16) g = 16;
-  const unsigned char* vals = (const unsigned char*)values;
-  const u64* sc = (const u64*)scores;
-  const unsigned gen = ++pl->use_gen;
-  unsigned* tags = t->ensure_own_tags(s);    // nullptr (no owner tags): every key takes the locked protocol
-  (void)gen;
-  {
-    const unsigned og = tags ? next_own_gen(t) : 0;
-    const unsigned par = pl->ups_uses[pl->kind == 1 ? 1 : 0]++ & 1u;   // (its own count per buffer: apply_planned uses of the plan do not touch the counters)
-    OwnCtrs* ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + par;
-    OwnCtrs* next_ctr = reinterpret_cast<OwnCtrs*>(pl->d_counts + 12) + (par ^ 1u);
-    // Left-over keys of the ownership pass.  Few (a big table): the remainder kernel walks their list with a handful of
-    // blocks.  Many (a small table): full grid.
-    const double nkeys = (double)key_blocks * 16.0;   // unique keys of the plan when its counts have arrived, else the id count
-    const unsigned rem_blocks = expect_leftover(nkeys, (double)t->cur.nb) < 2048.0 ? 32u : key_blocks;
-    const bool simple = t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !sc;
-    OwnArgs a{};
-    a.v = v; a.vals = vals; a.scores = sc; a.ks = keys_of(pl); a.keys = nullptr; a.nkeys = 0; a.ai = t->aux; a.sp = sp;
-    a.dflag = pl->dflag; a.tags = tags; a.items = pl->slow_items; a.item_cap = SLOW_CAP;
-    if (pl->kind == 1) launch_own<SRC_SET>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, rem_blocks, progress, progress_val);
-    else launch_own<SRC_PLAN>(s, g, simple, a, (size_t)key_blocks * 16, ctr, next_ctr, og, rem_blocks, progress, progress_val);
-  }
+  if (pl->kind == 1) launch_own<SRC_SET>(s, L.g, L.simple, L.a, (size_t)L.key_blocks * 16, L.ctr, L.next_ctr, L.og, L.rem_blocks, progress, progress_val);
+  else launch_own<SRC_PLAN>(s, L.g, L.simple, L.a, (size_t)L.key_blocks * 16, L.ctr, L.next_ctr, L.og, L.rem_blocks, progress, progress_val);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "upsert_planned: launch failed");
   step_epoch_public(t);
   return TFRA_OK;
@@ -1984,12 +2059,12 @@ extern "C" int tfra_sparse_plan_read(const tfra_sparse_plan_t* pl, uint32_t* cou
     if ((size_t)ncold > cap) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: buffers too small");
     const SetTab& tb = pl->set_tab[pl->set_parity];
     std::vector<unsigned> sl(ncold);
-    std::vector<uint2> pc((size_t)pl->set_m2 + 2);
+    std::vector<SetEnt> pc((size_t)pl->set_m2 + 2);
     if ((ncold && hipMemcpyAsync(keys, tb.ukeys, (size_t)ncold * 8, hipMemcpyDeviceToHost, s) != hipSuccess) ||
         (ncold && hipMemcpyAsync(sl.data(), tb.uslot, (size_t)ncold * 4, hipMemcpyDeviceToHost, s) != hipSuccess) ||
-        hipMemcpyAsync(pc.data(), tb.gpc, pc.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        hipMemcpyAsync(pc.data(), tb.ent, pc.size() * sizeof(SetEnt), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
-    for (unsigned i = 0; i < ncold; ++i) cnt[i] = pc[sl[i]].y;
+    for (unsigned i = 0; i < ncold; ++i) cnt[i] = pc[sl[i]].cnt;
     return TFRA_OK;
   }
   if ((size_t)nhot + ncold > cap) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: buffers too small");
@@ -2424,3 +2499,7 @@ extern "C" int tfra_table_step_prefetch_assign(tfra_table_t* tp, tfra_sparse_pla
   return step_prefetch_impl(tp, nullptr, plan_cur, ids_cur, rows_out, find_default, values, nullptr, scores, plan_next, ids_next,
                             n_next, main_stream, side_stream);
 }
+
+#define TFRA_STEP_HOST_PART
+#include "tfra_step_impl.h"
+#undef TFRA_STEP_HOST_PART

@@ -361,11 +361,12 @@ __device__ __forceinline__ void select_victim_merged(u64 b0, u64 b1, const i64 (
 // the most recent); otherwise the new key enters only if in_score >= the minimum score.
 // Returns the row whose key word now holds LOCKED_KEY (the caller writes row + score, then publishes
 // the key with publish_key), -1 when the key was not admitted, -3 when no victim could be taken.
+// victim_key (optional): receives the replaced key.
 // pre_k / pre_s (optional): key and score lines of (b0, b1) preloaded by the caller — a kernel that handles several keys
 // per group puts all of their lines in flight before resolving any (first attempt only; retries reload).
 __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 in_score, bool admit_always, int sub,
                                               int gshift, u64* victim_word, bool& claimed_empty,
-                                              const i64* pre_k = nullptr, const i64* pre_s = nullptr) {
+                                              const i64* pre_k = nullptr, const i64* pre_s = nullptr, i64* victim_key = nullptr) {
   u64 h;
   const u64 b0 = bucket0(key, v.nb, h);
   const u64 b1 = bucket1(h, b0, v.nb);
@@ -408,6 +409,7 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
       }
       claimed_empty = (best_key == EMPTY_KEY);
       *victim_word = best_word;
+      if (victim_key) *victim_key = best_key;   // the key this call replaces (the overlapped step checks it against the next lookup)
       return (i64)((best_word >> 4) * SLOTS + (best_word & 15));
     }
   }

@@ -69,6 +69,15 @@ class StepDesc(ctypes.Structure):
   ]
 
 
+class OverlapStep(ctypes.Structure):
+  """tfra_overlap_step (include/tfra_mi355x.h): one step of tfra_table_steps_overlap."""
+  _fields_ = [
+      ("struct_size", ctypes.c_uint32), ("default_is_full", ctypes.c_int32), ("n", ctypes.c_size_t), ("ids", ctypes.c_void_p),
+      ("rows_out", ctypes.c_void_p), ("exists_out", ctypes.c_void_p), ("defaults", ctypes.c_void_p), ("values_prev", ctypes.c_void_p),
+      ("scores_prev", ctypes.c_void_p), ("n_next", ctypes.c_size_t), ("ids_next", ctypes.c_void_p),
+  ]
+
+
 ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t),
                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p)
 
@@ -116,6 +125,12 @@ _SIGS = {
     "tfra_table_apply_planned": [_P, ctypes.POINTER(OptParams), _P, _P, _P, _P],
     "tfra_table_step_prefetch": [_P, ctypes.POINTER(OptParams), _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P],
     "tfra_table_step_prefetch_assign": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P],
+    "tfra_step_driver_create": [_P, ctypes.POINTER(_P)],
+    "tfra_step_driver_destroy": [_P],
+    "tfra_table_step_overlap": [_P, _SZ, _P, _P, _P, _P, _I, _P, _P, _SZ, _P, _P],
+    "tfra_table_step_overlap_flush": [_P, _P, _P, _P],
+    "tfra_table_steps_overlap": [_P, _SZ, _P, _P],
+    "tfra_step_driver_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_I), _P],
     "tfra_table_upsert_sparse": [_P, _SZ, _P, _P, _P, _P],
     "tfra_table_upsert_planned": [_P, _P, _P, _P, _P],
     "tfra_sparse_plan_read": [_P, _P, _P, _P, _P, _SZ, _P],

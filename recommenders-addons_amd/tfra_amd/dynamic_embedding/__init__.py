@@ -2,8 +2,8 @@
 (`/root/reference/tensorflow_recommenders_addons/dynamic_embedding/__init__.py`) for the hot path."""
 from . import device_ops
 from . import optimizer as optimizers
-from .optimizer import (CapturedTrainStep, DynamicEmbeddingOptimizer, MultiTablePrefetchStep, PrefetchAssignStep,
-                        PrefetchStep)
+from .optimizer import (CapturedTrainStep, DynamicEmbeddingOptimizer, MultiTablePrefetchStep, OverlapAssignStep,
+                        PrefetchAssignStep, PrefetchStep)
 from .restrict_policies import FrequencyRestrictPolicy, RestrictPolicy, TimestampRestrictPolicy
 from .table_ops import (SparsePlan, CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
                         KHkvHashTableMaxCapacity, KHkvHashTableMaxHbmForValuesByBytes)

@@ -674,3 +674,115 @@ class PrefetchAssignStep:
                          0 if nxt is None else nxt.numel(), self._main_h, self._side_h))
     self.cur = nxt_slot
     return out
+
+
+class OverlapAssignStep:
+  """The overlapped step (`tfra_table_step_overlap`, csrc/tfra_step_impl.h): same use as `PrefetchAssignStep` —
+
+      os_ = OverlapAssignStep(table).prime(first_ids)
+      for ...: rows = os_.step(values, next_ids)       # rows = lookup(batch i); values [n, dim] = what batch i writes back
+      os_.flush()                                       # before the table is used any other way
+
+  — and the same results as lookup(i); insert_or_assign(i); lookup(i+1); ... one after the other, but the write-back of
+  batch i runs in the SAME kernel launch as the lookup of batch i+1: ids the two batches share are served from `values` (which
+  must therefore stay unchanged until the next step has run), a key the write-back evicts although the next lookup asks for it
+  is corrected afterwards.  Two launches per step on one stream, no second stream, no host synchronisation.  `run()` enqueues
+  many steps with ONE host call."""
+
+  def __init__(self, table):
+    self.t = table
+    self.table = table._table if hasattr(table, "_table") else table
+    self.dev = self.table.device
+    self._h = ctypes.c_void_p()
+    _capi.call("tfra_step_driver_create", self.table._h, ctypes.byref(self._h))
+    self.default = self.table._default_value
+    self._ids = None
+    self._pending = None      # (ids, values) of the batch still to be written back: kept alive until it has been
+    self._keep = None
+    self._fn = _capi.lib().tfra_table_step_overlap
+    self._default_p = ctypes.c_void_p(self.default.data_ptr())
+
+  def __del__(self):
+    try:
+      if self._h:
+        _capi.lib().tfra_step_driver_destroy(self._h)
+        self._h = None
+    except Exception:
+      pass
+
+  def _as_ids(self, ids):
+    if torch.is_tensor(ids) and ids.dtype == torch.int64 and ids.dim() == 1 and ids.is_contiguous() and ids.device == self.dev:
+      return ids
+    return torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+
+  def prime(self, ids):
+    self._ids = self._as_ids(ids)
+    return self
+
+  def step(self, values, next_ids=None, return_exists=False):
+    from .table_ops import _stream
+    ids = self._ids
+    n = ids.numel()
+    dim, vdt, dev = self.table.dim, self.table.value_dtype, self.dev
+    if values.dtype != vdt or not values.is_contiguous() or values.shape != (n, dim):
+      values = values.reshape(n, dim).to(vdt).contiguous()
+    out = torch.empty((n, dim), dtype=vdt, device=dev)
+    ex = torch.empty(n, dtype=torch.bool, device=dev) if return_exists else None
+    nxt = self._as_ids(next_ids) if next_ids is not None else None
+    prev = self._pending
+    _capi.check(self._fn(self._h, n, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                         ctypes.c_void_p(ex.data_ptr()) if ex is not None else None, self._default_p, 0,
+                         ctypes.c_void_p(prev[1].data_ptr()) if prev is not None else None, None,
+                         0 if nxt is None else nxt.numel(), ctypes.c_void_p(nxt.data_ptr()) if nxt is not None else None, _stream(dev)))
+    self._keep = prev            # its buffers are read by the launch just enqueued
+    self._pending = (ids, values)
+    self._ids = nxt
+    return (out, ex) if return_exists else out
+
+  def flush(self):
+    from .table_ops import _stream
+    if self._pending is not None:
+      _capi.call("tfra_table_step_overlap_flush", self._h, ctypes.c_void_p(self._pending[1].data_ptr()), None, _stream(self.dev))
+      self._keep = self._pending
+      self._pending = None
+
+  def stats(self):
+    a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+    dc = (ctypes.c_uint32 * 3)()
+    _capi.call("tfra_step_driver_stats", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), dc)
+    return {"overlapped": a.value, "sequential": b.value, "pending": bool(c.value), "deferred_evictions": dc[0],
+            "victims_noted": dc[1], "rows_corrected": dc[2]}
+
+  def make_run(self, ids_list, values_list, outs, ids_after=None, values_before=None):
+    """Pre-builds the argument array of `tfra_table_steps_overlap` for the steps (ids_list[k], values_list[k]) -> outs[k]:
+    returns a callable that enqueues all of them with ONE host call.  values_before = the values of the batch pending when
+    the run starts (None: nothing pending); ids_after = the ids of the step behind the run (its plan is built by the run's
+    last launch).  The caller keeps every tensor alive and unchanged until the run has executed."""
+    from .table_ops import _stream
+    m = len(ids_list)
+    arr = (_capi.OverlapStep * m)()
+    for k in range(m):
+      q = arr[k]
+      q.struct_size = ctypes.sizeof(_capi.OverlapStep)
+      q.default_is_full = 0
+      q.n = ids_list[k].numel()
+      q.ids = ids_list[k].data_ptr()
+      q.rows_out = outs[k].data_ptr()
+      q.exists_out = None
+      q.defaults = self.default.data_ptr()
+      vp = values_before if k == 0 else values_list[k - 1]
+      q.values_prev = vp.data_ptr() if vp is not None else None
+      q.scores_prev = None
+      nx = ids_list[k + 1] if k + 1 < m else ids_after
+      q.n_next = nx.numel() if nx is not None else 0
+      q.ids_next = nx.data_ptr() if nx is not None else None
+    fn = _capi.lib().tfra_table_steps_overlap
+    h, dev = self._h, self.dev
+    last = (ids_list[-1], values_list[-1])
+
+    def run():
+      _capi.check(fn(h, m, arr, _stream(dev)))
+      self._pending = last
+      self._ids = ids_after
+    run._keep = (arr, ids_list, values_list, outs, ids_after, values_before)
+    return run

@@ -1,0 +1,199 @@
+"""GPU: the overlapped step (tfra_table_step_overlap, csrc/tfra_step_impl.h) — lookup of batch i+1 in the same launch as the
+write-back of batch i — must return exactly what the ops return one after the other (the reference's order:
+HkvHashTableOfTensorsGpu::Find / ::Insert, K/hkv_hashtable_op_gpu.cu.cc:182-290; Insert exclusive, Find shared).
+
+The check that needs no model of the eviction order: when a step call has run, the write-back of the PREVIOUS batch is
+complete and the write-back of this batch has not started, so the table is exactly in the state this batch's lookup must
+reflect — a plain tfra_table_find of the same ids (read-only, no scores touched) must return the same rows and exists flags,
+bit for bit.  On top of that: a dictionary oracle where nothing is evicted, forced conflicts (keys the write-back evicts
+while the next lookup asks for them), sentinel keys, repeats, steps without look-ahead, many steps from one host call."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  return torch, de
+
+
+def make_dense_table(torch, de, cap, dim, fill_keys, name, dtype=None):
+  """bounded LRU table at max_capacity, pre-filled, and known to the host as dense (> 60 % of the slots: the overlap's premise)"""
+  dtype = dtype or torch.float32
+  t = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name=name)
+  k = torch.from_numpy(fill_keys).cuda()
+  for lo in range(0, k.numel(), 20000):
+    kk = k[lo:lo + 20000]
+    t._table.upsert(kk, (kk.to(torch.float32)[:, None] % 1000).repeat(1, dim).to(dtype), unique_keys=True)
+    torch.cuda.synchronize()
+  for _ in range(3):   # the host learns the density from an asynchronous size read: give it calls to complete in
+    t._table.upsert(k[:16], (k[:16].to(torch.float32)[:, None] % 1000).repeat(1, dim).to(dtype), unique_keys=True)
+    torch.cuda.synchronize()
+  return t
+
+
+@pytest.mark.parametrize("cap,n", [(120_000, 5000), (1_200_000, 20000)])
+def test_overlap_step_equals_sequential_ops_no_eviction(env, cap, n):
+  """Universe = 62 % of the slots (dense, yet both home buckets of a key are never full): nothing is evicted, so a dictionary
+  is the oracle (the reference's CPU table semantics: last occurrence wins, misses read the default).  The small table has
+  thousands of left-over keys per step (two keys of a batch sharing a home bucket), the large one a handful."""
+  torch, de = env
+  dim = 64
+  rng = np.random.default_rng(cap)
+  imin = np.iinfo(np.int64).min
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  resident = universe[: int(universe.size * 0.99)]          # the last 1 % enter through the steps (misses first)
+  t = make_dense_table(torch, de, cap, dim, resident, "ovl_exact_%d" % cap)
+  tbl = t._table
+  latest = {int(k): float(int(k) % 1000) for k in resident}
+  drv = de.OverlapAssignStep(t)
+  nsteps = 10
+  batches = []
+  for s in range(nsteps + 1):
+    ids = universe[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % universe.size].astype(np.int64)
+    ids[rng.integers(0, n, size=n // 100)] = imin           # the two sentinel key values as ordinary keys
+    ids[rng.integers(0, n, size=n // 130)] = imin + 1
+    ids[: n // 6] = universe[7]                             # a hot id
+    rng.shuffle(ids)
+    batches.append(torch.from_numpy(ids).cuda())
+  drv.prime(batches[0])
+  for s in range(nsteps):
+    ids = batches[s]
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
+    look_ahead = batches[s + 1] if s % 4 != 3 else None      # every fourth step: the next ids are NOT announced
+    out, ex = drv.step(vals, look_ahead, return_exists=True)
+    if look_ahead is None:
+      drv.prime(batches[s + 1])
+    ref, rex = tbl.find(ids, return_exists=True)            # the table right now = what this lookup had to reflect
+    assert torch.equal(ex, rex), "step %d" % s
+    assert torch.equal(out, ref), "step %d" % s
+    ids_np = ids.cpu().numpy()
+    want = np.array([latest.get(int(k), 0.0) for k in ids_np], np.float32)
+    want_ex = np.array([int(k) in latest for k in ids_np])
+    np.testing.assert_array_equal(ex.cpu().numpy(), want_ex)
+    np.testing.assert_array_equal(out[:, 0].cpu().numpy(), want)
+    assert bool((out == out[:, :1]).all())
+    for i, k in enumerate(ids_np.tolist()):
+      latest[k] = 100000.0 * (s + 1) + i
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] == nsteps and st["sequential"] == 0 and not st["pending"], st
+  ek, ev = t.export()
+  assert ek.numel() == len(latest) == int(t.size().item())
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
+  tbl.check_errors()
+  assert tbl.slot_census()["locked"] == 0
+
+
+def test_overlap_step_evictions_and_forced_conflicts(env):
+  """A table filled to capacity, a third of every batch never-seen ids (each evicts the oldest entry of its two home buckets)
+  and a third the OLDEST resident keys — the likely victims: the write-back keeps meeting victims the next lookup asks for.
+  Checked against the table itself after every step (module docstring), plus: exists => the row of the key's last write;
+  a key of the batch just written back is present; size <= capacity; the conflict path really ran."""
+  torch, de = env
+  dim, cap, n, nsteps = 64, 60_000, 3000, 40
+  rng = np.random.default_rng(5)
+  fill = np.arange(1, cap + 1, dtype=np.int64) * 104729 + 11
+  t = make_dense_table(torch, de, cap, dim, fill, "ovl_evict")
+  tbl = t._table
+  last_write = {int(k): -1 for k in fill}       # key -> step of its last write (-1: the pre-fill); who is oldest
+  latest = {int(k): float(int(k) % 1000) for k in fill}
+  hot = fill[rng.integers(0, cap, size=400)]
+  fresh = 10_000_000
+
+  def make_batch(step):
+    nonlocal fresh
+    a = hot[(rng.zipf(1.2, size=n // 3)) % hot.size]
+    b = np.arange(fresh, fresh + n // 3, dtype=np.int64) * 31 + 5
+    fresh += n // 3
+    oldest = sorted(last_write, key=last_write.get)[: 4 * n]
+    c = np.array(oldest, np.int64)[rng.integers(0, len(oldest), size=n - a.size - b.size)]
+    ids = np.concatenate([a, b, c])
+    rng.shuffle(ids)
+    return ids
+
+  drv = de.OverlapAssignStep(t)
+  ids_np = make_batch(0)
+  drv.prime(torch.from_numpy(ids_np).cuda())
+  prev_keys = None
+  n_absent_old = 0
+  for s in range(nsteps):
+    ids = torch.from_numpy(ids_np).cuda()
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
+    for i, k in enumerate(ids_np.tolist()):     # (the next batch is drawn knowing this one's writes: who is oldest after it)
+      last_write[k] = s
+    nxt_np = make_batch(s + 1)
+    out, ex = drv.step(vals, torch.from_numpy(nxt_np).cuda(), return_exists=True)
+    ref, rex = tbl.find(ids, return_exists=True)
+    assert torch.equal(ex, rex), "step %d: %d exists flags differ" % (s, int((ex != rex).sum()))
+    assert torch.equal(out, ref), "step %d" % s
+    exn, outn = ex.cpu().numpy(), out[:, 0].cpu().numpy()
+    want = np.array([latest.get(int(k), 0.0) for k in ids_np], np.float32)
+    assert np.array_equal(outn[exn], want[exn]) and np.all(outn[~exn] == 0.0)
+    if prev_keys is not None:
+      again = np.isin(ids_np, prev_keys)
+      assert again.any() and exn[again].all()   # written one step ago: present, served from that step's values
+    n_absent_old += int((~exn).sum())
+    for i, k in enumerate(ids_np.tolist()):
+      latest[k] = 100000.0 * (s + 1) + i
+    prev_keys = np.unique(ids_np)
+    ids_np = nxt_np
+    assert int(t.size().item()) <= tbl.capacity()
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] == nsteps and st["sequential"] == 0, st
+  assert st["deferred_evictions"] > 0 and st["victims_noted"] > 0 and st["rows_corrected"] > 0, st
+  ek, ev = t.export()
+  ekn = ek.cpu().numpy()
+  assert np.unique(ekn).size == ekn.size
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ekn], np.float32))
+  tbl.check_errors()
+  assert tbl.slot_census()["locked"] == 0
+
+
+def test_overlap_many_steps_one_host_call_and_fallback(env):
+  """tfra_table_steps_overlap: 8 steps enqueued by ONE host call equal the same steps issued one by one; and a table the
+  overlap does not cover (not at capacity: it still walks and grows) runs the same entry points one op after the other."""
+  torch, de = env
+  dim, cap, n = 64, 200_000, 8192
+  rng = np.random.default_rng(9)
+  universe = np.arange(1, int(cap * 0.62) + 1, dtype=np.int64) * 6151 + 1
+  tabs = [make_dense_table(torch, de, cap, dim, universe, "ovl_run_%d" % i) for i in range(2)]
+  m = 8
+  ids = [torch.from_numpy(universe[(rng.zipf(1.2, size=n) * 13) % universe.size]).cuda() for _ in range(m + 1)]
+  vals = [(torch.randn((n, dim), device="cuda") * 0.01) for _ in range(m)]
+  outs = [torch.empty((n, dim), device="cuda") for _ in range(m)]
+  d0 = de.OverlapAssignStep(tabs[0])
+  run = d0.make_run(ids[:m], vals, outs, ids_after=ids[m])
+  run()
+  d1 = de.OverlapAssignStep(tabs[1]).prime(ids[0])
+  for k in range(m):
+    o = d1.step(vals[k], ids[k + 1])
+    assert torch.equal(o, outs[k]), k
+  d0.flush()
+  d1.flush()
+  assert d0.stats()["overlapped"] == m
+  a, b = tabs[0].export(), tabs[1].export()
+  ia, ib = torch.argsort(a[0]), torch.argsort(b[0])
+  assert torch.equal(a[0][ia], b[0][ib]) and torch.equal(a[1][ia], b[1][ib])
+  # fallback: a growing table (CuckooHashTable) through the same driver
+  g = de.CuckooHashTable(torch.int64, torch.float32, torch.zeros(dim), device="cuda:0", dim=dim, name="ovl_fallback")
+  dg = de.OverlapAssignStep(g).prime(ids[0])
+  ref = {}
+  for k in range(4):
+    o, ex = dg.step(vals[k], ids[k + 1], return_exists=True)
+    idn = ids[k].cpu().numpy()
+    want_ex = np.array([int(x) in ref for x in idn])
+    np.testing.assert_array_equal(ex.cpu().numpy(), want_ex)
+    for i, x in enumerate(idn.tolist()):
+      ref[x] = (k, i)
+  dg.flush()
+  assert dg.stats()["sequential"] == 4 and dg.stats()["overlapped"] == 0
+  uk = torch.from_numpy(np.array(sorted(ref), np.int64)).cuda()
+  got = g.lookup(uk)
+  want = torch.stack([vals[ref[int(x)][0]][ref[int(x)][1]] for x in uk.cpu().numpy()])
+  assert torch.equal(got, want)
