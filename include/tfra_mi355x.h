@@ -359,11 +359,17 @@ typedef struct {
   const int64_t* ids_next;
 } tfra_overlap_step;
 int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_overlap_step* steps, tfra_stream_t stream);
+/* tuning builds (TFRA_STEP_VARIANT & 16): per-role time stamps of the last launches, see csrc/tfra_step_impl.h */
+int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out);
 /* steps taken overlapped / one op after the other so far; whether a write-back is pending; device_counts[3] (optional,
  * synchronises the device) = {evictions the pass deferred because the next lookup wanted the victim, victims the remainder
  * pass noted, output rows it rewrote with the default row} */
 int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending,
-                           uint32_t* device_counts);
+                           uint32_t* device_counts, uint32_t* why_sequential);
+/* why_sequential (optional): why the last step that ran one op after the other did — 1 empty batch, 2 a buffer or the row
+ * size is not a multiple of 16 bytes, 4 no owner tags, 8 optimizer slots / not LRU / caller scores, 16 the table can still
+ * grow, 32 the table is not yet known to be dense (> 60 % of its slots, learned from asynchronous size reads), 64 the
+ * previous batch was empty, 128 TFRA_OPTION_CAPTURE_SAFE */
 
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */
 

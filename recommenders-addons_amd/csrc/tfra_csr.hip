@@ -905,8 +905,10 @@ template <int G>
 __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsigned char* __restrict__ vals, i64 key, unsigned last,
                                                  u64 in_score, const AuxInitPod& ai, const ScoreP& sp, int sub, int gshift,
                                                  int& fresh, int& failed, bool hinted = false, unsigned hint_word = 0,
-                                                 i64* evicted_key = nullptr) {
+                                                 i64* evicted_key = nullptr, int acc = 0, int acc_dt = 0) {
   // evicted_key (optional): set to the key this upsert replaced by eviction (untouched when it evicted nothing)
+  // acc: the reference's insert_or_accum for this key (accumrase_fn, cuckoohash_map.hh:619-633) instead of an assign —
+  //   1 (exists): present -> row += delta, one add per element; absent -> nothing.   2 (!exists): absent -> insert; present -> nothing
   const bool lru_like = sp.strategy == TFRA_EVICT_LRU || sp.strategy == TFRA_EVICT_EPOCHLRU;
   const u64 cmp = sp.strategy == TFRA_EVICT_EPOCHLFU ? ((sp.epoch << 32) | in_score) : in_score;
   i64 row = -1;
@@ -918,7 +920,20 @@ __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsig
     old = shfl_i64(old, gshift);
     if (old == key) { word = hint_word; row = (i64)((word >> 4) * SLOTS + (word & 15)); }
   }
-  for (int attempt = 0; attempt < 64 && row < 0; ++attempt) {
+  for (int attempt = 0; acc == 1 && attempt < 64 && row < 0; ++attempt) {   // accumulate: find the key (never claim a slot) and lock it
+    const i64 r = probe_find<true>(v, key, sub, gshift);
+    if (r < 0) return;                                   // absent & exists: dropped
+    if (r >= (i64)(v.nb * SLOTS)) { row = r; side = true; break; }
+    u64 rb;
+    unsigned rs;
+    split_row((u64)r, rb, rs);
+    const u64 wd = rb * 16 + rs;
+    i64 old = 0;
+    if (sub == 0) old = (i64)atomicCAS((u64*)key_word(v, wd), (u64)key, (u64)LOCKED_KEY);
+    old = shfl_i64(old, gshift);
+    if (old == key) { row = r; word = wd; }              // else: an evictor of this pass took the slot; look again
+  }
+  for (int attempt = 0; acc != 1 && attempt < 64 && row < 0; ++attempt) {
     // This pass is one wave-lifetime of dependent round trips (~1.2 us each): both home buckets' key AND score lines
     // travel together up front (first attempt) instead of b0 -> b1 -> score lines one after the other.
     u64 h;
@@ -948,6 +963,7 @@ __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsig
       break;
     }
     if (r < 0) { failed += (sub == 0); break; }
+    if (acc == 2 && !claimed) return;                    // present & !exists: dropped (nothing was claimed or locked)
     fresh += (claimed && sub == 0);
     is_new = is_new || claimed;
     if (r >= (i64)(v.nb * SLOTS)) { row = r; side = true; break; }   // sentinel keys live in the side rows: nothing evicts there
@@ -962,7 +978,11 @@ __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsig
   }
   if (row < 0) return;
   unsigned char* pr = row_ptr(v, row);
-  copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
+  if (acc == 1 && G == 16) {
+    const unsigned char* dl = vals + (size_t)last * v.field_bytes;
+    for (unsigned off = sub * 16; off < v.field_bytes; off += 256)
+      store_wt16(pr + off, add16_dt(*reinterpret_cast<const uint4*>(pr + off), *reinterpret_cast<const uint4*>(dl + off), acc_dt));
+  } else copy_bytes16_wt<G>(pr, vals + (size_t)last * v.field_bytes, v.field_bytes, sub);
   if (is_new) {
     for (unsigned f = 1; f < v.n_fields; ++f) {   // slot fields of the new row start at aux_init
       const unsigned pat = ai.pattern[(f - 1) & 3];
@@ -1031,6 +1051,8 @@ struct OwnArgs {
   unsigned* tags;
   OwnItem* items;          // [item_cap] left-over list of the launch
   unsigned item_cap;
+  const uint8_t* exists;   // ACC (insert_or_accum of unique keys, SRC_DIRECT): the caller's exists flag per key
+  int acc_dt;              // ACC: tfra_dtype of the rows
 };
 // (OwnArgs stays a read-only kernel argument: a private, modified copy would live in scratch memory — its aux_init
 // pattern is indexed dynamically — and every field access of the hot loop would become a scratch load.)
@@ -1049,7 +1071,7 @@ __device__ __forceinline__ OwnFlags own_setup(const OwnArgs& a) {
 
 // The keys the ownership pass leaves over: 32 blocks (a full grid on a small table, where they are most of the batch) of
 // the locked protocol over the item list; the flags of ALL keys when the list overflowed.
-template <int G, int SRC>
+template <int G, int SRC, bool ACC = false>
 __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const unsigned* slow_ctr, unsigned* zero4) {
   // slow_ctr == nullptr: there was no ownership pass (no owner tags): EVERY key of the launch, with the locked protocol.
   // This kernel is a chain of dependent round trips for a handful of keys: the group's first item travels together with the
@@ -1081,7 +1103,8 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
         w1 = reinterpret_cast<const uint4*>(a.items + i)[1];
       }
       const i64 key = (i64)(((u64)w0.y << 32) | w0.x);
-      locked_upsert_kv<G>(a.v, a.vals, key, w0.z, ((u64)w1.y << 32) | w1.x, a.ai, a.sp, sub, gshift, fresh, failed, w1.z != 0, w1.w);
+      locked_upsert_kv<G>(a.v, a.vals, key, w0.z, ((u64)w1.y << 32) | w1.x, a.ai, a.sp, sub, gshift, fresh, failed, (w1.z & 1u) != 0, w1.w, nullptr,
+                          ACC ? ((w1.z & 2u) ? 1 : 2) : 0, a.acc_dt);
       if (sub == 0) a.dflag[w0.w] = 0;
     } else {
       if (slow_ctr && a.dflag[i] != 4) continue;
@@ -1091,7 +1114,8 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
         const u64 in_one = a.scores ? a.scores[pc.x - 1] : 1;
         locked_upsert_kv<G>(a.v, a.vals, a.ks.ukeys[i], pc.x - 1, a.sp.strategy == TFRA_EVICT_LFU ? (a.scores ? in_one : (u64)pc.y) : in_one,
                             a.ai, a.sp, sub, gshift, fresh, failed);
-      } else locked_upsert_kv<G>(a.v, a.vals, a.keys[i], i, a.scores ? a.scores[i] : 1, a.ai, a.sp, sub, gshift, fresh, failed);
+      } else locked_upsert_kv<G>(a.v, a.vals, a.keys[i], i, a.scores ? a.scores[i] : 1, a.ai, a.sp, sub, gshift, fresh, failed, false, 0, nullptr,
+                                 ACC ? (a.exists[i] ? 1 : 2) : 0, a.acc_dt);
       if (slow_ctr && sub == 0) a.dflag[i] = 0;
     }
   }
@@ -1165,7 +1189,12 @@ __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
 // CF (the overlapped step, step_kernel): the lookup of the NEXT batch runs beside this pass and reads the table rows of every key
 // that is not in this batch — an entry this pass is about to EVICT must not be one of them: `cf` = the next batch's plan; a victim
 // that is in it defers the new key to the remainder pass (which runs after that lookup and corrects its output).
-template <int G, bool SIMPLE, int SRC, int U, bool CF = false>
+// ACC (SRC_DIRECT, 16-B granules): the reference's insert_or_accum of unique keys (accumrase_fn, cuckoohash_map.hh:619-633;
+// HkvHashTableOfTensorsGpu::Accum, K/hkv_hashtable_op_gpu.cu.cc:292-335) instead of an assign — a.exists[i] set: the key is
+// expected in the table, present => row += value row (one add per element), absent => dropped; not set: absent => insert,
+// present => dropped.  A dropped key writes nothing, whatever its claims say (the keys of a call are unique: any order of
+// them is a valid serial order).
+template <int G, bool SIMPLE, int SRC, int U, bool CF = false, bool ACC = false>
 __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
                                             int lane, int& fresh, const SetProbe* cf = nullptr, unsigned* cf_stat = nullptr) {
   const u64* const scores = SIMPLE ? nullptr : a.scores;
@@ -1180,6 +1209,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   if (SRC == SRC_PLAN) { kreg = ks.dkeys[gj]; kmreg = ks.keymap[gj]; }
   else if (SRC == SRC_SET) { kreg = ks.ukeys[gj]; kmreg = ks.uslot[gj]; }
   else kreg = a.keys[gj];
+  const unsigned exreg = ACC ? (unsigned)a.exists[gj] : 0u;
   u64 hreg;
   const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
   const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
@@ -1242,8 +1272,10 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   int why[U];   // 0 handled, 1 lost a claim, 2 cannot be placed within the home buckets: the locked protocol
   bool flag_b0[U];   // the key goes to b1 although b0 never overflowed before: finds must go on to b1
   unsigned bxc[U];   // bucket beyond the home buckets the key was found in (it must be claimed too); ~0: none
+  bool ex[U];        // ACC: the caller's exists flag
 #pragma unroll
   for (int u = 0; u < U; ++u) {
+    ex[u] = ACC && __shfl((int)exreg, u * 4 + grp) != 0;
     in_s[u] = 1;
     if (!fl.lru_like) in_s[u] = (u64)shfl_i64((i64)insreg, u * 4 + grp);   // (LRU-type scores ignore the input score)
     act[u] = 0; why[u] = 0; word[u] = 0; flag_b0[u] = false; bxc[u] = ~0u;
@@ -1273,7 +1305,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
           else if (stepn == 7) why[u] = 2;   // a long chain (an unbounded table): the general path
         }
       }
-      if (absent) {   // not in the table
+      if (absent && !(ACC && ex[u])) {   // not in the table (ACC: absent & exists is dropped)
         if (emp0) { word[u] = (u64)b0[u] * 16 + (__ffs(emp0) - 1); act[u] = 2; }   // first empty slot in probe order
         else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0[u] = !ovf0; }
         else if (fl.spec) {
@@ -1319,6 +1351,12 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
       if (__shfl((int)cx, gshift)) { act[u] = 0; why[u] = 1; }
     }
     if (!real) { act[u] = 0; why[u] = 0; }
+    if (ACC) {
+      if (act[u] == 1 && !ex[u]) act[u] = 0;                                   // present & !exists: dropped
+      if (why[u] == 1 && hint[u] && !ex[u]) { why[u] = 0; hint[u] = 0; }        // (the same, seen without the claim)
+      if (why[u] == 1 && !hint[u] && ex[u] && bxc[u] == ~0u) { }               // lost its claim, not seen: the remainder looks again
+      if (ex[u]) hint[u] |= 2u;                                                // the item carries the flag
+    }
     if (act[u] && flag_b0[u] && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
     if (sub == 0 && why[u]) a.dflag[gk[u]] = 4;
     fresh += (act[u] == 2 && sub == 0);
@@ -1357,6 +1395,15 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
 #pragma unroll
     for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(a.vals + (u64)last[u] * (u64)v.field_bytes + off);
     keep_live_u<U>(tmp);
+    if (ACC && G == 16) {   // accumulate: the rows themselves travel with the deltas (a key that only inserts adds nothing)
+      T cur[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = *reinterpret_cast<const T*>(dst[u] + off);
+      keep_live_u<U>(cur);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (act[u] == 1) *reinterpret_cast<uint4*>(&tmp[u]) = add16_dt(*reinterpret_cast<uint4*>(&cur[u]), *reinterpret_cast<uint4*>(&tmp[u]), a.acc_dt);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!act[u]) continue;
@@ -1390,7 +1437,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   }
 }
 
-template <int G, bool SIMPLE, int SRC, int U = 4>
+template <int G, bool SIMPLE, int SRC, int U = 4, bool ACC = false>
 __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, unsigned own_gen, unsigned* progress,
                                                          unsigned progress_val) {
   const int lane = threadIdx.x & 63;
@@ -1408,7 +1455,7 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
   const OwnFlags fl = own_setup<SIMPLE>(a);
   for (unsigned wbase = wave * (4 * U); wbase < total; wbase += nwaves * (4 * U)) {
     const unsigned i = wbase + (unsigned)(lane & 15);
-    own_batch16<G, SIMPLE, SRC, U>(a, fl, min(i, total - 1), (lane & 15) < 4 * U && i < total, own_gen, &ctr->n_a, lane, fresh);
+    own_batch16<G, SIMPLE, SRC, U, false, ACC>(a, fl, min(i, total - 1), (lane & 15) < 4 * U && i < total, own_gen, &ctr->n_a, lane, fresh);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(a.v, wave, fresh);
@@ -1903,6 +1950,18 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
 #undef TFRA_OWN
 }
 
+// the same pair as the reference's insert_or_accum (own_batch16: ACC) over a caller's unique keys; 16-byte granules only
+static void launch_own_accum(hipStream_t s, bool simple, const OwnArgs& a, size_t nkeys, OwnCtrs* ctr, OwnCtrs* next_ctr, unsigned og,
+                             unsigned rest_blocks) {
+  const bool half = nkeys <= 131072;
+  const unsigned blocks = (unsigned)std::max<size_t>(1, half ? (nkeys + 31) / 32 : (nkeys + 63) / 64);
+#define TFRA_OWN_ACC(SS, UU) upsert_own_kernel<16, SS, SRC_DIRECT, UU, true><<<blocks, 256, 0, s>>>(a, ctr, og, nullptr, 0)
+  if (simple) { if (half) TFRA_OWN_ACC(true, 2); else TFRA_OWN_ACC(true, 4); }
+  else { if (half) TFRA_OWN_ACC(false, 2); else TFRA_OWN_ACC(false, 4); }
+#undef TFRA_OWN_ACC
+  upsert_rest_kernel<16, SRC_DIRECT, true><<<rest_blocks, 256, 0, s>>>(a, &ctr->n_a, reinterpret_cast<unsigned*>(next_ctr));
+}
+
 // Expected left-over keys of an ownership pass over `nkeys` keys: two keys sharing a home bucket, (2 n)^2 / (2 nb).
 static double expect_leftover(double nkeys, double nb) { return 2.0 * nkeys * nkeys / nb; }
 
@@ -1992,8 +2051,11 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
 // or so many keys for the table's size that most of them would collide on a home bucket: a bulk load) — the caller runs
 // the locked two-phase kernels.  Caller holds t->mu and has called prepare_insert.
 namespace tfra {
-int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken) {
+int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken,
+                      const uint8_t* accum_exists) {
+  // accum_exists != nullptr: insert_or_accum (tfra_table_accum_or_assign with TFRA_FLAG_UNIQUE_KEYS) instead of an assign
   *taken = false;
+  if (accum_exists && (((size_t)t->field_bytes | (size_t)(uintptr_t)values) & 15)) return TFRA_OK;   // 16-byte granules only
   if (n == 0 || n > (1u << 24)) return TFRA_OK;
   const double expect = expect_leftover((double)n, (double)t->cur.nb);
   if (expect >= 2048.0) return TFRA_OK;   // most keys would collide on a home bucket (a bulk load): the locked kernels
@@ -2028,7 +2090,9 @@ int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const 
   a.v = t->view_of(t->cur); a.vals = (const unsigned char*)values; a.scores = scores; a.keys = keys; a.nkeys = (unsigned)n;
   a.ai = t->aux; a.sp = sp; a.dflag = (uint8_t*)t->own_ws + head; a.tags = tags;
   a.items = reinterpret_cast<OwnItem*>((unsigned char*)t->own_ws + 256); a.item_cap = SLOW_CAP;
-  launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, 32u, nullptr, 0);
+  a.exists = accum_exists; a.acc_dt = t->opts.value_dtype;
+  if (accum_exists) launch_own_accum(s, simple, a, n, ctr, next_ctr, og, 32u);
+  else launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, 32u, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: launch failed");
   *taken = true;
   return TFRA_OK;

@@ -474,6 +474,54 @@ template <> struct Granule<4> { typedef unsigned T; };
 template <> struct Granule<2> { typedef unsigned short T; };
 template <> struct Granule<1> { typedef unsigned char T; };
 
+// ---- typed accumulate of one 16-B granule: r[j] = a[j] + b[j], ONE add per element (ValueArray::operator+=,
+// K/lookup_impl/lookup_table_op_cpu.h:45-51); dt = tfra_dtype (uniform: a scalar branch) -----------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned add2_f16(unsigned a, unsigned b) {
+  const _Float16 a0 = __builtin_bit_cast(_Float16, (unsigned short)a), a1 = __builtin_bit_cast(_Float16, (unsigned short)(a >> 16));
+  const _Float16 b0 = __builtin_bit_cast(_Float16, (unsigned short)b), b1 = __builtin_bit_cast(_Float16, (unsigned short)(b >> 16));
+  const _Float16 r0 = (_Float16)((float)a0 + (float)b0), r1 = (_Float16)((float)a1 + (float)b1);
+  return (unsigned)__builtin_bit_cast(unsigned short, r0) | ((unsigned)__builtin_bit_cast(unsigned short, r1) << 16);
+}
+__device__ __forceinline__ unsigned add2_bf16(unsigned a, unsigned b) {
+  const unsigned short r0 = f32_to_bf16(bf16_to_f32((unsigned short)a) + bf16_to_f32((unsigned short)b));
+  const unsigned short r1 = f32_to_bf16(bf16_to_f32((unsigned short)(a >> 16)) + bf16_to_f32((unsigned short)(b >> 16)));
+  return (unsigned)r0 | ((unsigned)r1 << 16);
+}
+__device__ __forceinline__ unsigned add4_i8(unsigned a, unsigned b) {   // four wrapping int8 adds
+  return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+__device__ __forceinline__ uint4 add16_dt(uint4 a, uint4 b, int dt) {
+  uint4 r;
+  switch (dt) {
+    case TFRA_F32:
+      r.x = __float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x)); r.y = __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y));
+      r.z = __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z)); r.w = __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w));
+      break;
+    case TFRA_F16: r.x = add2_f16(a.x, b.x); r.y = add2_f16(a.y, b.y); r.z = add2_f16(a.z, b.z); r.w = add2_f16(a.w, b.w); break;
+    case TFRA_BF16: r.x = add2_bf16(a.x, b.x); r.y = add2_bf16(a.y, b.y); r.z = add2_bf16(a.z, b.z); r.w = add2_bf16(a.w, b.w); break;
+    case TFRA_I8: r.x = add4_i8(a.x, b.x); r.y = add4_i8(a.y, b.y); r.z = add4_i8(a.z, b.z); r.w = add4_i8(a.w, b.w); break;
+    case TFRA_I32: r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; r.w = a.w + b.w; break;
+    case TFRA_I64: {
+      const u64 s0 = (((u64)a.y << 32) | a.x) + (((u64)b.y << 32) | b.x), s1 = (((u64)a.w << 32) | a.z) + (((u64)b.w << 32) | b.z);
+      r.x = (unsigned)s0; r.y = (unsigned)(s0 >> 32); r.z = (unsigned)s1; r.w = (unsigned)(s1 >> 32);
+    } break;
+    default: {   // TFRA_F64
+      const double s0 = __longlong_as_double((i64)(((u64)a.y << 32) | a.x)) + __longlong_as_double((i64)(((u64)b.y << 32) | b.x));
+      const double s1 = __longlong_as_double((i64)(((u64)a.w << 32) | a.z)) + __longlong_as_double((i64)(((u64)b.w << 32) | b.z));
+      const u64 u0 = (u64)__double_as_longlong(s0), u1 = (u64)__double_as_longlong(s1);
+      r.x = (unsigned)u0; r.y = (unsigned)(u0 >> 32); r.z = (unsigned)u1; r.w = (unsigned)(u1 >> 32);
+    } break;
+  }
+  return r;
+}
+
 template <int G>
 __device__ __forceinline__ void copy_bytes16(unsigned char* dst, const unsigned char* src,
                                              unsigned bytes, int sub) {

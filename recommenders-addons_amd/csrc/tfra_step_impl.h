@@ -244,16 +244,28 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk) {
   if (lane == 0 && fresh) size_add(o.v, wave, fresh);
 }
 
-template <bool SIMPLE, int U, bool PLAN, int MINW>
+// TIMING (tuning builds only): every block notes its start and end on the device clock; per launch and role the earliest start
+// and the latest end are kept in a.stat (64-bit words behind the three counters): when does each role of a launch run?
+__device__ __forceinline__ void role_stamp(const StepArgs& a, int role, u64 t0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64* w = reinterpret_cast<u64*>(a.stat + 16) + ((size_t)(a.progress_val & 63u) * 3 + role) * 2;
+    atomicMin(w, t0);
+    atomicMax(w + 1, (u64)wall_clock64());
+  }
+}
+template <bool SIMPLE, int U, bool PLAN, int MINW, bool TIMING = false>
 __global__ __launch_bounds__(256, MINW) void step_kernel(const StepArgs a) {
   unsigned b = blockIdx.x;
+  const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
   if constexpr (PLAN) {
     __shared__ PlanLds L;
-    if (b < a.plan_blocks) { plan_role(a, b, L); return; }
+    if (b < a.plan_blocks) { plan_role(a, b, L); if (TIMING) role_stamp(a, 0, t0); return; }
     b -= a.plan_blocks;
   }
-  if (b < a.own_blocks) { own_role<SIMPLE, U>(a, b); return; }
+  if (b < a.own_blocks) { own_role<SIMPLE, U>(a, b); if (TIMING) role_stamp(a, 1, t0); return; }
   find_fwd_role(a, b - a.own_blocks);
+  if (TIMING) role_stamp(a, 2, t0);
 }
 
 // ---- the remainder of a step: left-over keys of the pass + corrections of the lookup's output ------------------------
@@ -371,6 +383,7 @@ struct tfra_step_driver {
   unsigned step_no = 0;
   int variant = 0;                         // TFRA_STEP_VARIANT (tuning): kernel instantiation
   unsigned long long n_overlapped = 0, n_sequential = 0;   // steps taken each way (tfra_step_driver_stats)
+  unsigned why_sequential = 0;             // why the last step that was not overlapped was not (bit mask, see step_overlap_one)
 };
 
 extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** out) {
@@ -386,12 +399,13 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   const size_t dn = 4 + 2 + SET_PAD;
   if (hipMalloc((void**)&d->dummy, dn * sizeof(SetEnt)) != hipSuccess) { d->dummy = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   fill_setent_kernel<<<1, 64, 0, nullptr>>>(d->dummy, dn);
-  if (hipMalloc((void**)&d->stat, 64) != hipSuccess || hipMemset(d->stat, 0, 64) != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
+  if (hipMalloc((void**)&d->stat, 64 + 64 * 3 * 16) != hipSuccess || hipMemset(d->stat, 0, 64 + 64 * 3 * 16) != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   if (hipHostMalloc((void**)&d->progress, 64, hipHostMallocDefault) != hipSuccess) { d->progress = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipHostMalloc"); }
   d->progress[0] = d->progress[1] = 0;
   if (hipDeviceSynchronize() != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_HIP, "step_driver_create: sync"); }
   const char* ev = std::getenv("TFRA_STEP_VARIANT");
   d->variant = ev ? std::atoi(ev) : 0;
+  if (d->variant & 16) (void)tfra_step_driver_timing(d, nullptr);
   *out = d;
   return TFRA_OK;
 }
@@ -408,7 +422,9 @@ extern "C" int tfra_step_driver_destroy(tfra_step_driver_t* d) {
   return TFRA_OK;
 }
 
-extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending, uint32_t* device_counts) {
+extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending, uint32_t* device_counts,
+                                      uint32_t* why_sequential) {
+  if (d && why_sequential) *why_sequential = d->why_sequential;
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_stats: null driver");
   if (overlapped) *overlapped = d->n_overlapped;
   if (sequential) *sequential = d->n_sequential;
@@ -421,10 +437,25 @@ extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* ove
   return TFRA_OK;
 }
 
+// tuning: the role time stamps of the last <= 64 launches made with TFRA_STEP_VARIANT & 16 — out[64][3][2] = {earliest block
+// start, latest block end} on the device clock (100 MHz) per launch slot (step % 64) and role (plan, write-back, lookup);
+// synchronises the device and re-arms the stamps.
+extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
+  if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_timing: null driver");
+  (void)hipSetDevice(d->t->device);
+  std::vector<uint64_t> init(64 * 3 * 2);
+  for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ULL; init[i + 1] = 0; }
+  if (hipDeviceSynchronize() != hipSuccess || (out && hipMemcpy(out, d->stat + 16, init.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) ||
+      hipMemcpy(d->stat + 16, init.data(), init.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+    return set_error(TFRA_ERR_HIP, "step_driver_timing: copy");
+  return TFRA_OK;
+}
+
 static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_tab[pl->set_parity].ent, pl->set_m2}; }
 
 template <bool PLAN>
 static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {
+  if (variant & 16) { step_kernel<true, 2, PLAN, 1, true><<<grid, 256, 0, s>>>(a); return; }
   switch (variant & 7) {
     case 1: step_kernel<true, 1, PLAN, 1><<<grid, 256, 0, s>>>(a); break;
     case 2: step_kernel<true, 2, PLAN, 6><<<grid, 256, 0, s>>>(a); break;
@@ -459,8 +490,12 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
   d->ahead = false;
   const bool aligned = (((uintptr_t)rows_out | (uintptr_t)defaults | (uintptr_t)values_prev | (size_t)t->field_bytes) & 15) == 0;
   unsigned* tags = t->ensure_own_tags(s);
-  const bool eligible = n > 0 && aligned && tags && t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !scores_prev &&
-                        t->at_max_capacity() && t->dense && (!plan_prev || plan_prev->n > 0) && !t->capture_safe;
+  const unsigned why = (n > 0 ? 0u : 1u) | (aligned ? 0u : 2u) | (tags ? 0u : 4u) |
+                       ((t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !scores_prev) ? 0u : 8u) |
+                       (t->at_max_capacity() ? 0u : 16u) | (t->dense ? 0u : 32u) | ((!plan_prev || plan_prev->n > 0) ? 0u : 64u) |
+                       (t->capture_safe ? 128u : 0u);
+  const bool eligible = why == 0;
+  if (!eligible) d->why_sequential = why;
   const unsigned step = ++d->step_no;
   if (!eligible) {
     // the same results one after the other: write-back of the previous batch, this lookup, the next batch's plan

@@ -289,13 +289,6 @@ __global__ void rearm_winner_kernel(TableView v, size_t n, const i64* __restrict
 }
 
 // ---- typed accumulate: row[j] += delta[j], one add per element (ValueArray::operator+=) ----
-__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 
 template <int DT>
 __device__ __forceinline__ void row_add(unsigned char* row, const unsigned char* delta, unsigned dim, int sub) {
@@ -1150,7 +1143,13 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
   // at max_capacity (eviction takes over) or after a failed growth there is nothing to decide
   // (bounded tables sit on the lattice max_nb / 2^j: the last doubling lands on max_nb, give or take the rounding)
   const bool can_grow = !growth_blocked && (!opts.max_capacity || cur.nb * 2 <= std::max<u64>(2, opts.max_capacity / SLOTS));
-  if (!can_grow) return poll_density(n, s);
+  if (!can_grow) {
+    // (the bound stays AT the soft threshold from here on: it is not advanced on this path, and a later, smaller call must
+    // not fall back under the threshold and skip the density poll — a table filled by a few big calls and then used with
+    // small ones never learned that it was dense)
+    size_ub = std::max(size_ub, (size_t)soft);
+    return poll_density(n, s);
+  }
   bool truly_past_soft = false;   // a completed read saw more live keys than max_load_factor allows: grow now, not at 92 %
   if (size_pending && hipEventQuery(size_event) == hipSuccess) {
     i64 v = *h_size;
@@ -1469,6 +1468,12 @@ int tfra_table_accum_or_assign(tfra_table_t* tp, size_t n, const int64_t* keys, 
   TableView v = t->view_of(t->cur);
   const i64* k = (const i64*)keys;
   if (flags & TFRA_FLAG_UNIQUE_KEYS) {
+    // unique keys (what TFRA hands the op: PY/dynamic_embedding_variable.py:1377-1378): the single pass with bucket ownership,
+    // as tfra_table_insert_or_assign does, whenever the batch is small for the table; else the locked kernels
+    bool taken = false;
+    rc = own_upsert_unique(t, s, n, k, vod, (const u64*)scores, &taken, exists);
+    if (rc) return rc;
+    if (taken) return TFRA_OK;   // (TableWrapper::accum does not step the epoch: lookup_table_op_hkv.h:539-546)
     dim3 grid((unsigned)((n * 16 + 255) / 256));
     uint8_t* deferred;
     rc = t->bounded_flags(n, s, &deferred);

@@ -130,7 +130,8 @@ _SIGS = {
     "tfra_table_step_overlap": [_P, _SZ, _P, _P, _P, _P, _I, _P, _P, _SZ, _P, _P],
     "tfra_table_step_overlap_flush": [_P, _P, _P, _P],
     "tfra_table_steps_overlap": [_P, _SZ, _P, _P],
-    "tfra_step_driver_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_I), _P],
+    "tfra_step_driver_timing": [_P, _P],
+    "tfra_step_driver_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_I), _P, _P],
     "tfra_table_upsert_sparse": [_P, _SZ, _P, _P, _P, _P],
     "tfra_table_upsert_planned": [_P, _P, _P, _P, _P],
     "tfra_sparse_plan_read": [_P, _P, _P, _P, _P, _SZ, _P],

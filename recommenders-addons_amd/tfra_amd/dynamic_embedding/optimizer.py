@@ -749,9 +749,24 @@ class OverlapAssignStep:
   def stats(self):
     a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
     dc = (ctypes.c_uint32 * 3)()
-    _capi.call("tfra_step_driver_stats", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), dc)
+    why = ctypes.c_uint32()
+    _capi.call("tfra_step_driver_stats", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), dc, ctypes.byref(why))
     return {"overlapped": a.value, "sequential": b.value, "pending": bool(c.value), "deferred_evictions": dc[0],
-            "victims_noted": dc[1], "rows_corrected": dc[2]}
+            "victims_noted": dc[1], "rows_corrected": dc[2], "why_sequential": why.value}
+
+  def timing(self):
+    """tuning (TFRA_STEP_VARIANT & 16): [(plan, write-back, lookup) spans in us relative to the launch's first block] per launch"""
+    buf = (ctypes.c_uint64 * (64 * 3 * 2))()
+    _capi.call("tfra_step_driver_timing", self._h, buf)
+    out = []
+    for k in range(64):
+      w = [buf[(k * 3 + r) * 2 + j] for r in range(3) for j in range(2)]
+      starts = [w[i] for i in (0, 2, 4) if w[i] != 2 ** 64 - 1]
+      if not starts:
+        continue
+      t0 = min(starts)
+      out.append([None if w[2 * r] == 2 ** 64 - 1 else ((w[2 * r] - t0) / 100.0, (w[2 * r + 1] - t0) / 100.0) for r in range(3)])
+    return out
 
   def make_run(self, ids_list, values_list, outs, ids_after=None, values_before=None):
     """Pre-builds the argument array of `tfra_table_steps_overlap` for the steps (ids_list[k], values_list[k]) -> outs[k]:

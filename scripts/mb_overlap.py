@@ -115,6 +115,12 @@ def main():
             r()
         fn = many
       us, hus, all_ = timed(fn)
+      tm = None
+      if v & 16:
+        import numpy as np
+        sp = [x for x in drv.timing() if all(y is not None for y in x)]
+        tm = {"launches": len(sp), "role_spans_us_median (start, end since the launch's first block)":
+              {r: [float(np.median([x[i][0] for x in sp])), float(np.median([x[i][1] for x in sp]))] for i, r in enumerate(("plan", "write_back", "lookup"))}}
       st = drv.stats()
       drv.flush()
       torch.cuda.synchronize()
@@ -124,7 +130,7 @@ def main():
       ok = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, ids[jlast], values)))
       table._table.check_errors()
       res["runs"].append({"driver": "step_overlap", "variant": v, "steps_per_host_call": D, "us_per_step": us, "host_us_per_step": hus,
-                          "windows": all_, "stats": st, "last_batch_ok": ok})
+                          "windows": all_, "stats": st, "last_batch_ok": ok, "timing": tm})
       print(res["runs"][-1], flush=True)
       del drv
   os.makedirs(os.path.dirname(args.out), exist_ok=True)
