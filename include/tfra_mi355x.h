@@ -359,6 +359,10 @@ typedef struct {
   const int64_t* ids_next;
 } tfra_overlap_step;
 int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_overlap_step* steps, tfra_stream_t stream);
+/* measurement: HIP events around the two launches of the next `steps` overlapped steps; _kernel_times waits for them and
+ * returns the average duration of the step launch and of the remainder launch in microseconds */
+int tfra_step_driver_time_kernels(tfra_step_driver_t* d, size_t steps);
+int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step_kernel_us, double* rest_kernel_us, size_t* steps);
 /* tuning builds (TFRA_STEP_VARIANT & 16): per-role time stamps of the last launches, see csrc/tfra_step_impl.h */
 int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out);
 /* steps taken overlapped / one op after the other so far; whether a write-back is pending; device_counts[3] (optional,

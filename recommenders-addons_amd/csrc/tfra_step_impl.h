@@ -53,11 +53,21 @@ struct StepArgs {
   SetTab pcur, pold;
   unsigned* next_use_count;
   unsigned plan_m2;
-  unsigned plan_blocks, own_blocks;
+  unsigned plan_blocks, own_blocks, find_blocks;
+  int interleave;              // own blocks spread among the lookup's blocks (else: all in front of them)
+  int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
+  u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
+  i64* patch_keys;             // step_rest_kernel: the launch's list of evicted keys that are ids of this batch
+  unsigned* patch_count;       // its length; patch_count_next: the next step's (two alternate)
+  unsigned* patch_count_next;
 };
 
 // ---- PLAN role: setplan_kernel<false> for 256 threads per 1024 ids -------------------------------------------------
+// (Tried and dropped, measured inside the step on the metric's configuration: 512 ids per block with half the LDS, the tiles
+// taken from the end of the batch backwards and a LOOK at the home slot before the atomics of an id that repeats in its tile
+// — every block of the role runs at the same time, nobody has installed anything yet when the others look, and twice the
+// blocks contend for the hot slots: the role went from 22 to 39 us and the step from 32 to 48.)
 constexpr unsigned SPK_IDS = 1024, SPK_LDS = 2048, SPK_PER = SPK_LDS / 256;
 struct PlanLds {
   i64 key[SPK_LDS];
@@ -65,8 +75,14 @@ struct PlanLds {
   unsigned n, base;
 };
 
+// (tuning) phase stamps of the plan role: a.tbuf + TIMING_SLOTS * TIMING_BLOCKS * 2 + (launch slot * 128 + block) * 8 + k
+__device__ __forceinline__ void plan_stamp(const StepArgs& a, unsigned blk, int k) {
+  if (a.tbuf && threadIdx.x == 0 && blk < 128)
+    a.tbuf[(size_t)64 * 4096 * 2 + ((size_t)(a.progress_val % 64u) * 128 + blk) * 8 + k] = (u64)wall_clock64();
+}
 __device__ __forceinline__ void plan_role(const StepArgs& a, unsigned blk, PlanLds& L) {
   const unsigned tid = threadIdx.x;
+  plan_stamp(a, blk, 0);
   const SetTab& cur = a.pcur;
   const SetTab& old = a.pold;
   const unsigned m2 = a.plan_m2;
@@ -82,6 +98,8 @@ __device__ __forceinline__ void plan_role(const StepArgs& a, unsigned blk, PlanL
     const unsigned g = blk * SPK_IDS + (unsigned)r * 256u + tid;
     id[r] = g < a.n_plan ? a.ids_plan[g] : 0;
   }
+  keep_live(id[0], id[1], id[2], id[3]);
+  plan_stamp(a, blk, 1);   // ids arrived
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const unsigned g = blk * SPK_IDS + (unsigned)r * 256u + tid;
@@ -99,6 +117,7 @@ __device__ __forceinline__ void plan_role(const StepArgs& a, unsigned blk, PlanL
     atomicMax(&L.pos[slot], g + 1u);
   }
   __syncthreads();
+  plan_stamp(a, blk, 2);   // LDS phase done
   // B: the block's distinct ids into the global table; the first probes of a thread's 8 slots travel together
   i64 mykey[SPK_PER], was[SPK_PER];
   unsigned myslot[SPK_PER], p1[SPK_PER], myidx[SPK_PER];
@@ -113,6 +132,7 @@ __device__ __forceinline__ void plan_role(const StepArgs& a, unsigned blk, PlanL
     mine[r] = false;
     if (p1[r]) was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
   }
+  if (a.tbuf) { keep_live(was[0], was[1], was[2], was[3]); plan_stamp(a, blk, 3); }   // first swaps back (wave 0)
 #pragma unroll
   for (int r = 0; r < (int)SPK_PER; ++r) {
     if (p1[r]) {
@@ -137,11 +157,13 @@ __device__ __forceinline__ void plan_role(const StepArgs& a, unsigned blk, PlanL
     }
   }
   __syncthreads();
+  plan_stamp(a, blk, 4);   // every swap chain of the block resolved
   if (tid == 0) L.base = L.n ? atomicAdd(cur.count, L.n) : 0u;
   // C: empty the slots the previous build used in the OTHER table
   for (unsigned i = blk * 256u + tid; i < n_old; i += a.plan_blocks * 256u)
     *reinterpret_cast<uint4*>(old.ent + old.uslot[i]) = make_uint4(0u, 0x80000000u, 0u, 0u);
   __syncthreads();
+  plan_stamp(a, blk, 5);   // list base back, other table emptied
 #pragma unroll
   for (int r = 0; r < (int)SPK_PER; ++r) {
     if (!mine[r]) continue;
@@ -179,12 +201,19 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
     b0[u] = (unsigned)__shfl((int)b0reg, j);
     b1[u] = (unsigned)__shfl((int)b1reg, j);
     idx[u] = min(base + (unsigned)j, last);
-    k0[u] = key_line(v, b0[u])[sub];
-    k1[u] = key_line(v, b1[u])[sub];
+  }
+  if (!a.serial_probe) {   // (tuning) the table's lines travel WITH the plan probe: every id pays two random lines of the table
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      k0[u] = key_line(v, b0[u])[sub];
+      k1[u] = key_line(v, b1[u])[sub];
+    }
   }
   keep_live(e.x, e.y, e.z, e.w);
-  keep_live(k0[0], k0[1], k0[2], k0[3]);
-  keep_live(k1[0], k1[1], k1[2], k1[3]);
+  if (!a.serial_probe) {
+    keep_live(k0[0], k0[1], k0[2], k0[3]);
+    keep_live(k1[0], k1[1], k1[2], k1[3]);
+  }
   // the plan probe, per key: a match in any of the four entries is the key; none and no EMPTY among them: go on (rare)
   const i64 ekey = (i64)(((u64)e.y << 32) | e.x);
   const bool match = resv ? (grp == 0 && ekey != EMPTY_KEY) : ekey == kreg;
@@ -200,11 +229,28 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
       if (k == EMPTY_KEY) break;
     }
   }
+  unsigned fwd_pos[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) fwd_pos[u] = (unsigned)__shfl((int)p1, u * 4 + grp);
+  if (a.serial_probe) {
+    // The table's lines BEHIND the plan probe, and only for the ids the plan does not hold: on a Zipf stream most positions of a
+    // batch repeat ids of the batch before (85 % on the metric's configuration), and every line of a 273-GB table is a random,
+    // TLB-missing access — the launch is bound by how many of those the memory system takes, not by wave slots.  The loads stay
+    // unconditional (one wait for all of them): a forwarded id reads one hot line of the plan instead.
+    const i64* hot = reinterpret_cast<const i64*>(a.fwd.ent);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      k0[u] = (fwd_pos[u] ? hot : key_line(v, b0[u]))[sub];
+      k1[u] = (fwd_pos[u] ? hot : key_line(v, b1[u]))[sub];
+    }
+    keep_live(k0[0], k0[1], k0[2], k0[3]);
+    keep_live(k1[0], k1[1], k1[2], k1[3]);
+  }
   const unsigned char* src[U];
   unsigned char* dst[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const unsigned fw = (unsigned)__shfl((int)p1, u * 4 + grp);
+    const unsigned fw = fwd_pos[u];
     i64 word = 0;
     if (!fw) word = probe_find_word(v, key[u], b0[u], b1[u], k0[u], sub, gshift, &k1[u]);
     if (a.exists && sub == 0) a.exists[idx[u]] = fw != 0 || word >= 0;
@@ -244,18 +290,19 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk) {
   if (lane == 0 && fresh) size_add(o.v, wave, fresh);
 }
 
-// TIMING (tuning builds only): every block notes its start and end on the device clock; per launch and role the earliest start
-// and the latest end are kept in a.stat (64-bit words behind the three counters): when does each role of a launch run?
+// TIMING (tuning builds only): every block notes its start and end on the device clock in a.tbuf (a slot per launch and block):
+// when does each role of a launch run?
+constexpr unsigned TIMING_BLOCKS = 4096, TIMING_SLOTS = 64;
 __device__ __forceinline__ void role_stamp(const StepArgs& a, int role, u64 t0) {
   __syncthreads();
-  if (threadIdx.x == 0) {
-    u64* w = reinterpret_cast<u64*>(a.stat + 16) + ((size_t)(a.progress_val & 63u) * 3 + role) * 2;
-    atomicMin(w, t0);
-    atomicMax(w + 1, (u64)wall_clock64());
+  if (threadIdx.x == 0 && a.tbuf && blockIdx.x < TIMING_BLOCKS) {
+    u64* w = a.tbuf + ((size_t)(a.progress_val % TIMING_SLOTS) * TIMING_BLOCKS + blockIdx.x) * 2;
+    w[0] = t0;
+    w[1] = (u64)wall_clock64();
   }
 }
-template <bool SIMPLE, int U, bool PLAN, int MINW, bool TIMING = false>
-__global__ __launch_bounds__(256, MINW) void step_kernel(const StepArgs a) {
+template <bool SIMPLE, int U, bool PLAN, bool TIMING>
+__device__ __forceinline__ void step_body(const StepArgs& a) {
   unsigned b = blockIdx.x;
   const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
   if constexpr (PLAN) {
@@ -263,35 +310,64 @@ __global__ __launch_bounds__(256, MINW) void step_kernel(const StepArgs a) {
     if (b < a.plan_blocks) { plan_role(a, b, L); if (TIMING) role_stamp(a, 0, t0); return; }
     b -= a.plan_blocks;
   }
+  // The write-back's O blocks are spread evenly among the lookup's F blocks (own block j at position floor(j (O + F) / O)):
+  // blocks are dispatched in index order, and a role whose blocks all come first fills every wave slot of the chip while
+  // the role behind it waits for them to retire — the roles then run one after the other, not side by side.
+  if (a.interleave) {
+    const unsigned O = a.own_blocks, T = O + a.find_blocks;
+    const unsigned c = O ? (unsigned)(((u64)b * O + T - 1) / T) : 0u;          // own blocks in front of position b
+    const bool is_own = c < O && (unsigned)(((u64)c * T) / O) == b;
+    if (is_own) { own_role<SIMPLE, U>(a, c); if (TIMING) role_stamp(a, 1, t0); return; }
+    find_fwd_role(a, b - c);
+    if (TIMING) role_stamp(a, 2, t0);
+    return;
+  }
   if (b < a.own_blocks) { own_role<SIMPLE, U>(a, b); if (TIMING) role_stamp(a, 1, t0); return; }
   find_fwd_role(a, b - a.own_blocks);
   if (TIMING) role_stamp(a, 2, t0);
 }
+// Instantiations (the SGPR budget is an attribute, not a template argument): 256-thread blocks are admitted per CU up to
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) — 106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
+#define TFRA_STEP_KERNEL(NAME, UU, PLAN, TIMING, NSGPR)                                                                  \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(NSGPR))) void NAME(const StepArgs a) { step_body<true, UU, PLAN, TIMING>(a); }
+TFRA_STEP_KERNEL(step_k_u2, 2, true, false, 104)
+TFRA_STEP_KERNEL(step_k_u1, 1, true, false, 104)
+TFRA_STEP_KERNEL(step_k_u4, 4, true, false, 104)
+TFRA_STEP_KERNEL(step_k_u1_s96, 1, true, false, 96)
+TFRA_STEP_KERNEL(step_k_u1_s80, 1, true, false, 80)
+TFRA_STEP_KERNEL(step_k_u2_t, 2, true, true, 104)
+TFRA_STEP_KERNEL(step_k_u1_t, 1, true, true, 104)
+TFRA_STEP_KERNEL(step_k_u1_s80_t, 1, true, true, 80)
+TFRA_STEP_KERNEL(step_k_u2_np, 2, false, false, 104)
+TFRA_STEP_KERNEL(step_k_u1_np, 1, false, false, 104)
+TFRA_STEP_KERNEL(step_k_u1_s80_np, 1, false, false, 80)
+#undef TFRA_STEP_KERNEL
 
 // ---- the remainder of a step: left-over keys of the pass + corrections of the lookup's output ------------------------
 // upsert_rest_kernel<16, SRC_SET> over the pass's item list (the flags of all keys when the list overflowed).  Runs AFTER the
 // launch that held the lookup, so an eviction here may hit a key that lookup has just returned a row for: every victim that is
-// one of this batch's ids (plan `nxt`) is noted by the block.  When a block has noted any, it waits until EVERY block of the
-// launch has finished its items (one arrival counter; blocks without such victims only arrive and leave — the grid is at most
-// 512 blocks, all resident), looks the victims up again and, for those that are absent now, rewrites the lookup's output
-// rows with the default row and clears their exists flags: what a lookup behind the write-back returns.  (A victim that is
-// present again was a key of the previous batch whose own left-over write came later in this kernel.)
-constexpr unsigned PATCH_CAP = 64;
+// one of this batch's ids (plan `nxt`) goes onto a list of the launch.  When every block has finished its items (one arrival
+// counter: the grid is at most 512 blocks, all resident, and every block arrives without waiting for anything) and the list is
+// not empty, ALL blocks look the listed victims up again and, for those that are absent now, rewrite the lookup's output rows
+// with the default row and clear their exists flags — what a lookup behind the write-back returns — each block for its share
+// of the batch's positions.  (A victim that is present again was a key of the previous batch whose own left-over write came
+// later in this kernel.)  The first form let the one block that had noted a victim scan the whole batch: 170 us for 131 072 ids,
+// and right after a bulk load in rank order the hottest ids are the least recently used entries: one step in eight paid it.
+constexpr unsigned PATCH_CAP = 64, PATCH_GCAP = 4096;
 __global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsigned* zero4) {
   __shared__ i64 s_patch[PATCH_CAP];
-  __shared__ unsigned s_np;
   __shared__ unsigned char s_absent[PATCH_CAP];
+  __shared__ unsigned s_nv;
   const OwnArgs& o = a.own;
   const unsigned* slow_ctr = &a.ctr->n_a;
   unsigned* arrived = &a.ctr->spare[0];
   const unsigned gi = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (threadIdx.x == 0) s_np = 0;
   const OwnItem* it0 = o.items + (gi < o.item_cap ? gi : 0u);
   const uint4 f0 = reinterpret_cast<const uint4*>(it0)[0], f1 = reinterpret_cast<const uint4*>(it0)[1];
   const unsigned counted = *slow_ctr;
   if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
-  if (counted == 0) return;
-  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.patch_count_next = 0;            // (the next step's list: its last reader is long gone)
+  if (counted == 0) return;                                                    // no items, no evictions, nothing to correct
   const bool listed = counted <= o.item_cap;
   const unsigned n = listed ? counted : o.ks.d_counts[0] + o.ks.d_counts[1];
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
@@ -316,10 +392,10 @@ __global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsign
     }
     if (vk != EMPTY_KEY && vk != LOCKED_KEY && a.n && set_contains_group(a.nxt, vk, sub, gshift)) {
       if (sub == 0) {
-        const unsigned at = atomicAdd(&s_np, 1u);
+        const unsigned at = atomicAdd(a.patch_count, 1u);
         atomicAdd(a.stat + 1, 1u);
-        if (at < PATCH_CAP) s_patch[at] = vk;
-        else atomicAdd(o.v.err_count, 1u);   // (64 such victims in one block's share: reported by check_errors, never silent)
+        if (at < PATCH_GCAP) __hip_atomic_store(a.patch_keys + at, vk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicAdd(o.v.err_count, 1u);   // (thousands of such victims in one step: reported by check_errors, never silent)
       }
     }
   }
@@ -328,37 +404,42 @@ __global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsign
     if (fresh) size_add(o.v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
     if (failed) atomicAdd(o.v.err_count, (unsigned)failed);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's table stores (write-through / agent-scope) are acknowledged
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's table stores and list entries (write-through / agent-scope) are acknowledged
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned np = min(s_np, PATCH_CAP);
-  if (np == 0) return;
   if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool ok = false;
     for (unsigned it = 0; it < (1u << 22) && !ok; ++it) {
       ok = __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x;
-      if (!ok) __builtin_amdgcn_s_sleep(16);
+      if (!ok) __builtin_amdgcn_s_sleep(8);
     }
     if (!ok) atomicAdd(o.v.err_count, 1u);   // (never seen: every block arrives without waiting for anything)
+    s_nv = min(__hip_atomic_load(a.patch_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), PATCH_GCAP);
   }
   __syncthreads();
-  // which of the noted victims are absent now?  (16 groups, one victim each per round; coherent loads)
-  for (unsigned q = threadIdx.x >> 4; q < np; q += 16) {
-    const i64 row = probe_find<true>(o.v, s_patch[q], sub, gshift);
-    if (sub == 0) s_absent[q] = row < 0 ? 1 : 0;
-  }
-  __syncthreads();
-  // those, against every id of the batch (rare: a scan of the ids by one block)
-  for (unsigned p = threadIdx.x; p < a.n; p += blockDim.x) {
-    const i64 id = a.ids[p];
-    bool hit = false;
-    for (unsigned q = 0; q < np; ++q) hit = hit || (s_absent[q] && s_patch[q] == id);
-    if (!hit) continue;
-    const unsigned char* d = a.defaults + (a.full ? (u64)p * (u64)o.v.field_bytes : 0);
-    unsigned char* w = a.out + (u64)p * (u64)o.v.field_bytes;
-    for (unsigned off = 0; off < o.v.field_bytes; off += 16) *reinterpret_cast<uint4*>(w + off) = *reinterpret_cast<const uint4*>(d + off);
-    if (a.exists) a.exists[p] = 0;
-    atomicAdd(a.stat + 2, 1u);
+  const unsigned nv = s_nv;
+  for (unsigned base = 0; base < nv; base += PATCH_CAP) {
+    const unsigned np = min(PATCH_CAP, nv - base);
+    // which of these victims are absent now?  (16 groups, one victim each per round; coherent loads)
+    for (unsigned q = threadIdx.x >> 4; q < np; q += 16) {
+      const i64 vk = __hip_atomic_load(a.patch_keys + base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const i64 row = probe_find<true>(o.v, vk, sub, gshift);
+      if (sub == 0) { s_patch[q] = vk; s_absent[q] = row < 0 ? 1 : 0; }
+    }
+    __syncthreads();
+    // those, against this block's share of the batch
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += gridDim.x * blockDim.x) {
+      const i64 id = a.ids[p];
+      bool hit = false;
+      for (unsigned q = 0; q < np; ++q) hit = hit || (s_absent[q] && s_patch[q] == id);
+      if (!hit) continue;
+      const unsigned char* d = a.defaults + (a.full ? (u64)p * (u64)o.v.field_bytes : 0);
+      unsigned char* w = a.out + (u64)p * (u64)o.v.field_bytes;
+      for (unsigned off = 0; off < o.v.field_bytes; off += 16) *reinterpret_cast<uint4*>(w + off) = *reinterpret_cast<const uint4*>(d + off);
+      if (a.exists) a.exists[p] = 0;
+      atomicAdd(a.stat + 2, 1u);
+    }
+    __syncthreads();
   }
 }
 
@@ -380,10 +461,16 @@ struct tfra_step_driver {
   SetEnt* dummy = nullptr;                 // an empty table (4 entries + the sentinel slots + padding): "no previous batch"
   unsigned* progress = nullptr;            // pinned: [0] step, [1] distinct keys the last started write-back saw
   unsigned* stat = nullptr;                // device: StepArgs::stat
+  u64* tbuf = nullptr;                     // device: StepArgs::tbuf (TFRA_STEP_VARIANT & 16)
+  unsigned last_rest_step = ~0u;           // step number of the last step_rest_kernel launch (it zeroes the next step's victim counter)
+  unsigned char* patch = nullptr;          // device: two counters (one 128-B line each) + two lists of PATCH_GCAP keys (step_rest_kernel)
+  unsigned tinfo[64][3] = {};              // per launch slot: plan blocks, own blocks, grid
   unsigned step_no = 0;
   int variant = 0;                         // TFRA_STEP_VARIANT (tuning): kernel instantiation
   unsigned long long n_overlapped = 0, n_sequential = 0;   // steps taken each way (tfra_step_driver_stats)
   unsigned why_sequential = 0;             // why the last step that was not overlapped was not (bit mask, see step_overlap_one)
+  std::vector<hipEvent_t> kev;             // tfra_step_driver_time_kernels: 3 events per timed step (before / between / behind its two launches)
+  size_t kev_left = 0, kev_used = 0;
 };
 
 extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** out) {
@@ -399,13 +486,17 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   const size_t dn = 4 + 2 + SET_PAD;
   if (hipMalloc((void**)&d->dummy, dn * sizeof(SetEnt)) != hipSuccess) { d->dummy = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   fill_setent_kernel<<<1, 64, 0, nullptr>>>(d->dummy, dn);
-  if (hipMalloc((void**)&d->stat, 64 + 64 * 3 * 16) != hipSuccess || hipMemset(d->stat, 0, 64 + 64 * 3 * 16) != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
+  if (hipMalloc((void**)&d->patch, 256 + 2 * PATCH_GCAP * 8) != hipSuccess || hipMemset(d->patch, 0, 256 + 2 * PATCH_GCAP * 8) != hipSuccess) { d->patch = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
+  if (hipMalloc((void**)&d->stat, 64) != hipSuccess || hipMemset(d->stat, 0, 64) != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   if (hipHostMalloc((void**)&d->progress, 64, hipHostMallocDefault) != hipSuccess) { d->progress = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipHostMalloc"); }
   d->progress[0] = d->progress[1] = 0;
   if (hipDeviceSynchronize() != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_HIP, "step_driver_create: sync"); }
   const char* ev = std::getenv("TFRA_STEP_VARIANT");
   d->variant = ev ? std::atoi(ev) : 0;
-  if (d->variant & 16) (void)tfra_step_driver_timing(d, nullptr);
+  if (d->variant & 16) {
+    const size_t bytes = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 16 + (size_t)64 * 128 * 8 * 8;
+    if (hipMalloc((void**)&d->tbuf, bytes) != hipSuccess || hipMemset(d->tbuf, 0, bytes) != hipSuccess) { d->tbuf = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
+  }
   *out = d;
   return TFRA_OK;
 }
@@ -417,6 +508,9 @@ extern "C" int tfra_step_driver_destroy(tfra_step_driver_t* d) {
   for (unsigned i = 0; i < tfra_step_driver::NPL; ++i) if (d->plans[i]) tfra_sparse_plan_destroy(d->plans[i]);
   if (d->dummy) (void)hipFree(d->dummy);
   if (d->stat) (void)hipFree(d->stat);
+  if (d->tbuf) (void)hipFree(d->tbuf);
+  if (d->patch) (void)hipFree(d->patch);
+  for (hipEvent_t e : d->kev) (void)hipEventDestroy(e);
   if (d->progress) (void)hipHostFree(d->progress);
   delete d;
   return TFRA_OK;
@@ -437,33 +531,109 @@ extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* ove
   return TFRA_OK;
 }
 
-// tuning: the role time stamps of the last <= 64 launches made with TFRA_STEP_VARIANT & 16 — out[64][3][2] = {earliest block
-// start, latest block end} on the device clock (100 MHz) per launch slot (step % 64) and role (plan, write-back, lookup);
-// synchronises the device and re-arms the stamps.
+// tuning: the block time stamps of the last <= 64 launches made with TFRA_STEP_VARIANT & 16, reduced per role —
+// out[64][3][2] = {earliest block start, latest block end} on the device clock (100 MHz) per launch slot (step % 64) and role
+// (plan, write-back, lookup), ~0 / 0 where nothing ran; synchronises the device and re-arms the stamps.
 extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_timing: null driver");
+  if (!d->tbuf) return set_error(TFRA_ERR_INVALID, "step_driver_timing: the driver was not created with TFRA_STEP_VARIANT & 16");
   (void)hipSetDevice(d->t->device);
-  std::vector<uint64_t> init(64 * 3 * 2);
-  for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ULL; init[i + 1] = 0; }
-  if (hipDeviceSynchronize() != hipSuccess || (out && hipMemcpy(out, d->stat + 16, init.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) ||
-      hipMemcpy(d->stat + 16, init.data(), init.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+  const size_t words = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 2;
+  std::vector<uint64_t> h(words);
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), d->tbuf, words * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(d->tbuf, 0, words * 8) != hipSuccess)
     return set_error(TFRA_ERR_HIP, "step_driver_timing: copy");
+  {   // plan phase stamps: median over launches and blocks of (stamp k - stamp 0), in ticks, behind the role spans
+    std::vector<uint64_t> ph((size_t)64 * 128 * 8);
+    const size_t off = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 2;
+    if (hipMemcpy(ph.data(), d->tbuf + off, ph.size() * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(d->tbuf + off, 0, ph.size() * 8) != hipSuccess)
+      return set_error(TFRA_ERR_HIP, "step_driver_timing: copy");
+    if (out) {
+      for (int k = 1; k <= 5; ++k) {
+        std::vector<uint64_t> dlt;
+        for (size_t i = 0; i < (size_t)64 * 128; ++i) if (ph[i * 8] && ph[i * 8 + k]) dlt.push_back(ph[i * 8 + k] - ph[i * 8]);
+        std::sort(dlt.begin(), dlt.end());
+        out[64 * 3 * 2 + (k - 1)] = dlt.empty() ? 0 : dlt[dlt.size() / 2];
+      }
+    }
+  }
+  if (!out) return TFRA_OK;
+  for (unsigned sl = 0; sl < TIMING_SLOTS; ++sl) {
+    const unsigned pb = d->tinfo[sl][0], ob = d->tinfo[sl][1], grid = std::min(d->tinfo[sl][2], TIMING_BLOCKS);
+    for (int r = 0; r < 3; ++r) { out[(sl * 3 + r) * 2] = ~0ULL; out[(sl * 3 + r) * 2 + 1] = 0; }
+    for (unsigned b = 0; b < grid; ++b) {
+      const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
+      if (!t1) continue;
+      int r = b < pb ? 0 : (b < pb + ob ? 1 : 2);
+      if (b >= pb && !(d->variant & 32)) {   // own blocks spread among the lookup's (step_body)
+        const unsigned bb = b - pb, O = ob, T = d->tinfo[sl][2] - pb;
+        const unsigned c = O ? (unsigned)(((uint64_t)bb * O + T - 1) / T) : 0u;
+        r = (c < O && (unsigned)(((uint64_t)c * T) / O) == bb) ? 1 : 2;
+      }
+      out[(sl * 3 + r) * 2] = std::min(out[(sl * 3 + r) * 2], t0);
+      out[(sl * 3 + r) * 2 + 1] = std::max(out[(sl * 3 + r) * 2 + 1], t1);
+    }
+    d->tinfo[sl][2] = 0;
+  }
+  return TFRA_OK;
+}
+
+// Measurement: HIP events around the two launches of the next `steps` overlapped steps (on the stream they are launched on);
+// tfra_step_driver_kernel_times then waits for them and returns the average duration of each launch in microseconds.
+extern "C" int tfra_step_driver_time_kernels(tfra_step_driver_t* d, size_t steps) {
+  if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_time_kernels: null driver");
+  (void)hipSetDevice(d->t->device);
+  while (d->kev.size() < steps * 3) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_driver_time_kernels: event");
+    d->kev.push_back(e);
+  }
+  d->kev_left = steps; d->kev_used = 0;
+  return TFRA_OK;
+}
+extern "C" int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step_kernel_us, double* rest_kernel_us, size_t* steps) {
+  if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_kernel_times: null driver");
+  double a = 0, b = 0;
+  for (size_t i = 0; i < d->kev_used; ++i) {
+    float x = 0, y = 0;
+    if (hipEventSynchronize(d->kev[i * 3 + 2]) != hipSuccess || hipEventElapsedTime(&x, d->kev[i * 3], d->kev[i * 3 + 1]) != hipSuccess ||
+        hipEventElapsedTime(&y, d->kev[i * 3 + 1], d->kev[i * 3 + 2]) != hipSuccess)
+      return set_error(TFRA_ERR_HIP, "step_driver_kernel_times: event");
+    a += x; b += y;
+  }
+  const double nn = d->kev_used ? (double)d->kev_used : 1.0;
+  if (step_kernel_us) *step_kernel_us = a / nn * 1e3;
+  if (rest_kernel_us) *rest_kernel_us = b / nn * 1e3;
+  if (steps) *steps = d->kev_used;
+  d->kev_left = 0; d->kev_used = 0;
   return TFRA_OK;
 }
 
 static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_tab[pl->set_parity].ent, pl->set_m2}; }
 
-template <bool PLAN>
-static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {
-  if (variant & 16) { step_kernel<true, 2, PLAN, 1, true><<<grid, 256, 0, s>>>(a); return; }
-  switch (variant & 7) {
-    case 1: step_kernel<true, 1, PLAN, 1><<<grid, 256, 0, s>>>(a); break;
-    case 2: step_kernel<true, 2, PLAN, 6><<<grid, 256, 0, s>>>(a); break;
-    case 4: step_kernel<true, 4, PLAN, 1><<<grid, 256, 0, s>>>(a); break;
-    default: step_kernel<true, 2, PLAN, 1><<<grid, 256, 0, s>>>(a); break;
+// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0 U=2 | 1 U=1 | 3 U=1, 80 SGPRs | 4 U=4 | 5 U=1, 96 SGPRs),
+// 8 the plan as a launch of its own, 16 time stamps
+static void launch_step(int variant, bool plan, unsigned grid, hipStream_t s, const StepArgs& a) {
+  const int k = variant & 7;
+  if (!plan) {
+    if (k == 1 || k == 5) step_k_u1_np<<<grid, 256, 0, s>>>(a);
+    else if (k == 3) step_k_u1_s80_np<<<grid, 256, 0, s>>>(a);
+    else step_k_u2_np<<<grid, 256, 0, s>>>(a);
+  } else if (variant & 16) {
+    if (k == 1 || k == 5) step_k_u1_t<<<grid, 256, 0, s>>>(a);
+    else if (k == 3) step_k_u1_s80_t<<<grid, 256, 0, s>>>(a);
+    else step_k_u2_t<<<grid, 256, 0, s>>>(a);
+  } else {
+    switch (k) {
+      case 1: step_k_u1<<<grid, 256, 0, s>>>(a); break;
+      case 3: step_k_u1_s80<<<grid, 256, 0, s>>>(a); break;
+      case 4: step_k_u4<<<grid, 256, 0, s>>>(a); break;
+      case 5: step_k_u1_s96<<<grid, 256, 0, s>>>(a); break;
+      default: step_k_u2<<<grid, 256, 0, s>>>(a); break;
+    }
   }
 }
-static int own_keys_per_block(int variant) { const int v = variant & 7; return v == 1 ? 16 : (v == 4 ? 64 : 32); }
+static int own_keys_per_block(int variant) { const int v = variant & 7; return (v == 1 || v == 3 || v == 5) ? 16 : (v == 4 ? 64 : 32); }
 
 // One step.  Caller holds d->t->step_mu.
 static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists_out, const void* defaults,
@@ -526,7 +696,9 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.own_blocks = 0;
       a.fwd = SetProbe{d->dummy, 4};
     }
-    a.progress = d->progress; a.progress_val = step; a.stat = d->stat;
+    a.progress = d->progress; a.progress_val = step; a.stat = d->stat; a.tbuf = d->tbuf;
+    a.patch_count = reinterpret_cast<unsigned*>(d->patch + 128 * (step & 1u)); a.patch_count_next = reinterpret_cast<unsigned*>(d->patch + 128 * ((step & 1u) ^ 1u));
+    a.patch_keys = reinterpret_cast<i64*>(d->patch + 256) + (size_t)PATCH_GCAP * (step & 1u);
     a.nxt = probe_of(plan_cur);
     a.n = (unsigned)n; a.ids = (const i64*)ids; a.out = (unsigned char*)rows_out; a.exists = exists_out;
     a.defaults = (const unsigned char*)defaults; a.full = default_is_full;
@@ -537,16 +709,23 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
         rc = setplan_prepare(plan_next, n_next, s, false, &P);
         if (rc) return rc;
         a.n_plan = (unsigned)n_next; a.ids_plan = (const i64*)ids_next; a.pcur = P.cur; a.pold = P.old; a.next_use_count = P.next_use_count;
-        a.plan_m2 = P.m2; a.plan_blocks = P.blocks;
+        a.plan_m2 = P.m2; a.plan_blocks = (unsigned)((n_next + SPK_IDS - 1) / SPK_IDS);   // (= P.blocks: 1024 ids per block)
       } else {
         rc = setplan_build(plan_next, n_next, ids_next, s, false);   // (tuning variant: the plan as a launch of its own, in front)
         if (rc) return rc;
       }
     }
     const unsigned find_blocks = (unsigned)((n + 63) / 64);
-    if (fused_plan) launch_step<true>(d->variant, a.plan_blocks + a.own_blocks + find_blocks, s, a);
-    else launch_step<false>(d->variant, a.own_blocks + find_blocks, s, a);
-    if (plan_prev) step_rest_kernel<<<std::min(L.rem_blocks, 512u), 256, 0, s>>>(a, reinterpret_cast<unsigned*>(L.next_ctr));   // (<= 512 blocks: all resident, see its arrival counter)
+    a.find_blocks = find_blocks; a.interleave = (d->variant & 32) ? 0 : 1; a.serial_probe = (d->variant & 64) ? 0 : 1;
+    if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = fused_plan ? a.plan_blocks : 0; ti[1] = a.own_blocks; ti[2] = ti[0] + ti[1] + find_blocks; }
+    const bool timed = d->kev_left > 0 && plan_prev;
+    if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3], s);
+    launch_step(d->variant, fused_plan, (fused_plan ? a.plan_blocks : 0u) + a.own_blocks + find_blocks, s, a);
+    if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s);
+    if (plan_prev && d->last_rest_step + 1 != step && hipMemsetAsync(a.patch_count, 0, 4, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: memset");
+    if (plan_prev) d->last_rest_step = step;
+    if (plan_prev) step_rest_kernel<<<std::max(std::min(L.rem_blocks, 512u), 128u), 256, 0, s>>>(a, reinterpret_cast<unsigned*>(L.next_ctr));   // (128 .. 512 blocks: all resident, see its arrival counter; the corrections take the whole grid)
+    if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
     if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: launch failed");
     if (plan_prev) step_epoch_public(t);
     d->n_overlapped += 1;

@@ -754,10 +754,20 @@ class OverlapAssignStep:
     return {"overlapped": a.value, "sequential": b.value, "pending": bool(c.value), "deferred_evictions": dc[0],
             "victims_noted": dc[1], "rows_corrected": dc[2], "why_sequential": why.value}
 
+  def time_kernels(self, steps):
+    """HIP events around the two launches of the next `steps` overlapped steps (on their stream); read with kernel_times()."""
+    _capi.call("tfra_step_driver_time_kernels", self._h, int(steps))
+
+  def kernel_times(self):
+    a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_size_t()
+    _capi.call("tfra_step_driver_kernel_times", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n))
+    return {"step_kernel_us": a.value, "rest_kernel_us": b.value, "steps": n.value}
+
   def timing(self):
     """tuning (TFRA_STEP_VARIANT & 16): [(plan, write-back, lookup) spans in us relative to the launch's first block] per launch"""
-    buf = (ctypes.c_uint64 * (64 * 3 * 2))()
+    buf = (ctypes.c_uint64 * (64 * 3 * 2 + 8))()
     _capi.call("tfra_step_driver_timing", self._h, buf)
+    self.plan_phases_us = {n: buf[64 * 3 * 2 + i] / 100.0 for i, n in enumerate(("ids_arrived", "lds_done", "first_swaps_back", "swap_chains_done", "count_back_and_cleared"))}
     out = []
     for k in range(64):
       w = [buf[(k * 3 + r) * 2 + j] for r in range(3) for j in range(2)]
