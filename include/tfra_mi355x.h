@@ -331,8 +331,12 @@ int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n
  *     rows_out[n, dim] / exists_out[n] (optional) = Find(ids) with the default fill of tfra_table_find;
  *     values_prev [n_prev, dim] = the rows to assign to the ids of the PREVIOUS call (NULL on the first call / after a
  *       flush); they must stay unchanged until this call's work has run;
- *     ids_next / n_next (optional) = the ids of the NEXT call, known one step ahead (an input pipeline): their
- *       de-duplication plan is built inside this call's launch; without them the next call builds it in front of its step.
+ *     ids_next / n_next and ids_next2 / n_next2 (optional) = the ids of the next call and of the one after it, as an input
+ *       pipeline knows them: the de-duplication plan of a batch is built over TWO launches without atomics (its distinct ids
+ *       are scattered into per-window segments by the launch two calls ahead, its table is built by the launch one call ahead).
+ *       With ids_next only, the plan of the next batch is built by a launch of its own in front of the step (round 3's plan
+ *       kernel); with neither, by the next call in front of ITS step.  ids must stay valid until their batch has been written
+ *       back (the call after the one that looked them up).
  *   tfra_table_step_overlap_flush(d, values_prev, scores_prev, stream) writes the last batch back: call it before the table
  *     is used through any other entry point.
  * Tables or calls the overlap does not cover (not a bounded LRU table at capacity, caller scores, optimizer slots, rows
@@ -342,7 +346,7 @@ int tfra_step_driver_create(tfra_table_t* t, tfra_step_driver_t** out);
 int tfra_step_driver_destroy(tfra_step_driver_t* d);
 int tfra_table_step_overlap(tfra_step_driver_t* d, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists_out,
                             const void* defaults, int default_is_full, const void* values_prev, const uint64_t* scores_prev,
-                            size_t n_next, const int64_t* ids_next, tfra_stream_t stream);
+                            size_t n_next, const int64_t* ids_next, size_t n_next2, const int64_t* ids_next2, tfra_stream_t stream);
 int tfra_table_step_overlap_flush(tfra_step_driver_t* d, const void* values_prev, const uint64_t* scores_prev, tfra_stream_t stream);
 /* `count` consecutive steps from ONE host call (the arguments of tfra_table_step_overlap per step). */
 typedef struct {
@@ -357,6 +361,8 @@ typedef struct {
   const uint64_t* scores_prev;
   size_t n_next;
   const int64_t* ids_next;
+  size_t n_next2;
+  const int64_t* ids_next2;
 } tfra_overlap_step;
 int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_overlap_step* steps, tfra_stream_t stream);
 /* measurement: HIP events around the two launches of the next `steps` overlapped steps; _kernel_times waits for them and
@@ -369,7 +375,9 @@ int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out);
  * synchronises the device) = {evictions the pass deferred because the next lookup wanted the victim, victims the remainder
  * pass noted, output rows it rewrote with the default row} */
 int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending,
-                           uint32_t* device_counts, uint32_t* why_sequential);
+                           uint32_t* device_counts, uint32_t* why_sequential, uint64_t* plans_built);
+/* plans_built[2] (optional): plans of a next batch built inside the step launch (from pairs scattered one launch earlier: ids
+ * known TWO batches ahead) / built by a launch of their own in front of the step (ids known one batch ahead only, or not at all) */
 /* why_sequential (optional): why the last step that ran one op after the other did — 1 empty batch, 2 a buffer or the row
  * size is not a multiple of 16 bytes, 4 no owner tags, 8 optimizer slots / not LRU / caller scores, 16 the table can still
  * grow, 32 the table is not yet known to be dense (> 60 % of its slots, learned from asynchronous size reads), 64 the

@@ -638,6 +638,13 @@ struct CsrKeys {
 struct SetEnt { i64 key; unsigned pos1, cnt; };   // key (EMPTY_KEY = free) | last position + 1 | occurrences
 __device__ __forceinline__ uint2 set_pc(const SetEnt* e) { return *reinterpret_cast<const uint2*>(&e->pos1); }
 // A SET plan's table as something to PROBE (read-only): is this key one of the batch's ids, and where is its last occurrence?
+// Probe chains stay inside a WINDOW of SET_WIN consecutive slots (home slot = hash & (m2 - 1); the slot behind the window's last
+// is its first): the overlapped step builds a plan one window per workgroup, in LDS, without atomics (tfra_step_impl.h), and
+// every other builder and every prober follows the same rule.  (m2 >= 2 n slots for n ids: a window overflows never.)
+constexpr unsigned SET_WIN = 2048, SET_WIN_LOG2 = 11;
+constexpr unsigned SEG_CAP = 32;   // pairs per (window, tile) segment of a scatter (tfra_step_impl.h); more: the overflow list
+__host__ __device__ __forceinline__ unsigned set_wmask(unsigned m2) { return (m2 < SET_WIN ? m2 : SET_WIN) - 1u; }
+__device__ __forceinline__ unsigned set_at(unsigned slot, unsigned g, unsigned wm) { return (slot & ~wm) | ((slot + g) & wm); }   // g slots on, inside the window
 struct SetProbe { const SetEnt* ent; unsigned m2; };   // m2 entries (a power of two) + the two sentinel slots + padding
 __device__ __forceinline__ unsigned set_home(const SetProbe& p, i64 key, u64 h) {   // h = fmix64(key)
   return is_reserved_key(key) ? p.m2 + (unsigned)reserved_index(key) : (unsigned)(h >> 20) & (p.m2 - 1);
@@ -647,15 +654,16 @@ __device__ __forceinline__ unsigned set_home(const SetProbe& p, i64 key, u64 h) 
 __device__ __forceinline__ bool set_contains_group(const SetProbe& p, i64 key, int sub, int gshift) {
   const bool resv = is_reserved_key(key);
   unsigned slot = set_home(p, key, fmix64((u64)key));
-  for (int round = 0; round < 4096; ++round) {
-    const unsigned e = resv ? slot + (unsigned)(sub & 3) : (slot + (unsigned)(sub & 3)) & (p.m2 - 1);
+  const unsigned wm = set_wmask(p.m2);
+  for (int round = 0; round < 512; ++round) {
+    const unsigned e = resv ? slot + (unsigned)(sub & 3) : set_at(slot, (unsigned)(sub & 3), wm);
     const i64 k = p.ent[e].key;
     const bool match = resv ? ((sub & 3) == 0 && k != EMPTY_KEY) : k == key;
     const unsigned mm = (unsigned)(__ballot(match && sub < 4) >> gshift) & 0xfu;
     const unsigned em = (unsigned)(__ballot(k == EMPTY_KEY && sub < 4) >> gshift) & 0xfu;
     if (mm) return true;
     if (em || resv) return false;
-    slot += 4;
+    slot = set_at(slot, 4u, wm);
   }
   return true;   // (a chain this long does not exist: 2 n slots for n ids; say "present", the conservative answer)
 }
@@ -1035,7 +1043,7 @@ struct OwnCtrs { unsigned n_a, spare[3]; };
 //   SRC_DIRECT  a caller's array of UNIQUE keys, value row i belongs to key i (tfra_table_insert_or_assign with
 //               TFRA_FLAG_UNIQUE_KEYS: the reference's Insert op, hkv_hashtable_op_gpu.cu.cc:253-290)
 //   SRC_SET     the distinct keys of a SET plan (assign-only: last position and count per key, no positions list)
-enum { SRC_PLAN = 0, SRC_DIRECT = 1, SRC_SET = 2 };
+enum { SRC_PLAN = 0, SRC_DIRECT = 1, SRC_SET = 2, SRC_GIVEN = 3 };   // SRC_GIVEN: the caller hands key and value position (the overlapped step: from LDS)
 
 struct OwnArgs {
   TableView v;
@@ -1196,7 +1204,8 @@ __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
 // them is a valid serial order).
 template <int G, bool SIMPLE, int SRC, int U, bool CF = false, bool ACC = false>
 __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
-                                            int lane, int& fresh, const SetProbe* cf = nullptr, unsigned* cf_stat = nullptr) {
+                                            int lane, int& fresh, const SetProbe* cf = nullptr, unsigned* cf_stat = nullptr,
+                                            i64 kgiven = 0, unsigned lastgiven = 0) {
   const u64* const scores = SIMPLE ? nullptr : a.scores;
   const TableView& v = a.v;
   const CsrKeys& ks = a.ks;
@@ -1208,6 +1217,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   u64 insreg = 1;
   if (SRC == SRC_PLAN) { kreg = ks.dkeys[gj]; kmreg = ks.keymap[gj]; }
   else if (SRC == SRC_SET) { kreg = ks.ukeys[gj]; kmreg = ks.uslot[gj]; }
+  else if (SRC == SRC_GIVEN) { kreg = kgiven; lastreg = lastgiven; }
   else kreg = a.keys[gj];
   const unsigned exreg = ACC ? (unsigned)a.exists[gj] : 0u;
   u64 hreg;
@@ -1251,7 +1261,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
     lastreg = pc.x - 1;
     const u64 in_one = scores ? scores[lastreg] : 1;
     insreg = a.sp.strategy == TFRA_EVICT_LFU ? (scores ? in_one : (u64)pc.y) : in_one;
-  } else {
+  } else if (SRC != SRC_GIVEN) {
     insreg = scores ? scores[lastreg] : 1;
   }
   // the claims, behind the loads in program order (a clamped duplicate must not claim: it would lock out the real key)
@@ -1544,7 +1554,7 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
       for (;;) {
         if (was[r] == EMPTY_KEY) { mine[r] = true; break; }
         if (was[r] == mykey[r]) break;
-        myslot[r] = (myslot[r] + 1) & (m2 - 1);
+        myslot[r] = set_at(myslot[r], 1u, set_wmask(m2));
         was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
       }
       atomicMax(&cur.ent[myslot[r]].pos1, p1[r]);
@@ -1645,6 +1655,19 @@ struct tfra_sparse_plan {
                                    // scores do not read them; a build through the public entry point always counts)
   uint8_t* set_dflag = nullptr;
   OwnItem* set_items = nullptr;
+  // the overlapped step (tfra_step_impl.h) builds a SET plan in two launches without atomics: launch 1 scatters every tile's
+  // distinct (id, last position) pairs into per-window segments, launch 2 builds each window of the table from its segments
+  void* segbuf = nullptr;
+  size_t seg_cap_ids = 0;          // ids the scatter buffers were sized for
+  SetEnt* seg_pairs = nullptr;     // [windows][tiles][SEG_CAP]
+  unsigned* seg_cnt = nullptr;     // [windows][tiles]
+  SetEnt* ovf_pairs = nullptr;     // pairs that did not fit their segment (an adversarial batch): appended with an atomic
+  unsigned* ovf_cnt = nullptr;
+  unsigned seg_tiles = 0;          // tiles of the last scatter
+  unsigned scat_use = 0;           // scatters into this object so far (its two overflow counters alternate)
+  const int64_t* scat_ids = nullptr;   // the batch whose pairs the segments hold (nullptr: none)
+  size_t scat_n = 0;
+  bool listless[2] = {false, false};   // table p was last built without its dense key list (by the overlapped step)
 };
 
 extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
@@ -1660,6 +1683,7 @@ extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
   if (!pl) return TFRA_OK;
   if (pl->buf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->buf); }
   if (pl->setbuf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->setbuf); }
+  if (pl->segbuf) { (void)hipSetDevice(pl->device); (void)hipDeviceSynchronize(); (void)hipFree(pl->segbuf); }
   if (pl->host_counts) (void)hipHostFree(pl->host_counts);
   if (pl->built_ev) (void)hipEventDestroy(pl->built_ev);
   delete pl;
@@ -1671,7 +1695,7 @@ static size_t plan_smem_bytes(unsigned cm) { return (size_t)cm * 36 + (size_t)TA
 // The SET plan of a batch (dim 0): see setplan_kernel.  setplan_prepare = everything but the launch (buffers, which of the two
 // tables, its counter words): the overlapped step builds the plan inside its own kernel (step_kernel's PLAN role).
 struct SetPlanLaunch { SetTab cur, old; unsigned* next_use_count; unsigned m2; unsigned blocks; };
-static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool counts, SetPlanLaunch* L) {
+static int setplan_ensure(tfra_sparse_plan* pl, size_t n, hipStream_t s) {   // the SET buffer, sized for n ids
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   if (pl->set_cap < n) {
@@ -1683,13 +1707,13 @@ static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool c
     unsigned m2 = 4096;
     while ((size_t)m2 < 2 * cap) m2 <<= 1;
     const size_t tab = al(((size_t)m2 + 2 + SET_PAD) * sizeof(SetEnt)) + al(cap * 8) + al(cap * 4);   // entries, ukeys, uslot
-    const size_t bytes = 512 + al(cap) + al((size_t)SLOW_CAP * sizeof(OwnItem)) + 2 * tab;
+    const size_t bytes = 512 + al((size_t)m2 + 8) + al((size_t)SLOW_CAP * sizeof(OwnItem)) + 2 * tab;   // (flag bytes: per key of a list, or per SLOT for the overlapped step)
     hipError_t e = hipMalloc(&pl->setbuf, bytes);
     if (e != hipSuccess) { pl->setbuf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
     if (hipMemsetAsync(pl->setbuf, 0, bytes, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
     unsigned char* w = (unsigned char*)pl->setbuf;
     pl->set_counts = (unsigned*)w; w += 512;          // [0..5] counts [6] ticket [8] any_deferred [12..19] OwnCtrs x2 [20,21] list counts [32] i64 count
-    pl->set_dflag = (uint8_t*)w; w += al(cap);
+    pl->set_dflag = (uint8_t*)w; w += al((size_t)m2 + 8);
     pl->set_items = (OwnItem*)w; w += al((size_t)SLOW_CAP * sizeof(OwnItem));
     for (int p = 0; p < 2; ++p) {
       SetTab& tb = pl->set_tab[p];
@@ -1700,7 +1724,13 @@ static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool c
       fill_setent_kernel<<<256, 256, 0, s>>>(tb.ent, (size_t)m2 + 2 + SET_PAD);
     }
     pl->set_cap = cap; pl->set_m2 = m2; pl->set_parity = 1; pl->set_use[0] = pl->set_use[1] = 0;
+    pl->listless[0] = pl->listless[1] = false;
   }
+  return TFRA_OK;
+}
+static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool counts, SetPlanLaunch* L) {
+  int rc = setplan_ensure(pl, n, s);
+  if (rc) return rc;
   const unsigned p = pl->set_parity ^ 1u;
   pl->gen += 1;
   const unsigned blocks = (unsigned)((n + SP_NT - 1) / SP_NT);
@@ -1710,12 +1740,51 @@ static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool c
   cur.count = count_word(p, use);
   old.count = count_word(p ^ 1u, pl->set_use[p ^ 1u]);   // (never used yet: a zero word)
   pl->set_tab[p].count = cur.count;
+  // a table that was last built by the overlapped step has no list of its used slots: empty all of it (this build's target must
+  // start empty, the other one is emptied through its list otherwise)
+  for (unsigned q = 0; q < 2; ++q)
+    if (pl->listless[q]) { fill_setent_kernel<<<256, 256, 0, s>>>(pl->set_tab[q].ent, (size_t)pl->set_m2 + 2 + SET_PAD); pl->listless[q] = false; }
   L->cur = cur; L->old = old; L->next_use_count = count_word(p, use + 1); L->m2 = pl->set_m2; L->blocks = blocks;
   pl->built_counts = counts;
   pl->set_parity = p;
   pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
   pl->n = n; pl->dim = 0; pl->kind = 1;
   return TFRA_OK;
+}
+// The same for a build WITHOUT the dense list and without atomics (the overlapped step: scatter launch + build launch): the
+// table that takes the build (every slot of it is written by the build launch), the scatter buffers sized for n ids.
+static int setplan_prepare_listless(tfra_sparse_plan* pl, size_t n, hipStream_t s) {
+  int rc = setplan_ensure(pl, n, s);
+  if (rc) return rc;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  if (pl->seg_cap_ids < pl->set_cap) {
+    if (pl->segbuf) { if (hipDeviceSynchronize() != hipSuccess || hipFree(pl->segbuf) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: free"); pl->segbuf = nullptr; }
+    const size_t wins = pl->set_m2 / SET_WIN, tiles = (pl->set_cap + 1023) / 1024;
+    const size_t bytes = 256 + al(wins * tiles * SEG_CAP * sizeof(SetEnt)) + al(wins * tiles * 4) + al(pl->set_cap * sizeof(SetEnt));
+    hipError_t e = hipMalloc(&pl->segbuf, bytes);
+    if (e != hipSuccess) { pl->segbuf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
+    if (hipMemsetAsync(pl->segbuf, 0, bytes, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+    unsigned char* w = (unsigned char*)pl->segbuf;
+    pl->ovf_cnt = (unsigned*)w; w += 256;
+    pl->seg_pairs = (SetEnt*)w; w += al(wins * tiles * SEG_CAP * sizeof(SetEnt));
+    pl->seg_cnt = (unsigned*)w; w += al(wins * tiles * 4);
+    pl->ovf_pairs = (SetEnt*)w;
+    pl->seg_cap_ids = pl->set_cap;
+  }
+  return TFRA_OK;
+}
+// ... and the bookkeeping of the build launch: the object's other table takes the build
+static SetTab setplan_take_listless(tfra_sparse_plan* pl, size_t n) {
+  const unsigned p = pl->set_parity ^ 1u;
+  pl->gen += 1;
+  const unsigned use = ++pl->set_use[p];
+  pl->set_tab[p].count = pl->set_counts + 64 + 8 * (2 * p + (use & 1u)) + 1;   // (unused by a list-less build: kept valid)
+  pl->listless[p] = true;
+  pl->built_counts = false;
+  pl->set_parity = p;
+  pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
+  pl->n = n; pl->dim = 0; pl->kind = 1;
+  return pl->set_tab[p];
 }
 static int setplan_build(tfra_sparse_plan* pl, size_t n, const int64_t* ids, hipStream_t s, bool counts) {
   SetPlanLaunch L;
@@ -2118,6 +2187,8 @@ extern "C" int tfra_sparse_plan_read(const tfra_sparse_plan_t* pl, uint32_t* cou
     return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
   const unsigned nhot = counts[0], ncold = counts[1], nbins = counts[3];
   if (!keys) return TFRA_OK;
+  if (pl->kind == 1 && pl->listless[pl->set_parity])
+    return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_read: this plan was built by the overlapped step, without a key list");
   if (pl->kind == 1) {   // SET plan: distinct keys and their occurrence counts; it keeps no positions list
     if (positions) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_read: an assign-only plan keeps the last position of a key, not the list of its positions");
     if ((size_t)ncold > cap) return set_error(TFRA_ERR_INVALID, "sparse_plan_read: buffers too small");

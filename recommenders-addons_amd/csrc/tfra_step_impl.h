@@ -33,10 +33,10 @@
 #ifdef TFRA_STEP_DEVICE_PART
 
 struct StepArgs {
-  OwnArgs own;                 // write-back of the PREVIOUS batch (SRC_SET: own.ks = its plan); own_blocks == 0: none pending
+  OwnArgs own;                 // write-back of the PREVIOUS batch (its keys come from `fwd`, the previous batch's plan); own_blocks == 0: none pending
   OwnCtrs* ctr;                // its left-over counters
   unsigned own_gen;
-  unsigned* progress;          // pinned: [0] step, [1] distinct keys of this write-back (sizes the next one's grid)
+  unsigned* progress;          // pinned: [0] step
   unsigned progress_val;
   SetProbe fwd;                // the previous batch's plan: ids found here are served from own.vals
   SetProbe nxt;                // THIS batch's plan: victims found here are not evicted in the pass
@@ -47,14 +47,15 @@ struct StepArgs {
   uint8_t* exists;
   const unsigned char* defaults;
   int full;
-  // plan role: the plan of the NEXT batch
-  unsigned n_plan;
-  const i64* ids_plan;
-  SetTab pcur, pold;
-  unsigned* next_use_count;
-  unsigned plan_m2;
-  unsigned plan_blocks, own_blocks, find_blocks;
-  int interleave;              // own blocks spread among the lookup's blocks (else: all in front of them)
+  // BUILD role: the plan of the NEXT batch, one window of its table per block, from the segments a scatter filled one launch ago
+  SetEnt* build_ent;           // the table (every slot is written)
+  unsigned build_m2, build_tiles, build_blocks;
+  const SetEnt* build_pairs; const unsigned* build_cnt; const SetEnt* build_ovf; const unsigned* build_ovf_cnt;
+  // SCATTER role: the batch after next, one tile of 1024 ids per block -> per (window, tile) segments
+  unsigned scat_n, scat_m2, scat_tiles, scat_blocks;
+  const i64* scat_ids;
+  SetEnt* scat_pairs; unsigned* scat_cnt; SetEnt* scat_ovf; unsigned* scat_ovf_cnt; unsigned* scat_ovf_cnt_next;   // (two overflow counters alternate: this scatter zeroes the next one's)
+  unsigned own_blocks, find_blocks;
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
   u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
@@ -63,119 +64,132 @@ struct StepArgs {
   unsigned* patch_count_next;
 };
 
-// ---- PLAN role: setplan_kernel<false> for 256 threads per 1024 ids -------------------------------------------------
-// (Tried and dropped, measured inside the step on the metric's configuration: 512 ids per block with half the LDS, the tiles
-// taken from the end of the batch backwards and a LOOK at the home slot before the atomics of an id that repeats in its tile
-// — every block of the role runs at the same time, nobody has installed anything yet when the others look, and twice the
-// blocks contend for the hot slots: the role went from 22 to 39 us and the step from 32 to 48.)
-constexpr unsigned SPK_IDS = 1024, SPK_LDS = 2048, SPK_PER = SPK_LDS / 256;
-struct PlanLds {
-  i64 key[SPK_LDS];
-  unsigned pos[SPK_LDS + 2];
-  unsigned n, base;
+// LDS of a block, whatever its role (24.6 KB): a 2048-slot table (scatter: the tile's ids; build: the window) or, for the
+// write-back, the compacted keys of its slice of the plan
+struct StepLds {
+  i64 key[SET_WIN];
+  unsigned pos[SET_WIN + 2];   // (+2: the two sentinel key values)
+  unsigned cnt[256];           // scatter: pairs per window
+  unsigned n;
 };
+constexpr unsigned OWN_SLICE = 288;   // plan slots per write-back block: ~25 keys at 22.7 K keys in 2^18 slots, 32 fit one round
 
-// (tuning) phase stamps of the plan role: a.tbuf + TIMING_SLOTS * TIMING_BLOCKS * 2 + (launch slot * 128 + block) * 8 + k
-__device__ __forceinline__ void plan_stamp(const StepArgs& a, unsigned blk, int k) {
-  if (a.tbuf && threadIdx.x == 0 && blk < 128)
-    a.tbuf[(size_t)64 * 4096 * 2 + ((size_t)(a.progress_val % 64u) * 128 + blk) * 8 + k] = (u64)wall_clock64();
-}
-__device__ __forceinline__ void plan_role(const StepArgs& a, unsigned blk, PlanLds& L) {
+// ---- SCATTER role: setplan_kernel's LDS phase, then plain stores ------------------------------------------------------
+// Equal ids of the tile meet in LDS (compare-and-swap on the key, max on position + 1); every distinct id then goes, with its
+// last position in the tile, into the segment (window of its home slot, this tile): a position inside the segment from an LDS
+// counter, a plain 16-byte store.  No global atomic (an id-heavy window — 32 distinct ids of ONE tile in ONE of the >= 128
+// windows — spills into an overflow list with one).  The round-3 plan kernel put every distinct id of every tile into ONE global
+// table with a compare-and-swap and a max: 100 K device-scope atomics per batch, the hot ids' slots taking one from every tile
+// — inside the step's launch each such round trip took 7 us (queues at the hot slots) and the role 21 us, as long as lookup
+// and write-back together.
+__device__ __forceinline__ void scatter_role(const StepArgs& a, unsigned tile, StepLds& L) {
   const unsigned tid = threadIdx.x;
-  plan_stamp(a, blk, 0);
-  const SetTab& cur = a.pcur;
-  const SetTab& old = a.pold;
-  const unsigned m2 = a.plan_m2;
-  const unsigned n_old = *old.count;
-  if (blk == 0 && tid == 0) *a.next_use_count = 0;
-  for (unsigned i = tid; i < SPK_LDS + 2; i += 256) { if (i < SPK_LDS) L.key[i] = EMPTY_KEY; L.pos[i] = 0; }
-  if (tid == 0) L.n = 0;
-  __syncthreads();
-  // A: equal ids of the block meet in LDS (4 ids per thread, coalesced)
+  const unsigned wins = a.scat_m2 >> SET_WIN_LOG2;
+  for (unsigned i = tid; i < SET_WIN + 2; i += 256) { if (i < SET_WIN) L.key[i] = EMPTY_KEY; L.pos[i] = 0; }
+  L.cnt[tid] = 0;
+  if (tile == 0 && tid == 0) *a.scat_ovf_cnt_next = 0;
   i64 id[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const unsigned g = blk * SPK_IDS + (unsigned)r * 256u + tid;
-    id[r] = g < a.n_plan ? a.ids_plan[g] : 0;
+    const unsigned g = tile * 1024u + (unsigned)r * 256u + tid;
+    id[r] = g < a.scat_n ? a.scat_ids[g] : 0;
   }
-  keep_live(id[0], id[1], id[2], id[3]);
-  plan_stamp(a, blk, 1);   // ids arrived
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const unsigned g = blk * SPK_IDS + (unsigned)r * 256u + tid;
-    if (g >= a.n_plan) continue;
+    const unsigned g = tile * 1024u + (unsigned)r * 256u + tid;
+    if (g >= a.scat_n) continue;
     unsigned slot;
-    if (is_reserved_key(id[r])) slot = SPK_LDS + (unsigned)reserved_index(id[r]);
+    if (is_reserved_key(id[r])) slot = SET_WIN + (unsigned)reserved_index(id[r]);
     else {
-      slot = (unsigned)(fmix64((u64)id[r]) >> 41) & (SPK_LDS - 1);
+      slot = (unsigned)(fmix64((u64)id[r]) >> 41) & (SET_WIN - 1);
       for (;;) {
         const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&L.key[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)id[r]);
         if (was == EMPTY_KEY || was == id[r]) break;
-        slot = (slot + 1) & (SPK_LDS - 1);
+        slot = (slot + 1) & (SET_WIN - 1);
       }
     }
     atomicMax(&L.pos[slot], g + 1u);
   }
   __syncthreads();
-  plan_stamp(a, blk, 2);   // LDS phase done
-  // B: the block's distinct ids into the global table; the first probes of a thread's 8 slots travel together
-  i64 mykey[SPK_PER], was[SPK_PER];
-  unsigned myslot[SPK_PER], p1[SPK_PER], myidx[SPK_PER];
-  bool mine[SPK_PER];
 #pragma unroll
-  for (int r = 0; r < (int)SPK_PER; ++r) {
-    const unsigned s = tid + (unsigned)r * 256u;
-    mykey[r] = L.key[s];
-    p1[r] = L.pos[s];
-    myslot[r] = (unsigned)(fmix64((u64)mykey[r]) >> 20) & (m2 - 1);
-    was[r] = 0;
-    mine[r] = false;
-    if (p1[r]) was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
+  for (int r = 0; r < (int)(SET_WIN / 256); ++r) {
+    const unsigned sl = tid + (unsigned)r * 256u;
+    const unsigned p1 = L.pos[sl];
+    if (!p1) continue;
+    const i64 key = L.key[sl];
+    const unsigned w = ((unsigned)(fmix64((u64)key) >> 20) & (a.scat_m2 - 1)) >> SET_WIN_LOG2;
+    const unsigned at = atomicAdd(&L.cnt[w], 1u);
+    const uint4 pair = make_uint4((unsigned)(u64)key, (unsigned)((u64)key >> 32), p1, 0u);
+    if (at < SEG_CAP) *reinterpret_cast<uint4*>(a.scat_pairs + ((size_t)w * a.scat_tiles + tile) * SEG_CAP + at) = pair;
+    else *reinterpret_cast<uint4*>(a.scat_ovf + atomicAdd(a.scat_ovf_cnt, 1u)) = pair;
   }
-  if (a.tbuf) { keep_live(was[0], was[1], was[2], was[3]); plan_stamp(a, blk, 3); }   // first swaps back (wave 0)
-#pragma unroll
-  for (int r = 0; r < (int)SPK_PER; ++r) {
-    if (p1[r]) {
+  if (tid < 2 && L.pos[SET_WIN + tid] != 0) {   // a sentinel key value occurred in this tile: window 0 carries it
+    const i64 key = EMPTY_KEY + (i64)tid;
+    const unsigned at = atomicAdd(&L.cnt[0], 1u);
+    const uint4 pair = make_uint4((unsigned)(u64)key, (unsigned)((u64)key >> 32), L.pos[SET_WIN + tid], 0u);
+    if (at < SEG_CAP) *reinterpret_cast<uint4*>(a.scat_pairs + ((size_t)0 * a.scat_tiles + tile) * SEG_CAP + at) = pair;
+    else *reinterpret_cast<uint4*>(a.scat_ovf + atomicAdd(a.scat_ovf_cnt, 1u)) = pair;
+  }
+  __syncthreads();
+  if (tid < wins) a.scat_cnt[(size_t)tid * a.scat_tiles + tile] = min(L.cnt[tid], SEG_CAP);
+}
+
+// ---- BUILD role: one window of the next batch's plan ---------------------------------------------------------------------
+// Thread t takes the pairs tile t left for this window (a handful), inserts them into the window's image in LDS (linear probing
+// inside the window, max on the position: the rule every prober follows, set_at) and the block writes the image out — all
+// 2048 slots, so the table needs no emptying between its uses.  Two dependent round trips (counts, pairs), no atomics.
+__device__ __forceinline__ void build_role(const StepArgs& a, unsigned win, StepLds& L) {
+  const unsigned tid = threadIdx.x;
+  for (unsigned i = tid; i < SET_WIN + 2; i += 256) { if (i < SET_WIN) L.key[i] = EMPTY_KEY; L.pos[i] = 0; }
+  const unsigned c = tid < a.build_tiles ? a.build_cnt[(size_t)win * a.build_tiles + tid] : 0u;
+  const unsigned novf = *a.build_ovf_cnt;
+  __syncthreads();
+  auto insert = [&](i64 key, unsigned p1) {
+    unsigned slot;
+    if (is_reserved_key(key)) slot = SET_WIN + (unsigned)reserved_index(key);
+    else {
+      slot = ((unsigned)(fmix64((u64)key) >> 20) & (a.build_m2 - 1)) & (SET_WIN - 1);
       for (;;) {
-        if (was[r] == EMPTY_KEY) { mine[r] = true; break; }
-        if (was[r] == mykey[r]) break;
-        myslot[r] = (myslot[r] + 1) & (m2 - 1);
-        was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
+        const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&L.key[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (was == EMPTY_KEY || was == key) break;
+        slot = (slot + 1) & (SET_WIN - 1);
       }
-      atomicMax(&cur.ent[myslot[r]].pos1, p1[r]);
     }
-    myidx[r] = mine[r] ? atomicAdd(&L.n, 1u) : 0u;
-  }
-  if (tid < 2 && L.pos[SPK_LDS + tid] != 0) {   // a sentinel key value occurred in this block
-    const unsigned sl = m2 + tid;
-    const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[sl].key), (unsigned long long)EMPTY_KEY, 1ULL);
-    atomicMax(&cur.ent[sl].pos1, L.pos[SPK_LDS + tid]);
-    if (w == EMPTY_KEY) {
-      const unsigned at = atomicAdd(cur.count, 1u);
-      cur.ukeys[at] = EMPTY_KEY + (i64)tid;
-      cur.uslot[at] = sl;
-    }
-  }
-  __syncthreads();
-  plan_stamp(a, blk, 4);   // every swap chain of the block resolved
-  if (tid == 0) L.base = L.n ? atomicAdd(cur.count, L.n) : 0u;
-  // C: empty the slots the previous build used in the OTHER table
-  for (unsigned i = blk * 256u + tid; i < n_old; i += a.plan_blocks * 256u)
-    *reinterpret_cast<uint4*>(old.ent + old.uslot[i]) = make_uint4(0u, 0x80000000u, 0u, 0u);
-  __syncthreads();
-  plan_stamp(a, blk, 5);   // list base back, other table emptied
+    atomicMax(&L.pos[slot], p1);
+  };
+  const SetEnt* seg = a.build_pairs + ((size_t)win * a.build_tiles + tid) * SEG_CAP;
+  for (unsigned j = 0; j < c; j += 4) {   // (c <= SEG_CAP; four pairs in flight)
+    uint4 pr[4];
 #pragma unroll
-  for (int r = 0; r < (int)SPK_PER; ++r) {
-    if (!mine[r]) continue;
-    cur.ukeys[L.base + myidx[r]] = mykey[r];
-    cur.uslot[L.base + myidx[r]] = myslot[r];
+    for (int q = 0; q < 4; ++q) pr[q] = *reinterpret_cast<const uint4*>(seg + min(j + (unsigned)q, c - 1));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (j + (unsigned)q < c) insert((i64)(((u64)pr[q].y << 32) | pr[q].x), pr[q].z);
+  }
+  for (unsigned i = tid; i < novf; i += 256) {   // (an adversarial batch)
+    const uint4 pr = *reinterpret_cast<const uint4*>(a.build_ovf + i);
+    const i64 key = (i64)(((u64)pr.y << 32) | pr.x);
+    const unsigned w = is_reserved_key(key) ? 0u : ((unsigned)(fmix64((u64)key) >> 20) & (a.build_m2 - 1)) >> SET_WIN_LOG2;
+    if (w == win) insert(key, pr.z);
+  }
+  __syncthreads();
+  SetEnt* out = a.build_ent + (size_t)win * SET_WIN;
+  const unsigned wslots = a.build_m2 < SET_WIN ? a.build_m2 : SET_WIN;
+  for (unsigned sl = tid; sl < wslots; sl += 256) {
+    const i64 k = L.key[sl];
+    *reinterpret_cast<uint4*>(out + sl) = make_uint4((unsigned)(u64)k, (unsigned)((u64)k >> 32), L.pos[sl], 0u);
+  }
+  if (win == 0 && tid < 2) {   // the two sentinel slots behind the table: key word = "taken" marker
+    const unsigned p1 = L.pos[SET_WIN + tid];
+    *reinterpret_cast<uint4*>(a.build_ent + a.build_m2 + tid) = p1 ? make_uint4(1u, 0u, p1, 0u) : make_uint4(0u, 0x80000000u, 0u, 0u);
   }
 }
 
 // ---- FIND role: find_kernel<16, 4, WT, PF1> + forwarding -----------------------------------------------------------
 // Lane j (and j+16, j+32, j+48) holds key j of the wave's 16 and hashes it; for the plan probe the FOUR replicas of a key
 // read four consecutive entries of its chain (one 16-B load per lane, all 64 lanes busy, no redundancy); the table probe is
-// find_kernel's (both home buckets' lines in flight).  One wait for everything, then rows.
+// find_kernel's (both home buckets' lines in flight).
 __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
   constexpr int U = 4;
   const TableView& v = a.own.v;
@@ -190,7 +204,8 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
   const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
   const bool resv = is_reserved_key(kreg);
   const unsigned home = set_home(a.fwd, kreg, hreg);
-  const unsigned eidx = resv ? home + (unsigned)grp : (home + (unsigned)grp) & (a.fwd.m2 - 1);
+  const unsigned wm = set_wmask(a.fwd.m2);
+  const unsigned eidx = resv ? home + (unsigned)grp : set_at(home, (unsigned)grp, wm);
   uint4 e = *reinterpret_cast<const uint4*>(a.fwd.ent + eidx);
   i64 key[U], k0[U], k1[U];
   unsigned b0[U], b1[U], idx[U];
@@ -222,8 +237,8 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
   p1 |= (unsigned)__shfl_xor((int)p1, 16); p1 |= (unsigned)__shfl_xor((int)p1, 32);
   stop |= (unsigned)__shfl_xor((int)stop, 16); stop |= (unsigned)__shfl_xor((int)stop, 32);
   if (!p1 && !stop) {
-    for (unsigned t = 4; t < a.fwd.m2; ++t) {
-      const SetEnt* q = a.fwd.ent + ((home + t) & (a.fwd.m2 - 1));
+    for (unsigned t = 4; t <= wm; ++t) {
+      const SetEnt* q = a.fwd.ent + set_at(home, t, wm);
       const i64 k = q->key;
       if (k == kreg) { p1 = q->pos1; break; }
       if (k == EMPTY_KEY) break;
@@ -235,8 +250,7 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
   if (a.serial_probe) {
     // The table's lines BEHIND the plan probe, and only for the ids the plan does not hold: on a Zipf stream most positions of a
     // batch repeat ids of the batch before (85 % on the metric's configuration), and every line of a 273-GB table is a random,
-    // TLB-missing access — the launch is bound by how many of those the memory system takes, not by wave slots.  The loads stay
-    // unconditional (one wait for all of them): a forwarded id reads one hot line of the plan instead.
+    // TLB-missing access.  The loads stay unconditional (one wait for all of them): a forwarded id reads one hot line of the plan.
     const i64* hot = reinterpret_cast<const i64*>(a.fwd.ent);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -268,32 +282,57 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
   }
 }
 
-// ---- OWN role: upsert_own_kernel<16, SIMPLE, SRC_SET, U> with the victim check ---------------------------------------
+// ---- OWN role: the ownership pass over the previous batch's plan, read straight from its TABLE ---------------------------
+// The plan keeps no dense list of its keys any more (that list was a returned atomic per tile and a dependent round trip of
+// the builder): the block takes a slice of OWN_SLICE slots of the plan's table (one 16-byte load per thread and a few more),
+// compacts the occupied ones in LDS — key, last position, slot (the key's flag byte) — and its four waves take them 4 U at a
+// time through own_batch16, victims checked against this batch's plan.
 template <bool SIMPLE, int U>
-__device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk) {
+__device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLds& L) {
   const OwnArgs& o = a.own;
-  const int lane = threadIdx.x & 63;
-  const unsigned total = o.ks.d_counts[0] + o.ks.d_counts[1];
-  const unsigned nwaves = a.own_blocks * 4u;
-  const unsigned wave = blk * 4u + (threadIdx.x >> 6);
-  int fresh = 0;
-  if (blk == 0 && threadIdx.x == 0 && a.progress) {
-    __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(a.progress + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned tid = threadIdx.x;
+  const int lane = tid & 63;
+  const unsigned lo = blk * OWN_SLICE, total_slots = a.fwd.m2 + 2;
+  if (tid == 0) L.n = 0;
+  uint4 e[2];
+  bool have[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned off = tid + (unsigned)r * 256u;
+    have[r] = off < OWN_SLICE && lo + off < total_slots;
+    e[r] = *reinterpret_cast<const uint4*>(a.fwd.ent + (have[r] ? lo + off : lo));
   }
+  if (blk == 0 && tid == 0 && a.progress) __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned slot = lo + tid + (unsigned)r * 256u;
+    const i64 k = (i64)(((u64)e[r].y << 32) | e[r].x);
+    if (have[r] && k != EMPTY_KEY) {
+      const unsigned at = atomicAdd(&L.n, 1u);
+      L.key[at] = slot >= a.fwd.m2 ? EMPTY_KEY + (i64)(slot - a.fwd.m2) : k;   // (sentinel slots hold a marker, the slot says which key)
+      L.pos[at] = e[r].z;
+      L.pos[1024 + at] = slot;
+    }
+  }
+  __syncthreads();
+  const unsigned cnt = L.n;
+  int fresh = 0;
   const OwnFlags fl = own_setup<SIMPLE>(o);
-  for (unsigned wbase = wave * (4 * U); wbase < total; wbase += nwaves * (4 * U)) {
+  for (unsigned wbase = (tid >> 6) * (4 * U); wbase < cnt; wbase += 4 * (4 * U)) {
     const unsigned i = wbase + (unsigned)(lane & 15);
-    own_batch16<16, SIMPLE, SRC_SET, U, true>(o, fl, min(i, total - 1), (lane & 15) < 4 * U && i < total, a.own_gen, &a.ctr->n_a, lane, fresh, &a.nxt, a.stat);
+    const unsigned c = min(i, cnt - 1);
+    own_batch16<16, SIMPLE, SRC_GIVEN, U, true>(o, fl, L.pos[1024 + c], (lane & 15) < 4 * U && i < cnt, a.own_gen, &a.ctr->n_a, lane, fresh, &a.nxt, a.stat,
+                                                L.key[c], L.pos[c] - 1u);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
-  if (lane == 0 && fresh) size_add(o.v, wave, fresh);
+  if (lane == 0 && fresh) size_add(o.v, blk * 4u + (tid >> 6), fresh);
 }
 
 // TIMING (tuning builds only): every block notes its start and end on the device clock in a.tbuf (a slot per launch and block):
 // when does each role of a launch run?
 constexpr unsigned TIMING_BLOCKS = 4096, TIMING_SLOTS = 64;
-__device__ __forceinline__ void role_stamp(const StepArgs& a, int role, u64 t0) {
+__device__ __forceinline__ void role_stamp(const StepArgs& a, u64 t0) {
   __syncthreads();
   if (threadIdx.x == 0 && a.tbuf && blockIdx.x < TIMING_BLOCKS) {
     u64* w = a.tbuf + ((size_t)(a.progress_val % TIMING_SLOTS) * TIMING_BLOCKS + blockIdx.x) * 2;
@@ -301,46 +340,42 @@ __device__ __forceinline__ void role_stamp(const StepArgs& a, int role, u64 t0) 
     w[1] = (u64)wall_clock64();
   }
 }
-template <bool SIMPLE, int U, bool PLAN, bool TIMING>
+// role of block b: 0 build, 1 scatter, 2 write-back, 3 lookup; *idx = its index in the role.  The builders come first (short
+// chains of dependent round trips, few blocks); the write-back's O blocks are spread evenly among the lookup's F blocks (own
+// block j at position floor(j (O + F) / O)): blocks are dispatched in index order, and a role whose blocks all come first
+// fills every wave slot of the chip while the role behind it waits for them to retire.
+__host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned O, unsigned F, unsigned* idx) {
+  if (b < build_blocks) { *idx = b; return 0; }
+  b -= build_blocks;
+  if (b < scat_blocks) { *idx = b; return 1; }
+  b -= scat_blocks;
+  const unsigned T = O + F;
+  const unsigned c = O ? (unsigned)(((unsigned long long)b * O + T - 1) / T) : 0u;   // own blocks in front of position b
+  if (c < O && (unsigned)(((unsigned long long)c * T) / O) == b) { *idx = c; return 2; }
+  *idx = b - c;
+  return 3;
+}
+template <bool SIMPLE, int U, bool TIMING>
 __device__ __forceinline__ void step_body(const StepArgs& a) {
-  unsigned b = blockIdx.x;
+  __shared__ StepLds L;
   const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
-  if constexpr (PLAN) {
-    __shared__ PlanLds L;
-    if (b < a.plan_blocks) { plan_role(a, b, L); if (TIMING) role_stamp(a, 0, t0); return; }
-    b -= a.plan_blocks;
-  }
-  // The write-back's O blocks are spread evenly among the lookup's F blocks (own block j at position floor(j (O + F) / O)):
-  // blocks are dispatched in index order, and a role whose blocks all come first fills every wave slot of the chip while
-  // the role behind it waits for them to retire — the roles then run one after the other, not side by side.
-  if (a.interleave) {
-    const unsigned O = a.own_blocks, T = O + a.find_blocks;
-    const unsigned c = O ? (unsigned)(((u64)b * O + T - 1) / T) : 0u;          // own blocks in front of position b
-    const bool is_own = c < O && (unsigned)(((u64)c * T) / O) == b;
-    if (is_own) { own_role<SIMPLE, U>(a, c); if (TIMING) role_stamp(a, 1, t0); return; }
-    find_fwd_role(a, b - c);
-    if (TIMING) role_stamp(a, 2, t0);
-    return;
-  }
-  if (b < a.own_blocks) { own_role<SIMPLE, U>(a, b); if (TIMING) role_stamp(a, 1, t0); return; }
-  find_fwd_role(a, b - a.own_blocks);
-  if (TIMING) role_stamp(a, 2, t0);
+  unsigned idx;
+  const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, &idx);
+  if (role == 0) build_role(a, idx, L);
+  else if (role == 1) scatter_role(a, idx, L);
+  else if (role == 2) own_role<SIMPLE, U>(a, idx, L);
+  else find_fwd_role(a, idx);
+  if (TIMING) role_stamp(a, t0);
 }
 // Instantiations (the SGPR budget is an attribute, not a template argument): 256-thread blocks are admitted per CU up to
-// floor(800 / (ceil(sgpr / 16) * 16 + 16)) — 106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
-#define TFRA_STEP_KERNEL(NAME, UU, PLAN, TIMING, NSGPR)                                                                  \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(NSGPR))) void NAME(const StepArgs a) { step_body<true, UU, PLAN, TIMING>(a); }
-TFRA_STEP_KERNEL(step_k_u2, 2, true, false, 104)
-TFRA_STEP_KERNEL(step_k_u1, 1, true, false, 104)
-TFRA_STEP_KERNEL(step_k_u4, 4, true, false, 104)
-TFRA_STEP_KERNEL(step_k_u1_s96, 1, true, false, 96)
-TFRA_STEP_KERNEL(step_k_u1_s80, 1, true, false, 80)
-TFRA_STEP_KERNEL(step_k_u2_t, 2, true, true, 104)
-TFRA_STEP_KERNEL(step_k_u1_t, 1, true, true, 104)
-TFRA_STEP_KERNEL(step_k_u1_s80_t, 1, true, true, 80)
-TFRA_STEP_KERNEL(step_k_u2_np, 2, false, false, 104)
-TFRA_STEP_KERNEL(step_k_u1_np, 1, false, false, 104)
-TFRA_STEP_KERNEL(step_k_u1_s80_np, 1, false, false, 80)
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) — ~106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
+#define TFRA_STEP_KERNEL(NAME, UU, TIMING, NSGPR)                                                                        \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(NSGPR))) void NAME(const StepArgs a) { step_body<true, UU, TIMING>(a); }
+TFRA_STEP_KERNEL(step_k_u2, 2, false, 104)
+TFRA_STEP_KERNEL(step_k_u1, 1, false, 104)
+TFRA_STEP_KERNEL(step_k_u1_s80, 1, false, 80)
+TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 104)
+TFRA_STEP_KERNEL(step_k_u1_t, 1, true, 104)
 #undef TFRA_STEP_KERNEL
 
 // ---- the remainder of a step: left-over keys of the pass + corrections of the lookup's output ------------------------
@@ -369,7 +404,7 @@ __global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsign
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.patch_count_next = 0;            // (the next step's list: its last reader is long gone)
   if (counted == 0) return;                                                    // no items, no evictions, nothing to correct
   const bool listed = counted <= o.item_cap;
-  const unsigned n = listed ? counted : o.ks.d_counts[0] + o.ks.d_counts[1];
+  const unsigned n = listed ? counted : a.fwd.m2 + 2;   // (the list overflowed: the flag byte of every slot of the plan's table)
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
   int fresh = 0, failed = 0;
@@ -386,8 +421,9 @@ __global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsign
       if (sub == 0) o.dflag[w0.w] = 0;
     } else {
       if (o.dflag[i] != 4) continue;
-      const uint2 pc = set_pc(o.ks.sent + o.ks.uslot[i]);
-      locked_upsert_kv<16>(o.v, o.vals, o.ks.ukeys[i], pc.x - 1, 1, o.ai, o.sp, sub, gshift, fresh, failed, false, 0, &vk);
+      const SetEnt* pe = a.fwd.ent + i;
+      const i64 key = i >= a.fwd.m2 ? EMPTY_KEY + (i64)(i - a.fwd.m2) : pe->key;
+      locked_upsert_kv<16>(o.v, o.vals, key, pe->pos1 - 1, 1, o.ai, o.sp, sub, gshift, fresh, failed, false, 0, &vk);
       if (sub == 0) o.dflag[i] = 0;
     }
     if (vk != EMPTY_KEY && vk != LOCKED_KEY && a.n && set_contains_group(a.nxt, vk, sub, gshift)) {
@@ -450,24 +486,28 @@ __global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsign
 struct tfra_step_driver {
   Table* t = nullptr;
   tfra_table_t* tp = nullptr;
-  static constexpr unsigned NPL = 4;      // plans in rotation: batch b uses plans[b % NPL] (previous, this, next: three alive at a time)
+  static constexpr unsigned NPL = 4;      // plans in rotation: batch b uses plans[b % NPL] (previous, this, next, the one being scattered)
   tfra_sparse_plan* plans[NPL] = {};
   unsigned seq = 0;                        // batches looked up so far
   bool pending = false;                    // the batch of the previous call still has to be written back
   unsigned pend_slot = 0;
+  const int64_t* pend_ids = nullptr;       // its ids (the caller keeps them until the batch has been written back)
+  size_t pend_n = 0;
   bool ahead = false;                      // plans[seq % NPL] already holds the plan of (ahead_ids, ahead_n): built by the last call
   const int64_t* ahead_ids = nullptr;
   size_t ahead_n = 0;
+  unsigned scat_uses = 0;                  // scatters so far (the overflow counter of a plan's segments alternates)
   SetEnt* dummy = nullptr;                 // an empty table (4 entries + the sentinel slots + padding): "no previous batch"
-  unsigned* progress = nullptr;            // pinned: [0] step, [1] distinct keys the last started write-back saw
+  unsigned* progress = nullptr;            // pinned: [0] step
   unsigned* stat = nullptr;                // device: StepArgs::stat
   u64* tbuf = nullptr;                     // device: StepArgs::tbuf (TFRA_STEP_VARIANT & 16)
+  unsigned tinfo[64][5] = {};              // per launch slot: build, scatter, own, lookup blocks, grid
   unsigned last_rest_step = ~0u;           // step number of the last step_rest_kernel launch (it zeroes the next step's victim counter)
   unsigned char* patch = nullptr;          // device: two counters (one 128-B line each) + two lists of PATCH_GCAP keys (step_rest_kernel)
-  unsigned tinfo[64][3] = {};              // per launch slot: plan blocks, own blocks, grid
   unsigned step_no = 0;
   int variant = 0;                         // TFRA_STEP_VARIANT (tuning): kernel instantiation
   unsigned long long n_overlapped = 0, n_sequential = 0;   // steps taken each way (tfra_step_driver_stats)
+  unsigned long long n_built_in_launch = 0, n_built_in_front = 0;   // plans of the next batch built by the step launch / by a launch of their own
   unsigned why_sequential = 0;             // why the last step that was not overlapped was not (bit mask, see step_overlap_one)
   std::vector<hipEvent_t> kev;             // tfra_step_driver_time_kernels: 3 events per timed step (before / between / behind its two launches)
   size_t kev_left = 0, kev_used = 0;
@@ -494,7 +534,7 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   const char* ev = std::getenv("TFRA_STEP_VARIANT");
   d->variant = ev ? std::atoi(ev) : 0;
   if (d->variant & 16) {
-    const size_t bytes = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 16 + (size_t)64 * 128 * 8 * 8;
+    const size_t bytes = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 16;
     if (hipMalloc((void**)&d->tbuf, bytes) != hipSuccess || hipMemset(d->tbuf, 0, bytes) != hipSuccess) { d->tbuf = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   }
   *out = d;
@@ -517,12 +557,13 @@ extern "C" int tfra_step_driver_destroy(tfra_step_driver_t* d) {
 }
 
 extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending, uint32_t* device_counts,
-                                      uint32_t* why_sequential) {
-  if (d && why_sequential) *why_sequential = d->why_sequential;
+                                      uint32_t* why_sequential, uint64_t* plans_built) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_stats: null driver");
+  if (why_sequential) *why_sequential = d->why_sequential;
   if (overlapped) *overlapped = d->n_overlapped;
   if (sequential) *sequential = d->n_sequential;
   if (pending) *pending = d->pending ? 1 : 0;
+  if (plans_built) { plans_built[0] = d->n_built_in_launch; plans_built[1] = d->n_built_in_front; }
   if (device_counts) {   // synchronises the device
     (void)hipSetDevice(d->t->device);
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(device_counts, d->stat, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
@@ -532,8 +573,8 @@ extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* ove
 }
 
 // tuning: the block time stamps of the last <= 64 launches made with TFRA_STEP_VARIANT & 16, reduced per role —
-// out[64][3][2] = {earliest block start, latest block end} on the device clock (100 MHz) per launch slot (step % 64) and role
-// (plan, write-back, lookup), ~0 / 0 where nothing ran; synchronises the device and re-arms the stamps.
+// out[64][4][2] = {earliest block start, latest block end} on the device clock (100 MHz) per launch slot (step % 64) and role
+// (build, scatter, write-back, lookup), ~0 / 0 where nothing ran; synchronises the device and re-arms the stamps.
 extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_timing: null driver");
   if (!d->tbuf) return set_error(TFRA_ERR_INVALID, "step_driver_timing: the driver was not created with TFRA_STEP_VARIANT & 16");
@@ -543,37 +584,20 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h.data(), d->tbuf, words * 8, hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemset(d->tbuf, 0, words * 8) != hipSuccess)
     return set_error(TFRA_ERR_HIP, "step_driver_timing: copy");
-  {   // plan phase stamps: median over launches and blocks of (stamp k - stamp 0), in ticks, behind the role spans
-    std::vector<uint64_t> ph((size_t)64 * 128 * 8);
-    const size_t off = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 2;
-    if (hipMemcpy(ph.data(), d->tbuf + off, ph.size() * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(d->tbuf + off, 0, ph.size() * 8) != hipSuccess)
-      return set_error(TFRA_ERR_HIP, "step_driver_timing: copy");
-    if (out) {
-      for (int k = 1; k <= 5; ++k) {
-        std::vector<uint64_t> dlt;
-        for (size_t i = 0; i < (size_t)64 * 128; ++i) if (ph[i * 8] && ph[i * 8 + k]) dlt.push_back(ph[i * 8 + k] - ph[i * 8]);
-        std::sort(dlt.begin(), dlt.end());
-        out[64 * 3 * 2 + (k - 1)] = dlt.empty() ? 0 : dlt[dlt.size() / 2];
-      }
-    }
-  }
   if (!out) return TFRA_OK;
   for (unsigned sl = 0; sl < TIMING_SLOTS; ++sl) {
-    const unsigned pb = d->tinfo[sl][0], ob = d->tinfo[sl][1], grid = std::min(d->tinfo[sl][2], TIMING_BLOCKS);
-    for (int r = 0; r < 3; ++r) { out[(sl * 3 + r) * 2] = ~0ULL; out[(sl * 3 + r) * 2 + 1] = 0; }
+    const unsigned* ti = d->tinfo[sl];
+    const unsigned grid = std::min(ti[4], TIMING_BLOCKS);
+    for (int r = 0; r < 4; ++r) { out[(sl * 4 + r) * 2] = ~0ULL; out[(sl * 4 + r) * 2 + 1] = 0; }
     for (unsigned b = 0; b < grid; ++b) {
       const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
       if (!t1) continue;
-      int r = b < pb ? 0 : (b < pb + ob ? 1 : 2);
-      if (b >= pb && !(d->variant & 32)) {   // own blocks spread among the lookup's (step_body)
-        const unsigned bb = b - pb, O = ob, T = d->tinfo[sl][2] - pb;
-        const unsigned c = O ? (unsigned)(((uint64_t)bb * O + T - 1) / T) : 0u;
-        r = (c < O && (unsigned)(((uint64_t)c * T) / O) == bb) ? 1 : 2;
-      }
-      out[(sl * 3 + r) * 2] = std::min(out[(sl * 3 + r) * 2], t0);
-      out[(sl * 3 + r) * 2 + 1] = std::max(out[(sl * 3 + r) * 2 + 1], t1);
+      unsigned idx;
+      const int r = step_role(b, ti[0], ti[1], ti[2], ti[3], &idx);
+      out[(sl * 4 + r) * 2] = std::min(out[(sl * 4 + r) * 2], t0);
+      out[(sl * 4 + r) * 2 + 1] = std::max(out[(sl * 4 + r) * 2 + 1], t1);
     }
-    d->tinfo[sl][2] = 0;
+    d->tinfo[sl][4] = 0;
   }
   return TFRA_OK;
 }
@@ -610,87 +634,84 @@ extern "C" int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step
 }
 
 static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_tab[pl->set_parity].ent, pl->set_m2}; }
+static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 && pl->listless[pl->set_parity]; }
 
-// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0 U=2 | 1 U=1 | 3 U=1, 80 SGPRs | 4 U=4 | 5 U=1, 96 SGPRs),
-// 8 the plan as a launch of its own, 16 time stamps
-static void launch_step(int variant, bool plan, unsigned grid, hipStream_t s, const StepArgs& a) {
+// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0 U=2 | 1 U=1 | 3 U=1, 80 SGPRs), 8 every plan as a launch of its own,
+// 16 time stamps, 64 the lookup reads the table's lines for every id
+static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {
   const int k = variant & 7;
-  if (!plan) {
-    if (k == 1 || k == 5) step_k_u1_np<<<grid, 256, 0, s>>>(a);
-    else if (k == 3) step_k_u1_s80_np<<<grid, 256, 0, s>>>(a);
-    else step_k_u2_np<<<grid, 256, 0, s>>>(a);
-  } else if (variant & 16) {
-    if (k == 1 || k == 5) step_k_u1_t<<<grid, 256, 0, s>>>(a);
-    else if (k == 3) step_k_u1_s80_t<<<grid, 256, 0, s>>>(a);
+  if (variant & 16) {
+    if (k == 1 || k == 3) step_k_u1_t<<<grid, 256, 0, s>>>(a);
     else step_k_u2_t<<<grid, 256, 0, s>>>(a);
-  } else {
-    switch (k) {
-      case 1: step_k_u1<<<grid, 256, 0, s>>>(a); break;
-      case 3: step_k_u1_s80<<<grid, 256, 0, s>>>(a); break;
-      case 4: step_k_u4<<<grid, 256, 0, s>>>(a); break;
-      case 5: step_k_u1_s96<<<grid, 256, 0, s>>>(a); break;
-      default: step_k_u2<<<grid, 256, 0, s>>>(a); break;
-    }
-  }
+  } else if (k == 1) step_k_u1<<<grid, 256, 0, s>>>(a);
+  else if (k == 3) step_k_u1_s80<<<grid, 256, 0, s>>>(a);
+  else step_k_u2<<<grid, 256, 0, s>>>(a);
 }
-static int own_keys_per_block(int variant) { const int v = variant & 7; return (v == 1 || v == 3 || v == 5) ? 16 : (v == 4 ? 64 : 32); }
 
-// One step.  Caller holds d->t->step_mu.
+// One step (n == 0 and no look-ahead: just the pending write-back, the flush).  Caller holds d->t->step_mu.
 static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists_out, const void* defaults,
                             int default_is_full, const void* values_prev, const uint64_t* scores_prev, size_t n_next,
-                            const int64_t* ids_next, hipStream_t s) {
+                            const int64_t* ids_next, size_t n_next2, const int64_t* ids_next2, hipStream_t s) {
   Table* t = d->t;
   if (n && (!ids || !rows_out || !defaults)) return set_error(TFRA_ERR_INVALID, "step_overlap: null buffer");
-  if (n > MAX_IDS || n_next > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "step_overlap: at most 2^18 ids per step");
+  if (n > MAX_IDS || n_next > MAX_IDS || n_next2 > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "step_overlap: at most 2^18 ids per step");
   if (d->pending && !values_prev) return set_error(TFRA_ERR_INVALID, "step_overlap: the previous step's batch has not been written back: values_prev is null");
-  if (n_next && !ids_next) return set_error(TFRA_ERR_INVALID, "step_overlap: null ids_next");
+  if ((n_next && !ids_next) || (n_next2 && !ids_next2)) return set_error(TFRA_ERR_INVALID, "step_overlap: null look-ahead ids");
   constexpr unsigned NPL = tfra_step_driver::NPL;
   const unsigned slot = d->seq % NPL;
   tfra_sparse_plan* plan_cur = d->plans[slot];
   tfra_sparse_plan* plan_prev = d->pending ? d->plans[d->pend_slot] : nullptr;
   tfra_sparse_plan* plan_next = d->plans[(d->seq + 1) % NPL];
+  tfra_sparse_plan* plan_next2 = d->plans[(d->seq + 2) % NPL];
   std::unique_lock<std::mutex> lock(t->mu);
   int rc = t->enter(s);
   if (rc) return rc;
+  const bool lfu = t->opts.strategy == TFRA_EVICT_LFU;
   // this batch's plan: built by the previous call (look-ahead), else here, in front of the step (one more launch)
-  if (!(d->ahead && d->ahead_ids == ids && d->ahead_n == n)) {
-    plan_cur->n = 0;
-    if (n) { rc = setplan_build(plan_cur, n, ids, s, t->opts.strategy == TFRA_EVICT_LFU); if (rc) return rc; }
+  if (n && !(d->ahead && d->ahead_ids == ids && d->ahead_n == n)) {
+    rc = setplan_build(plan_cur, n, ids, s, lfu);
+    if (rc) return rc;
+    d->n_built_in_front += 1;
   }
+  if (!n) plan_cur->n = 0;
   d->ahead = false;
-  const bool aligned = (((uintptr_t)rows_out | (uintptr_t)defaults | (uintptr_t)values_prev | (size_t)t->field_bytes) & 15) == 0;
   unsigned* tags = t->ensure_own_tags(s);
-  const unsigned why = (n > 0 ? 0u : 1u) | (aligned ? 0u : 2u) | (tags ? 0u : 4u) |
-                       ((t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU && !scores_prev) ? 0u : 8u) |
-                       (t->at_max_capacity() ? 0u : 16u) | (t->dense ? 0u : 32u) | ((!plan_prev || plan_prev->n > 0) ? 0u : 64u) |
-                       (t->capture_safe ? 128u : 0u);
-  const bool eligible = why == 0;
-  if (!eligible) d->why_sequential = why;
+  // what the TABLE must be for the overlap (constant over its life, but for `dense`) and what this CALL must be
+  const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU) ? 0u : 8u) |
+                             (t->at_max_capacity() ? 0u : 16u) | (t->dense ? 0u : 32u) | (t->capture_safe ? 128u : 0u) | ((t->field_bytes & 15u) ? 2u : 0u);
+  const bool aligned = (((uintptr_t)rows_out | (uintptr_t)defaults | (uintptr_t)values_prev) & 15) == 0;
+  const unsigned why = why_table | (aligned ? 0u : 2u) | (scores_prev ? 8u : 0u) | ((!plan_prev || plan_prev->n > 0) ? 0u : 64u);
+  const bool eligible = why == 0 && (n > 0 || plan_prev);
   const unsigned step = ++d->step_no;
   if (!eligible) {
+    if (n || plan_prev) d->why_sequential = why ? why : 1u;
     // the same results one after the other: write-back of the previous batch, this lookup, the next batch's plan
     if (plan_prev && plan_prev->n) {
-      rc = upsert_planned_impl(d->tp, plan_prev, values_prev, scores_prev, s, d->progress, step);
+      if (plan_is_listless(plan_prev)) {   // its plan has no key list (built by a step launch): build it again, with one
+        rc = setplan_build(plan_prev, d->pend_n, d->pend_ids, s, lfu);
+        if (rc) return rc;
+      }
+      rc = upsert_planned_impl(d->tp, plan_prev, values_prev, scores_prev, s, nullptr, 0);
       if (rc) return rc;
     }
     lock.unlock();
     if (n) { rc = tfra_table_find(d->tp, n, ids, rows_out, exists_out, defaults, default_is_full, s); if (rc) return rc; }
     if (n_next) {
-      rc = setplan_build(plan_next, n_next, ids_next, s, t->opts.strategy == TFRA_EVICT_LFU);
+      rc = setplan_build(plan_next, n_next, ids_next, s, lfu);
       if (rc) return rc;
+      d->n_built_in_front += 1;
     }
-    d->n_sequential += 1;
+    if (n || plan_prev) d->n_sequential += 1;
   } else {
     StepArgs a{};
     OwnLaunch L{};
-    const int kpb = own_keys_per_block(d->variant);
     if (plan_prev) {
-      rc = own_prepare(t, plan_prev, values_prev, nullptr, s, d->progress, &L);
+      rc = own_prepare(t, plan_prev, values_prev, nullptr, s, nullptr, &L);
       if (rc) return rc;
       a.own = L.a;
       a.ctr = L.ctr; a.own_gen = L.og;
-      a.own_blocks = (unsigned)std::max<size_t>(1, ((size_t)L.key_blocks * 16 + kpb - 1) / kpb);
       a.fwd = probe_of(plan_prev);
+      a.own_blocks = (a.fwd.m2 + 2 + OWN_SLICE - 1) / OWN_SLICE;
     } else {
       a.own.v = t->view_of(t->cur);
       a.own_blocks = 0;
@@ -699,50 +720,69 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.progress = d->progress; a.progress_val = step; a.stat = d->stat; a.tbuf = d->tbuf;
     a.patch_count = reinterpret_cast<unsigned*>(d->patch + 128 * (step & 1u)); a.patch_count_next = reinterpret_cast<unsigned*>(d->patch + 128 * ((step & 1u) ^ 1u));
     a.patch_keys = reinterpret_cast<i64*>(d->patch + 256) + (size_t)PATCH_GCAP * (step & 1u);
-    a.nxt = probe_of(plan_cur);
+    a.nxt = n ? probe_of(plan_cur) : SetProbe{d->dummy, 4};
     a.n = (unsigned)n; a.ids = (const i64*)ids; a.out = (unsigned char*)rows_out; a.exists = exists_out;
     a.defaults = (const unsigned char*)defaults; a.full = default_is_full;
-    const bool fused_plan = n_next > 0 && !(d->variant & 8);
+    a.find_blocks = (unsigned)((n + 63) / 64);
+    a.serial_probe = (d->variant & 64) ? 0 : 1;
+    // the next batch's plan: its pairs were scattered by the previous call's launch -> this launch builds the table; else a launch of its own, in front
     if (n_next) {
-      SetPlanLaunch P;
-      if (fused_plan) {
-        rc = setplan_prepare(plan_next, n_next, s, false, &P);
-        if (rc) return rc;
-        a.n_plan = (unsigned)n_next; a.ids_plan = (const i64*)ids_next; a.pcur = P.cur; a.pold = P.old; a.next_use_count = P.next_use_count;
-        a.plan_m2 = P.m2; a.plan_blocks = (unsigned)((n_next + SPK_IDS - 1) / SPK_IDS);   // (= P.blocks: 1024 ids per block)
+      if (plan_next->scat_ids == ids_next && plan_next->scat_n == n_next && !(d->variant & 8)) {
+        const SetTab tb = setplan_take_listless(plan_next, n_next);
+        a.build_ent = tb.ent; a.build_m2 = plan_next->set_m2; a.build_tiles = plan_next->seg_tiles; a.build_blocks = plan_next->set_m2 / SET_WIN;
+        a.build_pairs = plan_next->seg_pairs; a.build_cnt = plan_next->seg_cnt; a.build_ovf = plan_next->ovf_pairs;
+        a.build_ovf_cnt = plan_next->ovf_cnt + 32 * (plan_next->scat_use & 1u);
+        d->n_built_in_launch += 1;
       } else {
-        rc = setplan_build(plan_next, n_next, ids_next, s, false);   // (tuning variant: the plan as a launch of its own, in front)
+        rc = setplan_build(plan_next, n_next, ids_next, s, false);
         if (rc) return rc;
+        d->n_built_in_front += 1;
       }
+      plan_next->scat_ids = nullptr; plan_next->scat_n = 0;
     }
-    const unsigned find_blocks = (unsigned)((n + 63) / 64);
-    a.find_blocks = find_blocks; a.interleave = (d->variant & 32) ? 0 : 1; a.serial_probe = (d->variant & 64) ? 0 : 1;
-    if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = fused_plan ? a.plan_blocks : 0; ti[1] = a.own_blocks; ti[2] = ti[0] + ti[1] + find_blocks; }
+    // the batch after next: its distinct (id, last position) pairs go into plan_next2's segments
+    if (n_next2 && !(d->variant & 8)) {
+      rc = setplan_prepare_listless(plan_next2, n_next2, s);
+      if (rc) return rc;
+      plan_next2->scat_use += 1;
+      a.scat_n = (unsigned)n_next2; a.scat_ids = (const i64*)ids_next2; a.scat_m2 = plan_next2->set_m2;
+      a.scat_tiles = (unsigned)((n_next2 + 1023) / 1024); a.scat_blocks = a.scat_tiles;
+      a.scat_pairs = plan_next2->seg_pairs; a.scat_cnt = plan_next2->seg_cnt; a.scat_ovf = plan_next2->ovf_pairs;
+      a.scat_ovf_cnt = plan_next2->ovf_cnt + 32 * (plan_next2->scat_use & 1u);
+      a.scat_ovf_cnt_next = plan_next2->ovf_cnt + 32 * ((plan_next2->scat_use & 1u) ^ 1u);
+      plan_next2->seg_tiles = a.scat_tiles; plan_next2->scat_ids = ids_next2; plan_next2->scat_n = n_next2;
+    }
+    const unsigned grid = a.build_blocks + a.scat_blocks + a.own_blocks + a.find_blocks;
+    if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; }
     const bool timed = d->kev_left > 0 && plan_prev;
     if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3], s);
-    launch_step(d->variant, fused_plan, (fused_plan ? a.plan_blocks : 0u) + a.own_blocks + find_blocks, s, a);
+    launch_step(d->variant, grid, s, a);
     if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s);
     if (plan_prev && d->last_rest_step + 1 != step && hipMemsetAsync(a.patch_count, 0, 4, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: memset");
-    if (plan_prev) d->last_rest_step = step;
-    if (plan_prev) step_rest_kernel<<<std::max(std::min(L.rem_blocks, 512u), 128u), 256, 0, s>>>(a, reinterpret_cast<unsigned*>(L.next_ctr));   // (128 .. 512 blocks: all resident, see its arrival counter; the corrections take the whole grid)
+    if (plan_prev) {
+      d->last_rest_step = step;
+      step_rest_kernel<<<std::max(std::min(L.rem_blocks, 512u), 128u), 256, 0, s>>>(a, reinterpret_cast<unsigned*>(L.next_ctr));   // (128 .. 512 blocks: all resident, see its arrival counter; the corrections take the whole grid)
+    }
     if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
     if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: launch failed");
     if (plan_prev) step_epoch_public(t);
     d->n_overlapped += 1;
   }
   d->pending = n > 0;
-  d->pend_slot = slot;
+  d->pend_slot = slot; d->pend_ids = ids; d->pend_n = n;
   if (n_next) { d->ahead = true; d->ahead_ids = ids_next; d->ahead_n = n_next; }
-  d->seq += 1;
+  if (n) d->seq += 1;
   return TFRA_OK;
 }
 
 extern "C" int tfra_table_step_overlap(tfra_step_driver_t* d, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists_out,
                                        const void* defaults, int default_is_full, const void* values_prev, const uint64_t* scores_prev,
-                                       size_t n_next, const int64_t* ids_next, tfra_stream_t stream) {
+                                       size_t n_next, const int64_t* ids_next, size_t n_next2, const int64_t* ids_next2, tfra_stream_t stream) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_overlap: null driver");
+  if (!n) return set_error(TFRA_ERR_INVALID, "step_overlap: empty batch (tfra_table_step_overlap_flush writes a pending batch back)");
   std::lock_guard<std::mutex> step_lock(d->t->step_mu);
-  return step_overlap_one(d, n, ids, rows_out, exists_out, defaults, default_is_full, values_prev, scores_prev, n_next, ids_next, (hipStream_t)stream);
+  return step_overlap_one(d, n, ids, rows_out, exists_out, defaults, default_is_full, values_prev, scores_prev, n_next, ids_next, n_next2, ids_next2,
+                          (hipStream_t)stream);
 }
 
 extern "C" int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_overlap_step* steps, tfra_stream_t stream) {
@@ -751,8 +791,9 @@ extern "C" int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, con
   for (size_t i = 0; i < count; ++i) {
     const tfra_overlap_step& q = steps[i];
     if (q.struct_size != sizeof(tfra_overlap_step)) return set_error(TFRA_ERR_INVALID, "steps_overlap: struct_size mismatch");
+    if (!q.n) return set_error(TFRA_ERR_INVALID, "steps_overlap: empty batch");
     int rc = step_overlap_one(d, q.n, q.ids, q.rows_out, q.exists_out, q.defaults, q.default_is_full, q.values_prev, q.scores_prev, q.n_next,
-                              q.ids_next, (hipStream_t)stream);
+                              q.ids_next, q.n_next2, q.ids_next2, (hipStream_t)stream);
     if (rc) return rc;
   }
   return TFRA_OK;
@@ -763,12 +804,8 @@ extern "C" int tfra_table_step_overlap_flush(tfra_step_driver_t* d, const void* 
   std::lock_guard<std::mutex> step_lock(d->t->step_mu);
   if (!d->pending) return TFRA_OK;
   if (!values_prev) return set_error(TFRA_ERR_INVALID, "step_overlap_flush: null values_prev");
-  tfra_sparse_plan* plan_prev = d->plans[d->pend_slot];
-  std::lock_guard<std::mutex> lock(d->t->mu);
-  int rc = upsert_planned_impl(d->tp, plan_prev, values_prev, scores_prev, stream, d->progress, ++d->step_no);
-  if (rc) return rc;
-  d->pending = false;
-  return TFRA_OK;
+  // the pending write-back alone: a step without a lookup (its launch holds the ownership pass only), or the planned upsert
+  return step_overlap_one(d, 0, nullptr, nullptr, nullptr, nullptr, 0, values_prev, scores_prev, 0, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 #endif  // TFRA_STEP_HOST_PART

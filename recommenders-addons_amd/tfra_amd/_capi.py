@@ -75,6 +75,7 @@ class OverlapStep(ctypes.Structure):
       ("struct_size", ctypes.c_uint32), ("default_is_full", ctypes.c_int32), ("n", ctypes.c_size_t), ("ids", ctypes.c_void_p),
       ("rows_out", ctypes.c_void_p), ("exists_out", ctypes.c_void_p), ("defaults", ctypes.c_void_p), ("values_prev", ctypes.c_void_p),
       ("scores_prev", ctypes.c_void_p), ("n_next", ctypes.c_size_t), ("ids_next", ctypes.c_void_p),
+      ("n_next2", ctypes.c_size_t), ("ids_next2", ctypes.c_void_p),
   ]
 
 
@@ -127,13 +128,13 @@ _SIGS = {
     "tfra_table_step_prefetch_assign": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P],
     "tfra_step_driver_create": [_P, ctypes.POINTER(_P)],
     "tfra_step_driver_destroy": [_P],
-    "tfra_table_step_overlap": [_P, _SZ, _P, _P, _P, _P, _I, _P, _P, _SZ, _P, _P],
+    "tfra_table_step_overlap": [_P, _SZ, _P, _P, _P, _P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
     "tfra_table_step_overlap_flush": [_P, _P, _P, _P],
     "tfra_table_steps_overlap": [_P, _SZ, _P, _P],
     "tfra_step_driver_timing": [_P, _P],
     "tfra_step_driver_time_kernels": [_P, _SZ],
     "tfra_step_driver_kernel_times": [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_SZ)],
-    "tfra_step_driver_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_I), _P, _P],
+    "tfra_step_driver_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_I), _P, _P, _P],
     "tfra_table_upsert_sparse": [_P, _SZ, _P, _P, _P, _P],
     "tfra_table_upsert_planned": [_P, _P, _P, _P, _P],
     "tfra_sparse_plan_read": [_P, _P, _P, _P, _P, _SZ, _P],

@@ -680,8 +680,8 @@ class OverlapAssignStep:
   """The overlapped step (`tfra_table_step_overlap`, csrc/tfra_step_impl.h): same use as `PrefetchAssignStep` —
 
       os_ = OverlapAssignStep(table).prime(first_ids)
-      for ...: rows = os_.step(values, next_ids)       # rows = lookup(batch i); values [n, dim] = what batch i writes back
-      os_.flush()                                       # before the table is used any other way
+      for ...: rows = os_.step(values, next_ids, next2_ids)   # rows = lookup(batch i); values [n, dim] = what batch i writes back
+      os_.flush()                                             # before the table is used any other way
 
   — and the same results as lookup(i); insert_or_assign(i); lookup(i+1); ... one after the other, but the write-back of
   batch i runs in the SAME kernel launch as the lookup of batch i+1: ids the two batches share are served from `values` (which
@@ -699,6 +699,7 @@ class OverlapAssignStep:
     self._ids = None
     self._pending = None      # (ids, values) of the batch still to be written back: kept alive until it has been
     self._keep = None
+    self._keep2 = None
     self._fn = _capi.lib().tfra_table_step_overlap
     self._default_p = ctypes.c_void_p(self.default.data_ptr())
 
@@ -719,7 +720,10 @@ class OverlapAssignStep:
     self._ids = self._as_ids(ids)
     return self
 
-  def step(self, values, next_ids=None, return_exists=False):
+  def step(self, values, next_ids=None, next2_ids=None, return_exists=False):
+    """next_ids / next2_ids: the ids of the next step and of the one after it (an input pipeline knows them): with both, the
+    de-duplication plan of a batch is built inside the step launches, without atomics; with next_ids only, by a launch of its
+    own per step; with neither, in front of the next step."""
     from .table_ops import _stream
     ids = self._ids
     n = ids.numel()
@@ -729,12 +733,15 @@ class OverlapAssignStep:
     out = torch.empty((n, dim), dtype=vdt, device=dev)
     ex = torch.empty(n, dtype=torch.bool, device=dev) if return_exists else None
     nxt = self._as_ids(next_ids) if next_ids is not None else None
+    nx2 = self._as_ids(next2_ids) if next2_ids is not None else None
     prev = self._pending
     _capi.check(self._fn(self._h, n, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                          ctypes.c_void_p(ex.data_ptr()) if ex is not None else None, self._default_p, 0,
                          ctypes.c_void_p(prev[1].data_ptr()) if prev is not None else None, None,
-                         0 if nxt is None else nxt.numel(), ctypes.c_void_p(nxt.data_ptr()) if nxt is not None else None, _stream(dev)))
-    self._keep = prev            # its buffers are read by the launch just enqueued
+                         0 if nxt is None else nxt.numel(), ctypes.c_void_p(nxt.data_ptr()) if nxt is not None else None,
+                         0 if nx2 is None else nx2.numel(), ctypes.c_void_p(nx2.data_ptr()) if nx2 is not None else None, _stream(dev)))
+    self._keep = (prev, self._keep2)   # their buffers are read by the launch just enqueued
+    self._keep2 = nx2
     self._pending = (ids, values)
     self._ids = nxt
     return (out, ex) if return_exists else out
@@ -750,9 +757,11 @@ class OverlapAssignStep:
     a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
     dc = (ctypes.c_uint32 * 3)()
     why = ctypes.c_uint32()
-    _capi.call("tfra_step_driver_stats", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), dc, ctypes.byref(why))
+    pb = (ctypes.c_uint64 * 2)()
+    _capi.call("tfra_step_driver_stats", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), dc, ctypes.byref(why), pb)
     return {"overlapped": a.value, "sequential": b.value, "pending": bool(c.value), "deferred_evictions": dc[0],
-            "victims_noted": dc[1], "rows_corrected": dc[2], "why_sequential": why.value}
+            "victims_noted": dc[1], "rows_corrected": dc[2], "why_sequential": why.value, "plans_built_in_launch": pb[0],
+            "plans_built_in_front": pb[1]}
 
   def time_kernels(self, steps):
     """HIP events around the two launches of the next `steps` overlapped steps (on their stream); read with kernel_times()."""
@@ -764,25 +773,26 @@ class OverlapAssignStep:
     return {"step_kernel_us": a.value, "rest_kernel_us": b.value, "steps": n.value}
 
   def timing(self):
-    """tuning (TFRA_STEP_VARIANT & 16): [(plan, write-back, lookup) spans in us relative to the launch's first block] per launch"""
-    buf = (ctypes.c_uint64 * (64 * 3 * 2 + 8))()
+    """tuning (TFRA_STEP_VARIANT & 16): per launch, the (start, end) of each role — build, scatter, write-back, lookup — in us since
+    the launch's first block (None: the role did not run)"""
+    buf = (ctypes.c_uint64 * (64 * 4 * 2))()
     _capi.call("tfra_step_driver_timing", self._h, buf)
-    self.plan_phases_us = {n: buf[64 * 3 * 2 + i] / 100.0 for i, n in enumerate(("ids_arrived", "lds_done", "first_swaps_back", "swap_chains_done", "count_back_and_cleared"))}
+    none = 2 ** 64 - 1
     out = []
     for k in range(64):
-      w = [buf[(k * 3 + r) * 2 + j] for r in range(3) for j in range(2)]
-      starts = [w[i] for i in (0, 2, 4) if w[i] != 2 ** 64 - 1]
+      w = [(buf[(k * 4 + r) * 2], buf[(k * 4 + r) * 2 + 1]) for r in range(4)]
+      starts = [x[0] for x in w if x[0] != none]
       if not starts:
         continue
       t0 = min(starts)
-      out.append([None if w[2 * r] == 2 ** 64 - 1 else ((w[2 * r] - t0) / 100.0, (w[2 * r + 1] - t0) / 100.0) for r in range(3)])
+      out.append([None if x[0] == none else ((x[0] - t0) / 100.0, (x[1] - t0) / 100.0) for x in w])
     return out
 
-  def make_run(self, ids_list, values_list, outs, ids_after=None, values_before=None):
+  def make_run(self, ids_list, values_list, outs, ids_after=None, values_before=None, ids_after2=None):
     """Pre-builds the argument array of `tfra_table_steps_overlap` for the steps (ids_list[k], values_list[k]) -> outs[k]:
     returns a callable that enqueues all of them with ONE host call.  values_before = the values of the batch pending when
-    the run starts (None: nothing pending); ids_after = the ids of the step behind the run (its plan is built by the run's
-    last launch).  The caller keeps every tensor alive and unchanged until the run has executed."""
+    the run starts (None: nothing pending); ids_after / ids_after2 = the ids of the two steps behind the run (their plans are
+    built / started by the run's last launches).  The caller keeps every tensor alive and unchanged until the run has executed."""
     from .table_ops import _stream
     m = len(ids_list)
     arr = (_capi.OverlapStep * m)()
@@ -801,6 +811,9 @@ class OverlapAssignStep:
       nx = ids_list[k + 1] if k + 1 < m else ids_after
       q.n_next = nx.numel() if nx is not None else 0
       q.ids_next = nx.data_ptr() if nx is not None else None
+      n2 = ids_list[k + 2] if k + 2 < m else (ids_after if k + 2 == m else ids_after2)
+      q.n_next2 = n2.numel() if n2 is not None else 0
+      q.ids_next2 = n2.data_ptr() if n2 is not None else None
     fn = _capi.lib().tfra_table_steps_overlap
     h, dev = self._h, self.dev
     last = (ids_list[-1], values_list[-1])
@@ -809,5 +822,5 @@ class OverlapAssignStep:
       _capi.check(fn(h, m, arr, _stream(dev)))
       self._pending = last
       self._ids = ids_after
-    run._keep = (arr, ids_list, values_list, outs, ids_after, values_before)
+    run._keep = (arr, ids_list, values_list, outs, ids_after, values_before, ids_after2)
     return run

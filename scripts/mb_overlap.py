@@ -23,6 +23,7 @@ def main():
   ap.add_argument("--dim", type=int, default=64)
   ap.add_argument("--dtype", default="float32")
   ap.add_argument("--skip-old", action="store_true")
+  ap.add_argument("--one-ahead", action="store_true", help="D = 1: announce only the next batch (its plan is then built by a launch of its own)")
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mb_overlap.json"))
   args = ap.parse_args()
   import torch
@@ -98,7 +99,7 @@ def main():
         def one(w):
           for i in range(K):
             j = base[0]
-            drv.step(values, ids[(j + 1) % NB])
+            drv.step(values, ids[(j + 1) % NB], ids[(j + 2) % NB] if not args.one_ahead else None)
             base[0] += 1
         fn = one
       else:
@@ -109,7 +110,8 @@ def main():
             j0 = w * K + c * D
             il = [ids[(j0 + q) % NB] for q in range(D)]
             ol = [outs[q % 8] for q in range(D)]
-            rr.append(drv.make_run(il, [values] * D, ol, ids_after=ids[(j0 + D) % NB], values_before=None if (w == 0 and c == 0) else values))
+            rr.append(drv.make_run(il, [values] * D, ol, ids_after=ids[(j0 + D) % NB], values_before=None if (w == 0 and c == 0) else values,
+                                   ids_after2=ids[(j0 + D + 1) % NB]))
           runs.append(rr)
 
         def many(w):
@@ -126,8 +128,8 @@ def main():
         fn(0)
         K = K_save
         sp = [x for x in drv.timing() if all(y is not None for y in x)]
-        tm = {"launches": len(sp), "plan_phases_us_since_block_start_median": drv.plan_phases_us, "role_spans_us_median (start, end since the launch's first block)":
-              {r: [float(np.median([x[i][0] for x in sp])), float(np.median([x[i][1] for x in sp]))] for i, r in enumerate(("plan", "write_back", "lookup"))}}
+        tm = {"launches": len(sp), "role_spans_us_median (start, end since the launch's first block)":
+              {r: [float(np.median([x[i][0] for x in sp])), float(np.median([x[i][1] for x in sp]))] for i, r in enumerate(("build", "scatter", "write_back", "lookup"))} if sp else None}
       us, hus, all_ = timed(fn)
       st = drv.stats()
       drv.flush()

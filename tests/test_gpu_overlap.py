@@ -67,7 +67,8 @@ def test_overlap_step_equals_sequential_ops_dictionary_oracle(env, cap, n):
     ids = batches[s]
     vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
     look_ahead = batches[s + 1] if s % 4 != 3 else None      # every fourth step: the next ids are NOT announced
-    out, ex = drv.step(vals, look_ahead, return_exists=True)
+    ahead2 = batches[s + 2] if (s % 5 != 2 and look_ahead is not None and s + 2 <= nsteps) else None   # ... and not always two ahead
+    out, ex = drv.step(vals, look_ahead, ahead2, return_exists=True)
     if look_ahead is None:
       drv.prime(batches[s + 1])
     ref, rex = tbl.find(ids, return_exists=True)            # the table right now = what this lookup had to reflect
@@ -129,13 +130,23 @@ def test_overlap_step_evictions_and_forced_conflicts(env):
   drv.prime(torch.from_numpy(ids_np).cuda())
   prev_keys = None
   n_absent_old = 0
+  keep_alive, nxt2_np, nxt2_t = [], None, None
   for s in range(nsteps):
     ids = torch.from_numpy(ids_np).cuda()
     vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
     for i, k in enumerate(ids_np.tolist()):     # (the next batch is drawn knowing this one's writes: who is oldest after it)
       last_write[k] = s
-    nxt_np = make_batch(s + 1)
-    out, ex = drv.step(vals, torch.from_numpy(nxt_np).cuda(), return_exists=True)
+    # two batches are always announced — as the SAME device buffers from call to call, that is how the driver knows them again —
+    # so the plans are built by the step launches
+    if s == 0:
+      nxt_np = make_batch(s + 1)
+      nxt_t = torch.from_numpy(nxt_np).cuda()
+    else:
+      nxt_np, nxt_t = nxt2_np, nxt2_t
+    nxt2_np = make_batch(s + 2)
+    nxt2_t = torch.from_numpy(nxt2_np).cuda()
+    keep_alive.append((ids, nxt_t, nxt2_t))
+    out, ex = drv.step(vals, nxt_t, nxt2_t, return_exists=True)
     ref, rex = tbl.find(ids, return_exists=True)
     assert torch.equal(ex, rex), "step %d: %d exists flags differ" % (s, int((ex != rex).sum()))
     assert torch.equal(out, ref), "step %d" % s
@@ -156,6 +167,7 @@ def test_overlap_step_evictions_and_forced_conflicts(env):
   # (the host learns that the table is dense from asynchronous size reads: the first steps may still run one op after the other)
   assert st["overlapped"] + st["sequential"] == nsteps and st["overlapped"] >= nsteps - 8, st
   assert st["deferred_evictions"] > 0 and st["victims_noted"] > 0 and st["rows_corrected"] > 0, st
+  assert st["plans_built_in_launch"] >= nsteps - 10, st     # the two-launch, atomic-free plan build really ran
   ek, ev = t.export()
   ekn = ek.cpu().numpy()
   assert np.unique(ekn).size == ekn.size
