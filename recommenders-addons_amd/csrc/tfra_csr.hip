@@ -913,7 +913,8 @@ template <int G>
 __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsigned char* __restrict__ vals, i64 key, unsigned last,
                                                  u64 in_score, const AuxInitPod& ai, const ScoreP& sp, int sub, int gshift,
                                                  int& fresh, int& failed, bool hinted = false, unsigned hint_word = 0,
-                                                 i64* evicted_key = nullptr, int acc = 0, int acc_dt = 0) {
+                                                 i64* evicted_key = nullptr, int acc = 0, int acc_dt = 0, i64* given_back = nullptr,
+                                                 int* n_given_back = nullptr) {
   // evicted_key (optional): set to the key this upsert replaced by eviction (untouched when it evicted nothing)
   // acc: the reference's insert_or_accum for this key (accumrase_fn, cuckoohash_map.hh:619-633) instead of an assign —
   //   1 (exists): present -> row += delta, one add per element; absent -> nothing.   2 (!exists): absent -> insert; present -> nothing
@@ -962,7 +963,7 @@ __device__ __forceinline__ void locked_upsert_kv(const TableView& v, const unsig
       bool ce = false;
       u64 wd = 0;
       i64 vk = EMPTY_KEY;
-      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce, pre ? kk2 : nullptr, pre ? sc2 : nullptr, &vk);
+      r = evict_and_lock(v, key, cmp, lru_like, sub, gshift, &wd, ce, pre ? kk2 : nullptr, pre ? sc2 : nullptr, &vk, given_back, n_given_back);
       if (r == -1) break;                        // not admitted (its score is below every resident one): dropped
       if (r == -3) { failed += (sub == 0); break; }
       row = r; word = wd; is_new = true; evicted = !ce;
@@ -1368,7 +1369,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
       if (ex[u]) hint[u] |= 2u;                                                // the item carries the flag
     }
     if (act[u] && flag_b0[u] && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
-    if (sub == 0 && why[u]) a.dflag[gk[u]] = 4;
+    if (sub == 0 && why[u]) { if (CF) __hip_atomic_store(a.dflag + gk[u], (uint8_t)4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else a.dflag[gk[u]] = 4; }
     fresh += (act[u] == 2 && sub == 0);
   }
   {   // left-over keys of the wave -> the list: one atomic add for all of them
@@ -1388,7 +1389,8 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
             uint4 w;
             if (sub == 0) w = make_uint4((unsigned)(u64)key[u], (unsigned)((u64)key[u] >> 32), last[u], gk[u]);
             else w = make_uint4((unsigned)in_s[u], (unsigned)(in_s[u] >> 32), hint[u], (unsigned)word[u]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.items + pos) + sub * 16) = w;
+            if (CF) store_wt16(reinterpret_cast<unsigned char*>(a.items + pos) + sub * 16, w);   // (read by the tail role of the same launch)
+            else *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.items + pos) + sub * 16) = w;
           }
         }
         at += (unsigned)__popcll(sm[u]);
@@ -1438,10 +1440,11 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
               __hip_atomic_store(q + off, (unsigned char)(pat >> (8 * (off % a.ai.elem_bytes))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (sub == 0) *key_word(v, word[u]) = key[u];   // owned bucket: a plain store
+      if (sub == 0) { if (CF) store_wt8(key_word(v, word[u]), (u64)key[u]); else *key_word(v, word[u]) = key[u]; }   // owned bucket: a plain store (CF: write-through, the
+                                                                                                                   // left-over keys follow in the same launch)
     }
     if (!fl.with_scores) continue;
-    if (fl.lru) { if (sub == 0) *score_word(v, word[u]) = now; }
+    if (fl.lru) { if (sub == 0) { if (CF) store_wt8(score_word(v, word[u]), now); else *score_word(v, word[u]) = now; } }
     else if (act[u] == 3 && a.sp.strategy == TFRA_EVICT_LFU) { if (sub == 0) store_wt8(score_word(v, word[u]), in_s[u]); }   // the slot starts a new life
     else update_score<true>(v, (i64)((word[u] >> 4) * SLOTS + (word[u] & 15)), act[u] >= 2, a.sp.strategy, in_s[u], a.sp.epoch, sub);
   }

@@ -361,12 +361,14 @@ __device__ __forceinline__ void select_victim_merged(u64 b0, u64 b1, const i64 (
 // the most recent); otherwise the new key enters only if in_score >= the minimum score.
 // Returns the row whose key word now holds LOCKED_KEY (the caller writes row + score, then publishes
 // the key with publish_key), -1 when the key was not admitted, -3 when no victim could be taken.
-// victim_key (optional): receives the replaced key.
+// victim_key (optional): receives the replaced key.  given_back / n_given_back (optional): the keys whose slot this call locked
+// and gave back (up to 4 are kept; the count goes on).
 // pre_k / pre_s (optional): key and score lines of (b0, b1) preloaded by the caller — a kernel that handles several keys
 // per group puts all of their lines in flight before resolving any (first attempt only; retries reload).
 __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 in_score, bool admit_always, int sub,
                                               int gshift, u64* victim_word, bool& claimed_empty,
-                                              const i64* pre_k = nullptr, const i64* pre_s = nullptr, i64* victim_key = nullptr) {
+                                              const i64* pre_k = nullptr, const i64* pre_s = nullptr, i64* victim_key = nullptr,
+                                              i64* given_back = nullptr, int* n_given_back = nullptr) {
   u64 h;
   const u64 b0 = bucket0(key, v.nb, h);
   const u64 b1 = bucket1(h, b0, v.nb);
@@ -404,6 +406,8 @@ __device__ __forceinline__ i64 evict_and_lock(const TableView& v, i64 key, u64 i
         const u64 now = ((u64)(unsigned)__shfl((int)hi, gshift) << 32) | (unsigned)__shfl((int)lo, gshift);
         if (now != best_score) {
           if (sub == 0) __hip_atomic_store(key_word(v, best_word), best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // (the slot showed LOCKED for a moment: a lookup running beside this call may have missed the key)
+          if (given_back && n_given_back) { if (*n_given_back < 4) given_back[*n_given_back] = best_key; *n_given_back += 1; }
           continue;
         }
       }

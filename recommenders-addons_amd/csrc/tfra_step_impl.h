@@ -55,8 +55,13 @@ struct StepArgs {
   unsigned scat_n, scat_m2, scat_tiles, scat_blocks;
   const i64* scat_ids;
   SetEnt* scat_pairs; unsigned* scat_cnt; SetEnt* scat_ovf; unsigned* scat_ovf_cnt; unsigned* scat_ovf_cnt_next;   // (two overflow counters alternate: this scatter zeroes the next one's)
-  unsigned own_blocks, find_blocks;
+  unsigned own_blocks, find_blocks, tail_blocks;
+  unsigned* sync;              // this launch's counters, one 128-byte line each: [0] write-back blocks done, [32 .. 32*8] lookup blocks done
+                               // (8 shards), [32*9] tail blocks through their items; sync_next: the next launch's (two sets alternate)
+  unsigned* sync_next;
+  unsigned* zero4;             // the left-over counters of the plan's NEXT use (armed by the tail)
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
+  int prio;                    // (tuning) raised wave priority for the write-back and the tail
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
   u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
   i64* patch_keys;             // step_rest_kernel: the launch's list of evicted keys that are ids of this batch
@@ -72,7 +77,9 @@ struct StepLds {
   unsigned cnt[256];           // scatter: pairs per window
   unsigned n;
 };
-constexpr unsigned OWN_SLICE = 288;   // plan slots per write-back block: ~25 keys at 22.7 K keys in 2^18 slots, 32 fit one round
+constexpr unsigned OWN_SLICE = 288;   // plan slots per write-back block: ~25 keys at 22.7 K keys in 2^18 slots, 32 fit one round of the block's four
+                                      // waves.  (208 slots — no block ever needs a second round — makes 1261 blocks: they fill every wave slot of the
+                                      // chip before the first lookup block starts, and the step went from 31 to 35 us.)
 
 // ---- SCATTER role: setplan_kernel's LDS phase, then plain stores ------------------------------------------------------
 // Equal ids of the tile meet in LDS (compare-and-swap on the key, max on position + 1); every distinct id then goes, with its
@@ -267,7 +274,8 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
     const unsigned fw = fwd_pos[u];
     i64 word = 0;
     if (!fw) word = probe_find_word(v, key[u], b0[u], b1[u], k0[u], sub, gshift, &k1[u]);
-    if (a.exists && sub == 0) a.exists[idx[u]] = fw != 0 || word >= 0;
+    // (write-through like the rows: the tail's corrections come from another workgroup and must land BEHIND this store)
+    if (a.exists && sub == 0) __hip_atomic_store(a.exists + idx[u], (uint8_t)(fw != 0 || word >= 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     src[u] = fw ? a.own.vals + (u64)(fw - 1u) * (u64)v.field_bytes
                 : (word >= 0 ? word_row_ptr(v, (u64)word) : a.defaults + (a.full ? (u64)idx[u] * (u64)v.field_bytes : 0));
     dst[u] = a.out + (u64)idx[u] * (u64)v.field_bytes;
@@ -281,6 +289,12 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
     for (int u = 0; u < U; ++u) store_wt16(dst[u] + off, tmp[u]);
   }
 }
+// a lookup block is done: its output rows are in memory (write-through, acknowledged).  Only the tail's rare corrections wait for this.
+__device__ __forceinline__ void find_arrive(const StepArgs& a) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && a.tail_blocks) __hip_atomic_fetch_add(a.sync + 32 * (1 + (blockIdx.x & 7u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- OWN role: the ownership pass over the previous batch's plan, read straight from its TABLE ---------------------------
 // The plan keeps no dense list of its keys any more (that list was a returned atomic per tile and a dependent round trip of
@@ -292,6 +306,7 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   const OwnArgs& o = a.own;
   const unsigned tid = threadIdx.x;
   const int lane = tid & 63;
+  if (a.prio) __builtin_amdgcn_s_setprio(2);   // (the tail waits for the last of these blocks, the launch for the tail)
   const unsigned lo = blk * OWN_SLICE, total_slots = a.fwd.m2 + 2;
   if (tid == 0) L.n = 0;
   uint4 e[2];
@@ -327,6 +342,10 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(o.v, blk * 4u + (tid >> 6), fresh);
+  // this block's part of the pass is in memory (everything it wrote went write-through or by atomics): the tail may go on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // TIMING (tuning builds only): every block notes its start and end on the device clock in a.tbuf (a slot per launch and block):
@@ -340,21 +359,21 @@ __device__ __forceinline__ void role_stamp(const StepArgs& a, u64 t0) {
     w[1] = (u64)wall_clock64();
   }
 }
-// role of block b: 0 build, 1 scatter, 2 write-back, 3 lookup; *idx = its index in the role.  The builders come first (short
-// chains of dependent round trips, few blocks); the write-back's O blocks are spread evenly among the lookup's F blocks (own
-// block j at position floor(j (O + F) / O)): blocks are dispatched in index order, and a role whose blocks all come first
-// fills every wave slot of the chip while the role behind it waits for them to retire.
+// role of block b: 0 build, 1 scatter, 2 write-back, 3 lookup, 4 tail; *idx = its index in the role.  The builders come first
+// (short chains of dependent round trips, few blocks), then the whole write-back (the tail waits for it), the lookup, the tail.
+// (Spreading the write-back's blocks among the lookup's changed nothing: the launch is bound by what the memory system moves.)
 __host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned O, unsigned F, unsigned* idx) {
   if (b < build_blocks) { *idx = b; return 0; }
   b -= build_blocks;
   if (b < scat_blocks) { *idx = b; return 1; }
   b -= scat_blocks;
-  const unsigned T = O + F;
-  const unsigned c = O ? (unsigned)(((unsigned long long)b * O + T - 1) / T) : 0u;   // own blocks in front of position b
-  if (c < O && (unsigned)(((unsigned long long)c * T) / O) == b) { *idx = c; return 2; }
-  *idx = b - c;
-  return 3;
+  if (b < O) { *idx = b; return 2; }
+  b -= O;
+  if (b < F) { *idx = b; return 3; }
+  *idx = b - F;
+  return 4;
 }
+__device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepLds& L);
 template <bool SIMPLE, int U, bool TIMING>
 __device__ __forceinline__ void step_body(const StepArgs& a) {
   __shared__ StepLds L;
@@ -364,7 +383,8 @@ __device__ __forceinline__ void step_body(const StepArgs& a) {
   if (role == 0) build_role(a, idx, L);
   else if (role == 1) scatter_role(a, idx, L);
   else if (role == 2) own_role<SIMPLE, U>(a, idx, L);
-  else find_fwd_role(a, idx);
+  else if (role == 3) { find_fwd_role(a, idx); find_arrive(a); }
+  else tail_role(a, idx, L);
   if (TIMING) role_stamp(a, t0);
 }
 // Instantiations (the SGPR budget is an attribute, not a template argument): 256-thread blocks are admitted per CU up to
@@ -378,101 +398,130 @@ TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 104)
 TFRA_STEP_KERNEL(step_k_u1_t, 1, true, 104)
 #undef TFRA_STEP_KERNEL
 
-// ---- the remainder of a step: left-over keys of the pass + corrections of the lookup's output ------------------------
-// upsert_rest_kernel<16, SRC_SET> over the pass's item list (the flags of all keys when the list overflowed).  Runs AFTER the
-// launch that held the lookup, so an eviction here may hit a key that lookup has just returned a row for: every victim that is
-// one of this batch's ids (plan `nxt`) goes onto a list of the launch.  When every block has finished its items (one arrival
-// counter: the grid is at most 512 blocks, all resident, and every block arrives without waiting for anything) and the list is
-// not empty, ALL blocks look the listed victims up again and, for those that are absent now, rewrite the lookup's output rows
-// with the default row and clear their exists flags — what a lookup behind the write-back returns — each block for its share
-// of the batch's positions.  (A victim that is present again was a key of the previous batch whose own left-over write came
-// later in this kernel.)  The first form let the one block that had noted a victim scan the whole batch: 170 us for 131 072 ids,
-// and right after a bulk load in rank order the hottest ids are the least recently used entries: one step in eight paid it.
-constexpr unsigned PATCH_CAP = 64, PATCH_GCAP = 4096;
-__global__ __launch_bounds__(256) void step_rest_kernel(const StepArgs a, unsigned* zero4) {
-  __shared__ i64 s_patch[PATCH_CAP];
-  __shared__ unsigned char s_absent[PATCH_CAP];
-  __shared__ unsigned s_nv;
+// ---- TAIL role: the remainder of a step INSIDE its launch ------------------------------------------------------------------
+// The keys the pass left over (lost claims, evictions it deferred) with the locked protocol, and the corrections of the
+// lookup's output.  As a launch of its own behind the step this cost 5.5 us of dependent round trips plus two kernel
+// boundaries — a quarter of the step — for a dozen keys.  Here it is the LAST blocks of the grid (blocks are dispatched in index
+// order: when a tail block runs, every other block of the launch is running or done — nothing it waits for can be waiting for a
+// wave slot), which
+//   1. wait until every write-back block has arrived (a.sync[0]; their stores are write-through, acknowledged before they arrive),
+//   2. take the item list with the locked protocol, beside the lookup blocks still running — an eviction here may hit a key the
+//      lookup has returned (or is about to return) a row for: every victim that is one of this batch's ids (plan `nxt`) goes
+//      onto the launch's list;
+//   3. meet (a.sync[32*9]); if the list is not empty — rare — wait for every lookup block too, look the listed victims up again
+//      and, for those that are absent now, rewrite the lookup's output rows with the default row and clear their exists flags,
+//      each block for its share of the batch.  (A victim that is present again was a key of the previous batch whose own
+//      left-over write came later.)
+// The spins are bounded; a timeout is reported through the table's error counter, never silent.
+constexpr unsigned PATCH_CAP = 64, PATCH_GCAP = 4096, TAIL_BLOCKS = 32;
+__device__ __forceinline__ bool spin_until(const unsigned* ctr, unsigned want) {
+  for (unsigned it = 0; it < (1u << 22); ++it) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return false;
+}
+__device__ __forceinline__ uint4 load_coherent16(const void* p) {   // written write-through by another workgroup of this launch
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint4((unsigned)x, (unsigned)(x >> 32), (unsigned)y, (unsigned)(y >> 32));
+}
+__device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepLds& L) {
+  i64* s_patch = L.key;                                            // [PATCH_CAP]
+  i64* s_row = L.key + PATCH_CAP;                                  // [PATCH_CAP] row index now, -1: absent
+  unsigned& s_nv = L.n;
   const OwnArgs& o = a.own;
-  const unsigned* slow_ctr = &a.ctr->n_a;
-  unsigned* arrived = &a.ctr->spare[0];
-  const unsigned gi = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const OwnItem* it0 = o.items + (gi < o.item_cap ? gi : 0u);
-  const uint4 f0 = reinterpret_cast<const uint4*>(it0)[0], f1 = reinterpret_cast<const uint4*>(it0)[1];
-  const unsigned counted = *slow_ctr;
-  if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.patch_count_next = 0;            // (the next step's list: its last reader is long gone)
-  if (counted == 0) return;                                                    // no items, no evictions, nothing to correct
+  const unsigned tid = threadIdx.x;
+  const int lane = tid & 63, sub = lane & 15, gshift = lane & 48;
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
+  if (blk == 0) {   // arm what the next launch counts in (its users of two launches ago are long gone)
+    if (tid < 4 && a.zero4) a.zero4[tid] = 0;
+    if (tid >= 32 && tid < 42) a.sync_next[32 * (tid - 32)] = 0;
+    if (tid == 63) *a.patch_count_next = 0;
+  }
+  bool ok = true;
+  if (tid == 0) ok = spin_until(a.sync, a.own_blocks);
+  __syncthreads();
+  const unsigned counted = __hip_atomic_load(&a.ctr->n_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (counted == 0) return;                                        // no items, no evictions, nothing to correct (the same in every tail block)
   const bool listed = counted <= o.item_cap;
-  const unsigned n = listed ? counted : a.fwd.m2 + 2;   // (the list overflowed: the flag byte of every slot of the plan's table)
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
+  const unsigned n = listed ? counted : a.fwd.m2 + 2;              // (the list overflowed: the flag byte of every slot of the plan's table)
+  const unsigned gi = (blk * 256u + tid) >> 4, ngroups = (a.tail_blocks * 256u) >> 4;
   int fresh = 0, failed = 0;
+  // a key whose slot changed hands — or showed LOCKED for a moment — while the lookup was running, and which the lookup looks for
+  auto note = [&](i64 k) {
+    if (k == EMPTY_KEY || k == LOCKED_KEY || !a.n || !set_contains_group(a.nxt, k, sub, gshift)) return;
+    if (sub == 0) {
+      const unsigned at = atomicAdd(a.patch_count, 1u);
+      atomicAdd(a.stat + 1, 1u);
+      if (at < PATCH_GCAP) __hip_atomic_store(a.patch_keys + at, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else atomicAdd(o.v.err_count, 1u);   // (thousands of them in one step: reported by check_errors, never silent)
+    }
+  };
   for (unsigned i = gi; i < n; i += ngroups) {
-    i64 vk = EMPTY_KEY;
+    i64 vk = EMPTY_KEY, gb[4];
+    int ngb = 0;
     if (listed) {
-      uint4 w0 = f0, w1 = f1;
-      if (i != gi) {
-        w0 = reinterpret_cast<const uint4*>(o.items + i)[0];
-        w1 = reinterpret_cast<const uint4*>(o.items + i)[1];
-      }
+      const uint4 w0 = load_coherent16(o.items + i), w1 = load_coherent16(reinterpret_cast<const unsigned char*>(o.items + i) + 16);
       const i64 key = (i64)(((u64)w0.y << 32) | w0.x);
-      locked_upsert_kv<16>(o.v, o.vals, key, w0.z, ((u64)w1.y << 32) | w1.x, o.ai, o.sp, sub, gshift, fresh, failed, w1.z != 0, w1.w, &vk);
+      locked_upsert_kv<16>(o.v, o.vals, key, w0.z, ((u64)w1.y << 32) | w1.x, o.ai, o.sp, sub, gshift, fresh, failed, w1.z != 0, w1.w, &vk, 0, 0, gb, &ngb);
       if (sub == 0) o.dflag[w0.w] = 0;
     } else {
-      if (o.dflag[i] != 4) continue;
+      if (__hip_atomic_load(o.dflag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 4) continue;
       const SetEnt* pe = a.fwd.ent + i;
       const i64 key = i >= a.fwd.m2 ? EMPTY_KEY + (i64)(i - a.fwd.m2) : pe->key;
-      locked_upsert_kv<16>(o.v, o.vals, key, pe->pos1 - 1, 1, o.ai, o.sp, sub, gshift, fresh, failed, false, 0, &vk);
+      locked_upsert_kv<16>(o.v, o.vals, key, pe->pos1 - 1, 1, o.ai, o.sp, sub, gshift, fresh, failed, false, 0, &vk, 0, 0, gb, &ngb);
       if (sub == 0) o.dflag[i] = 0;
     }
-    if (vk != EMPTY_KEY && vk != LOCKED_KEY && a.n && set_contains_group(a.nxt, vk, sub, gshift)) {
-      if (sub == 0) {
-        const unsigned at = atomicAdd(a.patch_count, 1u);
-        atomicAdd(a.stat + 1, 1u);
-        if (at < PATCH_GCAP) __hip_atomic_store(a.patch_keys + at, vk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else atomicAdd(o.v.err_count, 1u);   // (thousands of such victims in one step: reported by check_errors, never silent)
-      }
-    }
+    note(vk);
+    for (int q = 0; q < ngb && q < 4; ++q) note(gb[q]);
+    if (ngb > 4 && sub == 0) atomicAdd(o.v.err_count, 1u);
   }
   for (int off = 32; off > 0; off >>= 1) { fresh += __shfl_xor(fresh, off); failed += __shfl_xor(failed, off); }
   if (lane == 0) {
-    if (fresh) size_add(o.v, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, fresh);
+    if (fresh) size_add(o.v, (blk * 256u + tid) >> 6, fresh);
     if (failed) atomicAdd(o.v.err_count, (unsigned)failed);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's table stores and list entries (write-through / agent-scope) are acknowledged
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool ok = false;
-    for (unsigned it = 0; it < (1u << 22) && !ok; ++it) {
-      ok = __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x;
-      if (!ok) __builtin_amdgcn_s_sleep(8);
+  if (tid == 0) {
+    __hip_atomic_fetch_add(a.sync + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = spin_until(a.sync + 32 * 9, a.tail_blocks) && ok;
+    unsigned nv = min(__hip_atomic_load(a.patch_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), PATCH_GCAP);
+    if (nv) {   // the corrections overwrite what the lookup wrote: every lookup block must be done
+      unsigned have = 0;
+      for (unsigned it = 0; it < (1u << 20) && have < a.find_blocks; ++it) {
+        have = 0;
+        for (int q = 1; q <= 8; ++q) have += __hip_atomic_load(a.sync + 32 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (have < a.find_blocks) __builtin_amdgcn_s_sleep(16);
+      }
+      ok = ok && have >= a.find_blocks;
     }
-    if (!ok) atomicAdd(o.v.err_count, 1u);   // (never seen: every block arrives without waiting for anything)
-    s_nv = min(__hip_atomic_load(a.patch_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), PATCH_GCAP);
+    if (!ok) atomicAdd(o.v.err_count, 1u);   // (never seen: nothing anybody waits for here waits for anything itself)
+    s_nv = nv;
   }
   __syncthreads();
   const unsigned nv = s_nv;
   for (unsigned base = 0; base < nv; base += PATCH_CAP) {
     const unsigned np = min(PATCH_CAP, nv - base);
-    // which of these victims are absent now?  (16 groups, one victim each per round; coherent loads)
-    for (unsigned q = threadIdx.x >> 4; q < np; q += 16) {
+    // where are these keys now?  (16 groups, one key each per round; coherent loads)  The lookup is done again for them:
+    for (unsigned q = tid >> 4; q < np; q += 16) {
       const i64 vk = __hip_atomic_load(a.patch_keys + base + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const i64 row = probe_find<true>(o.v, vk, sub, gshift);
-      if (sub == 0) { s_patch[q] = vk; s_absent[q] = row < 0 ? 1 : 0; }
+      if (sub == 0) { s_patch[q] = vk; s_row[q] = row; }
     }
     __syncthreads();
-    // those, against this block's share of the batch
-    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < a.n; p += gridDim.x * blockDim.x) {
+    // ... at this block's share of the batch's positions: the row the table holds now, or the default row
+    for (unsigned p = blk * 256u + tid; p < a.n; p += a.tail_blocks * 256u) {
       const i64 id = a.ids[p];
-      bool hit = false;
-      for (unsigned q = 0; q < np; ++q) hit = hit || (s_absent[q] && s_patch[q] == id);
-      if (!hit) continue;
-      const unsigned char* d = a.defaults + (a.full ? (u64)p * (u64)o.v.field_bytes : 0);
+      int hit = -1;
+      for (unsigned q = 0; q < np; ++q) if (s_patch[q] == id) hit = (int)q;
+      if (hit < 0) continue;
+      const i64 row = s_row[hit];
+      const unsigned char* d = row >= 0 ? row_ptr(o.v, row) : a.defaults + (a.full ? (u64)p * (u64)o.v.field_bytes : 0);
       unsigned char* w = a.out + (u64)p * (u64)o.v.field_bytes;
-      for (unsigned off = 0; off < o.v.field_bytes; off += 16) *reinterpret_cast<uint4*>(w + off) = *reinterpret_cast<const uint4*>(d + off);
-      if (a.exists) a.exists[p] = 0;
+      for (unsigned off = 0; off < o.v.field_bytes; off += 16) *reinterpret_cast<uint4*>(w + off) = load_coherent16(d + off);   // (a row another workgroup of this launch may have written)
+      if (a.exists) a.exists[p] = row >= 0;
       atomicAdd(a.stat + 2, 1u);
     }
     __syncthreads();
@@ -501,9 +550,9 @@ struct tfra_step_driver {
   unsigned* progress = nullptr;            // pinned: [0] step
   unsigned* stat = nullptr;                // device: StepArgs::stat
   u64* tbuf = nullptr;                     // device: StepArgs::tbuf (TFRA_STEP_VARIANT & 16)
-  unsigned tinfo[64][5] = {};              // per launch slot: build, scatter, own, lookup blocks, grid
-  unsigned last_rest_step = ~0u;           // step number of the last step_rest_kernel launch (it zeroes the next step's victim counter)
-  unsigned char* patch = nullptr;          // device: two counters (one 128-B line each) + two lists of PATCH_GCAP keys (step_rest_kernel)
+  unsigned tinfo[64][5] = {};              // per launch slot: build, scatter, own, lookup blocks, grid (the rest: tail)
+  unsigned last_tail_step = ~0u;           // step number of the last launch that had a tail (it zeroes the next launch's counters)
+  unsigned char* patch = nullptr;          // device: two victim counters (one 128-B line each) + two lists of PATCH_GCAP keys + two sets of 10 sync counters (tail_role)
   unsigned step_no = 0;
   int variant = 0;                         // TFRA_STEP_VARIANT (tuning): kernel instantiation
   unsigned long long n_overlapped = 0, n_sequential = 0;   // steps taken each way (tfra_step_driver_stats)
@@ -526,7 +575,8 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   const size_t dn = 4 + 2 + SET_PAD;
   if (hipMalloc((void**)&d->dummy, dn * sizeof(SetEnt)) != hipSuccess) { d->dummy = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   fill_setent_kernel<<<1, 64, 0, nullptr>>>(d->dummy, dn);
-  if (hipMalloc((void**)&d->patch, 256 + 2 * PATCH_GCAP * 8) != hipSuccess || hipMemset(d->patch, 0, 256 + 2 * PATCH_GCAP * 8) != hipSuccess) { d->patch = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
+  constexpr size_t PATCH_BYTES = 256 + 2 * PATCH_GCAP * 8 + 2 * 10 * 128;
+  if (hipMalloc((void**)&d->patch, PATCH_BYTES) != hipSuccess || hipMemset(d->patch, 0, PATCH_BYTES) != hipSuccess) { d->patch = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   if (hipMalloc((void**)&d->stat, 64) != hipSuccess || hipMemset(d->stat, 0, 64) != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
   if (hipHostMalloc((void**)&d->progress, 64, hipHostMallocDefault) != hipSuccess) { d->progress = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipHostMalloc"); }
   d->progress[0] = d->progress[1] = 0;
@@ -573,8 +623,9 @@ extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* ove
 }
 
 // tuning: the block time stamps of the last <= 64 launches made with TFRA_STEP_VARIANT & 16, reduced per role —
-// out[64][4][2] = {earliest block start, latest block end} on the device clock (100 MHz) per launch slot (step % 64) and role
-// (build, scatter, write-back, lookup), ~0 / 0 where nothing ran; synchronises the device and re-arms the stamps.
+// out[64][5][4] = {earliest block start, latest block end, median block duration, 95th percentile of the block durations} on the
+// device clock (100 MHz) per launch slot (step % 64) and role (build, scatter, write-back, lookup, tail), ~0 / 0 where nothing ran;
+// synchronises the device and re-arms the stamps.
 extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_timing: null driver");
   if (!d->tbuf) return set_error(TFRA_ERR_INVALID, "step_driver_timing: the driver was not created with TFRA_STEP_VARIANT & 16");
@@ -588,14 +639,22 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   for (unsigned sl = 0; sl < TIMING_SLOTS; ++sl) {
     const unsigned* ti = d->tinfo[sl];
     const unsigned grid = std::min(ti[4], TIMING_BLOCKS);
-    for (int r = 0; r < 4; ++r) { out[(sl * 4 + r) * 2] = ~0ULL; out[(sl * 4 + r) * 2 + 1] = 0; }
+    std::vector<uint64_t> dur[5];
+    for (int r = 0; r < 5; ++r) { out[(sl * 5 + r) * 4] = ~0ULL; out[(sl * 5 + r) * 4 + 1] = 0; out[(sl * 5 + r) * 4 + 2] = 0; out[(sl * 5 + r) * 4 + 3] = 0; }
     for (unsigned b = 0; b < grid; ++b) {
       const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
       if (!t1) continue;
       unsigned idx;
       const int r = step_role(b, ti[0], ti[1], ti[2], ti[3], &idx);
-      out[(sl * 4 + r) * 2] = std::min(out[(sl * 4 + r) * 2], t0);
-      out[(sl * 4 + r) * 2 + 1] = std::max(out[(sl * 4 + r) * 2 + 1], t1);
+      out[(sl * 5 + r) * 4] = std::min(out[(sl * 5 + r) * 4], t0);
+      out[(sl * 5 + r) * 4 + 1] = std::max(out[(sl * 5 + r) * 4 + 1], t1);
+      dur[r].push_back(t1 - t0);
+    }
+    for (int r = 0; r < 5; ++r) {
+      if (dur[r].empty()) continue;
+      std::sort(dur[r].begin(), dur[r].end());
+      out[(sl * 5 + r) * 4 + 2] = dur[r][dur[r].size() / 2];
+      out[(sl * 5 + r) * 4 + 3] = dur[r][dur[r].size() * 95 / 100];
     }
     d->tinfo[sl][4] = 0;
   }
@@ -724,7 +783,12 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.n = (unsigned)n; a.ids = (const i64*)ids; a.out = (unsigned char*)rows_out; a.exists = exists_out;
     a.defaults = (const unsigned char*)defaults; a.full = default_is_full;
     a.find_blocks = (unsigned)((n + 63) / 64);
+    a.tail_blocks = plan_prev ? TAIL_BLOCKS : 0u;
+    a.sync = reinterpret_cast<unsigned*>(d->patch + 256 + 2 * PATCH_GCAP * 8 + 1280 * (step & 1u));
+    a.sync_next = reinterpret_cast<unsigned*>(d->patch + 256 + 2 * PATCH_GCAP * 8 + 1280 * ((step & 1u) ^ 1u));
+    a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
+    a.prio = (d->variant & 32) ? 1 : 0;
     // the next batch's plan: its pairs were scattered by the previous call's launch -> this launch builds the table; else a launch of its own, in front
     if (n_next) {
       if (plan_next->scat_ids == ids_next && plan_next->scat_n == n_next && !(d->variant & 8)) {
@@ -752,18 +816,16 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.scat_ovf_cnt_next = plan_next2->ovf_cnt + 32 * ((plan_next2->scat_use & 1u) ^ 1u);
       plan_next2->seg_tiles = a.scat_tiles; plan_next2->scat_ids = ids_next2; plan_next2->scat_n = n_next2;
     }
-    const unsigned grid = a.build_blocks + a.scat_blocks + a.own_blocks + a.find_blocks;
+    const unsigned grid = a.build_blocks + a.scat_blocks + a.own_blocks + a.find_blocks + a.tail_blocks;
+    if (plan_prev && d->last_tail_step + 1 != step) {   // the launch before had no tail: nobody has zeroed this launch's counters
+      if (hipMemsetAsync(a.patch_count, 0, 4, s) != hipSuccess || hipMemsetAsync(a.sync, 0, 1280, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: memset");
+    }
+    if (plan_prev) d->last_tail_step = step;
     if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; }
     const bool timed = d->kev_left > 0 && plan_prev;
     if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3], s);
     launch_step(d->variant, grid, s, a);
-    if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s);
-    if (plan_prev && d->last_rest_step + 1 != step && hipMemsetAsync(a.patch_count, 0, 4, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: memset");
-    if (plan_prev) {
-      d->last_rest_step = step;
-      step_rest_kernel<<<std::max(std::min(L.rem_blocks, 512u), 128u), 256, 0, s>>>(a, reinterpret_cast<unsigned*>(L.next_ctr));   // (128 .. 512 blocks: all resident, see its arrival counter; the corrections take the whole grid)
-    }
-    if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
+    if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s); (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
     if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: launch failed");
     if (plan_prev) step_epoch_public(t);
     d->n_overlapped += 1;

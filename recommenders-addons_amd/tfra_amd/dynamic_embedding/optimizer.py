@@ -773,19 +773,19 @@ class OverlapAssignStep:
     return {"step_kernel_us": a.value, "rest_kernel_us": b.value, "steps": n.value}
 
   def timing(self):
-    """tuning (TFRA_STEP_VARIANT & 16): per launch, the (start, end) of each role — build, scatter, write-back, lookup — in us since
-    the launch's first block (None: the role did not run)"""
-    buf = (ctypes.c_uint64 * (64 * 4 * 2))()
+    """tuning (TFRA_STEP_VARIANT & 16): per launch and role — build, scatter, write-back, lookup, tail — (first block start, last
+    block end, median block duration, 95th percentile) in us, starts / ends since the launch's first block (None: the role did not run)"""
+    buf = (ctypes.c_uint64 * (64 * 5 * 4))()
     _capi.call("tfra_step_driver_timing", self._h, buf)
     none = 2 ** 64 - 1
     out = []
     for k in range(64):
-      w = [(buf[(k * 4 + r) * 2], buf[(k * 4 + r) * 2 + 1]) for r in range(4)]
+      w = [tuple(buf[(k * 5 + r) * 4 + j] for j in range(4)) for r in range(5)]
       starts = [x[0] for x in w if x[0] != none]
       if not starts:
         continue
       t0 = min(starts)
-      out.append([None if x[0] == none else ((x[0] - t0) / 100.0, (x[1] - t0) / 100.0) for x in w])
+      out.append([None if x[0] == none else ((x[0] - t0) / 100.0, (x[1] - t0) / 100.0, x[2] / 100.0, x[3] / 100.0) for x in w])
     return out
 
   def make_run(self, ids_list, values_list, outs, ids_after=None, values_before=None, ids_after2=None):

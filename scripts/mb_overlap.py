@@ -119,7 +119,7 @@ def main():
             r()
         fn = many
       tm = None
-      if v & 16:
+      if (v & 16) and D == 1:
         import numpy as np
         fn(0)
         drv.timing()     # re-arm: the stamps of the next 48 launches only
@@ -129,7 +129,8 @@ def main():
         K = K_save
         sp = [x for x in drv.timing() if all(y is not None for y in x)]
         tm = {"launches": len(sp), "role_spans_us_median (start, end since the launch's first block)":
-              {r: [float(np.median([x[i][0] for x in sp])), float(np.median([x[i][1] for x in sp]))] for i, r in enumerate(("build", "scatter", "write_back", "lookup"))} if sp else None}
+              {r: [float(np.median([x[i][j] for x in sp])) for j in range(4)] for i, r in enumerate(("build", "scatter", "write_back", "lookup", "tail"))} if sp else None,
+              "columns": "first block start, last block end, median block duration, p95 block duration"}
       us, hus, all_ = timed(fn)
       st = drv.stats()
       drv.flush()
