@@ -484,18 +484,19 @@ def run_bounded(args, torch, de, dev, cfg):
   verified = {}
   tm = Timer(torch)
 
-  # ---- driver 1 (`value`): the overlapped step — lookup of batch i+1 and write-back of batch i in ONE launch (store-to-load
-  # forwarding from batch i's plan), the plan of batch i+2 built inside the same launch, the left-over keys in a second one;
-  # D steps per host call (tfra_table_steps_overlap), one stream, nothing waits on the host.  Lookup outputs: a ring of D buffers.
-  ids = idf.keys(nsteps + 2)
+  # ---- driver 1 (`value`): the overlapped step — ONE launch per step: lookup of batch i+1 (ids of batch i served from the rows
+  # being written: store-to-load forwarding through batch i's plan), write-back of batch i, its left-over keys and the output
+  # corrections (tail), and the plans of the next two batches (built over two launches, without atomics); D steps per host call
+  # (tfra_table_steps_overlap), one stream, nothing waits on the host.  Lookup outputs: a ring of D buffers.
+  ids = idf.keys(nsteps + 3)
   uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
   D = 4 if K % 4 == 0 else (2 if K % 2 == 0 else 1)
   outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(D)]
   ovl = de.OverlapAssignStep(table).prime(ids[0])
   for i in range(W):
-    ovl.step(values, ids[i + 1])
+    ovl.step(values, ids[i + 1], ids[i + 2])
   runs = [ovl.make_run([ids[W + c * D + q] for q in range(D)], [values] * D, outs, ids_after=ids[W + (c + 1) * D],
-                       values_before=values if (W + c) else None) for c in range(WINDOWS * K // D)]
+                       values_before=values if (W + c) else None, ids_after2=ids[W + (c + 1) * D + 1]) for c in range(WINDOWS * K // D)]
 
   def ovl_step(i):   # timed_windows calls once per step: every D-th call enqueues D steps (K is a multiple of D)
     if (i - W) % D == 0:
@@ -505,7 +506,8 @@ def run_bounded(args, torch, de, dev, cfg):
   # per-launch durations of the same driver: HIP events on the launching stream around each of the two launches of 24 more steps
   ovl.time_kernels(24)
   for c in range(24 // D):
-    ovl.make_run([ids[(c * D + q) % nsteps] for q in range(D)], [values] * D, outs, ids_after=ids[((c + 1) * D) % nsteps], values_before=values)()
+    ovl.make_run([ids[(c * D + q) % nsteps] for q in range(D)], [values] * D, outs, ids_after=ids[((c + 1) * D) % nsteps], values_before=values,
+                 ids_after2=ids[((c + 1) * D + 1) % nsteps])()
   ktimes = ovl.kernel_times()
   ovl.flush()
   ovl_stats = ovl.stats()
@@ -557,11 +559,40 @@ def run_bounded(args, torch, de, dev, cfg):
   uniqs = [(ws, B, P(ids[i]), P(ubuf), P(ibuf), P(cbuf), st) for i in range(nsteps)]
   last_u = [0]
 
-  def op_surface(i):
+  def op_surface_find_first(i):   # round 3's sequence: Find(B) -> unique + host read -> Insert(U)
     _capi.check(lib.tfra_table_find(*finds[i]))
     _capi.check(lib.tfra_unique(*uniqs[i]))
     u = int(cbuf.item())
     last_u[0] = u
+    _capi.check(lib.tfra_table_insert_or_assign(tbl._h, u, P(ubuf), P(values), None, 1, st))
+
+  for i in range(W):
+    op_surface_find_first(i)
+  secs_opf, med_opf, _ = timed_windows(torch, None, 1, dev, K, op_surface_find_first, first=W)
+  u = last_u[0]
+  got, ex = table.lookup(ubuf[:u], return_exists=True)
+  verified["op_surface_find_first_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:u]))
+
+  # The reference's own order (embedding_lookup de-duplicates FIRST: PY/dynamic_embedding_ops.py:99-117,
+  # PY/dynamic_embedding_variable.py:1377-1378):
+  #   tf.unique(ids)          -> tfra_unique_unordered (two launches) + ONE host read of the count (tf.unique's output shape), here
+  #                              through pinned memory the second launch writes to: a stream sync, no copy
+  #   Find op (U ids)         -> tfra_table_find
+  #   tf.gather(rows, idx)    -> tfra_gather_rows (B rows)
+  #   Insert op (U ids)       -> tfra_table_insert_or_assign(TFRA_FLAG_UNIQUE_KEYS)
+  cpin = torch.zeros(1, dtype=torch.int64).pin_memory()
+  urows = torch.empty((B, dim), dtype=dtype, device=dev)
+  uniqs2 = [(ws, B, P(ids[i]), P(ubuf), P(ibuf), ctypes.c_void_p(cpin.data_ptr()), st) for i in range(nsteps)]
+  cur_stream = torch.cuda.current_stream(dev)
+  row_bytes = dim * values.element_size()
+
+  def op_surface(i):
+    _capi.check(lib.tfra_unique_unordered(*uniqs2[i]))
+    cur_stream.synchronize()
+    u = int(cpin[0])
+    last_u[0] = u
+    _capi.check(lib.tfra_table_find(tbl._h, u, P(ubuf), P(urows), None, P(dflt_row), 0, st))
+    _capi.check(lib.tfra_gather_rows(B, row_bytes, P(urows), P(ibuf), P(out_buf), st))
     _capi.check(lib.tfra_table_insert_or_assign(tbl._h, u, P(ubuf), P(values), None, 1, st))
 
   for i in range(W):
@@ -570,6 +601,33 @@ def run_bounded(args, torch, de, dev, cfg):
   u = last_u[0]
   got, ex = table.lookup(ubuf[:u], return_exists=True)
   verified["op_surface_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:u]))
+  # (the gather really returned the rows of the batch's ids: the lookup of the LAST batch, taken before its insert, against a plain find)
+  chk = idf.keys(1)[0]
+  _capi.check(lib.tfra_unique_unordered(ws, B, P(chk), P(ubuf), P(ibuf), ctypes.c_void_p(cpin.data_ptr()), st))
+  cur_stream.synchronize()
+  uu = int(cpin[0])
+  _capi.check(lib.tfra_table_find(tbl._h, uu, P(ubuf), P(urows), None, P(dflt_row), 0, st))
+  _capi.check(lib.tfra_gather_rows(B, row_bytes, P(urows), P(ibuf), P(out_buf), st))
+  verified["op_surface_unique_find_gather_equals_find"] = bool(torch.equal(out_buf, table.lookup(chk)))
+
+  # bp_v2 (`Accum` op, K/hkv_hashtable_op_gpu.cu.cc:292-335): Find(B) -> insert_or_accum of the batch's unique keys (prepared
+  # beforehand like the table-ops-only line below; every key exists: row += delta)
+  uqa = [torch.unique(ids[i]) for i in range(nsteps)]
+  ex_true = torch.ones(B, dtype=torch.bool, device=dev)
+
+  def accum_step(i):
+    _capi.check(lib.tfra_table_find(*finds[i]))
+    _capi.check(lib.tfra_table_accum_or_assign(tbl._h, uqa[i].numel(), P(uqa[i]), P(values), P(ex_true), None, 1, st))
+
+  before = table.lookup(uqa[nsteps - 1])
+  for i in range(W):
+    accum_step(i)
+  secs_acc, med_acc, _ = timed_windows(torch, None, 1, dev, K, accum_step, first=W)
+  got, ex = table.lookup(uqa[nsteps - 1], return_exists=True)
+  nu = uqa[nsteps - 1].numel()
+  # (the last batch's keys: present ones got exactly one more delta in the last step — rows other batches also touched moved further)
+  verified["accum_last_batch_rows_moved"] = bool(ex.any()) and not bool(torch.equal(got, before))
+  del before, uqa
   # the two table ops alone, the unique keys prepared beforehand
   uq = [torch.unique(ids[i]) for i in range(nsteps)]
   ins = [(tbl._h, uq[i].numel(), P(uq[i]), P(values), None, 1, st) for i in range(nsteps)]
@@ -645,13 +703,10 @@ def run_bounded(args, torch, de, dev, cfg):
   step_bytes = step_bytes_ = lookup_bytes + upsert_bytes
   prof = profile_summary()
   kernels = {
-      "step_kernel (ONE launch: lookup of batch i+1 with store-to-load forwarding + ownership write-back of batch i + plan of batch i+2)": {
+      "step_k (the step's ONE launch: lookup of batch i+1 with store-to-load forwarding + ownership write-back of batch i + its tail + plan builders)": {
           "avg_launch_us": ktimes["step_kernel_us"], "algorithmic_bytes_per_launch": step_bytes_, "unique_keys": U,
           "achieved_GBps": step_bytes_ / ktimes["step_kernel_us"] / 1e3, "frac": step_bytes_ / ktimes["step_kernel_us"] / 1e3 / HBM_PEAK_GBS,
-          "traffic": traffic_of(prof, cfg, "step_kernel"), "launches_timed": ktimes["steps"]},
-      "step_rest_kernel (the few keys the pass left over + corrections of the lookup's output)": {
-          "avg_launch_us": ktimes["rest_kernel_us"], "algorithmic_bytes_per_launch": 0, "achieved_GBps": 0.0, "frac": 0.0,
-          "traffic": traffic_of(prof, cfg, "step_rest_kernel")},
+          "traffic": traffic_of(prof, cfg, "step_k"), "launches_timed": ktimes["steps"]},
       "find_kernel<16,4,WT,PF1> (lookup; both home-bucket lines in flight)": {
           "avg_launch_us": find_us, "algorithmic_bytes_per_launch": lookup_bytes,
           "achieved_GBps": lookup_bytes / find_us / 1e3, "frac": lookup_bytes / find_us / 1e3 / HBM_PEAK_GBS,
@@ -665,7 +720,7 @@ def run_bounded(args, torch, de, dev, cfg):
           "achieved_GBps": upsert_bytes / insert_unique_us / 1e3, "frac": upsert_bytes / insert_unique_us / 1e3 / HBM_PEAK_GBS,
           "traffic": (traffic_of(prof, cfg, "upsert_own_kernel[direct]") or 0) + (traffic_of(prof, cfg, "upsert_rest_kernel[direct]") or 0) or None},
   }
-  on_step = list(kernels)[:2]   # the launches of the `value` step
+  on_step = list(kernels)[:1]   # the launch of the `value` step
   dom = max(on_step, key=lambda k: kernels[k]["avg_launch_us"])
   cfg_name = "2" if cfg == "c3" else "metric (dim 64 fp32, 1 B keys, Zipf-1.2)"
   res = {
@@ -678,6 +733,8 @@ def run_bounded(args, torch, de, dev, cfg):
       "value_look_ahead_driver": B * K / med_pf, "ms_per_step_look_ahead_driver": med_pf / K * 1e3,
       "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
       "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
+      "value_op_surface_find_first": B * K / med_opf, "ms_per_step_op_surface_find_first": med_opf / K * 1e3,
+      "value_accum": B * K / med_acc, "ms_per_step_accum": med_acc / K * 1e3,
       "value_op_surface_table_ops_only": B * K / med_tops, "ms_per_step_op_surface_table_ops_only": med_tops / K * 1e3,
       "config": {
           "workload": "BASELINE configs[%s]: bounded Hkv (LRU) table, %d slots (%.1f GB in HBM: key line + score line + 15 rows per "
@@ -697,21 +754,27 @@ def run_bounded(args, torch, de, dev, cfg):
           "host_enqueue_ms_per_step_look_ahead_driver": round(1e3 * host_pf / K, 4),
           "overlapped_step_stats": ovl_stats,
           "timing": {"value": timing_note(secs, K), "value_look_ahead_driver": timing_note(secs_pf, K), "value_plain_call": timing_note(secs_plain, K),
-                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_table_ops_only": timing_note(secs_tops, K)},
+                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_find_first": timing_note(secs_opf, K),
+                     "value_accum": timing_note(secs_acc, K), "value_op_surface_table_ops_only": timing_note(secs_tops, K)},
           "verified": verified,
           "drivers": {
-              "value": "tfra_table_steps_overlap (csrc/tfra_step_impl.h): per step TWO launches on one stream — step_kernel = lookup of "
-                       "batch i+1 (ids of batch i served from the rows being written: store-to-load forwarding through batch i's "
-                       "plan) + ownership write-back of batch i + plan of batch i+2, then step_rest_kernel (left-over keys, output "
-                       "corrections); results identical to lookup; insert; lookup; insert ... (needs the ids one batch ahead); %d steps "
-                       "per host call, lookup outputs in a ring of %d buffers" % (D, D),
+              "value": "tfra_table_steps_overlap (csrc/tfra_step_impl.h): ONE launch per step on one stream = lookup of batch i+1 (ids of "
+                       "batch i served from the rows being written: store-to-load forwarding through batch i's plan) + ownership "
+                       "write-back of batch i + its left-over keys and the output corrections (tail blocks of the same launch) + the "
+                       "plans of batches i+2 / i+3 (built over two launches, no atomics); results identical to lookup; insert; lookup; "
+                       "insert ... (needs the ids two batches ahead); %d steps per host call, lookup outputs in a ring of %d buffers" % (D, D),
               "value_look_ahead_driver": "round 3's driver, tfra_table_step_prefetch_assign: ONE C call per step = lookup + insert_or_assign "
                                          "of batch i on the main stream, plan of batch i+1 on a second stream, streams ordered by the host",
               "value_plain_call": "tfra_table_find then tfra_table_upsert_sparse, no look-ahead; upsert_sparse is a fused extra (plan "
                                   "built inside the call, repeats resolved on the device), not an op of the reference's surface",
-              "value_op_surface": "per step exactly the calls of tf_ops/mi355x_table_ops.h: tfra_table_find (B ids) -> tfra_unique + "
-                                  "one host read of the count (tf.unique's output shape) -> tfra_table_insert_or_assign(unique keys, "
-                                  "TFRA_FLAG_UNIQUE_KEYS)",
+              "value_op_surface": "the reference's own op order (embedding_lookup de-duplicates first, PY/dynamic_embedding_ops.py:99-117): "
+                                  "tfra_unique_unordered (B ids) + one host read of the count (tf.unique's output shape; through pinned "
+                                  "memory) -> tfra_table_find (U ids) -> tfra_gather_rows (B rows) -> tfra_table_insert_or_assign(U "
+                                  "unique keys, TFRA_FLAG_UNIQUE_KEYS): the calls of tf_ops/mi355x_table_ops.h",
+              "value_op_surface_find_first": "round 3's sequence: tfra_table_find (B ids) -> tfra_unique (ordered) + one blocking host read "
+                                             "-> tfra_table_insert_or_assign(U unique keys)",
+              "value_accum": "bp_v2: tfra_table_find (B ids) -> tfra_table_accum_or_assign(U unique keys prepared beforehand, exists = "
+                             "true: row += delta, TFRA_FLAG_UNIQUE_KEYS) on the single-pass ownership kernels",
               "value_op_surface_table_ops_only": "tfra_table_find (B ids) -> tfra_table_insert_or_assign(unique keys prepared beforehand)"},
           "plan_build_us_alone": plan_us, "tfra_unique_us_alone": unique_us,
           "export": export,
@@ -724,13 +787,13 @@ def run_bounded(args, torch, de, dev, cfg):
           "step_frac_look_ahead_driver": step_bytes / (med_pf / K) / 1e9 / HBM_PEAK_GBS,
           "step_frac_plain_call": step_bytes / (med_plain / K) / 1e9 / HBM_PEAK_GBS,
           "step_frac_op_surface": step_bytes / (med_ops / K) / 1e9 / HBM_PEAK_GBS,
+          "step_frac_accum": (lookup_bytes + U * (9 + 3 * Rb)) / (med_acc / K) / 1e9 / HBM_PEAK_GBS,
           "step_algorithmic_bytes": step_bytes,
           "step_bytes_definition": "B*(8+2*Rb) for the lookup + U*(16+2*Rb) for the write-back of the U unique keys (SURVEY §8d)",
           "by_survey_pair_count": B * 1048 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "kernels": kernels,
-          "timing": "HIP events on the launching stream around 20-24 launches, a different batch each (step_kernel / step_rest_kernel: "
-                    "recorded by the step driver around each of its two launches); the fused launch moves ALL of the step's "
-                    "algorithmic bytes, so its fraction is the step's",
+          "timing": "HIP events on the launching stream around 20-24 launches, a different batch each (step_k: recorded by the step "
+                    "driver around its launch); the fused launch moves ALL of the step's algorithmic bytes, so its fraction is the step's",
       },
   }
   del plans, table, tbl, uq, ins, finds
@@ -1096,7 +1159,8 @@ def main():
       args._growth = measure_growth(torch, de, dev, 128, torch.float16, args.slots // 4)   # reported under secondary.c3
     res = run_bounded(args, torch, de, dev, cfg)
     if not args.no_secondary and args.config is None:
-      keep = ("metric", "value", "value_plain_call", "value_op_surface", "value_op_surface_table_ops_only", "ms_per_step",
+      keep = ("metric", "value", "value_look_ahead_driver", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
+              "value_op_surface_table_ops_only", "ms_per_step",
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}
       for name, fn in (("c3", lambda: run_bounded(args, torch, de, dev, "c3")),       # configs[2]

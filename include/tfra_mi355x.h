@@ -395,6 +395,12 @@ int tfra_workspace_destroy(tfra_workspace_t* ws);
  * d_num_unique is a device int64 scalar (no host sync). */
 int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* unique_out,
                 int32_t* idx_out, int64_t* d_num_unique, tfra_stream_t stream);
+/* The same without tf.unique's first-occurrence ORDER (unique_out in no particular order, idx_out consistent with it): what
+ * embedding_lookup needs of tf.unique (PY/dynamic_embedding_ops.py:99-117 — the distinct ids feed Find / Insert, the inverse
+ * index the gather; the order is not observable there).  Two launches instead of three; n <= 2^18.  d_num_unique may be
+ * device-visible pinned host memory: the count then reaches the host without a copy. */
+int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* unique_out,
+                          int32_t* idx_out, int64_t* d_num_unique, tfra_stream_t stream);
 
 /* out[idx[i],:] += in[i,:] in index order per segment is NOT guaranteed; sums are accumulated in
  * fp32 with a fixed tree per segment => deterministic. out is [num_segments, dim], zeroed here. */

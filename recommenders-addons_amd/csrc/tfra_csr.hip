@@ -1506,7 +1506,8 @@ struct SetTab {   // one of the plan's two tables
 };
 
 // COUNTS: also count the occurrences of every id (LFU scores without caller scores; tfra_sparse_plan_read)
-template <bool COUNTS>
+// INDEX: the occurrence-count word of a key's table entry receives the key's position in the dense list instead (tfra_unique_unordered)
+template <bool COUNTS, bool INDEX = false>
 __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
                                                         unsigned* next_use_count) {
   __shared__ i64 s_key[SP_LDS];
@@ -1574,6 +1575,7 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
       const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
       cur.ukeys[at] = EMPTY_KEY + (i64)tid;
       cur.uslot[at] = sl;
+      if (INDEX) cur.ent[sl].cnt = at;
     }
   }
   __syncthreads();
@@ -1589,7 +1591,34 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
     if (!mine[r]) continue;
     cur.ukeys[s_base + myidx[r]] = mykey[r];
     cur.uslot[s_base + myidx[r]] = myslot[r];
+    if (INDEX) cur.ent[myslot[r]].cnt = s_base + myidx[r];
   }
+}
+
+// tfra_unique_unordered, second launch: idx[i] = position of ids[i] in the plan's dense list (a probe of the plan's table);
+// the list itself and its length are copied out on the way.
+__global__ __launch_bounds__(256) void unique_idx_kernel(size_t n, const i64* __restrict__ ids, SetProbe pr, const i64* __restrict__ ukeys,
+                                                         const unsigned* __restrict__ count, i64* __restrict__ unique_out, int* __restrict__ idx_out,
+                                                         i64* __restrict__ num_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned U = *count;
+  if (i == 0) *num_out = (i64)U;
+  if (i < U) unique_out[i] = ukeys[i];
+  if (i >= n) return;
+  const i64 id = ids[i];
+  unsigned slot = set_home(pr, id, fmix64((u64)id));
+  const unsigned wm = set_wmask(pr.m2);
+  int found = -1;
+  if (is_reserved_key(id)) found = (int)pr.ent[slot].cnt;
+  else {
+    for (unsigned g = 0; g <= wm; ++g) {
+      const SetEnt* e = pr.ent + set_at(slot, g, wm);
+      const i64 k = e->key;
+      if (k == id) { found = (int)e->cnt; break; }
+      if (k == EMPTY_KEY) break;
+    }
+  }
+  idx_out[i] = found;
 }
 
 #define TFRA_STEP_DEVICE_PART
@@ -2636,6 +2665,35 @@ extern "C" int tfra_table_step_prefetch_assign(tfra_table_t* tp, tfra_sparse_pla
                                                tfra_stream_t side_stream) {
   return step_prefetch_impl(tp, nullptr, plan_cur, ids_cur, rows_out, find_default, values, nullptr, scores, plan_next, ids_next,
                             n_next, main_stream, side_stream);
+}
+
+// tf.unique WITHOUT the first-occurrence order (which nothing on the embedding path observes: the distinct ids feed Find / Insert,
+// the inverse index feeds the gather — PY/dynamic_embedding_ops.py:99-117, PY/shadow_embedding_ops.py:316): the SET plan of the
+// ids IS their de-duplication — one launch — and a second launch turns it into the inverse index.  Two launches instead of the
+// three (formerly six) of tfra_unique, no look-back chain.
+extern "C" int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* unique_out, int32_t* idx_out,
+                                     int64_t* d_num_unique, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ws || !d_num_unique) return set_error(TFRA_ERR_INVALID, "unique: null argument");
+  { int cur_ = -1; if (hipGetDevice(&cur_) != hipSuccess || cur_ != ws->device) { if (hipSetDevice(ws->device) != hipSuccess) return set_error(TFRA_ERR_HIP, "unique: hipSetDevice"); } }
+  if (n == 0) { if (hipMemsetAsync(d_num_unique, 0, sizeof(int64_t), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "unique: memset"); return TFRA_OK; }
+  if (!ids || !unique_out || !idx_out) return set_error(TFRA_ERR_INVALID, "unique: null buffer");
+  if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "unique_unordered: at most 2^18 ids per call (tfra_unique takes more)");
+  if (!ws->uplan) {
+    tfra_sparse_plan* pl = nullptr;
+    int rc = tfra_sparse_plan_create(ws->device, &pl);
+    if (rc) return rc;
+    ws->uplan = pl;
+  }
+  tfra_sparse_plan* pl = reinterpret_cast<tfra_sparse_plan*>(ws->uplan);
+  SetPlanLaunch L;
+  int rc = setplan_prepare(pl, n, s, false, &L);
+  if (rc) return rc;
+  setplan_kernel<false, true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count);
+  unique_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, (const i64*)ids, SetProbe{L.cur.ent, L.m2}, L.cur.ukeys, L.cur.count, (i64*)unique_out,
+                                                               idx_out, (i64*)d_num_unique);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "unique_unordered: launch failed");
+  return TFRA_OK;
 }
 
 #define TFRA_STEP_HOST_PART

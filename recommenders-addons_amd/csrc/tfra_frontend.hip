@@ -649,6 +649,7 @@ int tfra_workspace_destroy(tfra_workspace_t* ws) {
   if (ws->unq_buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->unq_buf); }
   if (ws->unq_ev) (void)hipEventDestroy(ws->unq_ev);
   tfra::destroy_workspace_plan(ws->plan);
+  tfra::destroy_workspace_plan(ws->uplan);
   delete ws;
   return TFRA_OK;
 }

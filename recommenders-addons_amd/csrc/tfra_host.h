@@ -115,6 +115,7 @@ struct tfra_workspace {
   void* buf = nullptr;
   size_t bytes = 0;
   void* plan = nullptr;   // tfra_sparse_plan of tfra_reduce_by_key
+  void* uplan = nullptr;  // tfra_sparse_plan of tfra_unique_unordered
   // tfra_unique (up to 2^20 ids): two persistent hash sets that alternate and empty each other (no fill kernel per call)
   void* unq_buf = nullptr;
   size_t unq_cap = 0, unq_nmax = 0;

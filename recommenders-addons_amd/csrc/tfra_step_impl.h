@@ -61,7 +61,6 @@ struct StepArgs {
   unsigned* sync_next;
   unsigned* zero4;             // the left-over counters of the plan's NEXT use (armed by the tail)
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
-  int prio;                    // (tuning) raised wave priority for the write-back and the tail
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
   u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
   i64* patch_keys;             // step_rest_kernel: the launch's list of evicted keys that are ids of this batch
@@ -306,7 +305,6 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   const OwnArgs& o = a.own;
   const unsigned tid = threadIdx.x;
   const int lane = tid & 63;
-  if (a.prio) __builtin_amdgcn_s_setprio(2);   // (the tail waits for the last of these blocks, the launch for the tail)
   const unsigned lo = blk * OWN_SLICE, total_slots = a.fwd.m2 + 2;
   if (tid == 0) L.n = 0;
   uint4 e[2];
@@ -374,28 +372,29 @@ __host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blo
   return 4;
 }
 __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepLds& L);
-template <bool SIMPLE, int U, bool TIMING>
+// (A kernel gets the registers of its hungriest role for EVERY wave: the lookup alone needs 58, next to the locked protocol of the
+// tail 95 — 5 waves per SIMD.  Fewer registers for the lookup — one key per four lanes in the write-back, 69 registers, 7 waves —
+// changed nothing: the launch is bound by what the memory system moves.)
+template <bool SIMPLE, int U, bool TIMING, int ROLES = 3>
 __device__ __forceinline__ void step_body(const StepArgs& a) {
   __shared__ StepLds L;
   const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
   unsigned idx;
   const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, &idx);
-  if (role == 0) build_role(a, idx, L);
-  else if (role == 1) scatter_role(a, idx, L);
-  else if (role == 2) own_role<SIMPLE, U>(a, idx, L);
-  else if (role == 3) { find_fwd_role(a, idx); find_arrive(a); }
-  else tail_role(a, idx, L);
+  if (role == 0) { if (ROLES & 1) build_role(a, idx, L); }
+  else if (role == 1) { if (ROLES & 1) scatter_role(a, idx, L); }
+  else if (role == 2) { if (ROLES & 2) own_role<SIMPLE, U>(a, idx, L); }
+  else if (role == 3) { if (ROLES & 1) { find_fwd_role(a, idx); find_arrive(a); } }
+  else { if (ROLES & 2) tail_role(a, idx, L); }
   if (TIMING) role_stamp(a, t0);
 }
 // Instantiations (the SGPR budget is an attribute, not a template argument): 256-thread blocks are admitted per CU up to
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) — ~106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
-#define TFRA_STEP_KERNEL(NAME, UU, TIMING, NSGPR)                                                                        \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(NSGPR))) void NAME(const StepArgs a) { step_body<true, UU, TIMING>(a); }
-TFRA_STEP_KERNEL(step_k_u2, 2, false, 104)
-TFRA_STEP_KERNEL(step_k_u1, 1, false, 104)
-TFRA_STEP_KERNEL(step_k_u1_s80, 1, false, 80)
-TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 104)
-TFRA_STEP_KERNEL(step_k_u1_t, 1, true, 104)
+#define TFRA_STEP_KERNEL(NAME, UU, TIMING, NSGPR, ROLES)                                                                 \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(NSGPR))) void NAME(const StepArgs a) { step_body<true, UU, TIMING, ROLES>(a); }
+TFRA_STEP_KERNEL(step_k_u2, 2, false, 104, 3)
+TFRA_STEP_KERNEL(step_k_u1, 1, false, 104, 3)
+TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 104, 3)
 #undef TFRA_STEP_KERNEL
 
 // ---- TAIL role: the remainder of a step INSIDE its launch ------------------------------------------------------------------
@@ -433,7 +432,6 @@ __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepL
   const OwnArgs& o = a.own;
   const unsigned tid = threadIdx.x;
   const int lane = tid & 63, sub = lane & 15, gshift = lane & 48;
-  if (a.prio) __builtin_amdgcn_s_setprio(3);
   if (blk == 0) {   // arm what the next launch counts in (its users of two launches ago are long gone)
     if (tid < 4 && a.zero4) a.zero4[tid] = 0;
     if (tid >= 32 && tid < 42) a.sync_next[32 * (tid - 32)] = 0;
@@ -695,15 +693,12 @@ extern "C" int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step
 static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_tab[pl->set_parity].ent, pl->set_m2}; }
 static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 && pl->listless[pl->set_parity]; }
 
-// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0 U=2 | 1 U=1 | 3 U=1, 80 SGPRs), 8 every plan as a launch of its own,
-// 16 time stamps, 64 the lookup reads the table's lines for every id
-static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {
+// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0: 8 keys per wave in the write-back | 1: 4), 8 every plan as a launch of
+// its own, 16 time stamps, 64 the lookup reads the table's lines for every id
+static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {   // the overlapped step: one launch
   const int k = variant & 7;
-  if (variant & 16) {
-    if (k == 1 || k == 3) step_k_u1_t<<<grid, 256, 0, s>>>(a);
-    else step_k_u2_t<<<grid, 256, 0, s>>>(a);
-  } else if (k == 1) step_k_u1<<<grid, 256, 0, s>>>(a);
-  else if (k == 3) step_k_u1_s80<<<grid, 256, 0, s>>>(a);
+  if (variant & 16) step_k_u2_t<<<grid, 256, 0, s>>>(a);
+  else if (k == 1) step_k_u1<<<grid, 256, 0, s>>>(a);
   else step_k_u2<<<grid, 256, 0, s>>>(a);
 }
 
@@ -788,7 +783,6 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.sync_next = reinterpret_cast<unsigned*>(d->patch + 256 + 2 * PATCH_GCAP * 8 + 1280 * ((step & 1u) ^ 1u));
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
-    a.prio = (d->variant & 32) ? 1 : 0;
     // the next batch's plan: its pairs were scattered by the previous call's launch -> this launch builds the table; else a launch of its own, in front
     if (n_next) {
       if (plan_next->scat_ids == ids_next && plan_next->scat_n == n_next && !(d->variant & 8)) {
@@ -816,16 +810,22 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.scat_ovf_cnt_next = plan_next2->ovf_cnt + 32 * ((plan_next2->scat_use & 1u) ^ 1u);
       plan_next2->seg_tiles = a.scat_tiles; plan_next2->scat_ids = ids_next2; plan_next2->scat_n = n_next2;
     }
-    const unsigned grid = a.build_blocks + a.scat_blocks + a.own_blocks + a.find_blocks + a.tail_blocks;
     if (plan_prev && d->last_tail_step + 1 != step) {   // the launch before had no tail: nobody has zeroed this launch's counters
       if (hipMemsetAsync(a.patch_count, 0, 4, s) != hipSuccess || hipMemsetAsync(a.sync, 0, 1280, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: memset");
     }
     if (plan_prev) d->last_tail_step = step;
-    if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; }
     const bool timed = d->kev_left > 0 && plan_prev;
     if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3], s);
-    launch_step(d->variant, grid, s, a);
-    if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s); (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
+    {
+      // ONE launch: the lookup runs beside the write-back (forwarding, deferred evictions, corrections).  (Measured against it, on
+      // the metric's configuration: the same roles as TWO launches one after the other — write-back + tail, then lookup + plan
+      // builders, no forwarding — 52 us per step against 33: the write-back alone in its launch still takes 25 us.)
+      const unsigned grid = a.build_blocks + a.scat_blocks + a.own_blocks + a.find_blocks + a.tail_blocks;
+      if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; }
+      launch_step(d->variant, grid, s, a);
+      if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s);
+    }
+    if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
     if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: launch failed");
     if (plan_prev) step_epoch_public(t);
     d->n_overlapped += 1;

@@ -22,11 +22,13 @@ def _workspace(device):
   return _WS[key]
 
 
-def unique(ids):
+def unique(ids, ordered=True):
   """tf.unique (first-occurrence order): returns (unique[U], idx[n] int32, num_unique device scalar).
 
   `unique` is returned as a length-n buffer view trimmed with ONE host read of the count — the
-  same sync TF's `tf.unique` output-shape inference imposes (PY/dynamic_embedding_ops.py:99)."""
+  same sync TF's `tf.unique` output-shape inference imposes (PY/dynamic_embedding_ops.py:99).
+  ordered=False: the distinct ids in no particular order (tfra_unique_unordered, two launches instead of three; up to 2^18 ids)
+  — all embedding_lookup needs: the order of tf.unique's output is not observable behind the gather."""
   ids = ids.contiguous()
   flat = ids.reshape(-1)
   n = flat.numel()
@@ -34,7 +36,8 @@ def unique(ids):
   uniq = torch.empty(n, dtype=torch.int64, device=dev)
   idx = torch.empty(n, dtype=torch.int32, device=dev)
   cnt = torch.zeros((), dtype=torch.int64, device=dev)
-  _capi.call("tfra_unique", _workspace(dev), n, _ptr(flat), _ptr(uniq), _ptr(idx), _ptr(cnt), _stream(dev))
+  fn = "tfra_unique" if (ordered or n > (1 << 18)) else "tfra_unique_unordered"
+  _capi.call(fn, _workspace(dev), n, _ptr(flat), _ptr(uniq), _ptr(idx), _ptr(cnt), _stream(dev))
   u = int(cnt.item())
   return uniq[:u], idx, cnt
 

@@ -127,7 +127,7 @@ def main():
         K_save, K = K, 48
         fn(0)
         K = K_save
-        sp = [x for x in drv.timing() if all(y is not None for y in x)]
+        sp = [[y if y is not None else (0.0, 0.0, 0.0, 0.0) for y in x] for x in drv.timing()]
         tm = {"launches": len(sp), "role_spans_us_median (start, end since the launch's first block)":
               {r: [float(np.median([x[i][j] for x in sp])) for j in range(4)] for i, r in enumerate(("build", "scatter", "write_back", "lookup", "tail"))} if sp else None,
               "columns": "first block start, last block end, median block duration, p95 block duration"}

@@ -442,6 +442,26 @@ def test_unique_many_calls_one_workspace(env):
     np.testing.assert_array_equal(want[idx.cpu().numpy()], ids)
 
 
+def test_unique_unordered_matches_numpy_as_a_set(env):
+  """tfra_unique_unordered: the distinct ids in ANY order + a consistent inverse index (what embedding_lookup needs of tf.unique);
+  a sequence of calls on one workspace with sizes going up and down, the sentinel values and a hot id."""
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(17)
+  imin = np.iinfo(np.int64).min
+  for n in (7, 50_000, 3, 131_072, 1000, 262_144, 131_072, 1):
+    ids = (rng.zipf(1.2, size=n) % max(2, n // 2)).astype(np.int64) * 7919 - 11
+    if n > 100:
+      ids[rng.integers(0, n, size=n // 40)] = imin
+      ids[rng.integers(0, n, size=n // 50)] = imin + 1
+      ids[n // 3: n // 2] = 5
+    u, idx, cnt = de.device_ops.unique(torch.from_numpy(ids).cuda(), ordered=False)
+    un, idxn = u.cpu().numpy(), idx.cpu().numpy()
+    want = np.unique(ids)
+    assert int(cnt.item()) == want.size == un.size
+    np.testing.assert_array_equal(np.sort(un), want)
+    np.testing.assert_array_equal(un[idxn], ids)
+
+
 @pytest.mark.parametrize("owner_tags", [True, False])
 @pytest.mark.parametrize("driver", ["upsert_sparse", "step"])
 def test_sparse_write_back_lfu_scores_are_occurrence_counts(env, driver, owner_tags):
