@@ -61,6 +61,7 @@ struct StepArgs {
   unsigned* sync_next;
   unsigned* zero4;             // the left-over counters of the plan's NEXT use (armed by the tail)
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
+  int own_from_list;           // (tuning) the write-back walks the plan's dense key list (plans built by setplan_kernel) instead of its table
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
   u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
   i64* patch_keys;             // step_rest_kernel: the launch's list of evicted keys that are ids of this batch
@@ -346,6 +347,28 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// (tuning) the write-back over the plan's DENSE KEY LIST (a plan built by setplan_kernel, TFRA_STEP_VARIANT & 8 | 32): upsert_own_kernel's loop
+template <bool SIMPLE, int U>
+__device__ __forceinline__ void own_role_list(const StepArgs& a, unsigned blk) {
+  const OwnArgs& o = a.own;
+  const int lane = threadIdx.x & 63;
+  const unsigned total = o.ks.d_counts[0] + o.ks.d_counts[1];
+  const unsigned nwaves = a.own_blocks * 4u;
+  const unsigned wave = blk * 4u + (threadIdx.x >> 6);
+  if (blk == 0 && threadIdx.x == 0 && a.progress) __hip_atomic_store(a.progress + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int fresh = 0;
+  const OwnFlags fl = own_setup<SIMPLE>(o);
+  for (unsigned wbase = wave * (4 * U); wbase < total; wbase += nwaves * (4 * U)) {
+    const unsigned i = wbase + (unsigned)(lane & 15);
+    own_batch16<16, SIMPLE, SRC_SET, U, true>(o, fl, min(i, total - 1), (lane & 15) < 4 * U && i < total, a.own_gen, &a.ctr->n_a, lane, fresh, &a.nxt, a.stat);
+  }
+  for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
+  if (lane == 0 && fresh) size_add(o.v, wave, fresh);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // TIMING (tuning builds only): every block notes its start and end on the device clock in a.tbuf (a slot per launch and block):
 // when does each role of a launch run?
 constexpr unsigned TIMING_BLOCKS = 4096, TIMING_SLOTS = 64;
@@ -357,10 +380,16 @@ __device__ __forceinline__ void role_stamp(const StepArgs& a, u64 t0) {
     w[1] = (u64)wall_clock64();
   }
 }
-// role of block b: 0 build, 1 scatter, 2 write-back, 3 lookup, 4 tail; *idx = its index in the role.  The builders come first
-// (short chains of dependent round trips, few blocks), then the whole write-back (the tail waits for it), the lookup, the tail.
-// (Spreading the write-back's blocks among the lookup's changed nothing: the launch is bound by what the memory system moves.)
-__host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned O, unsigned F, unsigned* idx) {
+// role of block b: 0 build, 1 scatter, 2 write-back, 3 lookup, 4 tail; *idx = its index in the role.  Grid order: the builders
+// (short chains of dependent round trips, few blocks), the whole write-back (the tail waits for it), the lookup, the TAIL.
+// Tried, measured on the metric's configuration, dropped: (a) the write-back's blocks spread evenly among the lookup's — no
+// change; (b) the tail IN FRONT of the lookup's blocks, so that it holds its wave slots from the start instead of getting them
+// 18 us into the launch: its 32 polling blocks (one lane each, s_sleep between polls) slow the write-back they wait for from 19
+// to 34 us — the step went from 33 to 45 us.  Behind the lookup's blocks the tail starts when the write-back is (nearly) done
+// and hardly ever polls.
+__host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned O, unsigned F, unsigned T,
+                                                  unsigned* idx) {
+  (void)T;
   if (b < build_blocks) { *idx = b; return 0; }
   b -= build_blocks;
   if (b < scat_blocks) { *idx = b; return 1; }
@@ -380,10 +409,10 @@ __device__ __forceinline__ void step_body(const StepArgs& a) {
   __shared__ StepLds L;
   const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
   unsigned idx;
-  const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, &idx);
+  const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, a.tail_blocks, &idx);
   if (role == 0) { if (ROLES & 1) build_role(a, idx, L); }
   else if (role == 1) { if (ROLES & 1) scatter_role(a, idx, L); }
-  else if (role == 2) { if (ROLES & 2) own_role<SIMPLE, U>(a, idx, L); }
+  else if (role == 2) { if (ROLES & 2) { if (a.own_from_list) own_role_list<SIMPLE, U>(a, idx); else own_role<SIMPLE, U>(a, idx, L); } }
   else if (role == 3) { if (ROLES & 1) { find_fwd_role(a, idx); find_arrive(a); } }
   else { if (ROLES & 2) tail_role(a, idx, L); }
   if (TIMING) role_stamp(a, t0);
@@ -643,7 +672,7 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
       const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
       if (!t1) continue;
       unsigned idx;
-      const int r = step_role(b, ti[0], ti[1], ti[2], ti[3], &idx);
+      const int r = step_role(b, ti[0], ti[1], ti[2], ti[3], ti[4] - ti[0] - ti[1] - ti[2] - ti[3], &idx);
       out[(sl * 5 + r) * 4] = std::min(out[(sl * 5 + r) * 4], t0);
       out[(sl * 5 + r) * 4 + 1] = std::max(out[(sl * 5 + r) * 4 + 1], t1);
       dur[r].push_back(t1 - t0);
@@ -766,6 +795,12 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.ctr = L.ctr; a.own_gen = L.og;
       a.fwd = probe_of(plan_prev);
       a.own_blocks = (a.fwd.m2 + 2 + OWN_SLICE - 1) / OWN_SLICE;
+      if ((d->variant & 40) == 40 && !plan_is_listless(plan_prev)) {   // (tuning: 8 | 32)
+        a.own_from_list = 1;
+        const unsigned seen = d->progress[1];
+        const size_t est = seen ? std::min<size_t>(plan_prev->n, (size_t)seen + seen / 4 + 1024) : plan_prev->n;
+        a.own_blocks = (unsigned)std::max<size_t>(1, (est + 31) / 32);
+      }
     } else {
       a.own.v = t->view_of(t->cur);
       a.own_blocks = 0;
