@@ -173,7 +173,7 @@ class IdFactory:
 
 
 # ------------------------------------------------------------------ CPU baseline (reference engine)
-def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg):
+def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg, init_div=1):
   """Child process (no torch): builds the reference's CPU table with n_keys resident keys and times the ops on it.  Every rate
   is the MEDIAN of 3 repeats of a fixed number of batches; the pool size is fixed."""
   import oracle
@@ -205,7 +205,9 @@ def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg):
       out.append(units * iters / (time.perf_counter() - t0))
     return sorted(out)[len(out) // 2]
 
-  tab, create_s, fill_s = fill(n_keys)
+  # init_div > 1: the table is created for n_keys / init_div keys and GROWS under the (multi-threaded) fill — the constructor of a
+  # pre-sized libcuckoo table touches every bucket on ONE thread (a second per million keys), which a 256 M-key table cannot afford
+  tab, create_s, fill_s = fill(max(8192, n_keys // init_div))
   ops = {
       # Find on the batch WITH its repeats (not what TFRA issues — it de-duplicates first): every occurrence of the hot id takes the
       # same bucket spinlock, 0.15 M ids/s on a 128-thread pool; three batches only
@@ -240,11 +242,11 @@ def cpu_baseline(batch):
   TableWrapperOptimized + the LaunchTensors* launchers (K/cuckoo_hashtable_op.cc:39-182: static split of the keys over
   a persistent intra-op pool) — timed on this box's host cores: per op (find / insert_or_assign / insert_or_accum) and
   for the full lookup + write-back step, table pre-sized (init_size = N) and at the reference default (init_size = 8192,
-  growth included).  dim 64 fp32 rows (256 B).  N = the larger rung of (16 M, 4 M) resident keys whose table this
-  box builds within the time box (SURVEY §8d asks for the largest N the RAM holds; the constructor of a pre-sized libcuckoo
-  table touches every bucket on one thread — 16 s for 16 M keys, a minute for 64 M — so the time box, not the RAM, is what
-  binds); each rung runs in a child process
-  that is killed when it overruns.  Fixed pool size, every rate the median of 3 repeats."""
+  growth included).  dim 64 fp32 rows (256 B).  N = the largest rung of (256 M, 16 M, 4 M) resident keys whose table this
+  box builds within its time box (SURVEY §8d asks for the largest N the RAM holds; the constructor of a pre-sized libcuckoo
+  table touches every bucket on one thread — 16 s for 16 M keys — so the 256 M rung is created for N / 8 keys and grows under
+  the multi-threaded fill); each rung runs in a child process that is killed when it overruns.  Fixed pool size, every rate the
+  median of 3 repeats."""
   import multiprocessing as mp
   import oracle
   kind = "reference" if oracle.available("reference") else "port"
@@ -254,17 +256,21 @@ def cpu_baseline(batch):
     ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
   except (ValueError, OSError):
     ram = 0
-  rungs = [n for n in (16_000_000, 4_000_000) if n == 4_000_000 or (ram > 3 * n * 330 and cores >= 8)]
+  # (keys, init_size divisor, time box in s): 256 M keys (85 GB; grown from N / 8 by the multi-threaded fill) on a box that has the
+  # cores and the RAM, 16 M pre-sized as the fallback, 4 M as the last resort
+  rungs = [r for r in ((256_000_000, 8, 150.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
+           if r[0] == 4_000_000 or (ram > 3 * r[0] * 330 and cores >= (64 if r[0] > 16_000_000 else 8))]
+  if os.environ.get("TFRA_BENCH_CPU_KEYS"):
+    rungs = [(int(os.environ["TFRA_BENCH_CPU_KEYS"]), 8, 300.0)]
   t_begin = time.perf_counter()
   got, tried = None, []
   ctx = mp.get_context("spawn")
-  for n_keys in rungs:
-    last = n_keys == rungs[-1]
+  for n_keys, init_div, box in rungs:
+    last = (n_keys, init_div, box) == rungs[-1]
     parent, child = ctx.Pipe(duplex=False)
-    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, n_keys, threads, kind, last or n_keys <= 16_000_000))
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, n_keys, threads, kind, n_keys <= 16_000_000, init_div))
     pr.start()
     child.close()
-    box = 90.0 if last else 45.0
     if parent.poll(box):
       try:
         got = parent.recv()
@@ -289,8 +295,8 @@ def cpu_baseline(batch):
       "dedup_ids_per_s_numpy_unique_1_core": round(dedup_rate),
       "resident_keys": n_keys, "host_cores": cores, "host_ram_bytes": ram, "rungs_tried": tried,
       "sample": "per batch of %d Zipf-1.2 ids: unique + Find(distinct ids) + Insert(distinct ids) on a %d-key table (dim 64 fp32, "
-                "init_size = N, created in %.1f s), %d-thread pool (host has %d cores), median of 3 x 16 batches; %.0f s of CPU work"
-                % (batch, n_keys, got["create_s"], threads, cores, time.perf_counter() - t_begin),
+                "init_size = N / %d, created in %.1f s), %d-thread pool (host has %d cores), median of 3 x 16 batches; %.0f s of CPU work"
+                % (batch, n_keys, init_div, got["create_s"], threads, cores, time.perf_counter() - t_begin),
       "per_op": {k: round(v) for k, v in ops.items()},
       "per_op_per_core": {k: round(v / threads) for k, v in ops.items()},
       "prefill_keys_per_s_init_size_8192_growth_included": round(got["grow_rate"]) if got["grow_rate"] else None,
@@ -875,7 +881,8 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
     from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep, RoutedPrefetchStep
     route = os.environ.get("TFRA_BENCH_ROUTE", "native")
     ahead = int(os.environ.get("TFRA_ROUTE_AHEAD", "3"))   # batches whose ids are known before their step (input pipeline)
-    ids = idf.keys(nsteps + ahead + 1)
+    Wr = max(W, 8)   # the routed pipeline runs three batches ahead on its own streams: the first steps fill it (round 3: 5 warm-up steps, first window 136 us against 104)
+    ids = idf.keys(Wr + WINDOWS * K + ahead + 1)
     uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
     if route == "native":
       err = None
@@ -911,9 +918,9 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
       rs.feed(ids[i + ahead])
       return out
 
-    for i in range(W):
+    for i in range(Wr):
       routed(i)
-    secs, med, host_s = timed_windows(torch, dist, world, dev, K, routed, first=W)
+    secs, med, host_s = timed_windows(torch, dist, world, dev, K, routed, first=Wr)
     for _ in range(ahead):   # drain the batches fed ahead
       rs.lookup(); rs.apply(grads)
     torch.cuda.synchronize()
@@ -977,7 +984,8 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
           "parallelism": ("key-hash sharded x%d, RCCL alltoall" % world) if world > 1 else ("single GPU through the route driver (no transport)" if c4 else "single GPU"),
           "multi_rank_rccl_note": None if not c4 else "no RCCL communicator with more than one rank has been formed on the builder's side (one GPU per box): "
                                                       "the N>1 numbers are the driver's to measure; nothing is projected here",
-          "table_ops_per_s": 2 * value, "prefill_s": round(t_fill, 1),
+          "table_ops_per_s": world * (B + U) * K / med, "table_ops_per_s_counts": "B lookups + U fused row updates (the distinct keys of the batch) per GPU and step",
+          "prefill_s": round(t_fill, 1),
           "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4), "route": route, "route_note": route_note,
           "timing": {"value": timing_note(secs, K)},
           "drivers": {
@@ -1172,6 +1180,15 @@ def main():
         except Exception as e:   # noqa: BLE001 — a secondary measurement must not lose the line
           sec[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
       res["secondary"] = sec
+      # what a `--gpus N` run measures PER GPU is configs[3] through the route driver — not the metric's configuration above: the
+      # N = 1 point of that curve, at the top level so that a scaling record is built from like workloads
+      c4r = sec.get("c4", {})
+      res["scaling_point"] = {
+          "workload": c4r.get("config", {}).get("workload"), "value": c4r.get("value"), "ms_per_step": c4r.get("ms_per_step"), "n_gpus": 1,
+          "error": c4r.get("error"),
+          "note": "`bench.py --gpus N` (N > 1) runs THIS workload per GPU (configs[3]: hash-sharded table, ids / rows / gradients routed); "
+                  "compare its `value` with this one, not with the top-level `value` (the metric's single-GPU configuration).  No RCCL "
+                  "communicator with more than one rank has been formed on the builder's side (one GPU per box): nothing is projected."}
   elif cfg == "c5":
     assert world == 1, "c5 here is the one-GPU form of configs[4]"
     res = run_c5(args, torch, de, dev)
