@@ -244,9 +244,8 @@ def cpu_baseline(batch):
   for the full lookup + write-back step, table pre-sized (init_size = N) and at the reference default (init_size = 8192,
   growth included).  dim 64 fp32 rows (256 B).  N = the largest rung of (256 M, 16 M, 4 M) resident keys whose table this
   box builds within its time box (SURVEY §8d asks for the largest N the RAM holds; the constructor of a pre-sized libcuckoo
-  table touches every bucket on one thread — 16 s for 16 M keys — so the 256 M rung is created for N / 8 keys and grows under
-  the multi-threaded fill); each rung runs in a child process that is killed when it overruns.  Fixed pool size, every rate the
-  median of 3 repeats."""
+  table touches every bucket on one thread — between 0.04 and 1 s per million keys depending on the box); each rung runs in a
+  child process that is killed when it overruns.  Fixed pool size, every rate the median of 3 repeats."""
   import multiprocessing as mp
   import oracle
   kind = "reference" if oracle.available("reference") else "port"
@@ -256,9 +255,10 @@ def cpu_baseline(batch):
     ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
   except (ValueError, OSError):
     ram = 0
-  # (keys, init_size divisor, time box in s): 256 M keys (85 GB; grown from N / 8 by the multi-threaded fill) on a box that has the
-  # cores and the RAM, 16 M pre-sized as the fallback, 4 M as the last resort
-  rungs = [r for r in ((256_000_000, 8, 150.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
+  # (keys, init_size divisor, time box in s): 256 M keys (85 GB, pre-sized: on the round-4 box the constructor took 0.6 s per
+  # 16 M keys and the 128-thread fill 10 M keys/s — ~35 s; growing from N / 8 instead managed 1 M keys/s and overran) on a box
+  # that has the cores and the RAM, 16 M as the fallback, 4 M as the last resort
+  rungs = [r for r in ((256_000_000, 1, 120.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
            if r[0] == 4_000_000 or (ram > 3 * r[0] * 330 and cores >= (64 if r[0] > 16_000_000 else 8))]
   if os.environ.get("TFRA_BENCH_CPU_KEYS"):
     rungs = [(int(os.environ["TFRA_BENCH_CPU_KEYS"]), 8, 300.0)]

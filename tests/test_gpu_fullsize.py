@@ -277,3 +277,142 @@ def test_metric_config_1e9_slots_benchmarked_paths(env):
   import gc
   gc.collect()
   torch.cuda.empty_cache()
+
+
+def _full_table(torch, de, dim, dtype, cap, name):
+  try:
+    t = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                        evict_strategy=de.HkvEvictStrategy.LRU, name=name)
+  except Exception as e:   # a box with less free HBM than the benchmark needs
+    pytest.skip("%d slots do not allocate here: %s" % (cap, str(e)[:120]))
+  from bench import keys_of_ranks_torch
+  for lo in range(1, cap + 1, 4_000_000):
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(cap, lo + 3_999_999) + 1, dtype=torch.int64, device="cuda"))
+    t._table.upsert(k, row_of(torch, k, dim, dtype), unique_keys=True)
+  return t
+
+
+def _release(torch, *objs):
+  import gc
+  for o in objs:
+    del o
+  gc.collect()
+  torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("cfg", ["metric_dim64_f32", "configs2_dim128_f16"])
+def test_overlapped_step_1e9_slots(env, cfg):
+  """The driver behind bench.py's `value` (tfra_table_step_overlap: lookup of batch i+1, write-back of batch i, its tail and the
+  plan builders in ONE launch) at the metric's FULL size — 10^9 slots, 273 GB — and at configs[2]'s (dim 128 fp16, half of every
+  batch never-seen ids: an eviction per new key).  Per step: the lookup must equal a plain tfra_table_find issued right behind the
+  call (the table then holds exactly what this lookup had to reflect: module docstring of tests/test_gpu_overlap.py), resident keys
+  return their closed-form row, never-seen ids miss.  The batches are drawn so that the write-back's victims — the oldest
+  entries — ARE ids of the next lookup (ranks of the first pre-fill chunks): the deferred-eviction / correction path runs at size."""
+  torch, de = env
+  from bench import keys_of_ranks_torch
+  dim, dtype = (64, torch.float32) if cfg.startswith("metric") else (128, torch.float16)
+  B, cap, steps = 131072, 1_000_000_000, 10
+  t = _full_table(torch, de, dim, dtype, cap, "ovl_full_%s" % cfg)
+  tbl = t._table
+  capacity = tbl.capacity()
+  assert 0.9 * cap < int(t.size().item()) <= capacity
+  gen = torch.Generator(device="cuda").manual_seed(77)
+  fresh = cap + 1
+
+  def batch(step):
+    nonlocal fresh
+    # a third Zipf-ish hot ranks, a third of the OLDEST surviving ranks (the pre-fill went from rank 1 up and evicted the lowest ~5 %
+    # itself: ranks 40 M .. 120 M straddle that edge — some absent, the others the least recently used entries), a third never seen
+    hot = (torch.rand(B // 3, generator=gen, device="cuda") ** 8 * cap).to(torch.int64) + 1
+    old = torch.randint(40_000_000, 120_000_000, (B // 3,), generator=gen, device="cuda")
+    new = torch.arange(fresh, fresh + B - 2 * (B // 3), dtype=torch.int64, device="cuda")
+    fresh += new.numel()
+    r = torch.cat([hot, old, new])[torch.randperm(B, generator=gen, device="cuda")]
+    return keys_of_ranks_torch(torch, r), r > cap
+
+  ids = [batch(s) for s in range(steps + 2)]
+  drv = de.OverlapAssignStep(t).prime(ids[0][0])
+  written = {}
+  for s in range(steps):
+    k, is_new = ids[s]
+    vals = row_of(torch, k * 31 + (s + 1), dim, dtype) + (torch.arange(B, device="cuda")[:, None] % 5).to(dtype)   # position-dependent: WHICH occurrence is kept
+    out, ex = drv.step(vals, ids[s + 1][0], ids[s + 2][0], return_exists=True)
+    ref, rex = tbl.find(k, return_exists=True)
+    assert torch.equal(ex, rex), "step %d: %d exists flags differ" % (s, int((ex != rex).sum()))
+    assert torch.equal(out, ref), "step %d" % s
+    assert not bool(ex[is_new].any())                    # never-seen ids miss (a never-seen rank is drawn once)
+    assert int(t.size().item()) <= capacity
+    written[s] = (k, vals)
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] >= steps - 3 and st["deferred_evictions"] > 0 and st["rows_corrected"] > 0, st
+  assert st["plans_built_in_launch"] >= steps - 4, st
+  # the last batch is in the table, last occurrence wins
+  k, vals = written[steps - 1]
+  got, ex = t.lookup(k, return_exists=True)
+  uk, inv = torch.unique(k, return_inverse=True)
+  lp = torch.zeros(uk.numel(), dtype=torch.long, device="cuda")
+  lp.scatter_reduce_(0, inv, torch.arange(B, device="cuda"), reduce="amax", include_self=False)
+  assert bool(ex.all()) and torch.equal(got, vals[lp][inv])
+  c = tbl.slot_census()
+  assert c["locked"] == 0 and c["live"] == int(t.size().item()) <= capacity
+  tbl.check_errors()
+  _release(torch, drv, t, tbl, ids, written)
+
+
+def test_configs3_5e8_keys_routed_step_world1(env):
+  """configs[3]'s per-GPU workload at its full size: 5*10^8 resident keys behind the route driver (tfra_route_*, world 1: device
+  copies where the alltoalls would be), per-GPU batch 131 072 from a Zipf-like stream, fused SGD.  Closed-form rows: a lookup
+  returns row(key) for a key that has not been trained yet and row(key) - lr * (sum of its gradients) afterwards."""
+  torch, de = env
+  from bench import keys_of_ranks_torch
+  from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
+  dim, B, n_keys, lr = 64, 131072, 500_000_000, 0.5
+  opt = de.optimizers.SGD(lr)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  try:
+    var = de.Variable(dim=dim, devices=["cuda:0"], name="c4_full", initializer=0.0, init_size=int(n_keys * 1.05) + (1 << 20),
+                      **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    table = var.tables[0]
+    for lo in range(1, n_keys + 1, 4_000_000):
+      k = keys_of_ranks_torch(torch, torch.arange(lo, min(n_keys, lo + 3_999_999) + 1, dtype=torch.int64, device="cuda"))
+      table._table.upsert(k, row_of(torch, k, dim), unique_keys=True)
+  except Exception as e:
+    pytest.skip("5*10^8 keys do not fit here: %s" % str(e)[:120])
+  assert int(table.size().item()) == n_keys
+  gen = torch.Generator(device="cuda").manual_seed(5)
+  steps, ahead = 6, 3
+  ids = [keys_of_ranks_torch(torch, (torch.rand(B, generator=gen, device="cuda") ** 6 * n_keys).to(torch.int64) + 1) for _ in range(steps + ahead)]
+  rs = NativeRoutedStep(var, deo, partition_mode=0, max_batch=B)
+  for j in range(ahead):
+    rs.feed(ids[j])
+  gsum = {}   # key -> summed gradient so far, on the device: a dense accumulator over the ids seen
+  seen_k = torch.empty(0, dtype=torch.int64, device="cuda")
+  seen_g = torch.empty((0, dim), device="cuda")
+  for s in range(steps):
+    out = rs.lookup()
+    k = ids[s]
+    want = row_of(torch, k, dim)
+    if seen_k.numel():
+      pos = torch.searchsorted(seen_k, k).clamp(max=seen_k.numel() - 1)
+      hit = seen_k[pos] == k
+      want = torch.where(hit[:, None], want - lr * seen_g[pos], want)
+    # (the reference sum here is torch's index_add_ — atomics, any order — not the sequential oracle of the 1e-6 parity tests:
+    # a hot id's thousands of gradients sum to ~1, two fp32 summation orders of that differ by ~1e-6 of it)
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    g = torch.randn((B, dim), generator=gen, device="cuda") * 0.01
+    rs.apply(g)
+    uk, inv = torch.unique(k, return_inverse=True)
+    ug = torch.zeros((uk.numel(), dim), device="cuda").index_add_(0, inv, g)
+    allk = torch.cat([seen_k, uk])
+    allg = torch.cat([seen_g, ug])
+    seen_k, inv2 = torch.unique(allk, return_inverse=True)
+    seen_g = torch.zeros((seen_k.numel(), dim), device="cuda").index_add_(0, inv2, allg)
+    rs.feed(ids[s + ahead])
+  for _ in range(ahead):
+    rs.lookup(); rs.apply(torch.zeros((B, dim), device="cuda"))
+  torch.cuda.synchronize()
+  rs.close()
+  assert int(table.size().item()) == n_keys
+  table._table.check_errors()
+  _release(torch, rs, var, table, ids)
