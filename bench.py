@@ -737,6 +737,8 @@ def run_bounded(args, torch, de, dev, cfg):
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "f32",
       "data": "synthetic",
       "value_look_ahead_driver": B * K / med_pf, "ms_per_step_look_ahead_driver": med_pf / K * 1e3,
+      "faster_driver": "overlapped (value)" if med <= med_pf else "look_ahead (value_look_ahead_driver): many never-seen ids per batch make the "
+                       "write-back the long pole, and it runs faster as kernels of its own than as a role of the step launch",
       "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
       "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
       "value_op_surface_find_first": B * K / med_opf, "ms_per_step_op_surface_find_first": med_opf / K * 1e3,

@@ -60,6 +60,7 @@ struct StepArgs {
                                // (8 shards), [32*9] tail blocks through their items; sync_next: the next launch's (two sets alternate)
   unsigned* sync_next;
   unsigned* zero4;             // the left-over counters of the plan's NEXT use (armed by the tail)
+  int ablate;                  // (tuning) roles that return at once: 1 builders, 2 write-back + tail, 4 lookup, 8 tail
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
   int own_from_list;           // (tuning) the write-back walks the plan's dense key list (plans built by setplan_kernel) instead of its table
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
@@ -194,57 +195,57 @@ __device__ __forceinline__ void build_role(const StepArgs& a, unsigned win, Step
 }
 
 // ---- FIND role: find_kernel<16, 4, WT, PF1> + forwarding -----------------------------------------------------------
-// Lane j (and j+16, j+32, j+48) holds key j of the wave's 16 and hashes it; for the plan probe the FOUR replicas of a key
-// read four consecutive entries of its chain (one 16-B load per lane, all 64 lanes busy, no redundancy); the table probe is
-// find_kernel's (both home buckets' lines in flight).
+// A wave takes KW = 4 U ids (U = 4: 16, U = 8: 32): lane j < KW — and its 64 / KW replicas — holds id j and hashes it; for the
+// plan probe the replicas of an id read consecutive entries of its chain (one 16-B load per lane, all 64 lanes busy, no
+// redundancy); the table probe is find_kernel's, one 16-lane group per id, U ids per group in flight.
+// (Tried, U = 8: 32 ids per wave, twice the loads in flight in registers the write-back's roles need anyway — a lookup block then
+// takes 14.6 us instead of 7.4 for twice the ids, the step 34.5 us instead of 31.9: what a wave waits for is served at a rate, not
+// after a latency.  SQ counters of the launch: 12.8 K waves, 300 vector + 204 scalar instructions per wave, 77 % of the wave cycles
+// parked on s_waitcnt, L2 hit ratio 24 % — plan, value rows and table lines of eight XCDs' worth of batch do not fit eight 4-MB L2s.)
+template <int N, typename T>
+__device__ __forceinline__ void keep_live_n(T (&x)[N]) {
+  static_assert(N % 4 == 0, "keep_live_n: multiples of four");
+#pragma unroll
+  for (int q = 0; q < N; q += 4) keep_live(x[q], x[q + 1], x[q + 2], x[q + 3]);
+}
+template <int U>
 __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
-  constexpr int U = 4;
+  constexpr int KW = 4 * U, REP = 64 / KW;
   const TableView& v = a.own.v;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  const int rep = lane / KW;                       // which of the id's replicas this lane is
   const unsigned wave = blk * 4u + (threadIdx.x >> 6);
-  const unsigned base = wave * 16u;
+  const unsigned base = wave * (unsigned)KW;
   if (base >= a.n) return;
   const unsigned last = a.n - 1;
-  const i64 kreg = a.ids[min(base + (unsigned)sub, last)];
+  const i64 kreg = a.ids[min(base + (unsigned)(lane & (KW - 1)), last)];
   u64 hreg;
   const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
   const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
   const bool resv = is_reserved_key(kreg);
   const unsigned home = set_home(a.fwd, kreg, hreg);
   const unsigned wm = set_wmask(a.fwd.m2);
-  const unsigned eidx = resv ? home + (unsigned)grp : set_at(home, (unsigned)grp, wm);
+  const unsigned eidx = resv ? home + (unsigned)rep : set_at(home, (unsigned)rep, wm);
   uint4 e = *reinterpret_cast<const uint4*>(a.fwd.ent + eidx);
   i64 key[U], k0[U], k1[U];
-  unsigned b0[U], b1[U], idx[U];
+  unsigned b0[U], b1[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = u * 4 + grp;
     key[u] = shfl_i64(kreg, j);
     b0[u] = (unsigned)__shfl((int)b0reg, j);
     b1[u] = (unsigned)__shfl((int)b1reg, j);
-    idx[u] = min(base + (unsigned)j, last);
-  }
-  if (!a.serial_probe) {   // (tuning) the table's lines travel WITH the plan probe: every id pays two random lines of the table
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      k0[u] = key_line(v, b0[u])[sub];
-      k1[u] = key_line(v, b1[u])[sub];
-    }
   }
   keep_live(e.x, e.y, e.z, e.w);
-  if (!a.serial_probe) {
-    keep_live(k0[0], k0[1], k0[2], k0[3]);
-    keep_live(k1[0], k1[1], k1[2], k1[3]);
-  }
-  // the plan probe, per key: a match in any of the four entries is the key; none and no EMPTY among them: go on (rare)
+  // the plan probe, per id: a match in any of its replicas' entries is the id; none and no EMPTY among them: go on (rare)
   const i64 ekey = (i64)(((u64)e.y << 32) | e.x);
-  const bool match = resv ? (grp == 0 && ekey != EMPTY_KEY) : ekey == kreg;
+  const bool match = resv ? (rep == 0 && ekey != EMPTY_KEY) : ekey == kreg;
   unsigned p1 = match ? e.z : 0u;
   unsigned stop = (ekey == EMPTY_KEY || resv) ? 1u : 0u;
-  p1 |= (unsigned)__shfl_xor((int)p1, 16); p1 |= (unsigned)__shfl_xor((int)p1, 32);
-  stop |= (unsigned)__shfl_xor((int)stop, 16); stop |= (unsigned)__shfl_xor((int)stop, 32);
+#pragma unroll
+  for (int o = KW; o < 64; o <<= 1) { p1 |= (unsigned)__shfl_xor((int)p1, o); stop |= (unsigned)__shfl_xor((int)stop, o); }
   if (!p1 && !stop) {
-    for (unsigned t = 4; t <= wm; ++t) {
+    for (unsigned t = REP; t <= wm; ++t) {
       const SetEnt* q = a.fwd.ent + set_at(home, t, wm);
       const i64 k = q->key;
       if (k == kreg) { p1 = q->pos1; break; }
@@ -254,39 +255,40 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
   unsigned fwd_pos[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) fwd_pos[u] = (unsigned)__shfl((int)p1, u * 4 + grp);
-  if (a.serial_probe) {
+  {
     // The table's lines BEHIND the plan probe, and only for the ids the plan does not hold: on a Zipf stream most positions of a
     // batch repeat ids of the batch before (85 % on the metric's configuration), and every line of a 273-GB table is a random,
     // TLB-missing access.  The loads stay unconditional (one wait for all of them): a forwarded id reads one hot line of the plan.
+    // (Tried: the lines of every id in flight WITH the plan probe — one trip less, two random lines more per forwarded id: no gain.)
     const i64* hot = reinterpret_cast<const i64*>(a.fwd.ent);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       k0[u] = (fwd_pos[u] ? hot : key_line(v, b0[u]))[sub];
       k1[u] = (fwd_pos[u] ? hot : key_line(v, b1[u]))[sub];
     }
-    keep_live(k0[0], k0[1], k0[2], k0[3]);
-    keep_live(k1[0], k1[1], k1[2], k1[3]);
+    keep_live_n<U>(k0);
+    keep_live_n<U>(k1);
   }
   const unsigned char* src[U];
-  unsigned char* dst[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned fw = fwd_pos[u];
+    const unsigned idx = min(base + (unsigned)(u * 4 + grp), last);
     i64 word = 0;
     if (!fw) word = probe_find_word(v, key[u], b0[u], b1[u], k0[u], sub, gshift, &k1[u]);
     // (write-through like the rows: the tail's corrections come from another workgroup and must land BEHIND this store)
-    if (a.exists && sub == 0) __hip_atomic_store(a.exists + idx[u], (uint8_t)(fw != 0 || word >= 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.exists && sub == 0) __hip_atomic_store(a.exists + idx, (uint8_t)(fw != 0 || word >= 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     src[u] = fw ? a.own.vals + (u64)(fw - 1u) * (u64)v.field_bytes
-                : (word >= 0 ? word_row_ptr(v, (u64)word) : a.defaults + (a.full ? (u64)idx[u] * (u64)v.field_bytes : 0));
-    dst[u] = a.out + (u64)idx[u] * (u64)v.field_bytes;
+                : (word >= 0 ? word_row_ptr(v, (u64)word) : a.defaults + (a.full ? (u64)idx * (u64)v.field_bytes : 0));
   }
   for (unsigned off = sub * 16; off < v.field_bytes; off += 256) {
     uint4 tmp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const uint4*>(src[u] + off);
-    keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
+    keep_live_n<U>(tmp);
 #pragma unroll
-    for (int u = 0; u < U; ++u) store_wt16(dst[u] + off, tmp[u]);
+    for (int u = 0; u < U; ++u)
+      store_wt16(a.out + (u64)min(base + (unsigned)(u * 4 + grp), last) * (u64)v.field_bytes + off, tmp[u]);
   }
 }
 // a lookup block is done: its output rows are in memory (write-through, acknowledged).  Only the tail's rare corrections wait for this.
@@ -331,6 +333,9 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   }
   __syncthreads();
   const unsigned cnt = L.n;
+  // (Tried: ONE round per block — 16 U keys — and the few keys beyond it straight onto the item list, so that no block runs the
+  // chain of round trips twice: the slowest write-back blocks are not the ones with a second round — the role ended at 19 us as
+  // before — and the tail, with 60 items instead of a dozen, ran longer: 31.9 -> 37.3 us per step.)
   int fresh = 0;
   const OwnFlags fl = own_setup<SIMPLE>(o);
   for (unsigned wbase = (tid >> 6) * (4 * U); wbase < cnt; wbase += 4 * (4 * U)) {
@@ -386,7 +391,7 @@ __device__ __forceinline__ void role_stamp(const StepArgs& a, u64 t0) {
 // change; (b) the tail IN FRONT of the lookup's blocks, so that it holds its wave slots from the start instead of getting them
 // 18 us into the launch: its 32 polling blocks (one lane each, s_sleep between polls) slow the write-back they wait for from 19
 // to 34 us — the step went from 33 to 45 us.  Behind the lookup's blocks the tail starts when the write-back is (nearly) done
-// and hardly ever polls.
+// and hardly ever polls; (c) the write-back's blocks in front of the builders': no change.
 __host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned O, unsigned F, unsigned T,
                                                   unsigned* idx) {
   (void)T;
@@ -401,29 +406,33 @@ __host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blo
   return 4;
 }
 __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepLds& L);
-// (A kernel gets the registers of its hungriest role for EVERY wave: the lookup alone needs 58, next to the locked protocol of the
-// tail 95 — 5 waves per SIMD.  Fewer registers for the lookup — one key per four lanes in the write-back, 69 registers, 7 waves —
-// changed nothing: the launch is bound by what the memory system moves.)
-template <bool SIMPLE, int U, bool TIMING, int ROLES = 3>
+// A kernel gets the registers of its hungriest role for EVERY wave: the lookup and the builders need 58, the write-back 91, the
+// tail's locked protocol 113 — 4 blocks per CU for 32 blocks of the grid.  The kernels are compiled for 5 waves per SIMD
+// (amdgpu_waves_per_eu: 96 registers, six spilled ones, all in the tail): 1280 resident blocks instead of 1024, the lookup's
+// first blocks start with the launch instead of behind the builders — 33.3 -> 31.4 us per step.  6 waves (80 registers, 62
+// spilled, some in the write-back): 32.6 us.
+template <bool SIMPLE, int U, bool TIMING, int WAVES>
 __device__ __forceinline__ void step_body(const StepArgs& a) {
   __shared__ StepLds L;
   const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
   unsigned idx;
   const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, a.tail_blocks, &idx);
-  if (role == 0) { if (ROLES & 1) build_role(a, idx, L); }
-  else if (role == 1) { if (ROLES & 1) scatter_role(a, idx, L); }
-  else if (role == 2) { if (ROLES & 2) { if (a.own_from_list) own_role_list<SIMPLE, U>(a, idx); else own_role<SIMPLE, U>(a, idx, L); } }
-  else if (role == 3) { if (ROLES & 1) { find_fwd_role(a, idx); find_arrive(a); } }
-  else { if (ROLES & 2) tail_role(a, idx, L); }
+  if (role == 0) { if (!(a.ablate & 1)) build_role(a, idx, L); }
+  else if (role == 1) { if (!(a.ablate & 1)) scatter_role(a, idx, L); }
+  else if (role == 2) { if (!(a.ablate & 2)) { if (a.own_from_list) own_role_list<SIMPLE, U>(a, idx); else own_role<SIMPLE, U>(a, idx, L); } }
+  else if (role == 3) { if (!(a.ablate & 4)) find_fwd_role<4>(a, idx); find_arrive(a); }
+  else { if (!(a.ablate & (2 | 8))) tail_role(a, idx, L); }
   if (TIMING) role_stamp(a, t0);
 }
-// Instantiations (the SGPR budget is an attribute, not a template argument): 256-thread blocks are admitted per CU up to
+// Instantiations (the budgets are attributes, not template arguments): 256-thread blocks are admitted per CU up to
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) — ~106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
-#define TFRA_STEP_KERNEL(NAME, UU, TIMING, NSGPR, ROLES)                                                                 \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(NSGPR))) void NAME(const StepArgs a) { step_body<true, UU, TIMING, ROLES>(a); }
-TFRA_STEP_KERNEL(step_k_u2, 2, false, 104, 3)
-TFRA_STEP_KERNEL(step_k_u1, 1, false, 104, 3)
-TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 104, 3)
+#define TFRA_STEP_KERNEL(NAME, UU, TIMING, W)                                                                            \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(104), amdgpu_waves_per_eu(W, W))) void NAME(const StepArgs a) { step_body<true, UU, TIMING, W>(a); }
+TFRA_STEP_KERNEL(step_k_u2, 2, false, 5)
+TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 5)
+TFRA_STEP_KERNEL(step_k_u1, 1, false, 5)       // (tuning) 4 keys per wave in the write-back
+TFRA_STEP_KERNEL(step_k_u2_w4, 2, false, 4)    // (tuning) no spills, 4 blocks per CU
+TFRA_STEP_KERNEL(step_k_u2_w6, 2, false, 6)    // (tuning) 6 blocks per CU
 #undef TFRA_STEP_KERNEL
 
 // ---- TAIL role: the remainder of a step INSIDE its launch ------------------------------------------------------------------
@@ -581,6 +590,7 @@ struct tfra_step_driver {
   unsigned last_tail_step = ~0u;           // step number of the last launch that had a tail (it zeroes the next launch's counters)
   unsigned char* patch = nullptr;          // device: two victim counters (one 128-B line each) + two lists of PATCH_GCAP keys + two sets of 10 sync counters (tail_role)
   unsigned step_no = 0;
+  int ablate = 0; unsigned ablate_after = 40;   // TFRA_STEP_ABLATE / TFRA_STEP_ABLATE_AFTER (tuning: timing of the roles alone; results are wrong)
   int variant = 0;                         // TFRA_STEP_VARIANT (tuning): kernel instantiation
   unsigned long long n_overlapped = 0, n_sequential = 0;   // steps taken each way (tfra_step_driver_stats)
   unsigned long long n_built_in_launch = 0, n_built_in_front = 0;   // plans of the next batch built by the step launch / by a launch of their own
@@ -610,6 +620,8 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   if (hipDeviceSynchronize() != hipSuccess) { tfra_step_driver_destroy(d); return set_error(TFRA_ERR_HIP, "step_driver_create: sync"); }
   const char* ev = std::getenv("TFRA_STEP_VARIANT");
   d->variant = ev ? std::atoi(ev) : 0;
+  if (const char* ab = std::getenv("TFRA_STEP_ABLATE")) d->ablate = std::atoi(ab);
+  if (const char* ab = std::getenv("TFRA_STEP_ABLATE_AFTER")) d->ablate_after = (unsigned)std::atoi(ab);
   if (d->variant & 16) {
     const size_t bytes = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 16;
     if (hipMalloc((void**)&d->tbuf, bytes) != hipSuccess || hipMemset(d->tbuf, 0, bytes) != hipSuccess) { d->tbuf = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
@@ -722,12 +734,14 @@ extern "C" int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step
 static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_tab[pl->set_parity].ent, pl->set_m2}; }
 static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 && pl->listless[pl->set_parity]; }
 
-// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0: 8 keys per wave in the write-back | 1: 4), 8 every plan as a launch of
+// variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0: 8 keys per wave in the write-back, 5 blocks per CU | 1: 4 keys | 2: 4 blocks per CU | 3: 6), 8 every plan as a launch of
 // its own, 16 time stamps, 64 the lookup reads the table's lines for every id
 static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {   // the overlapped step: one launch
   const int k = variant & 7;
   if (variant & 16) step_k_u2_t<<<grid, 256, 0, s>>>(a);
   else if (k == 1) step_k_u1<<<grid, 256, 0, s>>>(a);
+  else if (k == 2) step_k_u2_w4<<<grid, 256, 0, s>>>(a);
+  else if (k == 3) step_k_u2_w6<<<grid, 256, 0, s>>>(a);
   else step_k_u2<<<grid, 256, 0, s>>>(a);
 }
 
@@ -818,6 +832,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.sync_next = reinterpret_cast<unsigned*>(d->patch + 256 + 2 * PATCH_GCAP * 8 + 1280 * ((step & 1u) ^ 1u));
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
+    a.ablate = (d->ablate && d->step_no >= d->ablate_after) ? d->ablate : 0;
     // the next batch's plan: its pairs were scattered by the previous call's launch -> this launch builds the table; else a launch of its own, in front
     if (n_next) {
       if (plan_next->scat_ids == ids_next && plan_next->scat_n == n_next && !(d->variant & 8)) {

@@ -23,6 +23,7 @@ def main():
   ap.add_argument("--dim", type=int, default=64)
   ap.add_argument("--dtype", default="float32")
   ap.add_argument("--skip-old", action="store_true")
+  ap.add_argument("--ablate", default="0", help="comma list of TFRA_STEP_ABLATE masks (1 builders, 2 write-back + tail, 4 lookup return at once after 40 steps: timing only)")
   ap.add_argument("--one-ahead", action="store_true", help="D = 1: announce only the next batch (its plan is then built by a launch of its own)")
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mb_overlap.json"))
   args = ap.parse_args()
@@ -88,8 +89,9 @@ def main():
   torch.cuda.synchronize()
   del ps
   depths = [int(x) for x in args.depth.split(",")]
-  for v in [int(x) for x in args.variants.split(",")]:
+  for v, ab in [(int(x), int(y)) for x in args.variants.split(",") for y in args.ablate.split(",")]:
     os.environ["TFRA_STEP_VARIANT"] = str(v)
+    os.environ["TFRA_STEP_ABLATE"] = str(ab)
     for D in depths:
       drv = de.OverlapAssignStep(table)
       base = [0]
@@ -139,8 +141,9 @@ def main():
       jlast = ((base[0] - 1) if D == 1 else (4 * K - 1)) % NB
       got, ex = table.lookup(ids[jlast], return_exists=True)
       ok = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, ids[jlast], values)))
-      table._table.check_errors()
-      res["runs"].append({"driver": "step_overlap", "variant": v, "steps_per_host_call": D, "us_per_step": us, "host_us_per_step": hus,
+      if not ab:
+        table._table.check_errors()
+      res["runs"].append({"driver": "step_overlap", "variant": v, "ablate": ab, "steps_per_host_call": D, "us_per_step": us, "host_us_per_step": hus,
                           "windows": all_, "stats": st, "last_batch_ok": ok, "timing": tm})
       print(res["runs"][-1], flush=True)
       del drv

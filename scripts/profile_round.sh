@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round: per workload (m1b = the default bench line, c3 / c2 = its secondaries) a
 # kernel-trace + stats run and separate PMC passes (as MI355X_MICROARCH.md prescribes; gpurun refuses --pmc combined
-# with API tracing).   Usage (on the GPU box, via gpurun):  bash scripts/profile_round.sh r03 ["m1b c3 c2"]
-TAG=${1:-r03}
-WORKLOADS=${2:-"m1b c3 c2"}
+# with API tracing).   Usage (on the GPU box, via gpurun):  bash scripts/profile_round.sh r04 ["m1b c3 c2 c4"]
+TAG=${1:-r04}
+WORKLOADS=${2:-"m1b c3 c2 c4"}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

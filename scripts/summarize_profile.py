@@ -17,12 +17,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ["find_kernel", "upsert_own_kernel", "upsert_rest_kernel", "setplan_kernel", "insert_unique_kernel",
            "insert_evict_kernel", "export_kernel", "csr_tile_kernel", "csr_bucket_kernel", "csr_scatter_kernel", "hot_sums_kernel",
-           "apply_csr_kernel", "apply_kernel", "density_kernel"]
-COMMANDS = {w: "python bench.py --config %s --no-secondary --no-cpu-baseline" % w for w in ("m1b", "c3", "c2")}
+           "apply_csr_kernel", "apply_kernel", "density_kernel", "unique_idx_kernel", "unq_insert_kernel", "gather_csr_kernel", "plan_dest_bins_kernel",
+           "plan_dest_keys_kernel", "part_scatter_kernel", "accum_kernel", "step_k"]
+WORKLOADS = ("m1b", "c3", "c2", "c4")
+COMMANDS = {w: "python bench.py --config %s --no-secondary --no-cpu-baseline" % w for w in WORKLOADS}
 SRC_NAMES = {"0": "plan", "1": "direct", "2": "set"}   # upsert_own_kernel<G, SIMPLE, SRC> / upsert_rest_kernel<G, SRC>: where the keys come from
 
 
 def short(name):
+  if re.search(r"\bstep_k_u\d", name):   # the overlapped step's one launch (csrc/tfra_step_impl.h: step_k_u2 / step_k_u1 / step_k_u2_t)
+    return "step_k"
   m = re.search(r"(\w+_kernel)\b", name)
   if not m or m.group(1) not in KERNELS:
     return None
@@ -96,7 +100,7 @@ def workload(src, tag, w, out_dir):
 
 
 def main():
-  tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+  tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
   src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
   # on the GPU box only gpurun_out/ travels back (<= 64 MiB): summarise there into gpurun_out/<dir>, copy into profiles/ at home
   out_dir = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
@@ -106,7 +110,7 @@ def main():
                      "Kernel averages mix the timed steps with the per-kernel timing loops of bench.py (same kernels, same shapes) and, for "
                      "insert_unique_kernel / insert_evict_kernel, are the 4 M-key pre-fill launches.  sq_per_wave: SQ_* counters per wave "
                      "(wave_quad_cycles in 4-cycle units; wait_any = parked on s_waitcnt, issue_stall = dependency / pipe stalls)."}
-  for w in ("m1b", "c3", "c2"):
+  for w in WORKLOADS:
     r = workload(src, tag, w, out_dir)
     if r:
       summary["workloads"][w] = r
