@@ -1169,7 +1169,7 @@ def main():
       args._growth = measure_growth(torch, de, dev, 128, torch.float16, args.slots // 4)   # reported under secondary.c3
     res = run_bounded(args, torch, de, dev, cfg)
     if not args.no_secondary and args.config is None:
-      keep = ("metric", "value", "value_look_ahead_driver", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
+      keep = ("metric", "value", "value_look_ahead_driver", "faster_driver", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
               "value_op_surface_table_ops_only", "ms_per_step",
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}
