@@ -34,7 +34,7 @@
 
 struct StepArgs {
   OwnArgs own;                 // write-back of the PREVIOUS batch (its keys come from `fwd`, the previous batch's plan); own_blocks == 0: none pending
-  OwnCtrs* ctr;                // its left-over counters
+  OwnCtrs* ctr;                // the plan's left-over counters (the step counts in sync[1]; these belong to the sequential path)
   unsigned own_gen;
   unsigned* progress;          // pinned: [0] step
   unsigned progress_val;
@@ -57,12 +57,12 @@ struct StepArgs {
   SetEnt* scat_pairs; unsigned* scat_cnt; SetEnt* scat_ovf; unsigned* scat_ovf_cnt; unsigned* scat_ovf_cnt_next;   // (two overflow counters alternate: this scatter zeroes the next one's)
   unsigned own_blocks, find_blocks, tail_blocks;
   unsigned* sync;              // this launch's counters, one 128-byte line each: [0] write-back blocks done, [32 .. 32*8] lookup blocks done
-                               // (8 shards), [32*9] tail blocks through their items; sync_next: the next launch's (two sets alternate)
+                               // (8 shards), [32*9] tail blocks through their items; sync_next: the next launch's (two sets alternate).  [1] the
+                               // write-back's left-over keys (item list length), [32*9+1] = patch_count: each read WITH the arrivals beside it
   unsigned* sync_next;
   unsigned* zero4;             // the left-over counters of the plan's NEXT use (armed by the tail)
   int ablate;                  // (tuning) roles that return at once: 1 builders, 2 write-back + tail, 4 lookup, 8 tail
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
-  int own_from_list;           // (tuning) the write-back walks the plan's dense key list (plans built by setplan_kernel) instead of its table
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
   u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
   i64* patch_keys;             // step_rest_kernel: the launch's list of evicted keys that are ids of this batch
@@ -341,7 +341,7 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   for (unsigned wbase = (tid >> 6) * (4 * U); wbase < cnt; wbase += 4 * (4 * U)) {
     const unsigned i = wbase + (unsigned)(lane & 15);
     const unsigned c = min(i, cnt - 1);
-    own_batch16<16, SIMPLE, SRC_GIVEN, U, true>(o, fl, L.pos[1024 + c], (lane & 15) < 4 * U && i < cnt, a.own_gen, &a.ctr->n_a, lane, fresh, &a.nxt, a.stat,
+    own_batch16<16, SIMPLE, SRC_GIVEN, U, true>(o, fl, L.pos[1024 + c], (lane & 15) < 4 * U && i < cnt, a.own_gen, a.sync + 1, lane, fresh, &a.nxt, a.stat,
                                                 L.key[c], L.pos[c] - 1u);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
@@ -352,27 +352,8 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// (tuning) the write-back over the plan's DENSE KEY LIST (a plan built by setplan_kernel, TFRA_STEP_VARIANT & 8 | 32): upsert_own_kernel's loop
-template <bool SIMPLE, int U>
-__device__ __forceinline__ void own_role_list(const StepArgs& a, unsigned blk) {
-  const OwnArgs& o = a.own;
-  const int lane = threadIdx.x & 63;
-  const unsigned total = o.ks.d_counts[0] + o.ks.d_counts[1];
-  const unsigned nwaves = a.own_blocks * 4u;
-  const unsigned wave = blk * 4u + (threadIdx.x >> 6);
-  if (blk == 0 && threadIdx.x == 0 && a.progress) __hip_atomic_store(a.progress + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  int fresh = 0;
-  const OwnFlags fl = own_setup<SIMPLE>(o);
-  for (unsigned wbase = wave * (4 * U); wbase < total; wbase += nwaves * (4 * U)) {
-    const unsigned i = wbase + (unsigned)(lane & 15);
-    own_batch16<16, SIMPLE, SRC_SET, U, true>(o, fl, min(i, total - 1), (lane & 15) < 4 * U && i < total, a.own_gen, &a.ctr->n_a, lane, fresh, &a.nxt, a.stat);
-  }
-  for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
-  if (lane == 0 && fresh) size_add(o.v, wave, fresh);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (Tried: the write-back over a DENSE KEY LIST of the plan — a plan built by setplan_kernel as a launch of its own — instead of
+// slices of its table: 8 keys for every wave, no empty slots to skip — 43.5 us per step against 45.0 with that plan launch, 33 without.)
 
 // TIMING (tuning builds only): every block notes its start and end on the device clock in a.tbuf (a slot per launch and block):
 // when does each role of a launch run?
@@ -419,7 +400,7 @@ __device__ __forceinline__ void step_body(const StepArgs& a) {
   const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, a.tail_blocks, &idx);
   if (role == 0) { if (!(a.ablate & 1)) build_role(a, idx, L); }
   else if (role == 1) { if (!(a.ablate & 1)) scatter_role(a, idx, L); }
-  else if (role == 2) { if (!(a.ablate & 2)) { if (a.own_from_list) own_role_list<SIMPLE, U>(a, idx); else own_role<SIMPLE, U>(a, idx, L); } }
+  else if (role == 2) { if (!(a.ablate & 2)) own_role<SIMPLE, U>(a, idx, L); }
   else if (role == 3) { if (!(a.ablate & 4)) find_fwd_role<4>(a, idx); find_arrive(a); }
   else { if (!(a.ablate & (2 | 8))) tail_role(a, idx, L); }
   if (TIMING) role_stamp(a, t0);
@@ -458,6 +439,18 @@ __device__ __forceinline__ bool spin_until(const unsigned* ctr, unsigned want) {
   }
   return false;
 }
+// the same on the LOW word of an 8-byte pair, read as one: *both = the pair as it was when the low word had reached `want` (a count
+// kept in the high word by those who arrive is complete then — their additions to it come before their arrival)
+__device__ __forceinline__ bool spin_until_pair(const unsigned* ctr, unsigned want, unsigned long long* both) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(ctr);
+  for (unsigned it = 0; it < (1u << 22); ++it) {
+    const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)v >= want) { *both = v; return true; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  *both = 0;
+  return false;
+}
 __device__ __forceinline__ uint4 load_coherent16(const void* p) {   // written write-through by another workgroup of this launch
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
   const unsigned long long x = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -473,12 +466,20 @@ __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepL
   if (blk == 0) {   // arm what the next launch counts in (its users of two launches ago are long gone)
     if (tid < 4 && a.zero4) a.zero4[tid] = 0;
     if (tid >= 32 && tid < 42) a.sync_next[32 * (tid - 32)] = 0;
-    if (tid == 63) *a.patch_count_next = 0;
+    if (tid == 62) a.sync_next[1] = 0;          // (the left-over count beside the write-back's arrivals)
+    if (tid == 63) *a.patch_count_next = 0;     // (the victim count beside the tail's arrivals)
   }
   bool ok = true;
-  if (tid == 0) ok = spin_until(a.sync, a.own_blocks);
+  // (the chain from here on is the end of the step — the lookup is done by the time the items are: the left-over count arrives WITH
+  // the write-back's last arrival, the victim count with the tail's.  Measured: no change, 8 dependent trips are left; neither did
+  // an item's value row fetched along with its bucket lines)
+  if (tid == 0) {
+    unsigned long long both;
+    ok = spin_until_pair(a.sync, a.own_blocks, &both);
+    L.cnt[1] = (unsigned)(both >> 32);
+  }
   __syncthreads();
-  const unsigned counted = __hip_atomic_load(&a.ctr->n_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned counted = L.cnt[1];
   if (counted == 0) return;                                        // no items, no evictions, nothing to correct (the same in every tail block)
   const bool listed = counted <= o.item_cap;
   const unsigned n = listed ? counted : a.fwd.m2 + 2;              // (the list overflowed: the flag byte of every slot of the plan's table)
@@ -522,8 +523,9 @@ __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepL
   __syncthreads();
   if (tid == 0) {
     __hip_atomic_fetch_add(a.sync + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok = spin_until(a.sync + 32 * 9, a.tail_blocks) && ok;
-    unsigned nv = min(__hip_atomic_load(a.patch_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), PATCH_GCAP);
+    unsigned long long both;
+    ok = spin_until_pair(a.sync + 32 * 9, a.tail_blocks, &both) && ok;
+    unsigned nv = min((unsigned)(both >> 32), PATCH_GCAP);   // a.patch_count, the word beside the arrivals
     if (nv) {   // the corrections overwrite what the lookup wrote: every lookup block must be done
       unsigned have = 0;
       for (unsigned it = 0; it < (1u << 20) && have < a.find_blocks; ++it) {
@@ -809,19 +811,12 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.ctr = L.ctr; a.own_gen = L.og;
       a.fwd = probe_of(plan_prev);
       a.own_blocks = (a.fwd.m2 + 2 + OWN_SLICE - 1) / OWN_SLICE;
-      if ((d->variant & 40) == 40 && !plan_is_listless(plan_prev)) {   // (tuning: 8 | 32)
-        a.own_from_list = 1;
-        const unsigned seen = d->progress[1];
-        const size_t est = seen ? std::min<size_t>(plan_prev->n, (size_t)seen + seen / 4 + 1024) : plan_prev->n;
-        a.own_blocks = (unsigned)std::max<size_t>(1, (est + 31) / 32);
-      }
     } else {
       a.own.v = t->view_of(t->cur);
       a.own_blocks = 0;
       a.fwd = SetProbe{d->dummy, 4};
     }
     a.progress = d->progress; a.progress_val = step; a.stat = d->stat; a.tbuf = d->tbuf;
-    a.patch_count = reinterpret_cast<unsigned*>(d->patch + 128 * (step & 1u)); a.patch_count_next = reinterpret_cast<unsigned*>(d->patch + 128 * ((step & 1u) ^ 1u));
     a.patch_keys = reinterpret_cast<i64*>(d->patch + 256) + (size_t)PATCH_GCAP * (step & 1u);
     a.nxt = n ? probe_of(plan_cur) : SetProbe{d->dummy, 4};
     a.n = (unsigned)n; a.ids = (const i64*)ids; a.out = (unsigned char*)rows_out; a.exists = exists_out;
@@ -830,6 +825,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.tail_blocks = plan_prev ? TAIL_BLOCKS : 0u;
     a.sync = reinterpret_cast<unsigned*>(d->patch + 256 + 2 * PATCH_GCAP * 8 + 1280 * (step & 1u));
     a.sync_next = reinterpret_cast<unsigned*>(d->patch + 256 + 2 * PATCH_GCAP * 8 + 1280 * ((step & 1u) ^ 1u));
+    a.patch_count = a.sync + 32 * 9 + 1; a.patch_count_next = a.sync_next + 32 * 9 + 1;   // (read with the tail's arrivals as one 8-byte word)
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
     a.ablate = (d->ablate && d->step_no >= d->ablate_after) ? d->ablate : 0;

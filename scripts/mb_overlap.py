@@ -23,6 +23,7 @@ def main():
   ap.add_argument("--dim", type=int, default=64)
   ap.add_argument("--dtype", default="float32")
   ap.add_argument("--skip-old", action="store_true")
+  ap.add_argument("--fill-frac", type=float, default=1.0, help="pre-fill (and draw ids from) only this fraction of the ranks: below ~0.6 nothing is ever evicted, every id of a batch is resident")
   ap.add_argument("--ablate", default="0", help="comma list of TFRA_STEP_ABLATE masks (1 builders, 2 write-back + tail, 4 lookup return at once after 40 steps: timing only)")
   ap.add_argument("--one-ahead", action="store_true", help="D = 1: announce only the next batch (its plan is then built by a launch of its own)")
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mb_overlap.json"))
@@ -45,15 +46,16 @@ def main():
   chunk = 4_000_000
   vals_fill = (torch.randn((chunk, dim), generator=gen, device=dev) * 0.01).to(dtype)
   t0 = time.perf_counter()
-  for lo in range(((slots - 1) // chunk) * chunk + 1, 0, -chunk):   # coldest ranks first: the hot ids are the most recently used
-    k = keys_of_ranks_torch(torch, torch.arange(lo, min(slots, lo + chunk - 1) + 1, dtype=torch.int64, device=dev))
+  n_ranks = int(slots * args.fill_frac)
+  for lo in range(((n_ranks - 1) // chunk) * chunk + 1, 0, -chunk):   # coldest ranks first: the hot ids are the most recently used
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(n_ranks, lo + chunk - 1) + 1, dtype=torch.int64, device=dev))
     table._table.upsert(k, vals_fill[:k.numel()], unique_keys=True)
   resident = int(table.size().item())
   print("prefill %.1f s, resident %d of %d" % (time.perf_counter() - t0, resident, slots), flush=True)
   del vals_fill
   K = args.steps
   NB = 4 * K + 8
-  idf = IdFactory(torch, dev, B, slots, args.new_key_ratio, slots + 1, SEED + 7)
+  idf = IdFactory(torch, dev, B, n_ranks, args.new_key_ratio, slots + 1, SEED + 7)
   ids = idf.keys(NB + 1)
   values = (torch.randn((B, dim), generator=gen, device=dev) * 0.01).to(dtype)
   outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(8)]
