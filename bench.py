@@ -185,14 +185,20 @@ def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg, init_di
   vals = (rng.standard_normal((batch, dim)) * 0.01).astype(np.float32)
   zero = np.zeros(dim, np.float32)
 
+  big = n_keys > 16_000_000
+  chunk = 4_000_000 if big else 500_000
+  rows = np.ascontiguousarray(np.broadcast_to(vals[:1], (min(chunk, n_keys), dim)))   # (materialised once: the fill must not time numpy copies)
+
   def fill(init_size):
     t0 = time.perf_counter()
     t = oracle.CpuTable(dim, np.float32, kind=kind, init_size=init_size, threads=threads)
     t_create = time.perf_counter() - t0
+    conn.send(("phase", "created", round(t_create, 1)))
     t0 = time.perf_counter()
-    for lo in range(1, n_keys + 1, 500_000):
-      k = keys_of_ranks(np.arange(lo, min(n_keys, lo + 499_999) + 1, dtype=np.int64))
-      t.insert(k, np.broadcast_to(vals[:1], (k.size, dim)))
+    for lo in range(1, n_keys + 1, chunk):
+      k = keys_of_ranks(np.arange(lo, min(n_keys, lo + chunk - 1) + 1, dtype=np.int64))
+      t.insert(k, rows[:k.size])
+    conn.send(("phase", "filled", round(time.perf_counter() - t0, 1)))
     return t, t_create, time.perf_counter() - t0
 
   def rate(fn, units, iters=16, repeats=3):
@@ -210,8 +216,8 @@ def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg, init_di
   tab, create_s, fill_s = fill(max(8192, n_keys // init_div))
   ops = {
       # Find on the batch WITH its repeats (not what TFRA issues — it de-duplicates first): every occurrence of the hot id takes the
-      # same bucket spinlock, 0.15 M ids/s on a 128-thread pool; three batches only
-      "find_with_repeats_ops_per_s": rate(lambda i: tab.find(batches[i % 8], zero), batch, iters=1),
+      # same bucket spinlock, 0.15 M ids/s on a 128-thread pool; three batches only (not at all on the 256 M-key rung: its time box)
+      "find_with_repeats_ops_per_s": None if big else rate(lambda i: tab.find(batches[i % 8], zero), batch, iters=1),
       # what embedding_lookup issues: unique first (PY/dynamic_embedding_ops.py:99), Find on the distinct ids
       "find_unique_ids_ops_per_s": rate(lambda i: tab.find(uniq[i % 8], zero), umean),
       "insert_or_assign_ops_per_s": rate(lambda i: tab.insert(uniq[i % 8], vals[:uniq[i % 8].size]), umean),
@@ -233,7 +239,7 @@ def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg, init_di
     tab, _, fill_s = fill(8192)
     grow_rate = n_keys / fill_s
     del tab
-  conn.send({"ops": ops, "dedup_rate": sorted(ded)[1], "grow_rate": grow_rate, "create_s": create_s, "unique_per_batch": umean})
+  conn.send(("done", {"ops": ops, "dedup_rate": sorted(ded)[1], "grow_rate": grow_rate, "create_s": create_s, "unique_per_batch": umean}))
   conn.close()
 
 
@@ -258,7 +264,7 @@ def cpu_baseline(batch):
   # (keys, init_size divisor, time box in s): 256 M keys (85 GB, pre-sized: on the round-4 box the constructor took 0.6 s per
   # 16 M keys and the 128-thread fill 10 M keys/s — ~35 s; growing from N / 8 instead managed 1 M keys/s and overran) on a box
   # that has the cores and the RAM, 16 M as the fallback, 4 M as the last resort
-  rungs = [r for r in ((256_000_000, 1, 120.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
+  rungs = [r for r in ((256_000_000, 1, 150.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
            if r[0] == 4_000_000 or (ram > 3 * r[0] * 330 and cores >= (64 if r[0] > 16_000_000 else 8))]
   if os.environ.get("TFRA_BENCH_CPU_KEYS"):
     rungs = [(int(os.environ["TFRA_BENCH_CPU_KEYS"]), 8, 300.0)]
@@ -271,16 +277,24 @@ def cpu_baseline(batch):
     pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, n_keys, threads, kind, n_keys <= 16_000_000, init_div))
     pr.start()
     child.close()
-    if parent.poll(box):
+    phases, t_rung = [], time.perf_counter()
+    while got is None:   # the worker reports its phases; the last message is the result
+      left = box - (time.perf_counter() - t_rung)
+      if left <= 0 or not parent.poll(left):
+        break
       try:
-        got = parent.recv()
+        msg = parent.recv()
       except EOFError:
-        got = None
+        break
+      if msg[0] == "done":
+        got = msg[1]
+      else:
+        phases.append(list(msg[1:]))
     pr.join(timeout=1.0)
     if pr.is_alive():
       pr.kill()   # the exact process started above
       pr.join()
-    tried.append({"keys": n_keys, "finished": got is not None, "seconds": round(time.perf_counter() - t_begin, 1)})
+    tried.append({"keys": n_keys, "finished": got is not None, "seconds": round(time.perf_counter() - t_begin, 1), "phases_s": phases})
     if got is not None:
       break
   if got is None:
@@ -297,8 +311,8 @@ def cpu_baseline(batch):
       "sample": "per batch of %d Zipf-1.2 ids: unique + Find(distinct ids) + Insert(distinct ids) on a %d-key table (dim 64 fp32, "
                 "init_size = N / %d, created in %.1f s), %d-thread pool (host has %d cores), median of 3 x 16 batches; %.0f s of CPU work"
                 % (batch, n_keys, init_div, got["create_s"], threads, cores, time.perf_counter() - t_begin),
-      "per_op": {k: round(v) for k, v in ops.items()},
-      "per_op_per_core": {k: round(v / threads) for k, v in ops.items()},
+      "per_op": {k: (round(v) if v is not None else None) for k, v in ops.items()},
+      "per_op_per_core": {k: (round(v / threads) if v is not None else None) for k, v in ops.items()},
       "prefill_keys_per_s_init_size_8192_growth_included": round(got["grow_rate"]) if got["grow_rate"] else None,
   }
 

@@ -720,7 +720,9 @@ __device__ __forceinline__ float4 sum_rows(const float* __restrict__ grads, cons
 // entry of their two home buckets and start from the default row / initial slot values, exactly like
 // apply_evict_kernel (tfra_optim.hip).
 // (Tried: amdgpu_waves_per_eu(4) on the 145-register form — 128 VGPRs with 7 spilled: gradient half 32.5 us instead of 31.5.
-// Without the pointer arrays — add_rows — it is 125 registers, 4 waves per SIMD, no spills: 28.7 us, step 57.2 instead of 59.9 us.)
+// Without the pointer arrays — add_rows — it is 125 registers, 4 waves per SIMD, no spills: 28.7 us, step 57.2 instead of 59.9 us.
+// Round 4: amdgpu_waves_per_eu(5, 5) on that form — 96 registers, 18 spilled for Adam: gradient half 28.7 -> 37.3 us, the step of
+// configs[1] 55.4 -> 62.3 us (A/B on one box, twice).  Five waves need a kernel that NEEDS 96 registers, not one that spills to them.)
 template <int KIND, bool PHASE2>
 __global__ __launch_bounds__(256) void apply_csr_kernel(TableView v, OptP o, int dim, const float* __restrict__ grads,
                                                         const float* __restrict__ partial, CsrKeys ks,
