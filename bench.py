@@ -606,7 +606,21 @@ def run_bounded(args, torch, de, dev, cfg):
   cur_stream = torch.cuda.current_stream(dev)
   row_bytes = dim * values.element_size()
 
+  ev_u = torch.cuda.Event()
+  cpin_p = ctypes.c_void_p(cpin.data_ptr())
+
   def op_surface(i):
+    # Find / gather / Insert take the count from the device (tfra_table_find_n / tfra_table_insert_or_assign_n): they are enqueued
+    # BEFORE the host reads it, and the read waits for the unique kernels only
+    _capi.check(lib.tfra_unique_unordered(*uniqs2[i]))
+    ev_u.record(cur_stream)
+    _capi.check(lib.tfra_table_find_n(tbl._h, B, cpin_p, P(ubuf), P(urows), None, P(dflt_row), 0, st))
+    _capi.check(lib.tfra_gather_rows(B, row_bytes, P(urows), P(ibuf), P(out_buf), st))
+    _capi.check(lib.tfra_table_insert_or_assign_n(tbl._h, B, cpin_p, P(ubuf), P(values), None, st))
+    ev_u.synchronize()
+    last_u[0] = int(cpin[0])      # tf.unique's output shape
+
+  def op_surface_sync(i):   # the same with the host read IN FRONT of Find (round 4's first form)
     _capi.check(lib.tfra_unique_unordered(*uniqs2[i]))
     cur_stream.synchronize()
     u = int(cpin[0])
@@ -618,6 +632,10 @@ def run_bounded(args, torch, de, dev, cfg):
   for i in range(W):
     op_surface(i)
   secs_ops, med_ops, _ = timed_windows(torch, None, 1, dev, K, op_surface, first=W)
+  torch.cuda.synchronize()
+  for i in range(W):
+    op_surface_sync(i)
+  secs_ops_sync, med_ops_sync, _ = timed_windows(torch, None, 1, dev, K, op_surface_sync, first=W)
   u = last_u[0]
   got, ex = table.lookup(ubuf[:u], return_exists=True)
   verified["op_surface_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:u]))
@@ -755,6 +773,7 @@ def run_bounded(args, torch, de, dev, cfg):
                        "write-back the long pole, and it runs faster as kernels of its own than as a role of the step launch",
       "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
       "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
+      "value_op_surface_host_read_first": B * K / med_ops_sync, "ms_per_step_op_surface_host_read_first": med_ops_sync / K * 1e3,
       "value_op_surface_find_first": B * K / med_opf, "ms_per_step_op_surface_find_first": med_opf / K * 1e3,
       "value_accum": B * K / med_acc, "ms_per_step_accum": med_acc / K * 1e3,
       "value_op_surface_table_ops_only": B * K / med_tops, "ms_per_step_op_surface_table_ops_only": med_tops / K * 1e3,
@@ -776,7 +795,7 @@ def run_bounded(args, torch, de, dev, cfg):
           "host_enqueue_ms_per_step_look_ahead_driver": round(1e3 * host_pf / K, 4),
           "overlapped_step_stats": ovl_stats,
           "timing": {"value": timing_note(secs, K), "value_look_ahead_driver": timing_note(secs_pf, K), "value_plain_call": timing_note(secs_plain, K),
-                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_find_first": timing_note(secs_opf, K),
+                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_find_first": timing_note(secs_opf, K), "value_op_surface_host_read_first": timing_note(secs_ops_sync, K),
                      "value_accum": timing_note(secs_acc, K), "value_op_surface_table_ops_only": timing_note(secs_tops, K)},
           "verified": verified,
           "drivers": {
@@ -790,9 +809,12 @@ def run_bounded(args, torch, de, dev, cfg):
               "value_plain_call": "tfra_table_find then tfra_table_upsert_sparse, no look-ahead; upsert_sparse is a fused extra (plan "
                                   "built inside the call, repeats resolved on the device), not an op of the reference's surface",
               "value_op_surface": "the reference's own op order (embedding_lookup de-duplicates first, PY/dynamic_embedding_ops.py:99-117): "
-                                  "tfra_unique_unordered (B ids) + one host read of the count (tf.unique's output shape; through pinned "
-                                  "memory) -> tfra_table_find (U ids) -> tfra_gather_rows (B rows) -> tfra_table_insert_or_assign(U "
-                                  "unique keys, TFRA_FLAG_UNIQUE_KEYS): the calls of tf_ops/mi355x_table_ops.h",
+                                  "tfra_unique_unordered (B ids; count into pinned memory) -> tfra_table_find_n -> tfra_gather_rows (B "
+                                  "rows) -> tfra_table_insert_or_assign_n (unique keys): Find and Insert read the count on the device and "
+                                  "are enqueued BEFORE the one host read of it (tf.unique's output shape), which waits for the unique "
+                                  "kernels only",
+              "value_op_surface_host_read_first": "the same ops with the host read in front of Find (tfra_table_find / "
+                                                  "tfra_table_insert_or_assign called with the count): the calls of tf_ops/mi355x_table_ops.h",
               "value_op_surface_find_first": "round 3's sequence: tfra_table_find (B ids) -> tfra_unique (ordered) + one blocking host read "
                                              "-> tfra_table_insert_or_assign(U unique keys)",
               "value_accum": "bp_v2: tfra_table_find (B ids) -> tfra_table_accum_or_assign(U unique keys prepared beforehand, exists = "
@@ -1183,7 +1205,7 @@ def main():
       args._growth = measure_growth(torch, de, dev, 128, torch.float16, args.slots // 4)   # reported under secondary.c3
     res = run_bounded(args, torch, de, dev, cfg)
     if not args.no_secondary and args.config is None:
-      keep = ("metric", "value", "value_look_ahead_driver", "faster_driver", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
+      keep = ("metric", "value", "value_look_ahead_driver", "faster_driver", "value_op_surface_host_read_first", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
               "value_op_surface_table_ops_only", "ms_per_step",
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}

@@ -115,6 +115,18 @@ int tfra_table_find(tfra_table_t* t, size_t n, const int64_t* keys, void* values
 int tfra_table_insert_or_assign(tfra_table_t* t, size_t n, const int64_t* keys, const void* values,
                                 const uint64_t* scores, uint32_t flags, tfra_stream_t stream);
 
+/* -- The same two ops with the key COUNT on the device: n = the length of the buffers, *d_n (a device int64, or pinned host
+ *    memory the device can read) = the number of keys in them; min(n, *d_n) keys are looked up / written.  For the chain
+ *    tfra_unique_unordered -> Find -> gather -> Insert of embedding_lookup (python/ops/dynamic_embedding_ops.py:99-117), where the
+ *    count is only the SHAPE of tf.unique's output: the host reads it while these calls already run.  insert_or_assign_n takes
+ *    unique keys (TFRA_FLAG_UNIQUE_KEYS semantics, the Insert op's contract) through the single-pass write-back and returns
+ *    TFRA_ERR_UNSUPPORTED when that pass cannot take the call (owner tags off, a bulk load): read the count and call the plain
+ *    entry point then.  A growing table sizes itself by n, the upper bound.                                                    */
+int tfra_table_find_n(tfra_table_t* t, size_t n, const int64_t* d_n, const int64_t* keys, void* values, uint8_t* exists,
+                      const void* defaults, int default_is_full, tfra_stream_t stream);
+int tfra_table_insert_or_assign_n(tfra_table_t* t, size_t n, const int64_t* d_n, const int64_t* keys, const void* values,
+                                  const uint64_t* scores, tfra_stream_t stream);
+
 /* -- accum_or_assign = TableWrapper::accum (lookup_table_op_hkv.h:539-546):
  *    absent & !exists -> insert row; present & exists -> row += delta (element order 0..dim-1,
  *    one add each); otherwise no-op.  Oracle: accumrase_fn (lib/cuckoo/cuckoohash_map.hh:619). */

@@ -1055,6 +1055,7 @@ struct OwnArgs {
   CsrKeys ks;              // SRC_PLAN
   const i64* keys;         // SRC_DIRECT
   unsigned nkeys;          // SRC_DIRECT
+  const long long* d_nkeys;   // SRC_DIRECT, optional: the key count on the device (nkeys = the buffers' length then)
   AuxInitPod ai;
   ScoreP sp;
   uint8_t* dflag;          // one byte per key of the launch: 4 = left over.  All zero between launches: only left-over keys
@@ -1068,6 +1069,11 @@ struct OwnArgs {
 // (OwnArgs stays a read-only kernel argument: a private, modified copy would live in scratch memory — its aux_init
 // pattern is indexed dynamically — and every field access of the hot loop would become a scratch load.)
 struct OwnFlags { bool with_scores, spec, lru, lru_like; };
+__device__ __forceinline__ unsigned direct_count(const OwnArgs& a) {   // keys of a SRC_DIRECT launch
+  if (!a.d_nkeys) return a.nkeys;
+  const long long dn = *a.d_nkeys;
+  return dn < 0 ? 0u : (unsigned)min((long long)a.nkeys, dn);
+}
 
 template <bool SIMPLE>
 __device__ __forceinline__ OwnFlags own_setup(const OwnArgs& a) {
@@ -1096,12 +1102,12 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
     f1 = reinterpret_cast<const uint4*>(it)[1];
   }
   unsigned total = 0;
-  if (!slow_ctr) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  if (!slow_ctr) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned counted = slow_ctr ? *slow_ctr : total;
   if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
   if (counted == 0) return;
   const bool listed = slow_ctr && counted <= a.item_cap;
-  if (slow_ctr && !listed) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  if (slow_ctr && !listed) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned n = listed ? counted : total;
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const unsigned ngroups = (gridDim.x * blockDim.x) >> 4;
@@ -1456,7 +1462,7 @@ template <int G, bool SIMPLE, int SRC, int U = 4, bool ACC = false>
 __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, unsigned own_gen, unsigned* progress,
                                                          unsigned progress_val) {
   const int lane = threadIdx.x & 63;
-  const unsigned total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : a.nkeys;
+  const unsigned total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int fresh = 0;
@@ -2155,7 +2161,7 @@ static int upsert_planned_impl(tfra_table_t* tp, const tfra_sparse_plan_t* pl, c
 // the locked two-phase kernels.  Caller holds t->mu and has called prepare_insert.
 namespace tfra {
 int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken,
-                      const uint8_t* accum_exists) {
+                      const uint8_t* accum_exists, const int64_t* d_n) {
   // accum_exists != nullptr: insert_or_accum (tfra_table_accum_or_assign with TFRA_FLAG_UNIQUE_KEYS) instead of an assign
   *taken = false;
   if (accum_exists && (((size_t)t->field_bytes | (size_t)(uintptr_t)values) & 15)) return TFRA_OK;   // 16-byte granules only
@@ -2193,7 +2199,7 @@ int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const 
   a.v = t->view_of(t->cur); a.vals = (const unsigned char*)values; a.scores = scores; a.keys = keys; a.nkeys = (unsigned)n;
   a.ai = t->aux; a.sp = sp; a.dflag = (uint8_t*)t->own_ws + head; a.tags = tags;
   a.items = reinterpret_cast<OwnItem*>((unsigned char*)t->own_ws + 256); a.item_cap = SLOW_CAP;
-  a.exists = accum_exists; a.acc_dt = t->opts.value_dtype;
+  a.exists = accum_exists; a.acc_dt = t->opts.value_dtype; a.d_nkeys = (const long long*)d_n;
   if (accum_exists) launch_own_accum(s, simple, a, n, ctr, next_ctr, og, 32u);
   else launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, 32u, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: launch failed");

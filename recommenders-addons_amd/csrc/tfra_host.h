@@ -103,7 +103,7 @@ struct Table {
 void destroy_own_plan(Table* t);   // tfra_csr.hip
 // insert_or_assign of UNIQUE keys as one ownership pass (tfra_csr.hip); *taken = false: not applicable, run the locked kernels
 int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const void* values, const u64* scores, bool* taken,
-                      const uint8_t* accum_exists = nullptr);   // accum_exists: insert_or_accum instead of an assign
+                      const uint8_t* accum_exists = nullptr, const int64_t* d_n = nullptr);   // accum_exists: insert_or_accum instead of an assign
 void destroy_workspace_plan(void* plan);   // tfra_csr.hip
 void step_epoch_public(Table* t);  // tfra_optim.hip
 

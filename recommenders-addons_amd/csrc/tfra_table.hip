@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
                                                    unsigned char* __restrict__ out,
                                                    uint8_t* __restrict__ exists,
                                                    const unsigned char* __restrict__ defaults,
-                                                   int full, unsigned field_off) {
+                                                   int full, unsigned field_off, const long long* __restrict__ d_n = nullptr) {
+  if (d_n) {   // tfra_table_find_n: the key count lives on the device (n = the buffers' length)
+    const long long dn = *d_n;
+    n = dn < 0 ? 0 : min(n, (size_t)dn);
+  }
   const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
   const int grp = lane >> 4;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1196,7 +1200,7 @@ int Table::prepare_insert(size_t n, hipStream_t s) {
 }  // namespace tfra
 
 static int find_impl(Table* t, hipStream_t s, int field, size_t n, const int64_t* keys, void* values,
-                     uint8_t* exists, const void* defaults, int full) {
+                     uint8_t* exists, const void* defaults, int full, const int64_t* d_n = nullptr) {
   if (n == 0) return TFRA_OK;
   if (!keys || !values || !defaults) return set_error(TFRA_ERR_INVALID, "find: null buffer");
   if (n >= (1ULL << 32)) return set_error(TFRA_ERR_INVALID, "find: more than 2^32-1 keys per call");
@@ -1211,15 +1215,16 @@ static int find_impl(Table* t, hipStream_t s, int field, size_t n, const int64_t
   const i64* k = (const i64*)keys;
   unsigned char* o = (unsigned char*)values;
   const unsigned char* d = (const unsigned char*)defaults;
+  const long long* dn = (const long long*)d_n;
   switch (g) {
     case 16:
-      if (t->dense) find_kernel<16, U, true, true><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo);
-      else find_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo);
+      if (t->dense) find_kernel<16, U, true, true><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo, dn);
+      else find_kernel<16, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo, dn);
       break;
-    case 8: find_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
-    case 4: find_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
-    case 2: find_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
-    default: find_kernel<1, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo); break;
+    case 8: find_kernel<8, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo, dn); break;
+    case 4: find_kernel<4, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo, dn); break;
+    case 2: find_kernel<2, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo, dn); break;
+    default: find_kernel<1, U><<<grid, block, 0, s>>>(v, n, k, o, exists, d, full, fo, dn); break;
   }
   HIP_TRY(hipGetLastError());
   return TFRA_OK;
@@ -1436,6 +1441,35 @@ int tfra_table_find(tfra_table_t* tp, size_t n, const int64_t* keys, void* value
                     const void* defaults, int default_is_full, tfra_stream_t stream) {
   TABLE_ENTER();
   return find_impl(t, s, 0, n, keys, values, exists, defaults, default_is_full);
+}
+
+int tfra_table_find_n(tfra_table_t* tp, size_t n, const int64_t* d_n, const int64_t* keys, void* values, uint8_t* exists,
+                      const void* defaults, int default_is_full, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (!d_n) return set_error(TFRA_ERR_INVALID, "find_n: null count");
+  return find_impl(t, s, 0, n, keys, values, exists, defaults, default_is_full, d_n);
+}
+
+// Unique keys, their number on the device: the ownership pass or nothing (the locked kernels size their scratch by the host's n).
+int tfra_table_insert_or_assign_n(tfra_table_t* tp, size_t n, const int64_t* d_n, const int64_t* keys, const void* values,
+                                  const uint64_t* scores, tfra_stream_t stream) {
+  TABLE_ENTER();
+  if (n == 0) return TFRA_OK;
+  if (!d_n || !keys || !values) return set_error(TFRA_ERR_INVALID, "insert_or_assign_n: null buffer");
+  if (n >= (1ULL << 31)) return set_error(TFRA_ERR_INVALID, "insert: more than 2^31-1 keys per call");
+  int rc = t->prepare_insert(n, s);   // (n is an upper bound of the keys: a growing table may grow a call early)
+  if (rc) return rc;
+  bool taken = false;
+  rc = own_upsert_unique(t, s, n, (const i64*)keys, values, (const u64*)scores, &taken, nullptr, d_n);
+  if (rc) return rc;
+  if (!taken) return set_error(TFRA_ERR_UNSUPPORTED, "insert_or_assign_n: the single-pass write-back cannot take this call (owner tags off, "
+                                                     "a bulk load, or no scratch while capturing): read the count and call tfra_table_insert_or_assign");
+  const int strat = t->opts.strategy;
+  if (strat == TFRA_EVICT_EPOCHLRU || strat == TFRA_EVICT_EPOCHLFU) {
+    t->curr_step += 1;
+    if (t->opts.step_per_epoch > 0 && t->curr_step > t->opts.step_per_epoch) { t->global_epoch += 1; t->curr_step = 1; }
+  }
+  return TFRA_OK;
 }
 
 int tfra_table_find_field(tfra_table_t* tp, int field, size_t n, const int64_t* keys, void* values,

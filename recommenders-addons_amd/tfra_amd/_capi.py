@@ -98,6 +98,8 @@ _SIGS = {
     "tfra_table_find": [_P, _SZ, _P, _P, _P, _P, _I, _P],
     "tfra_table_find_field": [_P, _I, _SZ, _P, _P, _P, _P, _I, _P],
     "tfra_table_insert_or_assign": [_P, _SZ, _P, _P, _P, ctypes.c_uint32, _P],
+    "tfra_table_find_n": [_P, _SZ, _P, _P, _P, _P, _P, ctypes.c_int, _P],
+    "tfra_table_insert_or_assign_n": [_P, _SZ, _P, _P, _P, _P, _P],
     "tfra_table_insert_field": [_P, _I, _SZ, _P, _P, ctypes.c_uint32, _P],
     "tfra_table_accum_or_assign": [_P, _SZ, _P, _P, _P, _P, ctypes.c_uint32, _P],
     "tfra_table_erase": [_P, _SZ, _P, _P],

@@ -213,6 +213,30 @@ class _DeviceTable:
       _capi.call("tfra_table_insert_or_assign", self._h, n, _ptr(keys), _ptr(values), _ptr(scores), flags,
                  _stream(self._device))
 
+  def find_n(self, keys, count, out=None, return_exists=False):
+    """find over the first `count[0]` entries of the buffer `keys`, the count read ON THE DEVICE (`count`: an int64 tensor on the
+    table's device, or pinned host memory): tfra_table_find_n.  Rows beyond the count are left as they are."""
+    keys = self._keys(keys)
+    n = keys.numel()
+    d = self._default_value.contiguous()
+    if out is None:
+      out = torch.empty((n, self._dim), dtype=self._value_dtype, device=self._device)
+    exists = torch.zeros(n, dtype=torch.bool, device=self._device) if return_exists else None
+    if n:
+      _capi.call("tfra_table_find_n", self._h, n, _ptr(count), _ptr(keys), _ptr(out), _ptr(exists), _ptr(d), 0, _stream(self._device))
+    return (out, exists) if return_exists else out
+
+  def upsert_n(self, keys, count, values, scores=None):
+    """insert_or_assign of the first `count[0]` UNIQUE keys of the buffer, the count read on the device
+    (tfra_table_insert_or_assign_n; raises when the single-pass write-back cannot take the call)."""
+    keys = self._keys(keys)
+    values = self._values_for(keys, values)
+    if scores is not None:
+      scores = scores.to(self._device, torch.int64).contiguous()
+    if keys.numel():
+      _capi.call("tfra_table_insert_or_assign_n", self._h, keys.numel(), _ptr(count), _ptr(keys), _ptr(values), _ptr(scores),
+                 _stream(self._device))
+
   def accum_or_assign(self, keys, values_or_deltas, exists, scores=None, unique_keys=False):
     keys = self._keys(keys)
     vod = self._values_for(keys, values_or_deltas, "values_or_deltas")

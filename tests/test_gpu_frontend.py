@@ -1003,3 +1003,53 @@ def test_fused_optimizers_on_half_tables(env, kind, vdtype):
   err = np.abs(got - want) / np.maximum(np.abs(want), 2.0 ** -14)
   assert float(np.quantile(err, 0.999)) <= 2 * ulp and float(err.max()) <= 4 * ulp, (float(err.max()), ulp)
   assert var.size() == keys.size
+
+
+def test_find_n_and_insert_n_take_the_count_on_the_device():
+  """tfra_table_find_n / tfra_table_insert_or_assign_n: the chain unique -> Find -> gather -> Insert of embedding_lookup
+  (python/ops/dynamic_embedding_ops.py:99-117) without the host reading the unique count in between; results identical to the
+  plain entry points called with the count."""
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding import device_ops
+  dim = 32
+  for bounded in (False, True):
+    kw = dict(init_capacity=600_000, max_capacity=600_000, evict_strategy=de.HkvEvictStrategy.LRU) if bounded else {}
+    cls = de.HkvHashTable if bounded else de.CuckooHashTable
+    ta = cls(torch.int64, torch.float32, torch.full((dim,), -1.0), device="cuda:0", dim=dim, name="n_a_%d" % bounded, **kw)
+    tb = cls(torch.int64, torch.float32, torch.full((dim,), -1.0), device="cuda:0", dim=dim, name="n_b_%d" % bounded, **kw)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.arange(1, 200_001, device="cuda", dtype=torch.int64) * 7919
+    for t in (ta, tb):
+      t._table.upsert(base, (base % 1000).to(torch.float32)[:, None].repeat(1, dim), unique_keys=True)
+    for step in range(4):
+      ids = base[torch.randint(0, 300, (4096,), generator=g, device="cuda") ** 2 % base.numel()]
+      ids[::7] = 10**12 + step * 10_000 + torch.arange(ids[::7].numel(), device="cuda")       # never-seen ids
+      uniq, idx, cnt = device_ops.unique(ids, ordered=False)
+      u = int(cnt.item()) if torch.is_tensor(cnt) else int(cnt)
+      ubuf = torch.full((ids.numel(),), -7, dtype=torch.int64, device="cuda")
+      ubuf[:u] = uniq[:u]
+      dcount = torch.tensor([u], dtype=torch.int64, device="cuda")
+      vals = torch.randn((ids.numel(), dim), generator=g, device="cuda")
+      # plain
+      want, wex = ta.lookup(ubuf[:u], return_exists=True)
+      ta._table.upsert(ubuf[:u], vals[:u], unique_keys=True)
+      # device count: the buffers are as long as the batch, the tail must stay untouched
+      out = torch.full((ids.numel(), dim), 123.0, device="cuda")
+      got, gex = tb._table.find_n(ubuf, dcount, out=out, return_exists=True)
+      tb._table.upsert_n(ubuf, dcount, vals)
+      assert torch.equal(got[:u], want) and torch.equal(gex[:u], wex)
+      assert bool((got[u:] == 123.0).all()) and not bool(gex[u:].any())
+      assert int(ta.size().item()) == int(tb.size().item())
+      a, b = ta.lookup(ubuf[:u]), tb.lookup(ubuf[:u])
+      assert torch.equal(a, b) and torch.equal(a, vals[:u])
+      assert not bool(tb.lookup(torch.tensor([-7], device="cuda"), return_exists=True)[1].any())   # the buffer's tail was never inserted
+    # a count of zero and a count beyond the buffer
+    z = torch.zeros(1, dtype=torch.int64, device="cuda")
+    before = int(tb.size().item())
+    tb._table.upsert_n(ubuf, z, vals)
+    assert int(tb.size().item()) == before
+    big = torch.tensor([10**9], dtype=torch.int64, device="cuda")
+    got = tb._table.find_n(ubuf[:u], big)
+    assert torch.equal(got, tb.lookup(ubuf[:u]))
+    tb._table.check_errors()
