@@ -261,10 +261,11 @@ def cpu_baseline(batch):
     ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
   except (ValueError, OSError):
     ram = 0
-  # (keys, init_size divisor, time box in s): 256 M keys (85 GB, pre-sized: on the round-4 box the constructor took 0.6 s per
-  # 16 M keys and the 128-thread fill 10 M keys/s — ~35 s; growing from N / 8 instead managed 1 M keys/s and overran) on a box
-  # that has the cores and the RAM, 16 M as the fallback, 4 M as the last resort
-  rungs = [r for r in ((256_000_000, 1, 150.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
+  # (keys, init_size divisor, time box in s): 256 M keys (85 GB, pre-sized) on a box that has the cores and the RAM — on a fresh
+  # round-4 box: constructor 9 s, 128-thread fill 33 s (7.7 M keys/s), the whole rung 47 s; the same rung started right after another
+  # bench run on the same box did not get through its fill in 150 s (once; the host was still giving back the first run's 85 GB),
+  # hence the box — 16 M as the fallback, 4 M as the last resort.  (Growing from N / 8 instead: 1 M keys/s, overran.)
+  rungs = [r for r in ((256_000_000, 1, 100.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
            if r[0] == 4_000_000 or (ram > 3 * r[0] * 330 and cores >= (64 if r[0] > 16_000_000 else 8))]
   if os.environ.get("TFRA_BENCH_CPU_KEYS"):
     rungs = [(int(os.environ["TFRA_BENCH_CPU_KEYS"]), 8, 300.0)]

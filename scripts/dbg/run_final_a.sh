@@ -1,3 +1,4 @@
 cd /root/repo
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r04_pytest_gpu.log 2>&1; tail -3 gpurun_out/r04_pytest_gpu.log
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_driver_args.json 2> gpurun_out/r04_bench_driver_args.err; tail -c 300 gpurun_out/r04_bench_driver_args.err
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r04_pytest_gpu.log 2>&1; tail -2 gpurun_out/r04_pytest_gpu.log
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_driver_args.json 2> gpurun_out/r04_bench_driver_args.err; tail -c 200 gpurun_out/r04_bench_driver_args.err
+timeout 900 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err; tail -c 200 gpurun_out/r04_bench_default.err
