@@ -1,3 +1,5 @@
+"""Prints the runs of scripts/mb_overlap.py output files: variant, ablation mask, steps per host call, us per step, windows, role time stamps.
+  python scripts/mb_overlap_show.py gpurun_out/mb_overlap.json ..."""
 import json, sys
 for f in sys.argv[1:]:
   d=json.load(open(f))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# SQ counter passes over the overlapped step: instructions and busy cycles per launch
-OUT=/root/repo/gpurun_out/pmc_sq
+# SQ counter passes over the overlapped step (scripts/mb_overlap.py): instructions, busy and wait cycles per launch of step_k.  TCP_* / TA_* counters abort on this image (and hang): do not add them.
+OUT=/root/repo/gpurun_out/pmc_step_sq
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -10,7 +10,7 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INS
 done
 python - <<'PY'
 import csv, glob, collections
-for f in sorted(glob.glob('/root/repo/gpurun_out/pmc_sq/*/p_counter_collection.csv')):
+for f in sorted(glob.glob('/root/repo/gpurun_out/pmc_step_sq/*/p_counter_collection.csv')):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']

@@ -1,3 +1,4 @@
+# scripts/profile_round.sh + scripts/summarize_profile.py on the GPU box; only the summaries (gpurun_out/prof_<tag>_summary) and small raw files travel back.
 cd /root/repo
 bash scripts/profile_round.sh r04 > gpurun_out/prof_r04.log 2>&1
 python scripts/summarize_profile.py r04 gpurun_out/prof_r04_summary > gpurun_out/prof_r04_summary.log 2>&1

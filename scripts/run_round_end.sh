@@ -1,3 +1,4 @@
+# What the driver runs at round end, in one gpurun call: the GPU test suite, the bench line with the driver's arguments, the default bench line.
 cd /root/repo
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r04_pytest_gpu.log 2>&1; tail -2 gpurun_out/r04_pytest_gpu.log
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r04_bench_driver_args.json 2> gpurun_out/r04_bench_driver_args.err; tail -c 200 gpurun_out/r04_bench_driver_args.err

@@ -1,3 +1,5 @@
+"""Prints the numbers of a bench.py JSON line that DESIGN.md / README.md quote.
+  python scripts/show_bench_line.py profiles/r04_bench_line_driver_args.json ..."""
 import json, sys
 for f in sys.argv[1:]:
   d=json.loads(open(f).read().strip().splitlines()[-1])
