@@ -668,6 +668,28 @@ __device__ __forceinline__ bool set_contains_group(const SetProbe& p, i64 key, i
   return true;   // (a chain this long does not exist: 2 n slots for n ids; say "present", the conservative answer)
 }
 
+// The same for TWO plans at once (lanes 0..3 probe p, lanes 4..7 probe q: one round trip for both): is the key in either?
+__device__ __forceinline__ bool set_contains_either_group(const SetProbe& p, const SetProbe& q, i64 key, int sub, int gshift) {
+  const bool resv = is_reserved_key(key);
+  const SetProbe& t = (sub & 4) ? q : p;
+  unsigned slot = set_home(t, key, fmix64((u64)key));
+  const unsigned wm = set_wmask(t.m2);
+  unsigned open = 3u;   // bit 0: still looking in p, bit 1: in q
+  for (int round = 0; round < 512 && open; ++round) {
+    const unsigned e = resv ? slot + (unsigned)(sub & 3) : set_at(slot, (unsigned)(sub & 3), wm);
+    const i64 k = t.ent[e].key;
+    const bool match = resv ? ((sub & 3) == 0 && k != EMPTY_KEY) : k == key;
+    const unsigned mm = (unsigned)(__ballot(match && sub < 8) >> gshift) & 0xffu;
+    const unsigned em = (unsigned)(__ballot(k == EMPTY_KEY && sub < 8) >> gshift) & 0xffu;
+    if ((mm & 0x0fu) && (open & 1u)) return true;
+    if ((mm & 0xf0u) && (open & 2u)) return true;
+    if ((em & 0x0fu) || resv) open &= ~1u;
+    if ((em & 0xf0u) || resv) open &= ~2u;
+    slot = set_at(slot, 4u, wm);
+  }
+  return open != 0;   // (a chain this long does not exist; "present" is the conservative answer)
+}
+
 // one coalesced 64-B load per key group: lane i holds word i of the key's record
 __device__ __forceinline__ unsigned load_record(const CsrKeys& ks, unsigned g, int sub, bool& many) {
   const unsigned km = ks.keymap[g];
@@ -1211,10 +1233,12 @@ __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
 // expected in the table, present => row += value row (one add per element), absent => dropped; not set: absent => insert,
 // present => dropped.  A dropped key writes nothing, whatever its claims say (the keys of a call are unique: any order of
 // them is a valid serial order).
-template <int G, bool SIMPLE, int SRC, int U, bool CF = false, bool ACC = false>
+template <int G, bool SIMPLE, int SRC, int U, bool CF = false, bool ACC = false, bool HF = false>
 __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
                                             int lane, int& fresh, const SetProbe* cf = nullptr, unsigned* cf_stat = nullptr,
-                                            i64 kgiven = 0, unsigned lastgiven = 0) {
+                                            i64 kgiven = 0, unsigned lastgiven = 0, const SetProbe* own_plan = nullptr) {
+  static_assert(!HF || CF, "HF: only with the plans of the overlapped step");
+  constexpr bool hf = HF;
   const u64* const scores = SIMPLE ? nullptr : a.scores;
   const TableView& v = a.v;
   const CsrKeys& ks = a.ks;
@@ -1275,7 +1299,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   }
   // the claims, behind the loads in program order (a clamped duplicate must not claim: it would lock out the real key)
   unsigned c0 = 0, c1 = 0;
-  if (grp == 0 && valid && !reserved) {
+  if (!hf && grp == 0 && valid && !reserved) {
     c0 = atomicExch(a.tags + b0reg, gen);
     c1 = atomicExch(a.tags + b1reg, gen);
   }
@@ -1340,7 +1364,8 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
               const int vsrc = gshift + (int)(best_word & 15u);
               const i64 ka = shfl_i64(kk[u][0], vsrc), kb = shfl_i64(kk[u][1], vsrc);
               const i64 vk = (best_word >> 4) == (u64)b1[u] ? kb : ka;
-              if (vk != EMPTY_KEY && set_contains_group(*cf, vk, sub, gshift)) {   // the next lookup wants it: deferred
+              // (HF: nor may it be a key of THIS batch — those are written without a claim, see below)
+              if (vk != EMPTY_KEY && (hf ? set_contains_either_group(*cf, *own_plan, vk, sub, gshift) : set_contains_group(*cf, vk, sub, gshift))) {   // the next lookup wants it: deferred
                 act[u] = 0; why[u] = 3;
                 if (cf_stat && sub == 0) atomicAdd(cf_stat, 1u);
               }
@@ -1352,19 +1377,42 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   }
   // ---- now the claims -------------------------------------------------------------------------------------------
   const unsigned lostreg = reserved ? 2u : ((c0 == gen || c1 == gen) ? 1u : 0u);   // (group 0's lanes)
+  // HF (the overlapped step): a HIT needs no claim.  It writes its own row and score word and nothing else of the bucket; the only
+  // writer that could take its slot away is an eviction, and an eviction never takes a key of this batch (the victim check above
+  // looks the victim up in the batch's own plan too).  Only the keys that CHANGE a bucket — a new key into a free slot or over a
+  // victim — claim their two home buckets, now, behind the decision: 96 % of a Zipf batch's keys issue no atomic at all, two keys of
+  // a batch sharing a home bucket no longer collide unless both are new, and the item list is empty in nearly every step.
+  bool lost_hf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) lost_hf[u] = false;
+  if (hf) {
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { lost_hf[u] = false; any = any || act[u] >= 2; }
+    if (__ballot(any)) {   // (wave-uniform: one more round trip for the waves that hold a new key)
+      unsigned cx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cx[u] = 0;
+        if (act[u] >= 2 && sub < 2) cx[u] = atomicExch(a.tags + (sub == 0 ? b0[u] : b1[u]), gen) == gen ? 1u : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) lost_hf[u] = ((__ballot(cx[u] != 0) >> gshift) & 0xffffu) != 0;
+    }
+  }
   unsigned last[U], hint[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int j = u * 4 + grp;
     last[u] = (unsigned)__shfl((int)lastreg, j);
-    const int lost = __shfl((int)lostreg, j);   // lane j of group 0 made the claims
     const bool real = __shfl((int)valid, j) != 0;
+    const int lost = hf ? ((real && !on[u]) ? 2 : (lost_hf[u] ? 1 : 0)) : __shfl((int)lostreg, j);   // (without HF: lane j of group 0 made the claims)
     hint[u] = 0;
     if (lost) {
       if (lost == 1 && act[u] == 1 && (word[u] >> 32) == 0) hint[u] = 1;   // found, not written: the remainder pass locks this very slot
       act[u] = 0; why[u] = lost;
     }
-    if (bxc[u] != ~0u && act[u]) {   // (rare) found beyond its home buckets: that bucket's claim
+    if (!hf && bxc[u] != ~0u && act[u]) {   // (rare) found beyond its home buckets: that bucket's claim
       unsigned cx = 0;
       if (sub == 0) cx = atomicExch(a.tags + bxc[u], gen) == gen ? 1u : 0u;
       if (__shfl((int)cx, gshift)) { act[u] = 0; why[u] = 1; }

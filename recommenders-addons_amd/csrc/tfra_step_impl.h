@@ -347,8 +347,8 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   for (unsigned wbase = (tid >> 6) * (4 * U); wbase < cnt; wbase += 4 * (4 * U)) {
     const unsigned i = wbase + (unsigned)(lane & 15);
     const unsigned c = min(i, cnt - 1);
-    own_batch16<16, SIMPLE, SRC_GIVEN, U, true>(o, fl, L.pos[1024 + c], (lane & 15) < 4 * U && i < cnt, a.own_gen, a.sync + 1, lane, fresh, &a.nxt, a.stat,
-                                                L.key[c], L.pos[c] - 1u);
+    own_batch16<16, SIMPLE, SRC_GIVEN, U, true, false, true>(o, fl, L.pos[1024 + c], (lane & 15) < 4 * U && i < cnt, a.own_gen, a.sync + 1, lane, fresh, &a.nxt,
+                                                             a.stat, L.key[c], L.pos[c] - 1u, &a.fwd);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(o.v, blk * 4u + (tid >> 6), fresh);
@@ -696,6 +696,23 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
       out[(sl * 5 + r) * 4] = std::min(out[(sl * 5 + r) * 4], t0);
       out[(sl * 5 + r) * 4 + 1] = std::max(out[(sl * 5 + r) * 4 + 1], t1);
       dur[r].push_back(t1 - t0);
+    }
+    if (std::getenv("TFRA_STEP_OCCUPANCY") && sl == 5 && grid) {   // (tuning) resident blocks per role, every microsecond of one launch
+      uint64_t tmin = ~0ULL, tmax = 0;
+      for (unsigned b = 0; b < grid; ++b) {
+        const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
+        if (t1) { tmin = std::min(tmin, t0); tmax = std::max(tmax, t1); }
+      }
+      for (uint64_t t = tmin; t < tmax; t += 100) {   // (the clock ticks at 100 MHz)
+        unsigned n[5] = {0, 0, 0, 0, 0};
+        for (unsigned b = 0; b < grid; ++b) {
+          const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
+          unsigned idx;
+          if (t1 && t0 <= t && t < t1) n[step_role(b, ti[0], ti[1], ti[2], ti[3], ti[4] - ti[0] - ti[1] - ti[2] - ti[3], &idx)] += 1;
+        }
+        std::fprintf(stderr, "t %2llu us: build %4u scatter %4u write-back %4u lookup %4u tail %3u  = %4u blocks\n", (unsigned long long)((t - tmin) / 100), n[0], n[1],
+                     n[2], n[3], n[4], n[0] + n[1] + n[2] + n[3] + n[4]);
+      }
     }
     for (int r = 0; r < 5; ++r) {
       if (dur[r].empty()) continue;
