@@ -32,9 +32,10 @@
 //            evictions) with the locked protocol, note every victim that batch i+1 looks up, and — if any — wait for the FIND
 //            blocks and correct their output rows.  Nothing a TAIL block waits for waits for anything itself.
 // One stream, no events, no host in the loop: the sequence is enqueued many steps ahead (tfra_table_steps_overlap).
-// Round-4 measurements on the metric's configuration (10^9 slots, 131 072 Zipf-1.2 ids, 22.7 K distinct): the launch 31.4-35.4 us
-// depending on the box; its roles ALONE (TFRA_STEP_ABLATE): builders 9.6 us, lookup + builders 19.8, write-back + tail 30.6
-// (write-back 19.5): the step is the write-back's chain of dependent round trips, everything else fits beside it.
+// Round-4 measurements on the metric's configuration (10^9 slots, 131 072 Zipf-1.2 ids, 22.7 K distinct): the launch 31-33 us
+// depending on the box; its roles ALONE (TFRA_STEP_ABLATE): builders 9.6 us, lookup + builders 19.8, write-back + tail 23.0 (30.6
+// while every key claimed its buckets up front and a dozen keys per step went through the tail).  27 K block-microseconds of waves that
+// wait on memory 78 % of their time, through 1280 block slots at ~70 %: DESIGN.md section 5.
 
 #ifdef TFRA_STEP_DEVICE_PART
 
