@@ -335,11 +335,11 @@ int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n
  * The driver defers the write-back of a batch to the NEXT call and runs it in the same kernel as that call's lookup; ids the
  * two batches share are served from `values_prev` (the rows being written), everything else from the table; an entry the
  * write-back would evict although this lookup looks for it is evicted after the lookup and the lookup's output corrected
- * (csrc/tfra_step_impl.h).  Ids may repeat (the last occurrence wins).  Two launches per step on ONE stream, nothing
+ * (csrc/tfra_step_impl.h).  Ids may repeat (the last occurrence wins).  ONE launch per step on ONE stream, nothing
  * waits on the host: steps can be enqueued any number ahead (tfra_table_steps_overlap) or captured into a graph.
  *
  *   tfra_table_step_overlap(d, n, ids, rows_out, exists_out, defaults, default_is_full, values_prev, scores_prev,
- *                           n_next, ids_next, stream)
+ *                           n_next, ids_next, n_next2, ids_next2, stream)
  *     rows_out[n, dim] / exists_out[n] (optional) = Find(ids) with the default fill of tfra_table_find;
  *     values_prev [n_prev, dim] = the rows to assign to the ids of the PREVIOUS call (NULL on the first call / after a
  *       flush); they must stay unchanged until this call's work has run;
@@ -377,8 +377,8 @@ typedef struct {
   const int64_t* ids_next2;
 } tfra_overlap_step;
 int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_overlap_step* steps, tfra_stream_t stream);
-/* measurement: HIP events around the two launches of the next `steps` overlapped steps; _kernel_times waits for them and
- * returns the average duration of the step launch and of the remainder launch in microseconds */
+/* measurement: HIP events around the launch of each of the next `steps` overlapped steps; _kernel_times waits for them and
+ * returns the average duration of the step launch in microseconds (rest_kernel_us: a second launch no longer exists, ~0) */
 int tfra_step_driver_time_kernels(tfra_step_driver_t* d, size_t steps);
 int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step_kernel_us, double* rest_kernel_us, size_t* steps);
 /* tuning builds (TFRA_STEP_VARIANT & 16): per-role time stamps of the last launches, see csrc/tfra_step_impl.h */

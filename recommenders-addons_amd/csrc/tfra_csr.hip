@@ -634,7 +634,7 @@ struct CsrKeys {
   const struct SetEnt* sent;
 };
 // One slot of a SET plan's open-addressing table: 16 B, so that a probe is ONE load (the overlapped step's lookup probes the
-// previous batch's plan for every id, tfra_step.hip... see step_kernel)
+// previous batch's plan for every id: find_fwd_role, tfra_step_impl.h)
 struct SetEnt { i64 key; unsigned pos1, cnt; };   // key (EMPTY_KEY = free) | last position + 1 | occurrences
 __device__ __forceinline__ uint2 set_pc(const SetEnt* e) { return *reinterpret_cast<const uint2*>(&e->pos1); }
 // A SET plan's table as something to PROBE (read-only): is this key one of the batch's ids, and where is its last occurrence?
@@ -1225,7 +1225,7 @@ __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
 // U: keys per 16-lane group in flight (the wave's batch is 4 U keys: lanes 0 .. 4U-1 of every group hold them).  2 for up
 // to a batch's worth of keys (22.7 K keys are 1420 waves of 16 keys on 1024 SIMDs: the 4 us of dependent cross-lane work
 // per wave halve, the waves double and still fit in one round), 4 beyond.
-// CF (the overlapped step, step_kernel): the lookup of the NEXT batch runs beside this pass and reads the table rows of every key
+// CF (the overlapped step, tfra_step_impl.h): the lookup of the NEXT batch runs beside this pass and reads the table rows of every key
 // that is not in this batch — an entry this pass is about to EVICT must not be one of them: `cf` = the next batch's plan; a victim
 // that is in it defers the new key to the remainder pass (which runs after that lookup and corrects its output).
 // ACC (SRC_DIRECT, 16-B granules): the reference's insert_or_accum of unique keys (accumrase_fn, cuckoohash_map.hh:619-633;
@@ -1781,7 +1781,7 @@ extern "C" int tfra_sparse_plan_destroy(tfra_sparse_plan_t* pl) {
 static size_t plan_smem_bytes(unsigned cm) { return (size_t)cm * 36 + (size_t)TABW * 4; }
 
 // The SET plan of a batch (dim 0): see setplan_kernel.  setplan_prepare = everything but the launch (buffers, which of the two
-// tables, its counter words): the overlapped step builds the plan inside its own kernel (step_kernel's PLAN role).
+// tables, its counter words): the overlapped step builds the plan inside its own kernel (the BUILD / SCATTER roles of tfra_step_impl.h).
 struct SetPlanLaunch { SetTab cur, old; unsigned* next_use_count; unsigned m2; unsigned blocks; };
 static int setplan_ensure(tfra_sparse_plan* pl, size_t n, hipStream_t s) {   // the SET buffer, sized for n ids
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_build: at most 2^18 ids per plan");
@@ -2128,7 +2128,7 @@ static unsigned next_own_gen(Table* t) {
 }
 
 // Host half of an ownership write-back of a plan's keys: everything but the launches (upsert_planned_impl launches the pair
-// upsert_own_kernel + upsert_rest_kernel, the overlapped step puts the pass into its step_kernel).
+// upsert_own_kernel + upsert_rest_kernel, the overlapped step puts the pass into its one launch).
 struct OwnLaunch {
   OwnArgs a;
   OwnCtrs* ctr; OwnCtrs* next_ctr;

@@ -72,7 +72,7 @@ struct StepArgs {
   int serial_probe;            // the lookup reads the table's lines only for the ids the previous batch's plan does not hold
   unsigned* stat;              // [0] evictions the pass deferred, [1] victims the remainder noted, [2] output rows corrected
   u64* tbuf;                   // TIMING: [TIMING_SLOTS][TIMING_BLOCKS][2] block start / end stamps (nullptr otherwise)
-  i64* patch_keys;             // step_rest_kernel: the launch's list of evicted keys that are ids of this batch
+  i64* patch_keys;             // tail: the launch's list of keys whose slot changed hands and which this batch looks up
   unsigned* patch_count;       // its length; patch_count_next: the next step's (two alternate)
   unsigned* patch_count_next;
 };
@@ -604,7 +604,7 @@ struct tfra_step_driver {
   unsigned long long n_overlapped = 0, n_sequential = 0;   // steps taken each way (tfra_step_driver_stats)
   unsigned long long n_built_in_launch = 0, n_built_in_front = 0;   // plans of the next batch built by the step launch / by a launch of their own
   unsigned why_sequential = 0;             // why the last step that was not overlapped was not (bit mask, see step_overlap_one)
-  std::vector<hipEvent_t> kev;             // tfra_step_driver_time_kernels: 3 events per timed step (before / between / behind its two launches)
+  std::vector<hipEvent_t> kev;             // tfra_step_driver_time_kernels: 3 events per timed step (before / behind its launch; the third marks the end of the step)
   size_t kev_left = 0, kev_used = 0;
 };
 
@@ -726,7 +726,7 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   return TFRA_OK;
 }
 
-// Measurement: HIP events around the two launches of the next `steps` overlapped steps (on the stream they are launched on);
+// Measurement: HIP events around the launch of each of the next `steps` overlapped steps (on the stream they are launched on);
 // tfra_step_driver_kernel_times then waits for them and returns the average duration of each launch in microseconds.
 extern "C" int tfra_step_driver_time_kernels(tfra_step_driver_t* d, size_t steps) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_time_kernels: null driver");

@@ -686,7 +686,7 @@ class OverlapAssignStep:
   — and the same results as lookup(i); insert_or_assign(i); lookup(i+1); ... one after the other, but the write-back of
   batch i runs in the SAME kernel launch as the lookup of batch i+1: ids the two batches share are served from `values` (which
   must therefore stay unchanged until the next step has run), a key the write-back evicts although the next lookup asks for it
-  is corrected afterwards.  Two launches per step on one stream, no second stream, no host synchronisation.  `run()` enqueues
+  is corrected afterwards.  ONE launch per step on one stream, no second stream, no host synchronisation.  `make_run()` enqueues
   many steps with ONE host call."""
 
   def __init__(self, table):
@@ -764,7 +764,7 @@ class OverlapAssignStep:
             "plans_built_in_front": pb[1]}
 
   def time_kernels(self, steps):
-    """HIP events around the two launches of the next `steps` overlapped steps (on their stream); read with kernel_times()."""
+    """HIP events around the launch of each of the next `steps` overlapped steps (on their stream); read with kernel_times()."""
     _capi.call("tfra_step_driver_time_kernels", self._h, int(steps))
 
   def kernel_times(self):
