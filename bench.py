@@ -305,7 +305,37 @@ def cpu_baseline(batch):
       break
   if got is None:
     return {"value": None, "unit": "lookup+insert pairs/s", "cores": threads, "kind": kind, "sample": "no rung finished: %s" % tried}
+  # SURVEY §8d's two small-table legs — Find on a batch WITH its repeats, and the pre-fill at the reference default init_size = 8192
+  # (growth included) — cannot run on the big rung inside its time box: a 4 M-key rung of their own (a child process, 60 s box)
+  small = None
+  if n_keys > 16_000_000 and not os.environ.get("TFRA_BENCH_CPU_KEYS"):
+    parent, child = ctx.Pipe(duplex=False)
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, 4_000_000, threads, kind, True, 1))
+    pr.start()
+    child.close()
+    t_rung = time.perf_counter()
+    while small is None:
+      left = 60.0 - (time.perf_counter() - t_rung)
+      if left <= 0 or not parent.poll(left):
+        break
+      try:
+        msg = parent.recv()
+      except EOFError:
+        break
+      if msg[0] == "done":
+        small = msg[1]
+    pr.join(timeout=1.0)
+    if pr.is_alive():
+      pr.kill()   # the exact process started above
+      pr.join()
+    tried.append({"keys": 4_000_000, "finished": small is not None, "seconds": round(time.perf_counter() - t_begin, 1), "legs": "find_with_repeats, growth from init_size 8192"})
+  else:
+    small = got
   ops, dedup_rate = got["ops"], got["dedup_rate"]
+  if small is not None and ops.get("find_with_repeats_ops_per_s") is None:
+    ops["find_with_repeats_ops_per_s"] = small["ops"].get("find_with_repeats_ops_per_s")
+  grow_rate = got["grow_rate"] or (small["grow_rate"] if small is not None else None)
+  small_keys = 4_000_000 if (small is not None and small is not got) else n_keys
   # the whole CPU step = de-duplicate the batch (tf.unique in the reference, single-threaded; numpy's stands in) +
   # Find + Insert on the distinct ids
   step_incl_dedup = 1.0 / (1.0 / dedup_rate + 1.0 / ops["step_pairs_per_s"])
@@ -319,7 +349,11 @@ def cpu_baseline(batch):
                 % (batch, n_keys, init_div, got["create_s"], threads, cores, time.perf_counter() - t_begin),
       "per_op": {k: (round(v) if v is not None else None) for k, v in ops.items()},
       "per_op_per_core": {k: (round(v / threads) if v is not None else None) for k, v in ops.items()},
-      "prefill_keys_per_s_init_size_8192_growth_included": round(got["grow_rate"]) if got["grow_rate"] else None,
+      "prefill_keys_per_s_init_size_8192_growth_included": round(grow_rate) if grow_rate else None,
+      "small_table_legs_keys": small_keys,
+      "not_run_1e9_keys": "the 256 M-key rung (85 GB) takes ~47 s on this host class (constructor 9 s on one thread + 128-thread fill 33 s, "
+                          "measured round 4); 10^9 keys scale that to ~190 s + 330 GB touched once — past the ~30 s the default run may "
+                          "spend on the CPU leg; TFRA_BENCH_CPU_KEYS=1000000000 runs it (300 s box)",
   }
 
 
@@ -526,21 +560,34 @@ def run_bounded(args, torch, de, dev, cfg):
   # being written: store-to-load forwarding through batch i's plan), write-back of batch i, its left-over keys and the output
   # corrections (tail), and the plans of the next two batches (built over two launches, without atomics); D steps per host call
   # (tfra_table_steps_overlap), one stream, nothing waits on the host.  Lookup outputs: a ring of D buffers.
-  ids = idf.keys(nsteps + 3)
-  uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
-  D = 4 if K % 4 == 0 else (2 if K % 2 == 0 else 1)
-  outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(D)]
-  ovl = de.OverlapAssignStep(table).prime(ids[0])
-  for i in range(W):
-    ovl.step(values, ids[i + 1], ids[i + 2])
-  runs = [ovl.make_run([ids[W + c * D + q] for q in range(D)], [values] * D, outs, ids_after=ids[W + (c + 1) * D],
-                       values_before=values if (W + c) else None, ids_after2=ids[W + (c + 1) * D + 1]) for c in range(WINDOWS * K // D)]
+  uniq_ratio = None
+  ovl = de.OverlapAssignStep(table)
 
-  def ovl_step(i):   # timed_windows calls once per step: every D-th call enqueues D steps (K is a multiple of D)
-    if (i - W) % D == 0:
-      runs[(i - W) // D]()
+  def time_overlapped(D):
+    """W warm-up steps, then the windows: D steps per host call (tfra_table_steps_overlap with D pre-built argument blocks; D = 1 =
+    one host call per step, what a trainer that gets the values of step i only after its lookup can issue)"""
+    nonlocal uniq_ratio
+    ids = idf.keys(nsteps + 3)
+    if uniq_ratio is None:
+      uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
+    outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(max(D, 2))]
+    ovl.prime(ids[0])
+    for i in range(W):
+      ovl.step(values, ids[i + 1], ids[i + 2])
+    runs = [ovl.make_run([ids[W + c * D + q] for q in range(D)], [values] * D, [outs[(c * D + q) % len(outs)] for q in range(D)],
+                         ids_after=ids[W + (c + 1) * D], values_before=values if (W + c) else None, ids_after2=ids[W + (c + 1) * D + 1])
+            for c in range(WINDOWS * K // D)]
 
-  secs, med, host_s = timed_windows(torch, None, 1, dev, K, ovl_step, first=W)
+    def ovl_step(i):   # timed_windows calls once per step: every D-th call enqueues D steps (K is a multiple of D)
+      if (i - W) % D == 0:
+        runs[(i - W) // D]()
+
+    r = timed_windows(torch, None, 1, dev, K, ovl_step, first=W)
+    return r, ids, outs
+
+  # the headline: ONE host call per step (D = 1)
+  D = 1
+  (secs, med, host_s), ids, outs = time_overlapped(1)
   # per-launch durations of the same driver: HIP events on the launching stream around each of the two launches of 24 more steps
   ovl.time_kernels(24)
   for c in range(24 // D):
@@ -555,7 +602,16 @@ def run_bounded(args, torch, de, dev, cfg):
   verified["overlapped_step_last_batch"] = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, last, values)))
   # (the host learns that the table is dense from asynchronous size reads: the first warm-up steps may still run one op after the other)
   verified["overlapped_step_every_timed_step_overlapped"] = ovl_stats["sequential"] <= W and ovl_stats["overlapped"] >= WINDOWS * K + 24
-  del ovl, runs, got, ex
+  del got, ex
+  # the same driver with 4 steps per host call (a bench-only mode: the values of steps i+1..i+3 would have to exist before their
+  # lookups return) — reported beside the headline, never as `value`
+  D4 = 4 if K % 4 == 0 else (2 if K % 2 == 0 else 1)
+  (secs_d4, med_d4, host_d4), ids_d4, outs_d4 = time_overlapped(D4)
+  ovl.flush()
+  ovl_stats_d4 = ovl.stats()
+  verified["overlapped_step_every_timed_step_overlapped"] = (verified["overlapped_step_every_timed_step_overlapped"] and
+                                                             ovl_stats_d4["overlapped"] - ovl_stats["overlapped"] >= WINDOWS * K)
+  del ovl, ids_d4, outs_d4
 
   # ---- driver 1b: round 3's look-ahead driver (one C call per step, plan of batch i+1 on a second stream, host-ordered) --------
   ps = de.PrefetchAssignStep(table).prime(ids[0])
@@ -752,9 +808,11 @@ def run_bounded(args, torch, de, dev, cfg):
   bad = [k for k, v in verified.items() if v is False]
   assert not bad, "bench verification failed: %s (overlapped step: %s)" % (bad, ovl_stats)
 
-  # `value` = the faster of the table's two step drivers on this workload (both are the product's; `faster_driver` names it, the other
-  # one is reported beside it): the overlapped step wins on the metric's stream, the look-ahead driver on a stream of mostly new keys
-  best_is_overlapped = med <= med_pf
+  # `value` = ONE driver per workload, chosen by RULE (de.assign_step_driver_for: the stream's share of never-seen ids), not by
+  # result: the overlapped step for streams that mostly revisit resident keys (the metric's), the look-ahead driver when more than
+  # a quarter of a batch are never-seen ids (configs[2]: the write-back with its evictions is the long pole and runs faster as
+  # kernels of its own).  The other driver's number is reported beside it.
+  best_is_overlapped = de.assign_step_driver_for(new_ratio) == "overlapped_step"
   med_best = med if best_is_overlapped else med_pf
   ms = med_best / K * 1e3
   value = B * K / med_best
@@ -791,10 +849,11 @@ def run_bounded(args, torch, de, dev, cfg):
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "f32",
       "data": "synthetic",
       "value_overlapped_step": B * K / med, "ms_per_step_overlapped_step": med / K * 1e3,
+      "value_overlapped_step_4_steps_per_host_call": B * K / med_d4, "ms_per_step_overlapped_step_4_steps_per_host_call": med_d4 / K * 1e3,
       "value_look_ahead_driver": B * K / med_pf, "ms_per_step_look_ahead_driver": med_pf / K * 1e3,
-      "faster_driver": "overlapped step (value = value_overlapped_step)" if best_is_overlapped else
-                       "look-ahead driver (value = value_look_ahead_driver): many never-seen ids per batch make the write-back the long pole, "
-                       "and it runs faster as kernels of its own than as a role of the step launch",
+      "driver": "overlapped_step" if best_is_overlapped else "look_ahead",
+      "driver_rule": "de.assign_step_driver_for(new_key_ratio): overlapped_step when <= 25 %% of a batch are never-seen ids, else look_ahead "
+                     "(new_key_ratio here: %.2f)" % new_ratio,
       "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
       "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
       "value_op_surface_host_read_first": B * K / med_ops_sync, "ms_per_step_op_surface_host_read_first": med_ops_sync / K * 1e3,
@@ -816,11 +875,12 @@ def run_bounded(args, torch, de, dev, cfg):
           "state_warm_steps_before_any_timing": state_warm_steps,
           "table_ops_per_s": (B + U) * K / med_best,
           "table_ops_per_s_counts": "B lookups + U row writes (the distinct keys of the batch) per step",
-          "host_enqueue_ms_per_step": round(1e3 * (host_s if best_is_overlapped else host_pf) / K, 4), "steps_per_host_call": D if best_is_overlapped else 1,
+          "host_enqueue_ms_per_step": round(1e3 * (host_s if best_is_overlapped else host_pf) / K, 4), "steps_per_host_call": 1,
           "host_enqueue_ms_per_step_overlapped_step": round(1e3 * host_s / K, 4),
+          "host_enqueue_ms_per_step_overlapped_step_4_steps_per_host_call": round(1e3 * host_d4 / K, 4),
           "host_enqueue_ms_per_step_look_ahead_driver": round(1e3 * host_pf / K, 4),
           "overlapped_step_stats": ovl_stats,
-          "timing": {"value": timing_note(secs, K), "value_look_ahead_driver": timing_note(secs_pf, K), "value_plain_call": timing_note(secs_plain, K),
+          "timing": {"value_overlapped_step": timing_note(secs, K), "value_overlapped_step_4_steps_per_host_call": timing_note(secs_d4, K), "value_look_ahead_driver": timing_note(secs_pf, K), "value_plain_call": timing_note(secs_plain, K),
                      "value_op_surface": timing_note(secs_ops, K), "value_op_surface_find_first": timing_note(secs_opf, K), "value_op_surface_host_read_first": timing_note(secs_ops_sync, K),
                      "value_accum": timing_note(secs_acc, K), "value_op_surface_table_ops_only": timing_note(secs_tops, K)},
           "verified": verified,
@@ -830,7 +890,8 @@ def run_bounded(args, torch, de, dev, cfg):
                        "batch i served from the rows being written: store-to-load forwarding through batch i's plan) + ownership "
                        "write-back of batch i + its left-over keys and the output corrections (tail blocks of the same launch) + the "
                        "plans of batches i+2 / i+3 (built over two launches, no atomics); results identical to lookup; insert; lookup; "
-                       "insert ... (needs the ids two batches ahead); %d steps per host call, lookup outputs in a ring of %d buffers" % (D, D),
+                       "insert ... (needs the ids two batches ahead); ONE host call per step (value_overlapped_step_4_steps_per_host_call: %d "
+                       "steps per call of tfra_table_steps_overlap — bench-only, a trainer has the values of step i only after its lookup)" % D4,
               "value_look_ahead_driver": "round 3's driver, tfra_table_step_prefetch_assign: ONE C call per step = lookup + insert_or_assign "
                                          "of batch i on the main stream, plan of batch i+1 on a second stream, streams ordered by the host",
               "value_plain_call": "tfra_table_find then tfra_table_upsert_sparse, no look-ahead; upsert_sparse is a fused extra (plan "
@@ -1187,6 +1248,116 @@ def run_c5(args, torch, de, dev):
   return res
 
 
+# ------------------------------------------------------------------ the ONE line the driver parses: < 6 KB
+LINE_LIMIT = 6000
+
+
+def _num(x, sig=5):
+  """numbers short enough for a compact line: ints stay, floats keep `sig` significant digits"""
+  if isinstance(x, bool) or x is None or isinstance(x, int):
+    return x
+  if isinstance(x, float):
+    if x != x or x in (float("inf"), float("-inf")):
+      return None
+    return float("%.*g" % (sig, x))
+  return x
+
+
+def _pick(d, keys):
+  return {k: _num(d[k]) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def _short(sv, n):
+  sv = "" if sv is None else str(sv)
+  return sv if len(sv) <= n else sv[: n - 1] + "…"
+
+
+def compact_line(res, detail_path=None):
+  """The bench line the driver keeps (its stdout tail is ~8 KB): value, roofline, cpu_baseline, scaling_point and ONE row per
+  secondary workload / driver variant; everything else — per-driver prose, timing windows, verification flags, per-op CPU tables,
+  per-kernel tables — goes to bench_detail.json (`detail`) and stderr."""
+  cfg, rf, cb = res.get("config", {}), res.get("roofline", {}), res.get("cpu_baseline")
+  line = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                     "dtype", "data"))
+  line["metric"] = _short(res.get("metric"), 200)
+  c = _pick(cfg, ("slots", "global_batch", "unique_ratio", "unique_keys_per_batch", "new_key_ratio", "steps_per_host_call",
+                  "host_enqueue_ms_per_step", "resident_after_prefill", "keys_per_gpu", "parallelism", "route", "tables", "rccl_ranks_seen"))
+  c["workload"] = _short(cfg.get("workload"), 360)
+  c["driver"] = res.get("driver") or cfg.get("driver")
+  if res.get("driver_rule"):
+    c["driver_rule"] = _short(res["driver_rule"], 170)
+  line["config"] = c
+  r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "step_frac",
+                 "step_algorithmic_bytes"))
+  r["kernel"] = _short(rf.get("kernel"), 150)
+  if r.get("traffic") is not None and r.get("algorithmic_bytes_per_launch"):
+    r["traffic_over_algorithmic"] = _num(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
+  line["roofline"] = r
+  if cb is not None:
+    b = _pick(cb, ("value", "unit", "cores", "kind", "resident_keys", "table_ops_only_pairs_per_s", "host_cores",
+                   "prefill_keys_per_s_init_size_8192_growth_included", "small_table_legs_keys"))
+    po = cb.get("per_op") or {}
+    for k in ("find_unique_ids_ops_per_s", "insert_or_assign_ops_per_s", "find_with_repeats_ops_per_s", "prefill_keys_per_s_init_size_N"):
+      if k in po:
+        b[k] = _num(po[k])
+    b["sample"] = _short(cb.get("sample"), 330)
+    line["cpu_baseline"] = b
+  sp = res.get("scaling_point")
+  if sp:
+    line["scaling_point"] = dict(_pick(sp, ("value", "ms_per_step", "n_gpus", "launches_per_step", "error")), workload=_short(sp.get("workload"), 200))
+  variants = {}
+  for k, v in res.items():   # one number per driver variant of the top-level workload
+    if k.startswith("value_") and isinstance(v, (int, float)):
+      variants[k[6:]] = _num(v, 4)
+  if variants:
+    line["variants_pairs_per_s"] = variants
+  sec = {}
+  for name, rr in (res.get("secondary") or {}).items():
+    if "error" in rr:
+      sec[name] = {"error": _short(rr["error"], 160)}
+      continue
+    row = _pick(rr, ("value", "ms_per_step", "driver"))
+    rrf, rcf = rr.get("roofline", {}), rr.get("config", {})
+    row.update({"step_frac": _num(rrf.get("step_frac"), 4), "kernel_frac": _num(rrf.get("frac"), 4),
+                "kernel": _short(rrf.get("kernel"), 60), "host_enqueue_ms_per_step": _num(rcf.get("host_enqueue_ms_per_step")),
+                "unique_keys_per_batch": rcf.get("unique_keys_per_batch")})
+    for k in ("value_overlapped_step", "value_look_ahead_driver", "value_op_surface", "value_plain_call"):
+      if k in rr:
+        row[k[6:]] = _num(rr[k], 4)
+    sec[name] = row
+  if sec:
+    line["secondary"] = sec
+  if detail_path:
+    line["detail"] = detail_path
+  out = json.dumps(line, separators=(",", ":"), ensure_ascii=False)
+  if len(out) > LINE_LIMIT:   # never lose the line: drop the optional blocks, largest first
+    for k in ("variants_pairs_per_s", "secondary"):
+      line.pop(k, None)
+      out = json.dumps(line, separators=(",", ":"), ensure_ascii=False)
+      if len(out) <= LINE_LIMIT:
+        break
+  return out
+
+
+def emit(res):
+  """bench_detail.json (everything) next to bench.py — and under gpurun_out/ when that exists, so that it comes back from a GPU
+  box — and the compact line as the LAST line on stdout (nothing long goes to stderr either: a driver may keep one merged tail)."""
+  detail = None
+  for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    try:
+      if d != ROOT and not os.path.isdir(d):
+        continue
+      with open(os.path.join(d, "bench_detail.json"), "w") as f:
+        json.dump(res, f, indent=1)
+      detail = detail or "bench_detail.json"
+    except OSError:
+      pass
+  print("[bench] full result: %s" % (detail or "bench_detail.json could not be written"), file=sys.stderr, flush=True)
+  import ctypes
+  ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: out before the JSON line, not after it
+  print(compact_line(res, detail), flush=True)
+
+
 # ------------------------------------------------------------------ main
 def main():
   ap = argparse.ArgumentParser()
@@ -1232,7 +1403,7 @@ def main():
       args._growth = measure_growth(torch, de, dev, 128, torch.float16, args.slots // 4)   # reported under secondary.c3
     res = run_bounded(args, torch, de, dev, cfg)
     if not args.no_secondary and args.config is None:
-      keep = ("metric", "value", "value_overlapped_step", "value_look_ahead_driver", "faster_driver", "value_op_surface_host_read_first", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
+      keep = ("metric", "value", "value_overlapped_step", "value_overlapped_step_4_steps_per_host_call", "value_look_ahead_driver", "driver", "driver_rule", "value_op_surface_host_read_first", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
               "value_op_surface_table_ops_only", "ms_per_step",
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}
@@ -1265,9 +1436,7 @@ def main():
   if rank == 0:
     if not args.no_cpu_baseline:
       res["cpu_baseline"] = cpu_baseline(args.batch)
-    import ctypes
-    ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: out before the JSON line, not after it
-    print(json.dumps(res), flush=True)
+    emit(res)
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()

@@ -336,7 +336,10 @@ int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n
  * two batches share are served from `values_prev` (the rows being written), everything else from the table; an entry the
  * write-back would evict although this lookup looks for it is evicted after the lookup and the lookup's output corrected
  * (csrc/tfra_step_impl.h).  Ids may repeat (the last occurrence wins).  ONE launch per step on ONE stream, nothing
- * waits on the host: steps can be enqueued any number ahead (tfra_table_steps_overlap) or captured into a graph.
+ * waits on the host: steps can be enqueued any number ahead (tfra_table_steps_overlap).  NOT for hipGraph capture: a launch
+ * carries host-side rotating state (which of two counter sets the previous launch's tail zeroed, the plan rotation, the
+ * ownership generation); a replayed launch would reuse counters nobody zeroed.  TFRA_OPTION_CAPTURE_SAFE tables take the
+ * sequential path inside the same entry points.
  *
  *   tfra_table_step_overlap(d, n, ids, rows_out, exists_out, defaults, default_is_full, values_prev, scores_prev,
  *                           n_next, ids_next, n_next2, ids_next2, stream)
@@ -348,7 +351,9 @@ int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n
  *       are scattered into per-window segments by the launch two calls ahead, its table is built by the launch one call ahead).
  *       With ids_next only, the plan of the next batch is built by a launch of its own in front of the step (round 3's plan
  *       kernel); with neither, by the next call in front of ITS step.  ids must stay valid until their batch has been written
- *       back (the call after the one that looked them up).
+ *       back (the call after the one that looked them up).  An announced batch is recognised by (address, length) when its
+ *       own call comes: from announcement to write-back its buffer must stay UNMODIFIED (a ring of id buffers needs at least
+ *       four entries when ids_next2 is used); a batch that was announced but is never stepped is forgotten by the next call.
  *   tfra_table_step_overlap_flush(d, values_prev, scores_prev, stream) writes the last batch back: call it before the table
  *     is used through any other entry point.
  * Tables or calls the overlap does not cover (not a bounded LRU table at capacity, caller scores, optimizer slots, rows

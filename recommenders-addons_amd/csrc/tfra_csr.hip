@@ -1755,7 +1755,7 @@ struct tfra_sparse_plan {
   unsigned scat_use = 0;           // scatters into this object so far (its two overflow counters alternate)
   const int64_t* scat_ids = nullptr;   // the batch whose pairs the segments hold (nullptr: none)
   size_t scat_n = 0;
-  bool listless[2] = {false, false};   // table p was last built without its dense key list (by the overlapped step)
+  unsigned char tab_state[2] = {0, 0}; // TAB_EMPTY / TAB_LISTED / TAB_LISTLESS: what each table holds (setplan_prepare)
 };
 
 extern "C" int tfra_sparse_plan_create(int device, tfra_sparse_plan_t** out) {
@@ -1812,8 +1812,23 @@ static int setplan_ensure(tfra_sparse_plan* pl, size_t n, hipStream_t s) {   // 
       fill_setent_kernel<<<256, 256, 0, s>>>(tb.ent, (size_t)m2 + 2 + SET_PAD);
     }
     pl->set_cap = cap; pl->set_m2 = m2; pl->set_parity = 1; pl->set_use[0] = pl->set_use[1] = 0;
-    pl->listless[0] = pl->listless[1] = false;
+    pl->tab_state[0] = pl->tab_state[1] = 0;
   }
+  return TFRA_OK;
+}
+// What each of the object's two tables holds (tab_state): the build rules differ in what they leave behind —
+//   a REGULAR build (setplan_kernel) needs an EMPTY target, leaves it LISTED (keys + the dense list of the slots they took) and
+//     empties the OTHER table through that table's list;
+//   a LIST-LESS build (the step launch's BUILD role) rewrites every slot of its target, leaves it LISTLESS and touches nothing else.
+// A plan object may see them in any order (a step driver whose look-ahead is sometimes missing: regular, list-less, regular on one
+// object left the third build's target holding the first batch's keys).  setplan_prepare makes both tables what the regular
+// build expects, whatever came before: a target that is not known empty is filled, an other table without a list is filled
+// instead of walked, and a filled table's counter words are zeroed (a list-less build zeroes none).
+enum : unsigned char { TAB_EMPTY = 0, TAB_LISTED = 1, TAB_LISTLESS = 2 };
+static int setplan_fill_table(tfra_sparse_plan* pl, unsigned q, hipStream_t s) {
+  fill_setent_kernel<<<256, 256, 0, s>>>(pl->set_tab[q].ent, (size_t)pl->set_m2 + 2 + SET_PAD);
+  if (hipMemsetAsync(pl->set_counts + 64 + 16 * q, 0, 16 * sizeof(unsigned), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
+  pl->tab_state[q] = TAB_EMPTY;
   return TFRA_OK;
 }
 static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool counts, SetPlanLaunch* L) {
@@ -1823,15 +1838,16 @@ static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool c
   pl->gen += 1;
   const unsigned blocks = (unsigned)((n + SP_NT - 1) / SP_NT);
   auto count_word = [&](unsigned tab, unsigned use) { return pl->set_counts + 64 + 8 * (2 * tab + (use & 1u)) + 1; };
+  if (pl->tab_state[p] != TAB_EMPTY && (rc = setplan_fill_table(pl, p, s)) != TFRA_OK) return rc;
+  if (pl->tab_state[p ^ 1u] == TAB_LISTLESS && (rc = setplan_fill_table(pl, p ^ 1u, s)) != TFRA_OK) return rc;
   const unsigned use = ++pl->set_use[p];
   SetTab cur = pl->set_tab[p], old = pl->set_tab[p ^ 1u];
   cur.count = count_word(p, use);
-  old.count = count_word(p ^ 1u, pl->set_use[p ^ 1u]);   // (never used yet: a zero word)
+  // the other table is walked through its list only when it has one; otherwise (never used, just filled) the list is empty: a word that is always zero
+  old.count = pl->tab_state[p ^ 1u] == TAB_LISTED ? count_word(p ^ 1u, pl->set_use[p ^ 1u]) : pl->set_counts + 120;
   pl->set_tab[p].count = cur.count;
-  // a table that was last built by the overlapped step has no list of its used slots: empty all of it (this build's target must
-  // start empty, the other one is emptied through its list otherwise)
-  for (unsigned q = 0; q < 2; ++q)
-    if (pl->listless[q]) { fill_setent_kernel<<<256, 256, 0, s>>>(pl->set_tab[q].ent, (size_t)pl->set_m2 + 2 + SET_PAD); pl->listless[q] = false; }
+  pl->tab_state[p] = TAB_LISTED; pl->tab_state[p ^ 1u] = TAB_EMPTY;
+  pl->scat_ids = nullptr; pl->scat_n = 0;   // (pairs a step launch scattered for this object belong to a batch this build replaces)
   L->cur = cur; L->old = old; L->next_use_count = count_word(p, use + 1); L->m2 = pl->set_m2; L->blocks = blocks;
   pl->built_counts = counts;
   pl->set_parity = p;
@@ -1867,7 +1883,7 @@ static SetTab setplan_take_listless(tfra_sparse_plan* pl, size_t n) {
   pl->gen += 1;
   const unsigned use = ++pl->set_use[p];
   pl->set_tab[p].count = pl->set_counts + 64 + 8 * (2 * p + (use & 1u)) + 1;   // (unused by a list-less build: kept valid)
-  pl->listless[p] = true;
+  pl->tab_state[p] = TAB_LISTLESS;
   pl->built_counts = false;
   pl->set_parity = p;
   pl->d_counts = pl->set_counts; pl->dflag = pl->set_dflag; pl->slow_items = pl->set_items; pl->any_deferred = pl->set_counts + 8;
@@ -2275,7 +2291,7 @@ extern "C" int tfra_sparse_plan_read(const tfra_sparse_plan_t* pl, uint32_t* cou
     return set_error(TFRA_ERR_HIP, "sparse_plan_read: copy");
   const unsigned nhot = counts[0], ncold = counts[1], nbins = counts[3];
   if (!keys) return TFRA_OK;
-  if (pl->kind == 1 && pl->listless[pl->set_parity])
+  if (pl->kind == 1 && pl->tab_state[pl->set_parity] == TAB_LISTLESS)
     return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_read: this plan was built by the overlapped step, without a key list");
   if (pl->kind == 1) {   // SET plan: distinct keys and their occurrence counts; it keeps no positions list
     if (positions) return set_error(TFRA_ERR_UNSUPPORTED, "sparse_plan_read: an assign-only plan keeps the last position of a key, not the list of its positions");

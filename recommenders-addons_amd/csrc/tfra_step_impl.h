@@ -485,8 +485,10 @@ __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepL
     ok = spin_until_pair(a.sync, a.own_blocks, &both);
     L.cnt[1] = (unsigned)(both >> 32);
   }
+  if (tid == 0) { L.cnt[2] = ok ? 1u : 0u; if (!ok) atomicAdd(o.v.err_count, 1u); }   // a timeout leaves keys unwritten: reported, never silent
   __syncthreads();
   const unsigned counted = L.cnt[1];
+  ok = L.cnt[2] != 0;
   if (counted == 0) return;                                        // no items, no evictions, nothing to correct (the same in every tail block)
   const bool listed = counted <= o.item_cap;
   const unsigned n = listed ? counted : a.fwd.m2 + 2;              // (the list overflowed: the flag byte of every slot of the plan's table)
@@ -758,7 +760,7 @@ extern "C" int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step
 }
 
 static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_tab[pl->set_parity].ent, pl->set_m2}; }
-static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 && pl->listless[pl->set_parity]; }
+static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 && pl->tab_state[pl->set_parity] == 2; }
 
 // variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0: 8 keys per wave in the write-back, 5 blocks per CU | 1: 4 keys | 2: 4 blocks per CU | 3: 6), 8 every plan as a launch of
 // its own, 16 time stamps, 64 the lookup reads the table's lines for every id
@@ -798,6 +800,14 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
   }
   if (!n) plan_cur->n = 0;
   d->ahead = false;
+  // Announced batches are recognised by (address, length).  Whatever this call does not consume is disarmed HERE, on every path: pairs
+  // scattered for a batch that is not announced again (no ids_next, the sequential path, a plan launch in front) must not meet a
+  // later batch that happens to live at the same address.
+  if (!(n_next && plan_next->scat_ids == ids_next && plan_next->scat_n == n_next)) { plan_next->scat_ids = nullptr; plan_next->scat_n = 0; }
+  plan_cur->scat_ids = nullptr; plan_cur->scat_n = 0;
+  if (plan_prev) { plan_prev->scat_ids = nullptr; plan_prev->scat_n = 0; }
+  // (plan_next2's segments are filled by this call or not at all)
+  plan_next2->scat_ids = nullptr; plan_next2->scat_n = 0;
   unsigned* tags = t->ensure_own_tags(s);
   // what the TABLE must be for the overlap (constant over its life, but for `dense`) and what this CALL must be
   const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU) ? 0u : 8u) |
@@ -819,6 +829,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     }
     lock.unlock();
     if (n) { rc = tfra_table_find(d->tp, n, ids, rows_out, exists_out, defaults, default_is_full, s); if (rc) return rc; }
+    plan_next->scat_ids = nullptr; plan_next->scat_n = 0;
     if (n_next) {
       rc = setplan_build(plan_next, n_next, ids_next, s, lfu);
       if (rc) return rc;

@@ -3,7 +3,7 @@
 from . import device_ops
 from . import optimizer as optimizers
 from .optimizer import (CapturedTrainStep, DynamicEmbeddingOptimizer, MultiTablePrefetchStep, OverlapAssignStep,
-                        PrefetchAssignStep, PrefetchStep)
+                        PrefetchAssignStep, PrefetchStep, assign_step_driver_for, assign_step_for)
 from .restrict_policies import FrequencyRestrictPolicy, RestrictPolicy, TimestampRestrictPolicy
 from .table_ops import (SparsePlan, CuckooHashTable, HkvEvictStrategy, HkvHashTable, KHkvHashTableInitCapacity,
                         KHkvHashTableMaxCapacity, KHkvHashTableMaxHbmForValuesByBytes)

@@ -676,6 +676,19 @@ class PrefetchAssignStep:
     return out
 
 
+def assign_step_driver_for(new_key_ratio):
+  """Which of the table's two step drivers a lookup + insert_or_assign stream should use, by RULE: 'overlapped_step'
+  (OverlapAssignStep: lookup i+1 and write-back i in one launch, shared ids forwarded) when at most a quarter of a batch's ids are
+  never-seen keys; 'look_ahead' (PrefetchAssignStep) beyond — every never-seen key on a full bounded table is an eviction, the
+  write-back becomes the long pole and runs faster as kernels of its own with the whole chip and its own register budget."""
+  return "overlapped_step" if float(new_key_ratio) <= 0.25 else "look_ahead"
+
+
+def assign_step_for(table, new_key_ratio=0.0):
+  """The step driver object assign_step_driver_for() names (same prime / step / flush interface)."""
+  return OverlapAssignStep(table) if assign_step_driver_for(new_key_ratio) == "overlapped_step" else PrefetchAssignStep(table)
+
+
 class OverlapAssignStep:
   """The overlapped step (`tfra_table_step_overlap`, csrc/tfra_step_impl.h): same use as `PrefetchAssignStep` —
 
@@ -696,6 +709,8 @@ class OverlapAssignStep:
     self._h = ctypes.c_void_p()
     _capi.call("tfra_step_driver_create", self.table._h, ctypes.byref(self._h))
     self.default = self.table._default_value
+    if self.default.dtype != self.table.value_dtype or not self.default.is_contiguous():
+      self.default = self.default.to(self.table.value_dtype).contiguous()
     self._ids = None
     self._pending = None      # (ids, values) of the batch still to be written back: kept alive until it has been
     self._keep = None
@@ -726,6 +741,9 @@ class OverlapAssignStep:
     own per step; with neither, in front of the next step."""
     from .table_ops import _stream
     ids = self._ids
+    if ids is None:
+      raise RuntimeError("OverlapAssignStep.step: no batch is primed — call prime(ids) first (and again after a step that "
+                         "announced no next_ids, or after a run made without ids_after)")
     n = ids.numel()
     dim, vdt, dev = self.table.dim, self.table.value_dtype, self.dev
     if values.dtype != vdt or not values.is_contiguous() or values.shape != (n, dim):

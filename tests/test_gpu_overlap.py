@@ -225,3 +225,138 @@ def test_overlap_many_steps_one_host_call_and_fallback(env):
   got = g.lookup(uk)
   want = torch.stack([vals[ref[int(x)][0]][ref[int(x)][1]] for x in uk.cpu().numpy()])
   assert torch.equal(got, want)
+
+
+def _dict_check(torch, tbl, ids, out, ex, latest, tag):
+  """rows / exists of one step against the table as it is now AND against the dictionary of last writes (keys that are present)"""
+  ref, rex = tbl.find(ids, return_exists=True)
+  assert torch.equal(ex, rex), tag
+  assert torch.equal(out, ref), tag
+  ids_np = ids.cpu().numpy()
+  want = np.array([latest.get(int(k), 0.0) for k in ids_np], np.float32)
+  want_ex = np.array([int(k) in latest for k in ids_np])
+  exn, outn = ex.cpu().numpy(), out[:, 0].cpu().numpy()
+  assert not np.any(exn & ~want_ex), tag
+  np.testing.assert_array_equal(outn[exn], want[exn], err_msg=str(tag))
+  assert np.all(outn[~exn] == 0.0), tag
+  return int(np.sum(~exn & want_ex))
+
+
+@pytest.mark.parametrize("pattern", ["phases", "restart8", "alternate"])
+def test_overlap_plan_objects_see_regular_and_listless_builds_in_any_order(env, pattern):
+  """The driver rotates four plan objects; each has two tables, and the two kinds of build leave them in different states (a
+  regular build — a plan launch in front of the step — wants an empty target and empties the other table through its key list; a
+  list-less build inside the step launch rewrites its target and empties nothing).  Regular, list-less, regular on ONE object used to
+  start the third build in a table still holding the first batch's keys: stale keys were written back and forwarded.  Look-ahead that
+  comes and goes (phases), a run of 8 steps without ids_after called again and again (restart8), every other step announced
+  (alternate) — all against a dictionary of last writes."""
+  torch, de = env
+  dim, cap, n, nsteps = 64, 400_000, 6000, 40
+  rng = np.random.default_rng({"phases": 1, "restart8": 2, "alternate": 3}[pattern])
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  t = make_dense_table(torch, de, cap, dim, universe, "ovl_mixed_%s" % pattern)
+  tbl = t._table
+  latest = {int(k): float(int(k) % 1000) for k in universe}
+  batches = [torch.from_numpy(universe[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % universe.size].astype(np.int64)).cuda()
+             for _ in range(nsteps + 3)]
+  vals = [(torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim).contiguous() for s in range(nsteps)]
+  drv = de.OverlapAssignStep(t)
+  evicted = 0
+  if pattern == "restart8":
+    outs = [torch.empty((n, dim), device="cuda") for _ in range(8)]
+    for lo in range(0, nsteps, 8):
+      run = drv.make_run(batches[lo:lo + 8], vals[lo:lo + 8], outs, ids_after=None, values_before=None)
+      run()
+      drv.flush()
+      torch.cuda.synchronize()
+      # the table after the run = all 8 write-backs; the LAST lookup's rows are what the dictionary held before its own write
+      for s in range(lo, lo + 8):
+        if s == lo + 7:
+          ids_np = batches[s].cpu().numpy()
+          want = np.array([latest.get(int(k), 0.0) for k in ids_np], np.float32)
+          got = outs[7][:, 0].cpu().numpy()
+          present = got != 0.0
+          np.testing.assert_array_equal(got[present], want[present])
+        for i, k in enumerate(batches[s].cpu().numpy().tolist()):
+          latest[k] = 100000.0 * (s + 1) + i
+      ek = torch.from_numpy(np.array(sorted(latest), np.int64)).cuda()
+      got, ex = t.lookup(ek, return_exists=True)
+      exn = ex.cpu().numpy()
+      assert exn.mean() > 0.99
+      wantv = np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32)
+      np.testing.assert_array_equal(got[:, 0].cpu().numpy()[exn], wantv[exn], err_msg="after run at %d" % lo)
+  else:
+    drv.prime(batches[0])
+    for s in range(nsteps):
+      if pattern == "phases":
+        two = (s // 5) % 2 == 1          # five steps without any look-ahead, five with both batches announced, ...
+        nxt = batches[s + 1] if two else None
+        nx2 = batches[s + 2] if two else None
+      else:
+        nxt = batches[s + 1] if s % 2 == 0 else None
+        nx2 = batches[s + 2] if s % 4 == 0 else None
+      out, ex = drv.step(vals[s], nxt, nx2, return_exists=True)
+      if nxt is None:
+        drv.prime(batches[s + 1])
+      evicted += _dict_check(torch, tbl, batches[s], out, ex, latest, (pattern, s))
+      for i, k in enumerate(batches[s].cpu().numpy().tolist()):
+        latest[k] = 100000.0 * (s + 1) + i
+    drv.flush()
+    st = drv.stats()
+    assert st["plans_built_in_launch"] > 0 and st["plans_built_in_front"] > 0, st
+  assert evicted <= nsteps * n // 100
+  ek, ev = t.export()
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
+  tbl.check_errors()
+  assert tbl.slot_census()["locked"] == 0
+
+
+def test_overlap_id_buffers_reused_at_the_same_address(env):
+  """A ring of four id buffers rewritten in place once their batch has been written back, with look-ahead that is sometimes
+  withdrawn: an announced batch is recognised by (address, length), so pairs scattered for a batch that is never stepped must not
+  be taken for a later batch that lives at the same address."""
+  torch, de = env
+  dim, cap, n, nsteps = 64, 300_000, 5000, 36
+  rng = np.random.default_rng(11)
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 104729 + 7
+  t = make_dense_table(torch, de, cap, dim, universe, "ovl_ring")
+  tbl = t._table
+  latest = {int(k): float(int(k) % 1000) for k in universe}
+  draw = lambda: torch.from_numpy(universe[(rng.zipf(1.15, size=n) * 41 + rng.integers(0, 64, size=n)) % universe.size].astype(np.int64)).cuda()
+  ring = [torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(6)]
+  vals = [(torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim).contiguous() for s in range(nsteps)]
+  drv = de.OverlapAssignStep(t)
+  # batch s lives in ring[s % 6]; the buffer is refilled only after batch s has been written back (two calls after its own)
+  content = {}
+  def fill(s):
+    b = draw()
+    ring[s % 6].copy_(b)
+    content[s] = b.clone()
+  for s in range(3):
+    fill(s)
+  drv.prime(ring[0])
+  for s in range(nsteps):
+    withdraw = s % 7 == 5            # announce s+2 now, then do NOT step it as announced: rewrite its buffer before its call
+    out, ex = drv.step(vals[s], ring[(s + 1) % 6], ring[(s + 2) % 6], return_exists=True)
+    torch.cuda.synchronize()
+    _dict_check(torch, tbl, content[s], out, ex, latest, ("ring", s))
+    for i, k in enumerate(content[s].cpu().numpy().tolist()):
+      latest[k] = 100000.0 * (s + 1) + i
+    fill(s + 3)
+    if withdraw:
+      # the input pipeline replaces batch s+2 (already scattered) — allowed only through a restart: flush, rewrite, prime
+      drv.flush()
+      fill(s + 1); fill(s + 2)
+      drv.prime(ring[(s + 1) % 6])
+  drv.flush()
+  ek, ev = t.export()
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
+  tbl.check_errors()
+
+
+def test_overlap_step_without_prime_raises(env):
+  torch, de = env
+  t = make_dense_table(torch, de, 60_000, 64, np.arange(1, 40_000, dtype=np.int64), "ovl_noprime")
+  drv = de.OverlapAssignStep(t)
+  with pytest.raises(RuntimeError, match="prime"):
+    drv.step(torch.zeros((4, 64), device="cuda"))
