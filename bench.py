@@ -1343,9 +1343,10 @@ def emit(res):
   """bench_detail.json (everything) next to bench.py — and under gpurun_out/ when that exists, so that it comes back from a GPU
   box — and the compact line as the LAST line on stdout (nothing long goes to stderr either: a driver may keep one merged tail)."""
   detail = None
-  for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+  dirs = [os.environ["TFRA_BENCH_DETAIL_DIR"]] if os.environ.get("TFRA_BENCH_DETAIL_DIR") else [ROOT, os.path.join(ROOT, "gpurun_out")]
+  for d in dirs:
     try:
-      if d != ROOT and not os.path.isdir(d):
+      if d == os.path.join(ROOT, "gpurun_out") and not os.path.isdir(d):
         continue
       with open(os.path.join(d, "bench_detail.json"), "w") as f:
         json.dump(res, f, indent=1)

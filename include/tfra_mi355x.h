@@ -386,13 +386,17 @@ int tfra_table_steps_overlap(tfra_step_driver_t* d, size_t count, const tfra_ove
  * returns the average duration of the step launch in microseconds (rest_kernel_us: a second launch no longer exists, ~0) */
 int tfra_step_driver_time_kernels(tfra_step_driver_t* d, size_t steps);
 int tfra_step_driver_kernel_times(tfra_step_driver_t* d, double* step_kernel_us, double* rest_kernel_us, size_t* steps);
-/* tuning builds (TFRA_STEP_VARIANT & 16): per-role time stamps of the last launches, see csrc/tfra_step_impl.h */
+/* tuning builds (TFRA_STEP_VARIANT & 16): per-role time stamps of the last launches, out[64][6][4], see csrc/tfra_step_impl.h */
 int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out);
 /* steps taken overlapped / one op after the other so far; whether a write-back is pending; device_counts[3] (optional,
  * synchronises the device) = {evictions the pass deferred because the next lookup wanted the victim, victims the remainder
  * pass noted, output rows it rewrote with the default row} */
 int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* overlapped, uint64_t* sequential, int* pending,
                            uint32_t* device_counts, uint32_t* why_sequential, uint64_t* plans_built);
+/* lookups whose positions had been sorted one launch ahead (the MAP role of csrc/tfra_step_impl.h: the next batch's positions probed
+ * in this batch's plan and packed by where their row comes from — needs ids_next): such a lookup reads no plan entry and, for the
+ * positions served from the rows being written, no table line */
+int tfra_step_driver_lookups_listed(const tfra_step_driver_t* d, uint64_t* out);
 /* plans_built[2] (optional): plans of a next batch built inside the step launch (from pairs scattered one launch earlier: ids
  * known TWO batches ahead) / built by a launch of their own in front of the step (ids known one batch ahead only, or not at all) */
 /* why_sequential (optional): why the last step that ran one op after the other did — 1 empty batch, 2 a buffer or the row

@@ -62,6 +62,16 @@ struct StepArgs {
   unsigned scat_n, scat_m2, scat_tiles, scat_blocks;
   const i64* scat_ids;
   SetEnt* scat_pairs; unsigned* scat_cnt; SetEnt* scat_ovf; unsigned* scat_ovf_cnt; unsigned* scat_ovf_cnt_next;   // (two overflow counters alternate: this scatter zeroes the next one's)
+  // MAP role: the positions of the NEXT batch, sorted by where their row will come from — probed in `nxt` (THIS batch's plan, the
+  // one the next lookup forwards from): entries {position, last position + 1 in this batch | 0, key}; per segment of 1024 positions
+  // the table entries from the front, the forwarded ones from the back.  find_list != nullptr: the list a MAP role made of THIS batch one launch ago
+  unsigned map_n, map_blocks;
+  const i64* map_ids;
+  uint4* map_out;
+  const uint4* find_list;
+  unsigned own_slice;          // plan slots per write-back block
+  int noack;                   // (tuning) lookup blocks do not wait for their stores
+  unsigned find_first;         // lookup blocks dispatched in FRONT of the write-back's (the list's table-bound chunks: the long chains start with the launch)
   unsigned own_blocks, find_blocks, tail_blocks;
   unsigned* sync;              // this launch's counters, one 128-byte line each: [0] write-back blocks done, [32 .. 32*8] lookup blocks done
                                // (8 shards), [32*9] tail blocks through their items; sync_next: the next launch's (two sets alternate).  [1] the
@@ -85,9 +95,14 @@ struct StepLds {
   unsigned cnt[256];           // scatter: pairs per window
   unsigned n;
 };
-constexpr unsigned OWN_SLICE = 288;   // plan slots per write-back block: ~25 keys at 22.7 K keys in 2^18 slots, 32 fit one round of the block's four
-                                      // waves.  (208 slots — no block ever needs a second round — makes 1261 blocks: they fill every wave slot of the
-                                      // chip before the first lookup block starts, and the step went from 31 to 35 us.)
+// Plan slots per write-back block (StepArgs::own_slice; TFRA_STEP_OWN_SLICE overrides it for tuning, <= 768).  Rounds 3-4 used 288
+// (~25 keys at 22.7 K keys in 2^18 slots: one round of the block's four waves; 911 blocks) — the write-back's blocks, dispatched in
+// front of the lookup's, then took every wave slot of the chip for the first 6 us of the launch.  With the lookup's blocks short
+// (MAP lists, below) the balance is elsewhere: 448 slots = 586 blocks of ~39 keys (two rounds) leave 300 slots to the lookup from
+// the first microsecond, and the write-back itself ENDS EARLIER (16 us instead of 19: fewer waves contend for the same lines).
+// Measured on the metric's configuration, one box: 288 -> 26.2 us per step, 384 -> 21.3, 448 -> 21.1, 512 -> 20.8 / 22.4 (two boxes),
+// 576 -> 24.1, 768 -> 29.2; configs[2]'s shape (78 K keys per batch): 192 -> 38.0, 288 -> 38.2, 512 -> 40.1.
+constexpr unsigned OWN_SLICE_DEFAULT = 448;
 
 // ---- SCATTER role: setplan_kernel's LDS phase, then plain stores ------------------------------------------------------
 // Equal ids of the tile meet in LDS (compare-and-swap on the key, max on position + 1); every distinct id then goes, with its
@@ -298,8 +313,161 @@ __device__ __forceinline__ void find_fwd_role(const StepArgs& a, unsigned blk) {
       store_wt16(a.out + (u64)min(base + (unsigned)(u * 4 + grp), last) * (u64)v.field_bytes + off, tmp[u]);
   }
 }
+// ---- MAP role (round 5): where will each position of the NEXT batch get its row from? -----------------------------------------
+// The lookup's chain was ids -> plan entry -> table lines -> rows -> stores, and 85 % of a Zipf batch's positions stop at the plan
+// entry (forwarded from the rows being written) — but a wave of 16 ids nearly always holds one that does not, so every wave went
+// the whole way.  The plan the next lookup forwards from (this batch's) is complete when this launch starts and the next ids are
+// announced: one launch AHEAD, off the lookup's chain, a block probes 1024 positions in it and writes them out as 16-byte entries
+// {position, last position + 1 | 0, key} into ITS segment of the list — positions that need the table packed from the front of
+// the segment, forwarded ones from its back: ranks by ballot and LDS, no atomic, no counter.  The next launch's lookup reads its
+// entries with its first (coalesced) trip; all but one wave per segment are of one kind, and a wave of forwarded positions goes
+// entry -> value rows -> stores: no hash, no plan probe, no table line.
+// (First form: ONE list, packed from both ends with two returned atomics per block — 31.0 -> 26.8 us per step on one box, its MAP
+// blocks 10 us long, most of it the atomics' round trip.)
+constexpr unsigned MAP_SEG = 1024;
+__device__ __forceinline__ void map_role(const StepArgs& a, unsigned tile, StepLds& L) {
+  const unsigned tid = threadIdx.x;
+  const int lane = tid & 63;
+  const unsigned wave = tid >> 6;
+  i64 id[4];
+  unsigned p1[4];
+  bool valid[4];
+  const unsigned wm = set_wmask(a.nxt.m2);
+  unsigned home[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned g = tile * MAP_SEG + (unsigned)r * 256u + tid;
+    valid[r] = g < a.map_n;
+    id[r] = a.map_ids[valid[r] ? g : a.map_n - 1];
+  }
+  uint4 e[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    home[r] = set_home(a.nxt, id[r], fmix64((u64)id[r]));
+    e[r] = *reinterpret_cast<const uint4*>(a.nxt.ent + home[r]);
+  }
+  keep_live(e[0], e[1], e[2], e[3]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const i64 ek = (i64)(((u64)e[r].y << 32) | e[r].x);
+    if (is_reserved_key(id[r])) p1[r] = ek != EMPTY_KEY ? e[r].z : 0u;
+    else if (ek == id[r]) p1[r] = e[r].z;
+    else if (ek == EMPTY_KEY) p1[r] = 0u;
+    else {   // (rare: the plan's table is < 10 % full) further down the chain, inside the window
+      p1[r] = 0u;
+      for (unsigned t = 1; t <= wm; ++t) {
+        const SetEnt* q = a.nxt.ent + set_at(home[r], t, wm);
+        const i64 k = q->key;
+        if (k == id[r]) { p1[r] = q->pos1; break; }
+        if (k == EMPTY_KEY) break;
+      }
+    }
+  }
+  // ranks inside the segment: per round and wave by ballot, across the waves by LDS
+  unsigned rank[4], nf_w = 0, nt_w = 0;
+  const u64 below = (1ULL << lane) - 1ULL;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const u64 mf = __ballot(valid[r] && p1[r] != 0), mt = __ballot(valid[r] && p1[r] == 0);
+    rank[r] = p1[r] ? nf_w + (unsigned)__popcll(mf & below) : nt_w + (unsigned)__popcll(mt & below);
+    nf_w += (unsigned)__popcll(mf); nt_w += (unsigned)__popcll(mt);
+  }
+  if (lane == 0) { L.cnt[wave] = nf_w; L.cnt[4 + wave] = nt_w; }
+  __syncthreads();
+  unsigned bf = 0, bt = 0;
+  for (unsigned w = 0; w < wave; ++w) { bf += L.cnt[w]; bt += L.cnt[4 + w]; }
+  const unsigned seg0 = tile * MAP_SEG, m = min(MAP_SEG, a.map_n - seg0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (!valid[r]) continue;
+    const unsigned g = seg0 + (unsigned)r * 256u + tid;
+    const unsigned at = p1[r] ? seg0 + m - 1u - (bf + rank[r]) : seg0 + bt + rank[r];
+    a.map_out[at] = make_uint4(g, p1[r], (unsigned)(u64)id[r], (unsigned)((u64)id[r] >> 32));
+  }
+}
+
+// ---- FIND role from a MAP list: T tiles of 16 entries per wave --------------------------------------------------------------
+// Block b takes chunk b / nseg of segment b % nseg (chunk-major: the FRONT chunks of every segment — the table-bound positions, the
+// long chains — are the first blocks of the role; the all-forwarded chunks fill in behind them).  A wave takes T consecutive tiles of
+// its chunk, the next tile's entries loaded before the current tile's rows are stored.
+template <int U, int T>
+__device__ __forceinline__ void find_list_role(const StepArgs& a, unsigned blk) {
+  constexpr int KW = 4 * U;
+  constexpr unsigned CH = 64u * (unsigned)T;   // entries per block
+  const TableView& v = a.own.v;
+  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48, grp = lane >> 4;
+  const unsigned nseg = (a.n + MAP_SEG - 1) / MAP_SEG;
+  const unsigned sg = blk % nseg, ch = blk / nseg;
+  const unsigned base0 = sg * MAP_SEG + ch * CH + (threadIdx.x >> 6) * (unsigned)(KW * T);
+  if (base0 >= a.n) return;
+  const unsigned last = a.n - 1;
+  uint4 ent = a.find_list[min(base0 + (unsigned)(lane & (KW - 1)), last)];
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    const unsigned base = base0 + (unsigned)(t * KW);
+    if (base >= a.n) break;
+    const uint4 cur = ent;
+    if (t + 1 < T) ent = a.find_list[min(base + (unsigned)KW + (unsigned)(lane & (KW - 1)), last)];
+    const bool all_fwd = __ballot(cur.y == 0) == 0ULL;
+    unsigned pos[U], fwd_pos[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = u * 4 + grp;
+      pos[u] = (unsigned)__shfl((int)cur.x, j);
+      fwd_pos[u] = (unsigned)__shfl((int)cur.y, j);
+    }
+    const unsigned char* src[U];
+    if (all_fwd) {   // (wave-uniform) every row of this tile is one of the rows being written
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        src[u] = a.own.vals + (u64)(fwd_pos[u] - 1u) * (u64)v.field_bytes;
+        if (a.exists && sub == 0) __hip_atomic_store(a.exists + pos[u], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      const i64 kreg = (i64)(((u64)cur.w << 32) | cur.z);
+      u64 hreg;
+      const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
+      const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
+      i64 key[U], k0[U], k1[U];
+      unsigned b0[U], b1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = u * 4 + grp;
+        key[u] = shfl_i64(kreg, j);
+        b0[u] = (unsigned)__shfl((int)b0reg, j);
+        b1[u] = (unsigned)__shfl((int)b1reg, j);
+      }
+      const i64* hot = reinterpret_cast<const i64*>(a.fwd.ent);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        k0[u] = (fwd_pos[u] ? hot : key_line(v, b0[u]))[sub];
+        k1[u] = (fwd_pos[u] ? hot : key_line(v, b1[u]))[sub];
+      }
+      keep_live_n<U>(k0);
+      keep_live_n<U>(k1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned fw = fwd_pos[u];
+        i64 word = 0;
+        if (!fw) word = probe_find_word(v, key[u], b0[u], b1[u], k0[u], sub, gshift, &k1[u]);
+        if (a.exists && sub == 0) __hip_atomic_store(a.exists + pos[u], (uint8_t)(fw != 0 || word >= 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        src[u] = fw ? a.own.vals + (u64)(fw - 1u) * (u64)v.field_bytes
+                    : (word >= 0 ? word_row_ptr(v, (u64)word) : a.defaults + (a.full ? (u64)pos[u] * (u64)v.field_bytes : 0));
+      }
+    }
+    for (unsigned off = sub * 16; off < v.field_bytes; off += 256) {
+      uint4 tmp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const uint4*>(src[u] + off);
+      keep_live_n<U>(tmp);
+#pragma unroll
+      for (int u = 0; u < U; ++u) store_wt16(a.out + (u64)pos[u] * (u64)v.field_bytes + off, tmp[u]);
+    }
+  }
+}
 // a lookup block is done: its output rows are in memory (write-through, acknowledged).  Only the tail's rare corrections wait for this.
 __device__ __forceinline__ void find_arrive(const StepArgs& a) {
+  if (a.noack) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && a.tail_blocks) __hip_atomic_fetch_add(a.sync + 32 * (1 + (blockIdx.x & 7u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -307,7 +475,7 @@ __device__ __forceinline__ void find_arrive(const StepArgs& a) {
 
 // ---- OWN role: the ownership pass over the previous batch's plan, read straight from its TABLE ---------------------------
 // The plan keeps no dense list of its keys any more (that list was a returned atomic per tile and a dependent round trip of
-// the builder): the block takes a slice of OWN_SLICE slots of the plan's table (one 16-byte load per thread and a few more),
+// the builder): the block takes a slice of own_slice slots of the plan's table (one 16-byte load per thread and a few more),
 // compacts the occupied ones in LDS — key, last position, slot (the key's flag byte) — and its four waves take them 4 U at a
 // time through own_batch16, victims checked against this batch's plan.
 template <bool SIMPLE, int U>
@@ -315,20 +483,20 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   const OwnArgs& o = a.own;
   const unsigned tid = threadIdx.x;
   const int lane = tid & 63;
-  const unsigned lo = blk * OWN_SLICE, total_slots = a.fwd.m2 + 2;
+  const unsigned lo = blk * a.own_slice, total_slots = a.fwd.m2 + 2;
   if (tid == 0) L.n = 0;
-  uint4 e[2];
-  bool have[2];
+  uint4 e[3];
+  bool have[3];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < 3; ++r) {
     const unsigned off = tid + (unsigned)r * 256u;
-    have[r] = off < OWN_SLICE && lo + off < total_slots;
+    have[r] = off < a.own_slice && lo + off < total_slots;
     e[r] = *reinterpret_cast<const uint4*>(a.fwd.ent + (have[r] ? lo + off : lo));
   }
   if (blk == 0 && tid == 0 && a.progress) __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < 3; ++r) {
     const unsigned slot = lo + tid + (unsigned)r * 256u;
     const i64 k = (i64)(((u64)e[r].y << 32) | e[r].x);
     if (have[r] && k != EMPTY_KEY) {
@@ -380,17 +548,21 @@ __device__ __forceinline__ void role_stamp(const StepArgs& a, u64 t0) {
 // 18 us into the launch: its 32 polling blocks (one lane each, s_sleep between polls) slow the write-back they wait for from 19
 // to 34 us — the step went from 33 to 45 us.  Behind the lookup's blocks the tail starts when the write-back is (nearly) done
 // and hardly ever polls; (c) the write-back's blocks in front of the builders': no change.
-__host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned O, unsigned F, unsigned T,
-                                                  unsigned* idx) {
+__host__ __device__ __forceinline__ int step_role(unsigned b, unsigned build_blocks, unsigned scat_blocks, unsigned map_blocks, unsigned F1, unsigned O,
+                                                  unsigned F, unsigned T, unsigned* idx) {
   (void)T;
   if (b < build_blocks) { *idx = b; return 0; }
   b -= build_blocks;
   if (b < scat_blocks) { *idx = b; return 1; }
   b -= scat_blocks;
+  if (b < map_blocks) { *idx = b; return 5; }   // (MAP: numbered behind the roles the tuning scripts know)
+  b -= map_blocks;
+  if (b < F1) { *idx = b; return 3; }            // the lookup's first blocks in front of the write-back's
+  b -= F1;
   if (b < O) { *idx = b; return 2; }
   b -= O;
-  if (b < F) { *idx = b; return 3; }
-  *idx = b - F;
+  if (b < F - F1) { *idx = F1 + b; return 3; }
+  *idx = b - (F - F1);
   return 4;
 }
 __device__ __forceinline__ void tail_role(const StepArgs& a, unsigned blk, StepLds& L);
@@ -404,23 +576,24 @@ __device__ __forceinline__ void step_body(const StepArgs& a) {
   __shared__ StepLds L;
   const u64 t0 = TIMING ? (u64)wall_clock64() : 0;
   unsigned idx;
-  const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.own_blocks, a.find_blocks, a.tail_blocks, &idx);
+  const int role = step_role(blockIdx.x, a.build_blocks, a.scat_blocks, a.map_blocks, a.find_first, a.own_blocks, a.find_blocks, a.tail_blocks, &idx);
   if (role == 0) { if (!(a.ablate & 1)) build_role(a, idx, L); }
   else if (role == 1) { if (!(a.ablate & 1)) scatter_role(a, idx, L); }
+  else if (role == 5) { if (!(a.ablate & 1)) map_role(a, idx, L); }
   else if (role == 2) { if (!(a.ablate & 2)) own_role<SIMPLE, U>(a, idx, L); }
-  else if (role == 3) { if (!(a.ablate & 4)) find_fwd_role<4>(a, idx); find_arrive(a); }
+  else if (role == 3) { if (!(a.ablate & 4)) { if (a.find_list) find_list_role<4, 1>(a, idx); else find_fwd_role<4>(a, idx); } find_arrive(a); }
   else { if (!(a.ablate & (2 | 8))) tail_role(a, idx, L); }
   if (TIMING) role_stamp(a, t0);
 }
 // Instantiations (the budgets are attributes, not template arguments): 256-thread blocks are admitted per CU up to
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) — ~106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
-#define TFRA_STEP_KERNEL(NAME, UU, TIMING, W)                                                                            \
+#define TFRA_STEP_KERNEL(NAME, UU, TIMING, W)                                                                        \
   __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(104), amdgpu_waves_per_eu(W, W))) void NAME(const StepArgs a) { step_body<true, UU, TIMING, W>(a); }
 TFRA_STEP_KERNEL(step_k_u2, 2, false, 5)
 TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 5)
-TFRA_STEP_KERNEL(step_k_u1, 1, false, 5)       // (tuning) 4 keys per wave in the write-back
-TFRA_STEP_KERNEL(step_k_u2_w4, 2, false, 4)    // (tuning) no spills, 4 blocks per CU
-TFRA_STEP_KERNEL(step_k_u2_w6, 2, false, 6)    // (tuning) 6 blocks per CU
+TFRA_STEP_KERNEL(step_k_u1, 1, false, 5)        // (tuning) 4 keys per wave in the write-back
+TFRA_STEP_KERNEL(step_k_u2_w4, 2, false, 4)     // (tuning) no spills, 4 blocks per CU
+TFRA_STEP_KERNEL(step_k_u2_w6, 2, false, 6)     // (tuning) 6 blocks per CU
 #undef TFRA_STEP_KERNEL
 
 // ---- TAIL role: the remainder of a step INSIDE its launch ------------------------------------------------------------------
@@ -597,7 +770,20 @@ struct tfra_step_driver {
   unsigned* progress = nullptr;            // pinned: [0] step
   unsigned* stat = nullptr;                // device: StepArgs::stat
   u64* tbuf = nullptr;                     // device: StepArgs::tbuf (TFRA_STEP_VARIANT & 16)
-  unsigned tinfo[64][5] = {};              // per launch slot: build, scatter, own, lookup blocks, grid (the rest: tail)
+  unsigned tinfo[64][7] = {};              // per launch slot: build, scatter, own, lookup blocks, grid (the rest: tail), map blocks, lookup blocks in front of the write-back
+  int find_first = 0;                      // TFRA_STEP_FIND_FIRST (tuning): lookup blocks in front of the write-back's
+  unsigned own_slice = OWN_SLICE_DEFAULT;  // TFRA_STEP_OWN_SLICE (tuning): plan slots per write-back block (<= 768)
+  int noack = 0;                           // TFRA_STEP_NOACK (tuning, results unsafe when the tail corrects rows): lookup blocks leave without waiting for their stores
+  // MAP lists (round 5): two buffers of up to MAX_IDS 16-byte entries alternate — one is read by this launch's lookup, the other filled for the next
+  unsigned char* mapbuf = nullptr;         // device: 2 x cap entries
+  size_t map_cap = 0;
+  unsigned map_slot = 0;                   // the list filled last
+  bool map_valid = false;                  // ... and what it holds: the positions of (map_ids, map_n) probed in map_plan's current table
+  const int64_t* map_ids = nullptr;
+  size_t map_n = 0;
+  const tfra_sparse_plan* map_plan = nullptr;
+  unsigned map_gen = 0;                    // (the plan's build generation at that time)
+  unsigned long long n_find_listed = 0;    // lookups served from a MAP list
   unsigned last_tail_step = ~0u;           // step number of the last launch that had a tail (it zeroes the next launch's counters)
   unsigned char* patch = nullptr;          // device: two victim counters (one 128-B line each) + two lists of PATCH_GCAP keys + two sets of 10 sync counters (tail_role)
   unsigned step_no = 0;
@@ -633,6 +819,9 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   d->variant = ev ? std::atoi(ev) : 0;
   if (const char* ab = std::getenv("TFRA_STEP_ABLATE")) d->ablate = std::atoi(ab);
   if (const char* ab = std::getenv("TFRA_STEP_ABLATE_AFTER")) d->ablate_after = (unsigned)std::atoi(ab);
+  if (const char* os_ = std::getenv("TFRA_STEP_OWN_SLICE")) d->own_slice = std::min(768u, std::max(64u, (unsigned)std::atoi(os_)));
+  if (const char* na = std::getenv("TFRA_STEP_NOACK")) d->noack = std::atoi(na);
+  if (const char* ff = std::getenv("TFRA_STEP_FIND_FIRST")) d->find_first = std::atoi(ff);
   if (d->variant & 16) {
     const size_t bytes = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 16;
     if (hipMalloc((void**)&d->tbuf, bytes) != hipSuccess || hipMemset(d->tbuf, 0, bytes) != hipSuccess) { d->tbuf = nullptr; tfra_step_driver_destroy(d); return set_error(TFRA_ERR_OOM, "step_driver_create: hipMalloc"); }
@@ -650,6 +839,7 @@ extern "C" int tfra_step_driver_destroy(tfra_step_driver_t* d) {
   if (d->stat) (void)hipFree(d->stat);
   if (d->tbuf) (void)hipFree(d->tbuf);
   if (d->patch) (void)hipFree(d->patch);
+  if (d->mapbuf) (void)hipFree(d->mapbuf);
   for (hipEvent_t e : d->kev) (void)hipEventDestroy(e);
   if (d->progress) (void)hipHostFree(d->progress);
   delete d;
@@ -672,9 +862,15 @@ extern "C" int tfra_step_driver_stats(const tfra_step_driver_t* d, uint64_t* ove
   return TFRA_OK;
 }
 
+extern "C" int tfra_step_driver_lookups_listed(const tfra_step_driver_t* d, uint64_t* out) {
+  if (!d || !out) return set_error(TFRA_ERR_INVALID, "step_driver_lookups_listed: null argument");
+  *out = d->n_find_listed;
+  return TFRA_OK;
+}
+
 // tuning: the block time stamps of the last <= 64 launches made with TFRA_STEP_VARIANT & 16, reduced per role —
-// out[64][5][4] = {earliest block start, latest block end, median block duration, 95th percentile of the block durations} on the
-// device clock (100 MHz) per launch slot (step % 64) and role (build, scatter, write-back, lookup, tail), ~0 / 0 where nothing ran;
+// out[64][6][4] = {earliest block start, latest block end, median block duration, 95th percentile of the block durations} on the
+// device clock (100 MHz) per launch slot (step % 64) and role (build, scatter, write-back, lookup, tail, map), ~0 / 0 where nothing ran;
 // synchronises the device and re-arms the stamps.
 extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   if (!d) return set_error(TFRA_ERR_INVALID, "step_driver_timing: null driver");
@@ -689,15 +885,16 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
   for (unsigned sl = 0; sl < TIMING_SLOTS; ++sl) {
     const unsigned* ti = d->tinfo[sl];
     const unsigned grid = std::min(ti[4], TIMING_BLOCKS);
-    std::vector<uint64_t> dur[5];
-    for (int r = 0; r < 5; ++r) { out[(sl * 5 + r) * 4] = ~0ULL; out[(sl * 5 + r) * 4 + 1] = 0; out[(sl * 5 + r) * 4 + 2] = 0; out[(sl * 5 + r) * 4 + 3] = 0; }
+    constexpr int NR = 6;
+    auto role_of = [&](unsigned b) { unsigned idx; return step_role(b, ti[0], ti[1], ti[5], ti[6], ti[2], ti[3], ti[4] - ti[0] - ti[1] - ti[5] - ti[2] - ti[3], &idx); };
+    std::vector<uint64_t> dur[NR];
+    for (int r = 0; r < NR; ++r) { out[(sl * NR + r) * 4] = ~0ULL; out[(sl * NR + r) * 4 + 1] = 0; out[(sl * NR + r) * 4 + 2] = 0; out[(sl * NR + r) * 4 + 3] = 0; }
     for (unsigned b = 0; b < grid; ++b) {
       const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
       if (!t1) continue;
-      unsigned idx;
-      const int r = step_role(b, ti[0], ti[1], ti[2], ti[3], ti[4] - ti[0] - ti[1] - ti[2] - ti[3], &idx);
-      out[(sl * 5 + r) * 4] = std::min(out[(sl * 5 + r) * 4], t0);
-      out[(sl * 5 + r) * 4 + 1] = std::max(out[(sl * 5 + r) * 4 + 1], t1);
+      const int r = role_of(b);
+      out[(sl * NR + r) * 4] = std::min(out[(sl * NR + r) * 4], t0);
+      out[(sl * NR + r) * 4 + 1] = std::max(out[(sl * NR + r) * 4 + 1], t1);
       dur[r].push_back(t1 - t0);
     }
     if (std::getenv("TFRA_STEP_OCCUPANCY") && sl == 5 && grid) {   // (tuning) resident blocks per role, every microsecond of one launch
@@ -707,21 +904,20 @@ extern "C" int tfra_step_driver_timing(tfra_step_driver_t* d, uint64_t* out) {
         if (t1) { tmin = std::min(tmin, t0); tmax = std::max(tmax, t1); }
       }
       for (uint64_t t = tmin; t < tmax; t += 100) {   // (the clock ticks at 100 MHz)
-        unsigned n[5] = {0, 0, 0, 0, 0};
+        unsigned n[NR] = {0, 0, 0, 0, 0, 0};
         for (unsigned b = 0; b < grid; ++b) {
           const uint64_t t0 = h[((size_t)sl * TIMING_BLOCKS + b) * 2], t1 = h[((size_t)sl * TIMING_BLOCKS + b) * 2 + 1];
-          unsigned idx;
-          if (t1 && t0 <= t && t < t1) n[step_role(b, ti[0], ti[1], ti[2], ti[3], ti[4] - ti[0] - ti[1] - ti[2] - ti[3], &idx)] += 1;
+          if (t1 && t0 <= t && t < t1) n[role_of(b)] += 1;
         }
-        std::fprintf(stderr, "t %2llu us: build %4u scatter %4u write-back %4u lookup %4u tail %3u  = %4u blocks\n", (unsigned long long)((t - tmin) / 100), n[0], n[1],
-                     n[2], n[3], n[4], n[0] + n[1] + n[2] + n[3] + n[4]);
+        std::fprintf(stderr, "t %2llu us: build %4u scatter %4u map %4u write-back %4u lookup %4u tail %3u  = %4u blocks\n", (unsigned long long)((t - tmin) / 100), n[0], n[1],
+                     n[5], n[2], n[3], n[4], n[0] + n[1] + n[2] + n[3] + n[4] + n[5]);
       }
     }
-    for (int r = 0; r < 5; ++r) {
+    for (int r = 0; r < NR; ++r) {
       if (dur[r].empty()) continue;
       std::sort(dur[r].begin(), dur[r].end());
-      out[(sl * 5 + r) * 4 + 2] = dur[r][dur[r].size() / 2];
-      out[(sl * 5 + r) * 4 + 3] = dur[r][dur[r].size() * 95 / 100];
+      out[(sl * NR + r) * 4 + 2] = dur[r][dur[r].size() / 2];
+      out[(sl * NR + r) * 4 + 3] = dur[r][dur[r].size() * 95 / 100];
     }
     d->tinfo[sl][4] = 0;
   }
@@ -800,6 +996,9 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
   }
   if (!n) plan_cur->n = 0;
   d->ahead = false;
+  // a MAP list is good for exactly one lookup: these ids, forwarded from that plan as it was built then
+  const bool list_ok = d->map_valid && n && d->map_ids == ids && d->map_n == n && plan_prev && d->map_plan == plan_prev && d->map_gen == plan_prev->gen;
+  d->map_valid = false;
   // Announced batches are recognised by (address, length).  Whatever this call does not consume is disarmed HERE, on every path: pairs
   // scattered for a batch that is not announced again (no ids_next, the sequential path, a plan launch in front) must not meet a
   // later batch that happens to live at the same address.
@@ -845,7 +1044,8 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.own = L.a;
       a.ctr = L.ctr; a.own_gen = L.og;
       a.fwd = probe_of(plan_prev);
-      a.own_blocks = (a.fwd.m2 + 2 + OWN_SLICE - 1) / OWN_SLICE;
+      a.own_slice = d->own_slice;
+      a.own_blocks = (a.fwd.m2 + 2 + a.own_slice - 1) / a.own_slice;
     } else {
       a.own.v = t->view_of(t->cur);
       a.own_blocks = 0;
@@ -863,7 +1063,28 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.patch_count = a.sync + 32 * 9 + 1; a.patch_count_next = a.sync_next + 32 * 9 + 1;   // (read with the tail's arrivals as one 8-byte word)
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
-    a.ablate = (d->ablate && d->step_no >= d->ablate_after) ? d->ablate : 0;
+    a.noack = d->noack;
+    if (list_ok) {
+      a.find_list = reinterpret_cast<const uint4*>(d->mapbuf + (size_t)d->map_slot * d->map_cap * 16);
+      d->n_find_listed += 1;
+      a.find_blocks = (unsigned)((n + MAP_SEG - 1) / MAP_SEG) * (MAP_SEG / 64u);   // chunk-major over whole segments
+      a.find_first = d->find_first > 0 ? std::min((unsigned)d->find_first, a.find_blocks) : 0u;
+    }
+    // the NEXT lookup's positions, probed in this batch's plan (complete before this launch): the MAP role
+    if (n && n_next && !(d->variant & 32)) {
+      if (d->map_cap < std::max(n_next, (size_t)4096)) {
+        if (d->mapbuf) { if (hipDeviceSynchronize() != hipSuccess || hipFree(d->mapbuf) != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: free"); d->mapbuf = nullptr; }
+        if (a.find_list) { a.find_list = nullptr; a.find_blocks = (unsigned)((n + 63) / 64); a.find_first = 0; }   // (it lived in the buffer just freed; n <= the old capacity < n_next)
+        size_t cap = 4096;
+        while (cap < n_next) cap <<= 1;
+        if (hipMalloc((void**)&d->mapbuf, 2 * cap * 16) != hipSuccess) { d->mapbuf = nullptr; d->map_cap = 0; return set_error(TFRA_ERR_OOM, "step_overlap: hipMalloc"); }
+        d->map_cap = cap;
+      }
+      const unsigned ms = a.find_list ? (d->map_slot ^ 1u) : 0u;
+      a.map_n = (unsigned)n_next; a.map_ids = (const i64*)ids_next; a.map_blocks = (unsigned)((n_next + MAP_SEG - 1) / MAP_SEG);
+      a.map_out = reinterpret_cast<uint4*>(d->mapbuf + (size_t)ms * d->map_cap * 16);
+      d->map_slot = ms; d->map_valid = true; d->map_ids = ids_next; d->map_n = n_next; d->map_plan = plan_cur; d->map_gen = plan_cur->gen;
+    }
     // the next batch's plan: its pairs were scattered by the previous call's launch -> this launch builds the table; else a launch of its own, in front
     if (n_next) {
       if (plan_next->scat_ids == ids_next && plan_next->scat_n == n_next && !(d->variant & 8)) {
@@ -901,8 +1122,8 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       // ONE launch: the lookup runs beside the write-back (forwarding, deferred evictions, corrections).  (Measured against it, on
       // the metric's configuration: the same roles as TWO launches one after the other — write-back + tail, then lookup + plan
       // builders, no forwarding — 52 us per step against 33: the write-back alone in its launch still takes 25 us.)
-      const unsigned grid = a.build_blocks + a.scat_blocks + a.own_blocks + a.find_blocks + a.tail_blocks;
-      if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; }
+      const unsigned grid = a.build_blocks + a.scat_blocks + a.map_blocks + a.own_blocks + a.find_blocks + a.tail_blocks;
+      if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; ti[5] = a.map_blocks; ti[6] = a.find_first; }
       launch_step(d->variant, grid, s, a);
       if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s);
     }

@@ -134,6 +134,7 @@ _SIGS = {
     "tfra_table_step_overlap_flush": [_P, _P, _P, _P],
     "tfra_table_steps_overlap": [_P, _SZ, _P, _P],
     "tfra_step_driver_timing": [_P, _P],
+    "tfra_step_driver_lookups_listed": [_P, ctypes.POINTER(ctypes.c_uint64)],
     "tfra_step_driver_time_kernels": [_P, _SZ],
     "tfra_step_driver_kernel_times": [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_SZ)],
     "tfra_step_driver_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(_I), _P, _P, _P],

@@ -777,9 +777,11 @@ class OverlapAssignStep:
     why = ctypes.c_uint32()
     pb = (ctypes.c_uint64 * 2)()
     _capi.call("tfra_step_driver_stats", self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), dc, ctypes.byref(why), pb)
+    ll = ctypes.c_uint64()
+    _capi.call("tfra_step_driver_lookups_listed", self._h, ctypes.byref(ll))
     return {"overlapped": a.value, "sequential": b.value, "pending": bool(c.value), "deferred_evictions": dc[0],
             "victims_noted": dc[1], "rows_corrected": dc[2], "why_sequential": why.value, "plans_built_in_launch": pb[0],
-            "plans_built_in_front": pb[1]}
+            "plans_built_in_front": pb[1], "lookups_listed": ll.value}
 
   def time_kernels(self, steps):
     """HIP events around the launch of each of the next `steps` overlapped steps (on their stream); read with kernel_times()."""
@@ -791,14 +793,14 @@ class OverlapAssignStep:
     return {"step_kernel_us": a.value, "rest_kernel_us": b.value, "steps": n.value}
 
   def timing(self):
-    """tuning (TFRA_STEP_VARIANT & 16): per launch and role — build, scatter, write-back, lookup, tail — (first block start, last
+    """tuning (TFRA_STEP_VARIANT & 16): per launch and role — build, scatter, write-back, lookup, tail, map — (first block start, last
     block end, median block duration, 95th percentile) in us, starts / ends since the launch's first block (None: the role did not run)"""
-    buf = (ctypes.c_uint64 * (64 * 5 * 4))()
+    buf = (ctypes.c_uint64 * (64 * 6 * 4))()
     _capi.call("tfra_step_driver_timing", self._h, buf)
     none = 2 ** 64 - 1
     out = []
     for k in range(64):
-      w = [tuple(buf[(k * 5 + r) * 4 + j] for j in range(4)) for r in range(5)]
+      w = [tuple(buf[(k * 6 + r) * 4 + j] for j in range(4)) for r in range(6)]
       starts = [x[0] for x in w if x[0] != none]
       if not starts:
         continue

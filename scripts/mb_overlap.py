@@ -26,6 +26,8 @@ def main():
   ap.add_argument("--fill-frac", type=float, default=1.0, help="pre-fill (and draw ids from) only this fraction of the ranks: below ~0.6 nothing is ever evicted, every id of a batch is resident")
   ap.add_argument("--ablate", default="0", help="comma list of TFRA_STEP_ABLATE masks (1 builders, 2 write-back + tail, 4 lookup return at once after 40 steps: timing only)")
   ap.add_argument("--one-ahead", action="store_true", help="D = 1: announce only the next batch (its plan is then built by a launch of its own)")
+  ap.add_argument("--find-tiles", default="288", help="comma list of TFRA_STEP_OWN_SLICE (plan slots per write-back block)")
+  ap.add_argument("--find-first", default="0", help="comma list of TFRA_STEP_FIND_FIRST (lookup blocks in front of the write-back's; -1: the driver's rule)")
   ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "mb_overlap.json"))
   args = ap.parse_args()
   import torch
@@ -91,9 +93,12 @@ def main():
   torch.cuda.synchronize()
   del ps
   depths = [int(x) for x in args.depth.split(",")]
-  for v, ab in [(int(x), int(y)) for x in args.variants.split(",") for y in args.ablate.split(",")]:
+  for v, ab, ft, ff in [(int(x), int(y), int(z), int(w)) for x in args.variants.split(",") for y in args.ablate.split(",")
+                        for z in args.find_tiles.split(",") for w in args.find_first.split(",")]:
     os.environ["TFRA_STEP_VARIANT"] = str(v)
     os.environ["TFRA_STEP_ABLATE"] = str(ab)
+    os.environ["TFRA_STEP_OWN_SLICE"] = str(ft)
+    os.environ["TFRA_STEP_FIND_FIRST"] = str(ff)
     for D in depths:
       drv = de.OverlapAssignStep(table)
       base = [0]
@@ -133,7 +138,7 @@ def main():
         K = K_save
         sp = [[y if y is not None else (0.0, 0.0, 0.0, 0.0) for y in x] for x in drv.timing()]
         tm = {"launches": len(sp), "role_spans_us_median (start, end since the launch's first block)":
-              {r: [float(np.median([x[i][j] for x in sp])) for j in range(4)] for i, r in enumerate(("build", "scatter", "write_back", "lookup", "tail"))} if sp else None,
+              {r: [float(np.median([x[i][j] for x in sp])) for j in range(4)] for i, r in enumerate(("build", "scatter", "write_back", "lookup", "tail", "map"))} if sp else None,
               "columns": "first block start, last block end, median block duration, p95 block duration"}
       us, hus, all_ = timed(fn)
       st = drv.stats()
@@ -145,7 +150,7 @@ def main():
       ok = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, ids[jlast], values)))
       if not ab:
         table._table.check_errors()
-      res["runs"].append({"driver": "step_overlap", "variant": v, "ablate": ab, "steps_per_host_call": D, "us_per_step": us, "host_us_per_step": hus,
+      res["runs"].append({"driver": "step_overlap", "variant": v, "ablate": ab, "own_slice": ft, "find_first": ff, "steps_per_host_call": D, "us_per_step": us, "host_us_per_step": hus,
                           "windows": all_, "stats": st, "last_batch_ok": ok, "timing": tm})
       print(res["runs"][-1], flush=True)
       del drv

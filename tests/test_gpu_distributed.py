@@ -143,7 +143,7 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   import json
   import subprocess
   import sys
-  env = dict(os.environ, TFRA_BENCH_BACKEND="gloo", TFRA_BENCH_ROUTE=route, HSA_ENABLE_IPC_MODE_LEGACY="0")
+  env = dict(os.environ, TFRA_BENCH_BACKEND="gloo", TFRA_BENCH_ROUTE=route, HSA_ENABLE_IPC_MODE_LEGACY="0", TFRA_BENCH_DETAIL_DIR=str(tmp_path))
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(29990 + (route == "native")), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
          "--c4-keys", "300000", "--batch", "8192", "--no-cpu-baseline"]
@@ -157,4 +157,6 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   assert "roofline" in d and d["unit"] == "pairs/s"
   # every N runs ONE per-GPU workload, BASELINE configs[3] (hash-sharded, per-GPU batch from the global Zipf, routed)
   assert d["config"]["workload"].startswith("BASELINE configs[3]") and d["config"]["route"] == route
-  assert d["config"]["timing"]["value"]["windows"] == 5 and d["config"]["timing"]["value"]["steps_per_window"] == 6
+  assert len(lines[0]) < 6000          # the driver keeps an ~8 KB tail of stdout: the line must fit whole
+  full = json.load(open(os.path.join(str(tmp_path), "bench_detail.json")))   # everything else: the detail file
+  assert full["config"]["timing"]["value"]["windows"] == 5 and full["config"]["timing"]["value"]["steps_per_window"] == 6

@@ -293,8 +293,8 @@ def test_overlap_plan_objects_see_regular_and_listless_builds_in_any_order(env, 
         nxt = batches[s + 1] if two else None
         nx2 = batches[s + 2] if two else None
       else:
-        nxt = batches[s + 1] if s % 2 == 0 else None
-        nx2 = batches[s + 2] if s % 4 == 0 else None
+        nxt = batches[s + 1] if s % 3 != 2 else None     # batches 3k+2 are scattered at step 3k and built at step 3k+1 (list-less),
+        nx2 = batches[s + 2] if s % 3 == 0 else None     # every other batch's plan is a launch of its own (regular)
       out, ex = drv.step(vals[s], nxt, nx2, return_exists=True)
       if nxt is None:
         drv.prime(batches[s + 1])
