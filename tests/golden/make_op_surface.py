@@ -80,5 +80,23 @@ def main():
   print(len(cops), "cuckoo ops;", len(out["gpu_kernels"]), "GPU kernels;", out["gpu_type_pairs"])
 
 
+def main_fused():
+  """The fused ops are this repository's own (no reference text to compare with): their surface is pinned as it is registered in
+  tf_ops/fused_ops_rocm.cc, so that a change of an input order / attr default shows up as a diff of the golden file."""
+  root = os.path.dirname(os.path.dirname(HERE))
+  text = open(os.path.join(root, "tf_ops", "fused_ops_rocm.cc")).read()
+  out = {"source": ["tf_ops/fused_ops_rocm.cc"], "ops": parse_register_ops(text), "gpu_kernels": parse_gpu_registrations_detailed(text),
+         "replaces": {
+             "TFRA>HkvHashTableEmbeddingLookup": "python/ops/dynamic_embedding_ops.py:99-117 (tf.unique + embedding_lookup + tf.gather)",
+             "TFRA>HkvHashTableApplySparse*": "python/ops/dynamic_embedding_optimizer.py:165-204 (_resource_apply_sparse_duplicate_indices + (1+S) finds / upserts), slots :870-958",
+             "TFRA>HkvHashTableLookupAssignStep": "core/kernels/hkv_hashtable_op_gpu.cu.cc:182-290 (Find + Insert in order)",
+             "TFRA>Route*": "python/ops/shadow_embedding_ops.py:397-447 (HvdAllToAllEmbedding's alltoall route)"}}
+  with open(os.path.join(HERE, "fused_op_surface.json"), "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)
+  print(len(out["ops"]), "fused ops;", len(out["gpu_kernels"]), "GPU kernels")
+
+
 if __name__ == "__main__":
-  main()
+  if os.path.isdir(REF):
+    main()
+  main_fused()

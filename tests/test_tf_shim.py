@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "tf_ops", "hkv_ops_rocm.cc")
 SHIM_CUCKOO = os.path.join(ROOT, "tf_ops", "cuckoo_ops_rocm.cc")
 SHIM_COMMON = os.path.join(ROOT, "tf_ops", "mi355x_table_ops.h")
+SHIM_FUSED = os.path.join(ROOT, "tf_ops", "fused_ops_rocm.cc")
+GOLDEN_FUSED = os.path.join(ROOT, "tests", "golden", "fused_op_surface.json")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "hkv_op_surface.json")
 GOLDEN_CUCKOO = os.path.join(ROOT, "tests", "golden", "cuckoo_op_surface.json")
 
@@ -74,7 +76,7 @@ def test_shim_binds_only_declared_abi_entry_points():
 @pytest.mark.skipif(shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"), reason="needs g++ and the ROCm headers")
 def test_shim_is_valid_cxx_against_the_tensorflow_api_it_uses():
   """-fsyntax-only against tf_ops/stub/ (declarations of the TensorFlow 2.16 API the shim names) + the real C ABI header."""
-  for src in (SHIM, SHIM_CUCKOO):
+  for src in (SHIM, SHIM_CUCKOO, SHIM_FUSED):
     cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "tf_ops", "stub"),
            "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", src]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -112,3 +114,51 @@ def test_cuckoo_golden_surface_is_what_the_reference_registers_now():
   text = open(os.path.join(mod.REF, "kernels", "cuckoo_hashtable_op_gpu.cu.cc")).read()
   assert ops == want["ops"] and mod.parse_gpu_registrations_detailed(text) == want["gpu_kernels"]
   assert mod.parse_cuckoo_gpu_types(text) == want["gpu_type_pairs"]
+
+
+def test_fused_shim_registers_the_fused_paths_as_ops_with_gpu_kernels():
+  """tf_ops/fused_ops_rocm.cc: what north_star names next to the table ops — the sparse embedding_lookup gather and the optimizer
+  scatter-update — plus the overlapped step and the multi-GPU route, each ONE registered op over the C ABI.  Surface pinned in
+  tests/golden/fused_op_surface.json (tests/golden/make_op_surface.py); every op has its DEVICE_GPU kernel; nothing collides with the
+  reference's ops."""
+  mod = _extractor()
+  text = open(SHIM_FUSED).read()
+  want = json.load(open(GOLDEN_FUSED))
+  got = mod.parse_register_ops(text)
+  assert got == want["ops"]
+  kernels = mod.parse_gpu_registrations_detailed(text)
+  assert kernels == want["gpu_kernels"] and set(kernels) == set(got)
+  names = set(got)
+  for o in ("Sgd", "Adam", "Adagrad", "Ftrl"):
+    assert "TFRA>HkvHashTableApplySparse" + o in names and "TFRA>RouteApply" + o in names
+  assert {"TFRA>HkvHashTableOfTensorsWithSlots", "TFRA>HkvHashTableEmbeddingLookup", "TFRA>HkvHashTableInsertN", "TFRA>HkvHashTableLookupAssignStep",
+          "TFRA>HkvHashTableLookupAssignFlush", "TFRA>RcclUniqueId", "TFRA>RouteCreate", "TFRA>RouteFeed", "TFRA>RouteLookup"} <= names
+  ref = set(json.load(open(GOLDEN))["ops"]) | set(json.load(open(GOLDEN_CUCKOO))["ops"])
+  assert not (names & ref)                                         # loaded next to the reference's ops: no name registered twice
+  # the creator with slots = the reference creator's attrs + the two new ones, so TFRA's Python wrapper passes the same kwargs
+  base = json.load(open(GOLDEN))["ops"]["TFRA>HkvHashTableOfTensors"]
+  slots = got["TFRA>HkvHashTableOfTensorsWithSlots"]
+  assert set(base["attrs"]) < set(slots["attrs"]) and slots["outputs"] == base["outputs"] and slots["stateful"]
+  assert sorted(set(slots["attrs"]) - set(base["attrs"])) == ["optimizer_slots: int >= 0 = 0", "slot_init: list(float) = []"]
+  # the lookup op returns everything embedding_lookup_unique needs without a host read: rows, unique ids, inverse index, count
+  assert got["TFRA>HkvHashTableEmbeddingLookup"]["outputs"] == ["values: value_dtype", "unique_ids: key_dtype", "idx: int32", "num_unique: int64"]
+  # hyper-parameters are host-memory scalar inputs (a schedule is a tensor), like TensorFlow's ResourceSparseApply* ops
+  assert got["TFRA>HkvHashTableApplySparseAdam"]["inputs"][4:] == ["lr: float", "beta1_power: float", "beta2_power: float", "beta1: float",
+                                                                   "beta2: float", "epsilon: float"]
+  for name in names:
+    if "ApplySparse" in name or "RouteApply" in name:
+      m = __import__("re").search(r'Name\("%s"\)((?:[\s\\]*\.\w+(?:<[^>]*>)?\([^()]*\))*)' % name.replace(">", ">"), text)
+      assert m and '.HostMemory("lr")' in m.group(1), name
+
+
+def test_fused_shim_binds_only_declared_abi_entry_points_and_reaches_the_fused_calls():
+  import re
+  hdr = open(os.path.join(ROOT, "include", "tfra_mi355x.h")).read()
+  declared = set(re.findall(r"\b(tfra_\w+)\s*\(", hdr))
+  used = set(re.findall(r"\b(tfra_[a-z_0-9]+)\(", open(SHIM_FUSED).read() + open(SHIM_COMMON).read()))
+  used -= {"tfra_mi355x"}
+  assert used <= declared, sorted(used - declared)
+  for fn in ("tfra_table_apply_sparse", "tfra_unique_unordered", "tfra_table_find_n", "tfra_gather_rows", "tfra_table_insert_or_assign_n",
+             "tfra_step_driver_create", "tfra_table_step_overlap", "tfra_table_step_overlap_flush", "tfra_workspace_create",
+             "tfra_rccl_unique_id", "tfra_rccl_transport_create", "tfra_route_create", "tfra_route_feed", "tfra_route_lookup", "tfra_route_apply"):
+    assert fn in used, fn

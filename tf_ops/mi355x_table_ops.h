@@ -116,14 +116,51 @@ class MI355XHashTable final : public lookup::LookupInterface {
     o.step_per_epoch = step_per_epoch;
     o.reserved_key_start_bit = reserved_bit;
     o.device = -1;
+    // `TFRA>HkvHashTableOfTensorsWithSlots` (fused_ops_rocm.cc): S optimizer slot vectors co-located with every row ([p|m|v]); the
+    // reference's creators do not have the attrs: a plain table
+    int64_t slots = 0;
+    if (GetNodeAttr(def, "optimizer_slots", &slots).ok() && slots > 0) {
+      OP_REQUIRES(ctx, slots <= 4, errors::InvalidArgument("optimizer_slots: at most 4"));
+      o.aux_fields = static_cast<int32_t>(slots);
+      std::vector<float> init;
+      if (GetNodeAttr(def, "slot_init", &init).ok())
+        for (size_t i = 0; i < init.size() && i < 4; ++i) o.aux_init[i] = init[i];
+    }
     AllocatorAttributes attr;
     alloc_user_.device = ctx->device()->GetAllocator(attr);
     tfra_allocator bridge = {&TfAllocator::Alloc, &TfAllocator::Free, &alloc_user_};
     OP_REQUIRES_OK(ctx, ToStatus(tfra_table_create(&o, &bridge, &table_)));
   }
-  ~MI355XHashTable() override { tfra_table_destroy(table_); }
+  ~MI355XHashTable() override {
+    if (step_.driver) tfra_step_driver_destroy(step_.driver);
+    if (ws_) tfra_workspace_destroy(ws_);
+    tfra_table_destroy(table_);
+  }
 
   size_t dim() const { return static_cast<size_t>(value_shape_.dim_size(0)); }
+  tfra_table_t* raw() const { return table_; }   // for the fused ops (fused_ops_rocm.cc)
+  // scratch of the front-end kernels (tfra_unique_unordered ...): one per table, ops of one table are stream-ordered
+  Status Workspace(tfra_workspace_t** out) {
+    mutex_lock l(aux_mu_);
+    if (!ws_) TF_RETURN_IF_ERROR(ToStatus(tfra_workspace_create(-1, &ws_)));
+    *out = ws_;
+    return OkStatus();
+  }
+  // the overlapped step (tfra_table_step_overlap): its driver, and the tensors of the batches in flight — held so that their
+  // buffers outlive the launches that read them
+  struct StepState {
+    mutex mu;
+    tfra_step_driver_t* driver = nullptr;
+    bool pending = false, has_next = false, has_next2 = false;
+    int64_t pending_n = 0;
+    Tensor cur_ids, keep_prev_ids, keep_prev_values, next, next2;
+  };
+  Status Step(StepState** out) {
+    mutex_lock l(aux_mu_);
+    if (!step_.driver) TF_RETURN_IF_ERROR(ToStatus(tfra_step_driver_create(table_, &step_.driver)));
+    *out = &step_;
+    return OkStatus();
+  }
 
   // ---- LookupInterface -------------------------------------------------------------------------------
   size_t size() const override {
@@ -234,6 +271,9 @@ class MI355XHashTable final : public lookup::LookupInterface {
   TensorShape value_shape_;
   TfAllocator alloc_user_{nullptr};
   tfra_table_t* table_ = nullptr;
+  mutex aux_mu_;
+  tfra_workspace_t* ws_ = nullptr;
+  StepState step_;
 };
 
 // =========================================== op kernels ===========================================

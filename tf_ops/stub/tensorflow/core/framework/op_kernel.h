@@ -37,7 +37,7 @@ template <class... A> Status ResourceExhausted(A...);
     if (!_s.ok()) return _s;                       \
   } while (0)
 
-enum DataType { DT_INVALID = 0, DT_FLOAT = 1, DT_INT32 = 3, DT_INT8 = 6, DT_STRING = 7, DT_INT64 = 9, DT_BOOL = 10,
+enum DataType { DT_INVALID = 0, DT_FLOAT = 1, DT_INT32 = 3, DT_UINT8 = 4, DT_INT8 = 6, DT_STRING = 7, DT_INT64 = 9, DT_BOOL = 10,
                 DT_BFLOAT16 = 14, DT_HALF = 19, DT_RESOURCE = 20, DT_UINT64 = 23 };
 using DataTypeVector = std::vector<DataType>;
 std::string DataTypeString(DataType);
