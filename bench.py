@@ -703,6 +703,21 @@ def run_bounded(args, torch, de, dev, cfg):
     _capi.check(lib.tfra_gather_rows(B, row_bytes, P(urows), P(ibuf), P(out_buf), st))
     _capi.check(lib.tfra_table_insert_or_assign(tbl._h, u, P(ubuf), P(values), None, 1, st))
 
+  def op_surface_fused(i):
+    # what the registered fused TF ops issue (tf_ops/fused_ops_rocm.cc): TFRA>HkvHashTableEmbeddingLookup = Find of all B ids + the
+    # unique ids / inverse index for the backward pass, TFRA>HkvHashTableInsertN = Insert of the unique keys, count on the device —
+    # no host read anywhere (every output has the upper-bound shape [B])
+    _capi.check(lib.tfra_table_find(*finds[i]))
+    _capi.check(lib.tfra_unique_unordered(*uniqs2[i]))
+    _capi.check(lib.tfra_table_insert_or_assign_n(tbl._h, B, cpin_p, P(ubuf), P(values), None, st))
+
+  for i in range(W):
+    op_surface_fused(i)
+  secs_opfu, med_opfu, _ = timed_windows(torch, None, 1, dev, K, op_surface_fused, first=W)
+  torch.cuda.synchronize()
+  u = int(cpin[0])
+  got, ex = table.lookup(ubuf[:u], return_exists=True)
+  verified["op_surface_fused_ops_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:u]))
   for i in range(W):
     op_surface(i)
   secs_ops, med_ops, _ = timed_windows(torch, None, 1, dev, K, op_surface, first=W)
@@ -856,6 +871,7 @@ def run_bounded(args, torch, de, dev, cfg):
                      "(new_key_ratio here: %.2f)" % new_ratio,
       "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
       "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
+      "value_op_surface_fused_ops": B * K / med_opfu, "ms_per_step_op_surface_fused_ops": med_opfu / K * 1e3,
       "value_op_surface_host_read_first": B * K / med_ops_sync, "ms_per_step_op_surface_host_read_first": med_ops_sync / K * 1e3,
       "value_op_surface_find_first": B * K / med_opf, "ms_per_step_op_surface_find_first": med_opf / K * 1e3,
       "value_accum": B * K / med_acc, "ms_per_step_accum": med_acc / K * 1e3,
@@ -881,7 +897,7 @@ def run_bounded(args, torch, de, dev, cfg):
           "host_enqueue_ms_per_step_look_ahead_driver": round(1e3 * host_pf / K, 4),
           "overlapped_step_stats": ovl_stats,
           "timing": {"value_overlapped_step": timing_note(secs, K), "value_overlapped_step_4_steps_per_host_call": timing_note(secs_d4, K), "value_look_ahead_driver": timing_note(secs_pf, K), "value_plain_call": timing_note(secs_plain, K),
-                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_find_first": timing_note(secs_opf, K), "value_op_surface_host_read_first": timing_note(secs_ops_sync, K),
+                     "value_op_surface": timing_note(secs_ops, K), "value_op_surface_fused_ops": timing_note(secs_opfu, K), "value_op_surface_find_first": timing_note(secs_opf, K), "value_op_surface_host_read_first": timing_note(secs_ops_sync, K),
                      "value_accum": timing_note(secs_acc, K), "value_op_surface_table_ops_only": timing_note(secs_tops, K)},
           "verified": verified,
           "drivers": {
@@ -901,6 +917,9 @@ def run_bounded(args, torch, de, dev, cfg):
                                   "rows) -> tfra_table_insert_or_assign_n (unique keys): Find and Insert read the count on the device and "
                                   "are enqueued BEFORE the one host read of it (tf.unique's output shape), which waits for the unique "
                                   "kernels only",
+              "value_op_surface_fused_ops": "the registered fused TF ops' call sequence (tf_ops/fused_ops_rocm.cc): tfra_table_find (B ids) + "
+                                            "tfra_unique_unordered (unique ids, inverse index, count on the device) = TFRA>HkvHashTableEmbeddingLookup, "
+                                            "tfra_table_insert_or_assign_n = TFRA>HkvHashTableInsertN; no host read",
               "value_op_surface_host_read_first": "the same ops with the host read in front of Find (tfra_table_find / "
                                                   "tfra_table_insert_or_assign called with the count): the calls of tf_ops/mi355x_table_ops.h",
               "value_op_surface_find_first": "round 3's sequence: tfra_table_find (B ids) -> tfra_unique (ordered) + one blocking host read "
@@ -1404,7 +1423,7 @@ def main():
       args._growth = measure_growth(torch, de, dev, 128, torch.float16, args.slots // 4)   # reported under secondary.c3
     res = run_bounded(args, torch, de, dev, cfg)
     if not args.no_secondary and args.config is None:
-      keep = ("metric", "value", "value_overlapped_step", "value_overlapped_step_4_steps_per_host_call", "value_look_ahead_driver", "driver", "driver_rule", "value_op_surface_host_read_first", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
+      keep = ("metric", "value", "value_overlapped_step", "value_overlapped_step_4_steps_per_host_call", "value_look_ahead_driver", "driver", "driver_rule", "value_op_surface_fused_ops", "value_op_surface_host_read_first", "value_plain_call", "value_op_surface", "value_op_surface_find_first", "value_accum",
               "value_op_surface_table_ops_only", "ms_per_step",
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}

@@ -1751,6 +1751,7 @@ struct tfra_sparse_plan {
   unsigned* seg_cnt = nullptr;     // [windows][tiles]
   SetEnt* ovf_pairs = nullptr;     // pairs that did not fit their segment (an adversarial batch): appended with an atomic
   unsigned* ovf_cnt = nullptr;
+  unsigned* ucnt = nullptr;        // [windows <= 256] distinct keys per window of the last list-less build (the step launch's BUILD role)
   unsigned seg_tiles = 0;          // tiles of the last scatter
   unsigned scat_use = 0;           // scatters into this object so far (its two overflow counters alternate)
   const int64_t* scat_ids = nullptr;   // the batch whose pairs the segments hold (nullptr: none)
@@ -1864,12 +1865,13 @@ static int setplan_prepare_listless(tfra_sparse_plan* pl, size_t n, hipStream_t 
   if (pl->seg_cap_ids < pl->set_cap) {
     if (pl->segbuf) { if (hipDeviceSynchronize() != hipSuccess || hipFree(pl->segbuf) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: free"); pl->segbuf = nullptr; }
     const size_t wins = pl->set_m2 / SET_WIN, tiles = (pl->set_cap + 1023) / 1024;
-    const size_t bytes = 256 + al(wins * tiles * SEG_CAP * sizeof(SetEnt)) + al(wins * tiles * 4) + al(pl->set_cap * sizeof(SetEnt));
+    const size_t bytes = 256 + 1024 + al(wins * tiles * SEG_CAP * sizeof(SetEnt)) + al(wins * tiles * 4) + al(pl->set_cap * sizeof(SetEnt));
     hipError_t e = hipMalloc(&pl->segbuf, bytes);
     if (e != hipSuccess) { pl->segbuf = nullptr; return set_error(e == hipErrorOutOfMemory ? TFRA_ERR_OOM : TFRA_ERR_HIP, "sparse_plan_build: hipMalloc"); }
     if (hipMemsetAsync(pl->segbuf, 0, bytes, s) != hipSuccess) return set_error(TFRA_ERR_HIP, "sparse_plan_build: memset");
     unsigned char* w = (unsigned char*)pl->segbuf;
     pl->ovf_cnt = (unsigned*)w; w += 256;
+    pl->ucnt = (unsigned*)w; w += 1024;
     pl->seg_pairs = (SetEnt*)w; w += al(wins * tiles * SEG_CAP * sizeof(SetEnt));
     pl->seg_cnt = (unsigned*)w; w += al(wins * tiles * 4);
     pl->ovf_pairs = (SetEnt*)w;

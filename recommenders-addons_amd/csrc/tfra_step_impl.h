@@ -58,6 +58,10 @@ struct StepArgs {
   SetEnt* build_ent;           // the table (every slot is written)
   unsigned build_m2, build_tiles, build_blocks;
   const SetEnt* build_pairs; const unsigned* build_cnt; const SetEnt* build_ovf; const unsigned* build_ovf_cnt;
+  unsigned* build_ucnt;        // [windows] distinct keys per window of the table being built (plain stores: no atomic on a hot word —
+                               // 586 fire-and-forget adds from the write-back's blocks to ONE counter cost the launch 4 us)
+  const unsigned* own_ucnt;    // the same array of the plan being written back (nullptr: not built by a step launch); block 0 sums it
+  unsigned own_ucnt_n;         // into progress[1] (pinned): the host sizes later launches' slices from it
   // SCATTER role: the batch after next, one tile of 1024 ids per block -> per (window, tile) segments
   unsigned scat_n, scat_m2, scat_tiles, scat_blocks;
   const i64* scat_ids;
@@ -70,7 +74,6 @@ struct StepArgs {
   uint4* map_out;
   const uint4* find_list;
   unsigned own_slice;          // plan slots per write-back block
-  int noack;                   // (tuning) lookup blocks do not wait for their stores
   unsigned find_first;         // lookup blocks dispatched in FRONT of the write-back's (the list's table-bound chunks: the long chains start with the launch)
   unsigned own_blocks, find_blocks, tail_blocks;
   unsigned* sync;              // this launch's counters, one 128-byte line each: [0] write-back blocks done, [32 .. 32*8] lookup blocks done
@@ -101,7 +104,10 @@ struct StepLds {
 // (MAP lists, below) the balance is elsewhere: 448 slots = 586 blocks of ~39 keys (two rounds) leave 300 slots to the lookup from
 // the first microsecond, and the write-back itself ENDS EARLIER (16 us instead of 19: fewer waves contend for the same lines).
 // Measured on the metric's configuration, one box: 288 -> 26.2 us per step, 384 -> 21.3, 448 -> 21.1, 512 -> 20.8 / 22.4 (two boxes),
-// 576 -> 24.1, 768 -> 29.2; configs[2]'s shape (78 K keys per batch): 192 -> 38.0, 288 -> 38.2, 512 -> 40.1.
+// 576 -> 24.1, 768 -> 29.2.  The optimum follows the keys per block, not the slots: the driver sizes the slice for ~40 keys from the
+// distinct-key count of an earlier batch (the tail leaves it in pinned memory), between 96 and 512 slots — a batch of all-distinct
+// ids (m2 = 2 n: every second slot taken) gets 96-slot slices instead of 224 keys = seven rounds per block; configs[2]'s 78 K keys
+// per batch 128 (measured there, per-step with 65 K evictions: 96 -> 72 us, 160 -> 76, 288 -> 66, 448 -> 88).
 constexpr unsigned OWN_SLICE_DEFAULT = 448;
 
 // ---- SCATTER role: setplan_kernel's LDS phase, then plain stores ------------------------------------------------------
@@ -172,6 +178,7 @@ __device__ __forceinline__ void scatter_role(const StepArgs& a, unsigned tile, S
 __device__ __forceinline__ void build_role(const StepArgs& a, unsigned win, StepLds& L) {
   const unsigned tid = threadIdx.x;
   for (unsigned i = tid; i < SET_WIN + 2; i += 256) { if (i < SET_WIN) L.key[i] = EMPTY_KEY; L.pos[i] = 0; }
+  if (tid == 0) L.n = 0;
   const unsigned c = tid < a.build_tiles ? a.build_cnt[(size_t)win * a.build_tiles + tid] : 0u;
   const unsigned novf = *a.build_ovf_cnt;
   __syncthreads();
@@ -206,9 +213,18 @@ __device__ __forceinline__ void build_role(const StepArgs& a, unsigned win, Step
   __syncthreads();
   SetEnt* out = a.build_ent + (size_t)win * SET_WIN;
   const unsigned wslots = a.build_m2 < SET_WIN ? a.build_m2 : SET_WIN;
+  unsigned occ = 0;
   for (unsigned sl = tid; sl < wslots; sl += 256) {
     const i64 k = L.key[sl];
-    *reinterpret_cast<uint4*>(out + sl) = make_uint4((unsigned)(u64)k, (unsigned)((u64)k >> 32), L.pos[sl], 0u);
+    const unsigned p1 = L.pos[sl];
+    occ += p1 != 0;
+    *reinterpret_cast<uint4*>(out + sl) = make_uint4((unsigned)(u64)k, (unsigned)((u64)k >> 32), p1, 0u);
+  }
+  if (a.build_ucnt) {   // distinct keys of this window (for the host's choice of the write-back's slice size, two launches from now)
+    for (int off = 32; off > 0; off >>= 1) occ += (unsigned)__shfl_xor((int)occ, off);
+    if ((tid & 63) == 0) atomicAdd(&L.n, occ);
+    __syncthreads();
+    if (tid == 0) a.build_ucnt[win] = L.n;
   }
   if (win == 0 && tid < 2) {   // the two sentinel slots behind the table: key word = "taken" marker
     const unsigned p1 = L.pos[SET_WIN + tid];
@@ -467,7 +483,6 @@ __device__ __forceinline__ void find_list_role(const StepArgs& a, unsigned blk) 
 }
 // a lookup block is done: its output rows are in memory (write-through, acknowledged).  Only the tail's rare corrections wait for this.
 __device__ __forceinline__ void find_arrive(const StepArgs& a) {
-  if (a.noack) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0 && a.tail_blocks) __hip_atomic_fetch_add(a.sync + 32 * (1 + (blockIdx.x & 7u)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -494,7 +509,17 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
     e[r] = *reinterpret_cast<const uint4*>(a.fwd.ent + (have[r] ? lo + off : lo));
   }
   if (blk == 0 && tid == 0 && a.progress) __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool publish = blk == 0 && a.own_ucnt && a.progress;   // (block-uniform)
+  unsigned ucnt = 0;
+  if (publish) {
+    if (tid == 0) L.cnt[200] = 0;
+    ucnt = tid < a.own_ucnt_n ? a.own_ucnt[tid] : 0u;
+  }
   __syncthreads();
+  if (publish) {
+    for (int off = 32; off > 0; off >>= 1) ucnt += (unsigned)__shfl_xor((int)ucnt, off);
+    if (lane == 0) atomicAdd(&L.cnt[200], ucnt);
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const unsigned slot = lo + tid + (unsigned)r * 256u;
@@ -508,6 +533,7 @@ __device__ __forceinline__ void own_role(const StepArgs& a, unsigned blk, StepLd
   }
   __syncthreads();
   const unsigned cnt = L.n;
+  if (publish && tid == 0) __hip_atomic_store(a.progress + 1, L.cnt[200], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // this batch's distinct keys
   // (Tried: ONE round per block — 16 U keys — and the few keys beyond it straight onto the item list, so that no block runs the
   // chain of round trips twice: the slowest write-back blocks are not the ones with a second round — the role ended at 19 us as
   // before — and the tail, with 60 items instead of a dozen, ran longer: 31.9 -> 37.3 us per step.)
@@ -773,7 +799,7 @@ struct tfra_step_driver {
   unsigned tinfo[64][7] = {};              // per launch slot: build, scatter, own, lookup blocks, grid (the rest: tail), map blocks, lookup blocks in front of the write-back
   int find_first = 0;                      // TFRA_STEP_FIND_FIRST (tuning): lookup blocks in front of the write-back's
   unsigned own_slice = OWN_SLICE_DEFAULT;  // TFRA_STEP_OWN_SLICE (tuning): plan slots per write-back block (<= 768)
-  int noack = 0;                           // TFRA_STEP_NOACK (tuning, results unsafe when the tail corrects rows): lookup blocks leave without waiting for their stores
+  bool own_slice_fixed = false;            // ... given: no adaptation to the batch's distinct-key count
   // MAP lists (round 5): two buffers of up to MAX_IDS 16-byte entries alternate — one is read by this launch's lookup, the other filled for the next
   unsigned char* mapbuf = nullptr;         // device: 2 x cap entries
   size_t map_cap = 0;
@@ -819,8 +845,7 @@ extern "C" int tfra_step_driver_create(tfra_table_t* tp, tfra_step_driver_t** ou
   d->variant = ev ? std::atoi(ev) : 0;
   if (const char* ab = std::getenv("TFRA_STEP_ABLATE")) d->ablate = std::atoi(ab);
   if (const char* ab = std::getenv("TFRA_STEP_ABLATE_AFTER")) d->ablate_after = (unsigned)std::atoi(ab);
-  if (const char* os_ = std::getenv("TFRA_STEP_OWN_SLICE")) d->own_slice = std::min(768u, std::max(64u, (unsigned)std::atoi(os_)));
-  if (const char* na = std::getenv("TFRA_STEP_NOACK")) d->noack = std::atoi(na);
+  if (const char* os_ = std::getenv("TFRA_STEP_OWN_SLICE")) { d->own_slice = std::min(768u, std::max(64u, (unsigned)std::atoi(os_))); d->own_slice_fixed = true; }
   if (const char* ff = std::getenv("TFRA_STEP_FIND_FIRST")) d->find_first = std::atoi(ff);
   if (d->variant & 16) {
     const size_t bytes = (size_t)TIMING_SLOTS * TIMING_BLOCKS * 16;
@@ -1044,7 +1069,14 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       a.own = L.a;
       a.ctr = L.ctr; a.own_gen = L.og;
       a.fwd = probe_of(plan_prev);
+      if (plan_is_listless(plan_prev) && plan_prev->ucnt) { a.own_ucnt = plan_prev->ucnt; a.own_ucnt_n = plan_prev->set_m2 / SET_WIN; }
+      // ~40 keys per write-back block (two rounds of its four waves): the slice follows the density of the plan's table, known from
+      // the distinct-key count an earlier launch's tail left in pinned memory (0: none yet)
       a.own_slice = d->own_slice;
+      if (!d->own_slice_fixed) {
+        const unsigned u_est = __atomic_load_n(d->progress + 1, __ATOMIC_RELAXED);
+        if (u_est) a.own_slice = std::min(512u, std::max(96u, (unsigned)(40ull * (a.fwd.m2 + 2) / u_est) & ~31u));
+      }
       a.own_blocks = (a.fwd.m2 + 2 + a.own_slice - 1) / a.own_slice;
     } else {
       a.own.v = t->view_of(t->cur);
@@ -1063,7 +1095,6 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.patch_count = a.sync + 32 * 9 + 1; a.patch_count_next = a.sync_next + 32 * 9 + 1;   // (read with the tail's arrivals as one 8-byte word)
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
-    a.noack = d->noack;
     if (list_ok) {
       a.find_list = reinterpret_cast<const uint4*>(d->mapbuf + (size_t)d->map_slot * d->map_cap * 16);
       d->n_find_listed += 1;
@@ -1092,6 +1123,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
         a.build_ent = tb.ent; a.build_m2 = plan_next->set_m2; a.build_tiles = plan_next->seg_tiles; a.build_blocks = plan_next->set_m2 / SET_WIN;
         a.build_pairs = plan_next->seg_pairs; a.build_cnt = plan_next->seg_cnt; a.build_ovf = plan_next->ovf_pairs;
         a.build_ovf_cnt = plan_next->ovf_cnt + 32 * (plan_next->scat_use & 1u);
+        a.build_ucnt = plan_next->ucnt;
         d->n_built_in_launch += 1;
       } else {
         rc = setplan_build(plan_next, n_next, ids_next, s, false);

@@ -97,7 +97,10 @@ def main():
                         for z in args.find_tiles.split(",") for w in args.find_first.split(",")]:
     os.environ["TFRA_STEP_VARIANT"] = str(v)
     os.environ["TFRA_STEP_ABLATE"] = str(ab)
-    os.environ["TFRA_STEP_OWN_SLICE"] = str(ft)
+    if ft > 0:
+      os.environ["TFRA_STEP_OWN_SLICE"] = str(ft)
+    else:
+      os.environ.pop("TFRA_STEP_OWN_SLICE", None)   # 0: the driver's own (adaptive) choice
     os.environ["TFRA_STEP_FIND_FIRST"] = str(ff)
     for D in depths:
       drv = de.OverlapAssignStep(table)

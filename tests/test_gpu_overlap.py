@@ -360,3 +360,28 @@ def test_overlap_step_without_prime_raises(env):
   drv = de.OverlapAssignStep(t)
   with pytest.raises(RuntimeError, match="prime"):
     drv.step(torch.zeros((4, 64), device="cuda"))
+
+
+def test_overlap_all_distinct_ids(env):
+  """Batches of all-distinct ids (uniform over a large universe): every second slot of the plan's table is taken, the driver cuts the
+  write-back into smaller slices once it has seen a batch's distinct-key count (pinned memory) — same results either way."""
+  torch, de = env
+  dim, cap, n, nsteps = 64, 800_000, 8192, 12
+  rng = np.random.default_rng(21)
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  t = make_dense_table(torch, de, cap, dim, universe, "ovl_distinct")
+  tbl = t._table
+  latest = {int(k): float(int(k) % 1000) for k in universe}
+  batches = [torch.from_numpy(rng.choice(universe, size=n, replace=False)).cuda() for _ in range(nsteps + 2)]
+  drv = de.OverlapAssignStep(t).prime(batches[0])
+  for s in range(nsteps):
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim).contiguous()
+    out, ex = drv.step(vals, batches[s + 1], batches[s + 2], return_exists=True)
+    torch.cuda.synchronize()
+    _dict_check(torch, tbl, batches[s], out, ex, latest, ("distinct", s))
+    for i, k in enumerate(batches[s].cpu().numpy().tolist()):
+      latest[k] = 100000.0 * (s + 1) + i
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] >= nsteps - 4 and st["lookups_listed"] >= nsteps - 6, st
+  tbl.check_errors()

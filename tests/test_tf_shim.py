@@ -158,7 +158,37 @@ def test_fused_shim_binds_only_declared_abi_entry_points_and_reaches_the_fused_c
   used = set(re.findall(r"\b(tfra_[a-z_0-9]+)\(", open(SHIM_FUSED).read() + open(SHIM_COMMON).read()))
   used -= {"tfra_mi355x"}
   assert used <= declared, sorted(used - declared)
-  for fn in ("tfra_table_apply_sparse", "tfra_unique_unordered", "tfra_table_find_n", "tfra_gather_rows", "tfra_table_insert_or_assign_n",
+  for fn in ("tfra_table_apply_sparse", "tfra_unique_unordered", "tfra_table_find", "tfra_table_insert_or_assign_n",
              "tfra_step_driver_create", "tfra_table_step_overlap", "tfra_table_step_overlap_flush", "tfra_workspace_create",
              "tfra_rccl_unique_id", "tfra_rccl_transport_create", "tfra_route_create", "tfra_route_feed", "tfra_route_lookup", "tfra_route_apply"):
     assert fn in used, fn
+
+
+def test_tfra_side_binding_calls_registered_ops_with_their_signatures():
+  """tf_ops/tfra_fused_binding.py (the Python a TFRA maintainer adds: INTEGRATION.md §2.1) is valid Python and every generated-wrapper
+  call in it — `ops.tfra_<snake_case_op>(inputs..., attr=...)` — names a registered fused op, passes exactly its inputs positionally
+  and only its attrs by keyword."""
+  import ast
+  import re
+  mod = _extractor()
+  ops = mod.parse_register_ops(open(SHIM_FUSED).read())
+  snake = {re.sub(r"(?<!^)(?=[A-Z])", "_", n.split(">")[1]).lower(): (n, d) for n, d in ops.items()}
+  src = open(os.path.join(ROOT, "tf_ops", "tfra_fused_binding.py")).read()
+  tree = ast.parse(src)
+  seen = set()
+  for node in ast.walk(tree):
+    if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr.startswith("tfra_"):
+      key = node.func.attr[len("tfra_"):]
+      assert key in snake, node.func.attr
+      name, d = snake[key]
+      seen.add(name)
+      assert len(node.args) == len(d["inputs"]), (name, len(node.args), d["inputs"])
+      attrs = {a.split(":")[0].strip() for a in d["attrs"]} | {"name"}
+      for kw in node.keywords:
+        assert kw.arg in attrs, (name, kw.arg)
+  # every family of fused ops is bound from Python
+  for want in ("TFRA>HkvHashTableOfTensorsWithSlots", "TFRA>HkvHashTableEmbeddingLookup", "TFRA>HkvHashTableApplySparseAdam",
+               "TFRA>HkvHashTableApplySparseSgd", "TFRA>HkvHashTableApplySparseAdagrad", "TFRA>HkvHashTableApplySparseFtrl",
+               "TFRA>HkvHashTableLookupAssignStep", "TFRA>HkvHashTableLookupAssignFlush", "TFRA>RcclUniqueId", "TFRA>RouteCreate",
+               "TFRA>RouteFeed", "TFRA>RouteLookup", "TFRA>RouteApplyAdam"):
+    assert want in seen, want

@@ -9,7 +9,8 @@
  *                                              create_slots (PY/dynamic_embedding_optimizer.py:870-958) keeps in S more tables
  *   TFRA>HkvHashTableEmbeddingLookup           ids [..] -> rows [.., dim], unique ids, inverse index, count: tf.unique + Find + tf.gather
  *                                              (PY/dynamic_embedding_ops.py:99-117) with NO host read in between — every output has
- *                                              the upper-bound shape [B], the count stays on the device
+ *                                              the upper-bound shape [B], the count stays on the device; the rows come from ONE find of
+ *                                              all B ids (repeats hit L2: cheaper than find(U) + gather(B))
  *   TFRA>HkvHashTableInsertN                   Insert of the first `num` of B keys (`num` a device scalar: the lookup's count)
  *   TFRA>HkvHashTableApplySparse{Sgd,Adam,Adagrad,Ftrl}
  *                                              ids WITH repeats + their gradient rows -> duplicate sums + one fused update per key on
@@ -263,6 +264,9 @@ static T* Out(Tensor* t) { return reinterpret_cast<T*>(const_cast<char*>(t->tens
 static float HostScalar(OpKernelContext* ctx, int i) { return ctx->input(i).scalar<float>()(); }
 
 // ---- tf.unique + Find + tf.gather as one op, no host read (PY/dynamic_embedding_ops.py:99-117) ---------------------------
+// The reference de-duplicates BEFORE the lookup because a CPU (or HKV) find is paid per key; here a find of all B ids is one
+// 12-us kernel whose repeats hit L2, cheaper than find(U) + gather(B): values = Find(ids) directly, and the unique ids / inverse
+// index (what the backward pass and a cache-fill Insert need) come from tfra_unique_unordered next to it.  Same rows, bit for bit.
 class EmbeddingLookupOp : public OpKernel {
  public:
   using OpKernel::OpKernel;
@@ -277,19 +281,14 @@ class EmbeddingLookupOp : public OpKernel {
     OP_REQUIRES_OK(ctx, ctx->allocate_output("idx", TensorShape({n}), &idx));
     OP_REQUIRES_OK(ctx, ctx->allocate_output("num_unique", TensorShape({}), &num));
     if (n == 0) return;
-    Tensor urows;
-    OP_REQUIRES_OK(ctx, ctx->allocate_temp(t->value_dtype(), TensorShape({n, dim}), &urows));
     tfra_stream_t st = StreamOf(ctx);
     tfra_workspace_t* ws = nullptr;
     OP_REQUIRES_OK(ctx, t->Workspace(&ws));
-    // is_full_default as in Find: one default row per id (then per UNIQUE id it cannot be: broadcast is required here)
     OP_REQUIRES(ctx, dflt.NumElements() == dim, errors::InvalidArgument("EmbeddingLookup: default_value must be one row [dim]"));
+    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_find(t->raw(), static_cast<size_t>(n), In<int64_t>(ids), Out<char>(values), nullptr,
+                                                 dflt.tensor_data().data(), 0, st)));
     OP_REQUIRES_OK(ctx, ToStatus(tfra_unique_unordered(ws, static_cast<size_t>(n), In<int64_t>(ids), Out<int64_t>(unique_ids), Out<int32_t>(idx),
                                                        Out<int64_t>(num), st)));
-    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_find_n(t->raw(), static_cast<size_t>(n), Out<int64_t>(num), Out<int64_t>(unique_ids), Out<char>(&urows),
-                                                   nullptr, dflt.tensor_data().data(), 0, st)));
-    OP_REQUIRES_OK(ctx, ToStatus(tfra_gather_rows(static_cast<size_t>(n), static_cast<size_t>(dim) * DataTypeSize(t->value_dtype()), Out<char>(&urows),
-                                                  Out<int32_t>(idx), Out<char>(values), st)));
   }
 };
 
