@@ -999,7 +999,7 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
   tm = Timer(torch)
   single = not c4 and world == 1
   secs_plain = med_plain = None
-  route, route_note, rs = None, None, None
+  route, route_note, rs, rccl_ranks = None, None, None, None
   if single:
     ids = idf.keys(nsteps + 1)
     uniq_ratio = float(np.mean([torch.unique(ids[i]).numel() / B for i in range(4)]))
@@ -1063,6 +1063,7 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
       rs.feed(ids[i + ahead])
       return out
 
+    rccl_ranks = getattr(rs, "rccl_ranks", None)
     for i in range(Wr):
       routed(i)
     secs, med, host_s = timed_windows(torch, dist, world, dev, K, routed, first=Wr)
@@ -1132,6 +1133,7 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
           "table_ops_per_s": world * (B + U) * K / med, "table_ops_per_s_counts": "B lookups + U fused row updates (the distinct keys of the batch) per GPU and step",
           "prefill_s": round(t_fill, 1),
           "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4), "route": route, "route_note": route_note,
+          "rccl_ranks_seen": rccl_ranks,   # ncclCommCount of the route driver's own communicators (None: no RCCL transport — one rank, or gloo-staged)
           "timing": {"value": timing_note(secs, K)},
           "drivers": {
               "value": ("tfra_table_step_prefetch: ONE C call per step = lookup + hot sums + fused Adam of batch i on the main "

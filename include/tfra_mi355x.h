@@ -516,6 +516,8 @@ int tfra_rccl_unique_id(const char* librccl_path, void* id_out /* TFRA_RCCL_ID_B
 int tfra_rccl_transport_create(const char* librccl_path, const void* ids, int rank, int world, int device,
                                tfra_transport* out);
 int tfra_rccl_transport_destroy(tfra_transport* tr);
+/* ranks of the transport's communicators as RCCL itself reports them (ncclCommCount, both channels) */
+int tfra_rccl_transport_ranks(const tfra_transport* tr, int* out);
 
 /*    The driver.  feed() hands a batch to the id-only half of the route, which runs ahead of the step on the driver's
  *    own streams: the de-duplication plan of the batch and its distinct ids grouped by owner (a helper thread launches

@@ -44,6 +44,7 @@ struct RcclApi {
   decltype(&ncclSend) send = nullptr;
   decltype(&ncclRecv) recv = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;   // optional (reporting only)
 };
 
 int load_rccl(const char* path, RcclApi* api) {
@@ -62,6 +63,7 @@ int load_rccl(const char* path, RcclApi* api) {
   TFRA_SYM(recv, "ncclRecv");
   TFRA_SYM(error_string, "ncclGetErrorString");
 #undef TFRA_SYM
+  api->comm_count = reinterpret_cast<decltype(api->comm_count)>(dlsym(api->lib, "ncclCommCount"));
   return TFRA_OK;
 }
 
@@ -398,6 +400,22 @@ int tfra_rccl_transport_create(const char* librccl_path, const void* ids, int ra
     }
   }
   out->ctx = c; out->rank = rank; out->world = world; out->alltoallv = rccl_alltoallv;
+  return TFRA_OK;
+}
+
+// How many ranks the transport's communicators REALLY span, as RCCL reports it (ncclCommCount on both channels; they must agree):
+// what `bench.py --gpus N` prints as rccl_ranks_seen, so that a scaling record shows that an N-rank communicator was formed.
+int tfra_rccl_transport_ranks(const tfra_transport* tr, int* out) {
+  if (!tr || !tr->ctx || !out) return set_error(TFRA_ERR_INVALID, "rccl transport: null argument");
+  const RcclCtx* c = static_cast<const RcclCtx*>(tr->ctx);
+  if (!c->api.comm_count) return set_error(TFRA_ERR_UNSUPPORTED, "rccl transport: librccl has no ncclCommCount");
+  int n[2] = {0, 0};
+  for (int ch = 0; ch < 2; ++ch) {
+    ncclResult_t r = c->api.comm_count(c->comm[ch], &n[ch]);
+    if (r != ncclSuccess) return rccl_fail(c->api, r, "ncclCommCount");
+  }
+  if (n[0] != n[1]) return set_error(TFRA_ERR_HIP, "rccl transport: the two channels' communicators disagree on their size");
+  *out = n[0];
   return TFRA_OK;
 }
 

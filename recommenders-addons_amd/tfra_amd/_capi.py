@@ -158,6 +158,7 @@ _SIGS = {
     "tfra_rccl_unique_id": [ctypes.c_char_p, _P],
     "tfra_rccl_transport_create": [ctypes.c_char_p, _P, _I, _I, _I, ctypes.POINTER(Transport)],
     "tfra_rccl_transport_destroy": [ctypes.POINTER(Transport)],
+    "tfra_rccl_transport_ranks": [ctypes.POINTER(Transport), ctypes.POINTER(_I)],
     "tfra_route_create": [_P, ctypes.POINTER(Transport), _I, _SZ, ctypes.c_uint32, ctypes.POINTER(_P)],
     "tfra_route_destroy": [_P],
     "tfra_route_feed": [_P, _SZ, _P, _I, _P],

@@ -461,6 +461,13 @@ class NativeRoutedStep:
       tr = ctypes.byref(self._staged.struct)
     elif transport is not None:
       raise ValueError("transport: 'auto', 'rccl', 'staged' or None")
+    self.rccl_ranks = None   # ranks of the RCCL communicators as RCCL reports them (None: no RCCL transport)
+    if self._rccl is not None:
+      n = ctypes.c_int(0)
+      _capi.call("tfra_rccl_transport_ranks", ctypes.byref(self._rccl), ctypes.byref(n))
+      self.rccl_ranks = n.value
+      if self.rccl_ranks != self.world:
+        raise RuntimeError("NativeRoutedStep: the RCCL communicators span %d ranks, the process group %d" % (self.rccl_ranks, self.world))
     self._h = ctypes.c_void_p()
     _capi.call("tfra_route_create", self.table._h, tr, int(partition_mode), int(max_batch),
                0 if threaded else _capi.ROUTE_NO_THREAD, ctypes.byref(self._h))

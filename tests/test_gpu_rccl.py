@@ -1,0 +1,115 @@
+"""(e) on a box with at least TWO GPUs: the real RCCL transport (`tfra_rccl_transport_create`: grouped ncclSend / ncclRecv over xGMI on
+the driver's own communicators) under `NativeRoutedStep`, one process per GPU, compared with ONE oracle table that sees every rank's
+batches — exactly the check of tests/test_gpu_distributed.py (which stages the collectives through gloo because two ranks on one GPU
+cannot form an RCCL communicator).  Skips on a 1-GPU box (the builder's pool); runs by itself wherever the suite meets 2 or 8 GPUs, so
+the multi-rank RCCL path is exercised outside `bench.py --gpus N` too.
+
+Reference: PY/shadow_embedding_ops.py:397-447 (__alltoall_embedding_lookup__), python/kernel_tests/horovod_sync_train_test.py:265-376."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+DIM, STEPS, LR = 8, 6, 0.5
+
+
+def _n_gpus():
+  try:
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+  except Exception:   # noqa: BLE001
+    return 0
+
+
+def _batch(rank, step):
+  rng = np.random.default_rng(7000 * step + rank)
+  ids = (rng.zipf(1.3, size=(4, 600 + 70 * rank)).astype(np.int64) % 6000) * 7919 - 4321   # negative keys too
+  g = (rng.standard_normal((ids.size, DIM)) * 0.01).astype(np.float32)
+  return ids, g
+
+
+def _worker(rank, world, port, out_dir):
+  import torch
+  import torch.distributed as dist
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import NativeRoutedStep
+  os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  torch.cuda.set_device(rank)
+  dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+  try:
+    dev = "cuda:%d" % rank
+    opt = de.optimizers.SGD(LR)
+    var = de.Variable(dim=DIM, name="rccl_w%d_r%d" % (world, rank), initializer=0.5, devices=[dev], **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    rs = NativeRoutedStep(var, deo, partition_mode=0, transport="rccl", max_batch=4096)
+    assert rs.world == world and rs._rccl is not None          # the real transport: one RCCL communicator pair with `world` ranks
+    batches = [_batch(rank, s) for s in range(STEPS)]
+    dev_ids = [torch.from_numpy(b[0]).to(dev) for b in batches]
+    torch.cuda.synchronize()
+    for s in range(min(3, STEPS)):
+      rs.feed(dev_ids[s])
+    looked = []
+    for step in range(STEPS):
+      out = rs.lookup()
+      looked.append(out.cpu().numpy().reshape(batches[step][0].shape + (DIM,)))
+      rs.apply(torch.from_numpy(batches[step][1]).to(dev))
+      if step + 3 < STEPS:
+        rs.feed(dev_ids[step + 3])
+    torch.cuda.synchronize()
+    rs.close()
+    k, v = var.export()
+    k = k.cpu().numpy()
+    assert np.all(((k & 0x7FFFFFFF) % world) == rank)           # default_partition_fn: this shard's keys only
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), keys=k, vals=v.cpu().numpy(), **{"look%d" % i: x for i, x in enumerate(looked)})
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs at least two GPUs on the box (one process per GPU, RCCL over xGMI)")
+@pytest.mark.parametrize("world", [2, 8])
+def test_native_route_over_real_rccl(world, tmp_path):
+  import torch
+  import torch.multiprocessing as mp
+  import oracle
+  from oracle import optimizers as oopt
+  if torch.cuda.device_count() < world:
+    pytest.skip("%d GPUs needed, %d visible" % (world, torch.cuda.device_count()))
+  mp.spawn(_worker, args=(world, 29940 + world, str(tmp_path)), nprocs=world, join=True)
+  res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+  tab = oracle.CpuTable(DIM)
+  dflt = np.full(DIM, 0.5, np.float32)
+  for step in range(STEPS):
+    batches = [_batch(r, step) for r in range(world)]
+    for r, (ids, g) in enumerate(batches):
+      want = tab.find(ids.reshape(-1), dflt).reshape(ids.shape + (DIM,))
+      np.testing.assert_allclose(res[r]["look%d" % step], want, rtol=1e-6, atol=1e-6)
+    all_ids = np.concatenate([b[0].reshape(-1) for b in batches])
+    all_g = np.concatenate([b[1] for b in batches])
+    uniq, gsum, _ = oopt.segment_sum_by_key(all_ids, all_g)
+    tab.insert(uniq, oopt.sgd(tab.find(uniq, dflt), gsum, LR))
+  ek, ev = tab.export_sorted()
+  gk = np.concatenate([r["keys"] for r in res])
+  gv = np.concatenate([r["vals"] for r in res])
+  o = np.argsort(gk)
+  np.testing.assert_array_equal(gk[o], ek)            # every key lives on exactly one shard
+  np.testing.assert_allclose(gv[o], ev, rtol=1e-6, atol=1e-6)
+
+
+def test_rccl_entry_points_exist_and_refuse_bad_arguments():
+  """On any box: the transport's entry points are exported and fail loudly (no GPU pair needed)."""
+  import ctypes
+  from tfra_amd import _capi
+  lib = _capi.lib()
+  assert hasattr(lib, "tfra_rccl_unique_id") and hasattr(lib, "tfra_rccl_transport_create") and hasattr(lib, "tfra_rccl_transport_destroy")
+  tr = _capi.Transport()
+  rc = lib.tfra_rccl_transport_create(b"/nonexistent/librccl.so", b"\0" * (2 * _capi.RCCL_ID_BYTES), 0, 2, 0, ctypes.byref(tr))
+  assert rc != 0 and b"rccl" in lib.tfra_last_error().lower()
