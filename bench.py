@@ -17,8 +17,10 @@ One "step" = one pass of the hot path over one batch of synthetic ids.  Configur
       5*10^8 keys each, hash-sharded by the reference's default partitioner, dim=64 fp32, per-GPU batch B drawn from the
       GLOBAL Zipf-1.2 over the N*5*10^8 keys, ids / rows / gradients routed by tfra_route_* (RCCL alltoall over xGMI; at
       N=1 the same driver without a transport):  routed lookup(B) -> routed fused SGD write-back of the batch's keys.
-  c5  configs[4] on one GPU (26 tables, fused FTRL), not part of the default invocation.
-  The default invocation at N=1 prints m1b as the top-level line and c3 / c2 / c4 under "secondary".
+  c5  configs[4]: 26 tables, dims {16,32,64,128}, fused FTRL.  `--config c5` on one GPU: the local multi-table drivers
+      (tfra_multi_step_prefetch ...) plus the N = 1 point of the routed form; `--config c5 --gpus N`: every table hash-sharded over
+      the N ranks, one tfra_route per table on one shared transport (MultiTableRoutedStep), per-GPU batch B per table.
+  The default invocation at N=1 prints m1b as the top-level line and c3 / c2 / c4 / c5 (routed, small tables) under "secondary".
 
 `value` = ids looked up AND written back per second (lookup+insert pairs/s), whole job.  On the assign workloads (m1b, c3) the
 faster of the table's two step drivers, both reported (`faster_driver` names it):
@@ -1188,7 +1190,7 @@ def run_c5(args, torch, de, dev):
   most of the HBM, dims cycling {16, 32, 64, 128}, one id per table per sample (batch B per table), combined lookup +
   FTRL write-back.  One C call per step for all tables (tfra_multi_step_prefetch) vs one PrefetchStep call per table vs
   plain per-table calls."""
-  NT, B, K, W = 26, args.batch, max(10, args.steps // 4), max(3, args.warmup // 4)
+  NT, B, K, W = 26, args.batch, max(10, args.steps // 4), max(6, args.warmup // 4)   # (>= 6 warm-up steps: the per-table drivers rotate four plan objects, each allocates at its first use)
   dims = [16, 32, 64, 128]
   free, _ = torch.cuda.mem_get_info()
   budget = 0.70 * free   # bytes for the rows of all tables at load factor <= 0.75
@@ -1266,6 +1268,99 @@ def run_c5(args, torch, de, dev):
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / t_multi / 1e9 / HBM_PEAK_GBS, "traffic": None,
                    "step_algorithmic_bytes": step_bytes, "step_frac": step_bytes / t_multi / 1e9 / HBM_PEAK_GBS},
   }
+  return res
+
+
+def run_c5_routed(args, torch, dist, de, dev, world, rank, budget_frac=0.5):
+  """BASELINE configs[4] through the route, ANY number of GPUs (also 1): 26 tables, each hash-sharded over the ranks by the
+  reference's default partitioner; per GPU the key counts of run_c5 (log-spaced, scaled to `budget_frac` of the HBM), dims cycling
+  {16, 32, 64, 128}, per-GPU batch B per table from the GLOBAL Zipf-1.2 over the table's world x keys, fused FTRL at the owner.
+  One `tfra_route` per table on ONE shared transport (one pair of RCCL communicators), driven by MultiTableRoutedStep's three
+  multi-table calls per step (feed / lookup / apply).  Weak scaling: per-GPU work is fixed as N grows."""
+  from tfra_amd.dynamic_embedding.distributed import MultiTableRoutedStep
+  NT, B, K, W = 26, args.batch, max(6, args.steps // 4), max(4, args.warmup // 2)
+  dims = [16, 32, 64, 128]
+  free, _ = torch.cuda.mem_get_info()
+  shape = np.logspace(7.0, 9.0, NT)
+  row_bytes = np.array([3 * dims[i % 4] * 4 + 8.6 for i in range(NT)])
+  scale = budget_frac * free * 0.70 / float(np.sum(shape * row_bytes))
+  sizes = np.maximum((shape * scale).astype(np.int64), 100_000)     # keys PER GPU and table
+  opt = de.optimizers.Ftrl(0.05, l1_regularization_strength=1e-3, l2_regularization_strength=1e-3)
+  deo = de.DynamicEmbeddingOptimizer(opt)
+  gen = torch.Generator(device=dev).manual_seed(SEED + rank)
+  rng = np.random.default_rng(SEED + 5 + 1000 * rank)
+  tabs, ids, grads = [], [], []
+  t0 = time.perf_counter()
+  NB = 8
+  for i in range(NT):
+    d, n_local = dims[i % 4], int(sizes[i])
+    n_total = n_local * world
+    v = de.Variable(dim=d, name="c5r_%d_r%d" % (i, rank), initializer=0.0, init_size=int(n_local * 1.1) + (1 << 16), devices=[str(dev)],
+                    **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+    zero = torch.zeros((4_000_000, d), device=dev)
+    for lo in range(1, n_total + 1, 4_000_000):
+      k = keys_of_ranks_torch(torch, torch.arange(lo, min(n_total, lo + 3_999_999) + 1, dtype=torch.int64, device=dev) + (i << 40))
+      if world > 1:
+        k = k[((k & 0x7FFFFFFF) % world) == rank]   # default_partition_fn (PY/dynamic_embedding_variable.py:165-197)
+      v.tables[0]._table.upsert(k, zero[:k.numel()], unique_keys=True)
+    del zero
+    tabs.append(v)
+    ranks = zipf_bounded(rng, NB * B, n_total).reshape(NB, B)
+    ids.append([keys_of_ranks_torch(torch, torch.from_numpy(ranks[j]).to(dev) + (i << 40)) for j in range(NB)])
+    grads.append(torch.randn((B, d), generator=gen, device=dev) * 0.01)
+  torch.cuda.synchronize()
+  t_fill = time.perf_counter() - t0
+  keys_per_gpu = int(sum(int(v.size().item()) for v in tabs))
+  force_a2a = os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist.is_initialized()
+  ms = MultiTableRoutedStep(tabs, deo, partition_mode=0, force_collectives=force_a2a, max_batch=B)
+  ahead = 3
+  for j in range(ahead):
+    ms.feed([x[j % NB] for x in ids])
+
+  def step(i):
+    out = ms.lookup()
+    ms.apply(grads)
+    ms.feed([x[(i + ahead) % NB] for x in ids])
+    return out
+
+  for i in range(W):
+    step(i)
+  secs, med, host_s = timed_windows(torch, dist, world, dev, K, step, first=W, windows=3)
+  for _ in range(ahead):
+    ms.lookup(); ms.apply(grads)
+  torch.cuda.synchronize()
+  rccl_ranks = ms.rccl_ranks
+  ms.close()
+  for v in tabs:
+    v.tables[0]._table.check_errors()
+  Rb = np.array([dims[i % 4] * 4 for i in range(NT)], dtype=np.float64)
+  uniq = np.array([float(torch.unique(ids[i][0]).numel()) for i in range(NT)])
+  step_bytes = float(np.sum(B * (8 + 2 * Rb) + B * (8 + Rb) + uniq * (8 + 7 * Rb)))
+  t_step = med / K
+  res = {
+      "metric": "embedding lookup+insert pairs/s (26 hash-sharded tables per GPU, dims {16,32,64,128}, Zipf-1.2, routed lookup + routed fused FTRL)",
+      "value": world * NT * B / t_step, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": t_step * 1e3,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {
+          "workload": "BASELINE configs[4]: 26 tables x %d shard(s), %d resident keys per GPU in total (%d ... %d per table and GPU, log-spaced), "
+                      "dims cycling {16,32,64,128} fp32 rows [p|accum|linear], per-GPU batch=%d ids per table and step from the GLOBAL Zipf-1.2, "
+                      "routed lookup + routed fused FTRL (one tfra_route per table, one shared transport)"
+                      % (world, keys_per_gpu, int(sizes.min()), int(sizes.max()), B),
+          "tables": NT, "global_batch": NT * B * world, "keys_per_gpu": keys_per_gpu, "prefill_s": round(t_fill, 1),
+          "parallelism": ("26 tables, each key-hash sharded x%d, RCCL alltoall (shared communicators)" % world) if world > 1
+                         else "single GPU through the route driver (no transport)",
+          "route": "native", "rccl_ranks_seen": rccl_ranks, "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
+          "timing": {"value": timing_note(secs, K)},
+          "driver": "MultiTableRoutedStep: tfra_route_feed / _lookup / _apply per table from three multi-table calls per step"},
+      "roofline": {"bound": "hbm", "kernel": "whole step (26 tables x routed find + gradient sums + apply_csr<FTRL>)", "achieved": step_bytes / t_step / 1e9,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                   "algorithmic_bytes_per_launch": step_bytes, "avg_launch_us": t_step * 1e6,
+                   "step_algorithmic_bytes": step_bytes, "step_frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS},
+  }
+  del ms, tabs
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
   return res
 
 
@@ -1389,7 +1484,8 @@ def main():
   ap.add_argument("--c5-streams", type=int, default=4)
   ap.add_argument("--c5-workers", type=int, default=1)
   ap.add_argument("--config", choices=["m1b", "c3", "c2", "c4", "c5"], default=None,
-                  help="default: m1b on one GPU (the metric's own configuration; c3 / c2 / c4 as secondary), c4 per GPU for N>1")
+                  help="default: m1b on one GPU (the metric's own configuration; c3 / c2 / c4 / c5 as secondary), c4 per GPU for N>1; "
+                       "c5 with --gpus N: 26 hash-sharded tables per GPU through the multi-table route")
   ap.add_argument("--slots", type=int, default=1_000_000_000, help="m1b / c3: slots of the bounded table")
   ap.add_argument("--keys", type=int, default=100_000_000, help="c2: resident keys")
   ap.add_argument("--c4-keys", type=int, default=500_000_000, help="c4: resident keys PER GPU")
@@ -1431,7 +1527,8 @@ def main():
       sec = {}
       for name, fn in (("c3", lambda: run_bounded(args, torch, de, dev, "c3")),       # configs[2]
                        ("c2", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c2")),   # configs[1]
-                       ("c4", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c4"))):  # configs[3] at N=1: the first point of the N-GPU curve
+                       ("c4", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c4")),   # configs[3] at N=1: the first point of the N-GPU curve
+                       ("c5", lambda: run_c5_routed(args, torch, dist, de, dev, 1, 0, budget_frac=0.2))):   # configs[4] at N=1 through the sharded multi-table route
         try:
           r = fn()
           sec[name] = {k: r[k] for k in keep if k in r}
@@ -1448,8 +1545,19 @@ def main():
                   "compare its `value` with this one, not with the top-level `value` (the metric's single-GPU configuration).  No RCCL "
                   "communicator with more than one rank has been formed on the builder's side (one GPU per box): nothing is projected."}
   elif cfg == "c5":
-    assert world == 1, "c5 here is the one-GPU form of configs[4]"
-    res = run_c5(args, torch, de, dev)
+    if world == 1 and not dist.is_initialized():
+      res = run_c5(args, torch, de, dev)     # the local drivers on one GPU ...
+      import gc
+      gc.collect()
+      torch.cuda.empty_cache()
+      try:                                     # ... and the N = 1 point of the routed, sharded form every `--gpus N --config c5` run measures
+        rr = run_c5_routed(args, torch, dist, de, dev, 1, 0)
+        res["value_routed"] = rr["value"]; res["ms_per_step_routed"] = rr["ms_per_step"]
+        res["scaling_point"] = {"workload": rr["config"]["workload"], "value": rr["value"], "ms_per_step": rr["ms_per_step"], "n_gpus": 1}
+      except Exception as e:   # noqa: BLE001
+        res["scaling_point"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    else:
+      res = run_c5_routed(args, torch, dist, de, dev, world, rank)
   elif cfg == "c2":
     assert world == 1, "c2 is a single-GPU configuration (N > 1 runs configs[3]: --config c4)"
     res = run_sharded(args, torch, dist, de, dev, 1, 0, "c2")

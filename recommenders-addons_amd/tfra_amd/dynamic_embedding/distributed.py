@@ -412,7 +412,7 @@ class NativeRoutedStep:
   None (single rank, device copies).  Reference: PY/shadow_embedding_ops.py:397-447."""
 
   def __init__(self, var, optimizer, group=None, partition_mode=0, force_collectives=False, transport="auto", max_batch=1 << 18,
-               threaded=True):
+               threaded=True, share_transport_of=None):
     import ctypes
     from .. import _capi
     from .optimizer import DynamicEmbeddingOptimizer
@@ -430,8 +430,15 @@ class NativeRoutedStep:
       transport = None if not collectives else ("rccl" if dist.get_backend(group) == "nccl" else "staged")
     self._staged = None
     self._rccl = None
+    self._owns_transport = True
     tr = None
-    if transport == "rccl":
+    if share_transport_of is not None:
+      # many tables, ONE pair of communicators (MultiTableRoutedStep): the collectives of every route are issued by the calling
+      # thread in call order, the same on every rank, so routes may share a transport; only the first one owns (and destroys) it
+      self._owns_transport = False
+      self._staged, self._rccl = share_transport_of._staged, share_transport_of._rccl
+      tr = ctypes.byref(self._rccl) if self._rccl is not None else (ctypes.byref(self._staged.struct) if self._staged is not None else None)
+    elif transport == "rccl":
       lib = _loaded_librccl().encode()
       # rank 0 makes the two unique ids; a status byte travels with them so that a failure there raises on EVERY rank
       # instead of leaving the others waiting in the broadcast
@@ -531,12 +538,53 @@ class NativeRoutedStep:
     if getattr(self, "_h", None) is not None and self._h:
       self._capi.call("tfra_route_destroy", self._h)
       self._h = None
-    if self._rccl is not None:
+    if self._rccl is not None and self._owns_transport:
       self._capi.call("tfra_rccl_transport_destroy", self._ctypes.byref(self._rccl))
-      self._rccl = None
+    self._rccl = None
 
   def __del__(self):
     try:
       self.close()
     except Exception:
       pass
+
+
+class MultiTableRoutedStep:
+  """BASELINE configs[4] across GPUs: many embedding tables (a DLRM's 26), EACH hash-sharded over the ranks by the reference's
+  default partitioner, one `tfra_route` per table on ONE shared transport (one pair of RCCL communicators for all tables), driven by
+  single multi-table calls:
+
+      ms = MultiTableRoutedStep(variables, deo); ms.feed(ids_per_table) x 3
+      for ...: rows = ms.lookup(); ...; ms.apply(grads_per_table); ms.feed(next_ids_per_table)
+
+  Per table the sequence and the results are `NativeRoutedStep`'s (reference: the per-table `__alltoall_embedding_lookup__` of
+  PY/shadow_embedding_ops.py:397-447 + the optimizer's sparse apply); every rank calls with the tables in the same order, so the
+  collectives of all tables interleave identically everywhere.  One optimizer step (`begin_step`) covers all tables of an apply."""
+
+  def __init__(self, variables, optimizer, group=None, partition_mode=0, force_collectives=False, transport="auto", max_batch=1 << 18,
+               threaded=False):
+    self.deo = optimizer
+    self.steps = []
+    for v in variables:
+      self.steps.append(NativeRoutedStep(v, optimizer, group=group, partition_mode=partition_mode, force_collectives=force_collectives,
+                                         transport=transport, max_batch=max_batch, threaded=threaded,
+                                         share_transport_of=self.steps[0] if self.steps else None))
+    self.world = self.steps[0].world
+    self.rccl_ranks = self.steps[0].rccl_ranks
+
+  def feed(self, ids_list):
+    for s_, ids in zip(self.steps, ids_list):
+      s_.feed(ids)
+
+  def lookup(self):
+    return [s_.lookup() for s_ in self.steps]
+
+  def apply(self, grads_list):
+    p = self.deo.begin_step()
+    for s_, g in zip(self.steps, grads_list):
+      s_.apply(g, p)
+
+  def close(self):
+    for s_ in reversed(self.steps):   # the owner of the transport last
+      s_.close()
+    self.steps = []

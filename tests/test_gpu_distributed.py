@@ -160,3 +160,88 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   assert len(lines[0]) < 6000          # the driver keeps an ~8 KB tail of stdout: the line must fit whole
   full = json.load(open(os.path.join(str(tmp_path), "bench_detail.json")))   # everything else: the detail file
   assert full["config"]["timing"]["value"]["windows"] == 5 and full["config"]["timing"]["value"]["steps_per_window"] == 6
+
+
+# ---- configs[4] across ranks: several tables, each hash-sharded, one route per table on ONE shared transport, fused FTRL ----------
+MT_DIMS, MT_STEPS = (8, 16, 4), 4
+
+
+def _mt_batch(rank, step, table):
+  rng = np.random.default_rng(9000 * step + 10 * rank + table)
+  ids = (rng.zipf(1.3, size=900 + 60 * rank + 30 * table).astype(np.int64) % 4000) * 104729 + table * 7 - 999
+  g = (rng.standard_normal((ids.size, MT_DIMS[table])) * 0.01).astype(np.float32)
+  return ids, g
+
+
+def _worker_multi_table(rank, world, port, out_dir):
+  import torch
+  import torch.distributed as dist
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import MultiTableRoutedStep
+  os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+  try:
+    opt = de.optimizers.Ftrl(0.05, l1_regularization_strength=1e-3, l2_regularization_strength=1e-3)
+    deo = de.DynamicEmbeddingOptimizer(opt)
+    tabs = [de.Variable(dim=d, name="mt_w2_t%d_r%d" % (i, rank), initializer=0.25, devices=["cuda:0"], **de.DynamicEmbeddingOptimizer.variable_kwargs(opt))
+            for i, d in enumerate(MT_DIMS)]
+    ms = MultiTableRoutedStep(tabs, deo, partition_mode=0, transport="staged", max_batch=4096)
+    assert ms.world == 2 and len(ms.steps) == len(MT_DIMS)
+    assert all(s_._staged is ms.steps[0]._staged for s_ in ms.steps)      # ONE transport for all tables
+    batches = [[_mt_batch(rank, s, t) for t in range(len(MT_DIMS))] for s in range(MT_STEPS)]
+    dev_ids = [[torch.from_numpy(b[0]).cuda() for b in row] for row in batches]
+    torch.cuda.synchronize()
+    for s in range(min(2, MT_STEPS)):
+      ms.feed(dev_ids[s])
+    looked = []
+    for step in range(MT_STEPS):
+      rows = ms.lookup()
+      looked.append([r.cpu().numpy() for r in rows])
+      ms.apply([torch.from_numpy(b[1]).cuda() for b in batches[step]])
+      if step + 2 < MT_STEPS:
+        ms.feed(dev_ids[step + 2])
+    assert deo.iterations == MT_STEPS          # ONE optimizer step per multi-table apply
+    torch.cuda.synchronize()
+    ms.close()
+    out = {}
+    for i, v in enumerate(tabs):
+      k, val = v.export()
+      k = k.cpu().numpy()
+      assert np.all(((k & 0x7FFFFFFF) % world) == rank)
+      out["keys%d" % i], out["vals%d" % i] = k, val.cpu().numpy()
+      for s in range(MT_STEPS):
+        out["look%d_%d" % (s, i)] = looked[s][i]
+    np.savez(os.path.join(out_dir, "mt_rank%d.npz" % rank), **out)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_multi_table_route_world2_ftrl_vs_oracle(tmp_path):
+  """BASELINE configs[4] in small: three tables of different dims, each sharded over two ranks (both on cuda:0, collectives staged
+  through gloo), MultiTableRoutedStep with fused FTRL — every table equal to ONE oracle table that sees both ranks' batches, rule by
+  oracle/optimizers.py (pinned to TensorFlow's published FTRL answers)."""
+  import torch
+  import torch.multiprocessing as mp
+  import oracle
+  from oracle import optimizers as oopt
+  assert torch.cuda.is_available()
+  world = 2
+  mp.spawn(_worker_multi_table, args=(world, 29975, str(tmp_path)), nprocs=world, join=True)
+  res = [np.load(tmp_path / ("mt_rank%d.npz" % r)) for r in range(world)]
+  hp = dict(lr=0.05, lr_power=-0.5, l1=1e-3, l2=1e-3, init_acc=0.1)
+  for t, dim in enumerate(MT_DIMS):
+    tabs = [oracle.CpuTable(dim) for _ in range(3)]
+    ora = oopt.SparseOptimizerOracle("ftrl", tabs[0], tabs[1:], hp, 0.25)
+    dflt = np.full(dim, 0.25, np.float32)
+    for step in range(MT_STEPS):
+      batches = [_mt_batch(r, step, t) for r in range(world)]
+      for r, (ids, g) in enumerate(batches):
+        np.testing.assert_allclose(res[r]["look%d_%d" % (step, t)], tabs[0].find(ids, dflt), rtol=1e-6, atol=1e-6)
+      ora.apply(np.concatenate([b[0] for b in batches]), np.concatenate([b[1] for b in batches]))
+    ek, ev = tabs[0].export_sorted()
+    gk = np.concatenate([r["keys%d" % t] for r in res])
+    gv = np.concatenate([r["vals%d" % t] for r in res])
+    o = np.argsort(gk)
+    np.testing.assert_array_equal(gk[o], ek)
+    np.testing.assert_allclose(gv[o], ev, rtol=2e-6, atol=2e-6)

@@ -129,7 +129,14 @@ class MI355XHashTable final : public lookup::LookupInterface {
     AllocatorAttributes attr;
     alloc_user_.device = ctx->device()->GetAllocator(attr);
     tfra_allocator bridge = {&TfAllocator::Alloc, &TfAllocator::Free, &alloc_user_};
-    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_create(&o, &bridge, &table_)));
+    // TFRA_TABLE_ALLOCATOR=hip: the table's bytes come from the HIP driver instead of TensorFlow's allocator.  That is what lets a
+    // table of 4 GiB or more live in a reserved address range and GROW IN PLACE (hipMemAddressReserve / hipMemMap: DESIGN §3; with a
+    // caller's allocator the library can only grow by copying, which stops at a third of the HBM) — the way to reach a 10^9-slot
+    // table by growth under TensorFlow.  The process must then leave the memory to the driver: TF_FORCE_GPU_ALLOW_GROWTH=true or a
+    // per_process_gpu_memory_fraction below the table's share.  Default: TensorFlow's allocator, like TFOrDefaultAllocator.
+    const char* from = std::getenv("TFRA_TABLE_ALLOCATOR");
+    const bool hip_bytes = from != nullptr && std::string(from) == "hip";
+    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_create(&o, hip_bytes ? nullptr : &bridge, &table_)));
   }
   ~MI355XHashTable() override {
     if (step_.driver) tfra_step_driver_destroy(step_.driver);
