@@ -183,6 +183,16 @@ class IdFactory:
 def _cpu_baseline_worker(conn, batch, n_keys, threads, kind, growth_leg, init_div=1):
   """Child process (no torch): builds the reference's CPU table with n_keys resident keys and times the ops on it.  Every rate
   is the MEDIAN of 3 repeats of a fixed number of batches; the pool size is fixed."""
+  try:
+    _cpu_baseline_worker_body(conn, batch, n_keys, threads, kind, growth_leg, init_div)
+  except BaseException as e:   # noqa: BLE001 — the parent reports it instead of a silent EOF
+    try:
+      conn.send(("error", "%s: %s" % (type(e).__name__, str(e)[:300])))
+    except Exception:   # noqa: BLE001
+      pass
+
+
+def _cpu_baseline_worker_body(conn, batch, n_keys, threads, kind, growth_leg, init_div=1):
   import oracle
   dim = 64
   rng = np.random.default_rng(SEED)
@@ -275,63 +285,59 @@ def cpu_baseline(batch):
   rungs = [r for r in ((256_000_000, 1, 100.0), (16_000_000, 1, 45.0), (4_000_000, 1, 90.0))
            if r[0] == 4_000_000 or (ram > 3 * r[0] * 330 and cores >= (64 if r[0] > 16_000_000 else 8))]
   if os.environ.get("TFRA_BENCH_CPU_KEYS"):
-    rungs = [(int(os.environ["TFRA_BENCH_CPU_KEYS"]), 8, 300.0)]
+    rungs = [(int(os.environ["TFRA_BENCH_CPU_KEYS"]), int(os.environ.get("TFRA_BENCH_CPU_INIT_DIV", "8")), float(os.environ.get("TFRA_BENCH_CPU_BOX_S", "300")))]
   t_begin = time.perf_counter()
   got, tried = None, []
   ctx = mp.get_context("spawn")
-  for n_keys, init_div, box in rungs:
-    last = (n_keys, init_div, box) == rungs[-1]
+
+  def run_rung(n_keys, init_div, box, growth_leg, note=None):
+    """one table size in a child process, killed when it overruns its time box; -> the worker's result or None"""
     parent, child = ctx.Pipe(duplex=False)
-    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, n_keys, threads, kind, n_keys <= 16_000_000, init_div))
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, n_keys, threads, kind, growth_leg, init_div))
     pr.start()
     child.close()
-    phases, t_rung = [], time.perf_counter()
-    while got is None:   # the worker reports its phases; the last message is the result
+    phases, t_rung, res, err = [], time.perf_counter(), None, None
+    while res is None and err is None:   # the worker reports its phases; the last message is the result
       left = box - (time.perf_counter() - t_rung)
       if left <= 0 or not parent.poll(left):
         break
       try:
         msg = parent.recv()
       except EOFError:
+        err = "the worker exited without a result"
         break
       if msg[0] == "done":
-        got = msg[1]
+        res = msg[1]
+      elif msg[0] == "error":
+        err = msg[1]
       else:
         phases.append(list(msg[1:]))
     pr.join(timeout=1.0)
     if pr.is_alive():
       pr.kill()   # the exact process started above
       pr.join()
-    tried.append({"keys": n_keys, "finished": got is not None, "seconds": round(time.perf_counter() - t_begin, 1), "phases_s": phases})
+    rec = {"keys": n_keys, "finished": res is not None, "seconds": round(time.perf_counter() - t_begin, 1), "phases_s": phases}
+    if err:
+      rec["error"] = err
+    if note:
+      rec["legs"] = note
+    tried.append(rec)
+    return res
+
+  # SURVEY §8d's two small-table legs — Find on a batch WITH its repeats, and the pre-fill at the reference default init_size = 8192
+  # (growth included) — do not fit the big rung's time box: a 4 M-key rung of their own, FIRST (behind the big rung the host is still
+  # giving back its 85 GB, and the small child died there once)
+  small = None
+  if rungs[0][0] > 16_000_000 and not os.environ.get("TFRA_BENCH_CPU_KEYS"):
+    small = run_rung(4_000_000, 1, 60.0, True, "find_with_repeats, growth from init_size 8192")
+  n_keys = init_div = None
+  for n_keys, init_div, box in rungs:
+    got = run_rung(n_keys, init_div, box, n_keys <= 16_000_000)
     if got is not None:
       break
   if got is None:
     return {"value": None, "unit": "lookup+insert pairs/s", "cores": threads, "kind": kind, "sample": "no rung finished: %s" % tried}
-  # SURVEY §8d's two small-table legs — Find on a batch WITH its repeats, and the pre-fill at the reference default init_size = 8192
-  # (growth included) — cannot run on the big rung inside its time box: a 4 M-key rung of their own (a child process, 60 s box)
-  small = None
-  if n_keys > 16_000_000 and not os.environ.get("TFRA_BENCH_CPU_KEYS"):
-    parent, child = ctx.Pipe(duplex=False)
-    pr = ctx.Process(target=_cpu_baseline_worker, args=(child, batch, 4_000_000, threads, kind, True, 1))
-    pr.start()
-    child.close()
-    t_rung = time.perf_counter()
-    while small is None:
-      left = 60.0 - (time.perf_counter() - t_rung)
-      if left <= 0 or not parent.poll(left):
-        break
-      try:
-        msg = parent.recv()
-      except EOFError:
-        break
-      if msg[0] == "done":
-        small = msg[1]
-    pr.join(timeout=1.0)
-    if pr.is_alive():
-      pr.kill()   # the exact process started above
-      pr.join()
-    tried.append({"keys": 4_000_000, "finished": small is not None, "seconds": round(time.perf_counter() - t_begin, 1), "legs": "find_with_repeats, growth from init_size 8192"})
-  else:
+  if small is None and n_keys <= 16_000_000:
     small = got
   ops, dedup_rate = got["ops"], got["dedup_rate"]
   if small is not None and ops.get("find_with_repeats_ops_per_s") is None:
