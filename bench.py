@@ -359,9 +359,10 @@ def cpu_baseline(batch):
       "per_op_per_core": {k: (round(v / threads) if v is not None else None) for k, v in ops.items()},
       "prefill_keys_per_s_init_size_8192_growth_included": round(grow_rate) if grow_rate else None,
       "small_table_legs_keys": small_keys,
-      "not_run_1e9_keys": "the 256 M-key rung (85 GB) takes ~47 s on this host class (constructor 9 s on one thread + 128-thread fill 33 s, "
-                          "measured round 4); 10^9 keys scale that to ~190 s + 330 GB touched once — past the ~30 s the default run may "
-                          "spend on the CPU leg; TFRA_BENCH_CPU_KEYS=1000000000 runs it (300 s box)",
+      "not_run_1e9_keys": "measured once (round 5, profiles/r05_cpu_baseline_1e9.json, TFRA_BENCH_CPU_KEYS=1000000000 TFRA_BENCH_CPU_INIT_DIV=1): "
+                          "constructor 36 s on one thread + 128-thread fill 110 s + ops = 169 s of CPU work for 19.3 M pairs/s (table ops "
+                          "alone 35 M) — six times the ~30 s the default run may spend on the CPU leg; the 256 M-key rung (85 GB, ~40 s) is the "
+                          "largest that fits",
   }
 
 
@@ -597,20 +598,22 @@ def run_bounded(args, torch, de, dev, cfg):
   D = 1
   (secs, med, host_s), ids, outs = time_overlapped(1)
   # per-launch durations of the same driver: HIP events on the launching stream around each of the two launches of 24 more steps
+  # (FRESH batches: re-used ones would find their never-seen ids resident by now — configs[2]'s launch timed on re-used ids showed 38 us
+  # where the windows run at 70: no evictions left)
+  kt_ids = idf.keys(24 + 3)
   ovl.time_kernels(24)
-  for c in range(24 // D):
-    ovl.make_run([ids[(c * D + q) % nsteps] for q in range(D)], [values] * D, outs, ids_after=ids[((c + 1) * D) % nsteps], values_before=values,
-                 ids_after2=ids[((c + 1) * D + 1) % nsteps])()
+  for c in range(24):
+    ovl.make_run([kt_ids[c]], [values], outs, ids_after=kt_ids[c + 1], values_before=values, ids_after2=kt_ids[c + 2])()
   ktimes = ovl.kernel_times()
   ovl.flush()
   ovl_stats = ovl.stats()
   size_after = int(table.size().item())
-  last = ids[(24 - 1) % nsteps]
+  last = kt_ids[24 - 1]
   got, ex = table.lookup(last, return_exists=True)
   verified["overlapped_step_last_batch"] = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, last, values)))
   # (the host learns that the table is dense from asynchronous size reads: the first warm-up steps may still run one op after the other)
   verified["overlapped_step_every_timed_step_overlapped"] = ovl_stats["sequential"] <= W and ovl_stats["overlapped"] >= WINDOWS * K + 24
-  del got, ex
+  del got, ex, kt_ids
   # the same driver with 4 steps per host call (a bench-only mode: the values of steps i+1..i+3 would have to exist before their
   # lookups return) — reported beside the headline, never as `value`
   D4 = 4 if K % 4 == 0 else (2 if K % 2 == 0 else 1)
