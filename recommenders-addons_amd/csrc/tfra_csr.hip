@@ -1563,20 +1563,28 @@ struct SetTab {   // one of the plan's two tables
 
 // COUNTS: also count the occurrences of every id (LFU scores without caller scores; tfra_sparse_plan_read)
 // INDEX: the occurrence-count word of a key's table entry receives the key's position in the dense list instead (tfra_unique_unordered)
-template <bool COUNTS, bool INDEX = false>
+// FUSED (tfra_unique_unordered in ONE launch, INDEX only, grids of <= 128 blocks — all co-resident on half the chip): the kernel also
+// writes the inverse index idx_out[i] = position of ids[i] in the dense list, the list itself into unique_out and — the last block to
+// finish, by ticket — its length into num_out.  A key's dense index exists once the block that INSTALLED the key has drawn its base
+// from the append counter; the other blocks holding the key poll the entry's index word (index + 1, 0 = not yet) — one poller per
+// block and distinct id (the block's ids share the answer through LDS), a wait of one atomic's round trip.
+template <bool COUNTS, bool INDEX = false, bool FUSED = false>
 __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
-                                                        unsigned* next_use_count) {
+                                                        unsigned* next_use_count, i64* __restrict__ unique_out = nullptr,
+                                                        int* __restrict__ idx_out = nullptr, i64* __restrict__ num_out = nullptr) {
+  static_assert(!FUSED || (INDEX && !COUNTS), "FUSED: the unique-with-index build");
   __shared__ i64 s_key[SP_LDS];
   __shared__ unsigned s_pos[SP_LDS + 2], s_cnt[SP_LDS + 2];
   __shared__ unsigned s_n, s_base;
   const unsigned tid = threadIdx.x;
   const unsigned n_old = *old.count;
-  if (blockIdx.x == 0 && tid == 0) *next_use_count = 0;
-  for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS) s_cnt[i] = 0; }
+  if (blockIdx.x == 0 && tid == 0) { *next_use_count = 0; next_use_count[5] = 0; }   // ([5]: the next use's ticket of a FUSED build, beside its count)
+  for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS || FUSED) s_cnt[i] = 0; }
   if (tid == 0) s_n = 0;
   __syncthreads();
   // ---- A: equal ids of the block meet in LDS ---------------------------------------------------------------
   const size_t gid = (size_t)blockIdx.x * SP_NT + tid;
+  unsigned lds_slot = 0;   // FUSED: where this thread's id sits in the block's LDS table
   if (gid < n) {
     const i64 id = ids[gid];
     unsigned slot;
@@ -1591,6 +1599,7 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
     }
     atomicMax(&s_pos[slot], (unsigned)gid + 1u);
     if (COUNTS) atomicAdd(&s_cnt[slot], 1u);
+    lds_slot = slot;
   }
   __syncthreads();
   // ---- B: the block's distinct ids into the global table: the first probes of both of a thread's keys travel together ----
@@ -1631,7 +1640,8 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
       const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
       cur.ukeys[at] = EMPTY_KEY + (i64)tid;
       cur.uslot[at] = sl;
-      if (INDEX) cur.ent[sl].cnt = at;
+      if (FUSED) { unique_out[at] = EMPTY_KEY + (i64)tid; __hip_atomic_store(&cur.ent[sl].cnt, at + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else if (INDEX) cur.ent[sl].cnt = at;
     }
   }
   __syncthreads();
@@ -1647,7 +1657,39 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
     if (!mine[r]) continue;
     cur.ukeys[s_base + myidx[r]] = mykey[r];
     cur.uslot[s_base + myidx[r]] = myslot[r];
-    if (INDEX) cur.ent[myslot[r]].cnt = s_base + myidx[r];
+    if (FUSED) { unique_out[s_base + myidx[r]] = mykey[r]; __hip_atomic_store(&cur.ent[myslot[r]].cnt, s_base + myidx[r] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    else if (INDEX) cur.ent[myslot[r]].cnt = s_base + myidx[r];
+  }
+  if (FUSED) {
+    // the dense index of every distinct id of the block -> LDS (s_cnt is free here): drawn above for the keys this block installed,
+    // polled from the entry for the others (their installer is a resident block: the grid is at most 128 blocks)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (!have[r]) continue;
+      unsigned v = mine[r] ? s_base + myidx[r] + 1u : 0u;
+      for (unsigned it = 0; !v && it < (1u << 24); ++it) {
+        v = __hip_atomic_load(&cur.ent[myslot[r]].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!v) __builtin_amdgcn_s_sleep(2);
+      }
+      s_cnt[tid + (unsigned)r * SP_NT] = v;
+    }
+    if (tid < 2 && s_pos[SP_LDS + tid] != 0) {   // a sentinel key value occurred in this block
+      unsigned v = 0;
+      for (unsigned it = 0; !v && it < (1u << 24); ++it) {
+        v = __hip_atomic_load(&cur.ent[m2 + tid].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!v) __builtin_amdgcn_s_sleep(2);
+      }
+      s_cnt[SP_LDS + tid] = v;
+    }
+    __syncthreads();
+    if (gid < n) idx_out[gid] = (int)s_cnt[lds_slot] - 1;   // (-1 only after a poll that timed out: never seen)
+    // the list's length, once every block has added its share: the last block to get here writes it
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* ticket = cur.count + 5;
+      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+        *num_out = (i64)__hip_atomic_load(cur.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -2763,9 +2805,14 @@ extern "C" int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64
   SetPlanLaunch L;
   int rc = setplan_prepare(pl, n, s, false, &L);
   if (rc) return rc;
-  setplan_kernel<false, true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count);
-  unique_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, (const i64*)ids, SetProbe{L.cur.ent, L.m2}, L.cur.ukeys, L.cur.count, (i64*)unique_out,
-                                                               idx_out, (i64*)d_num_unique);
+  if (L.blocks <= 128) {   // ONE launch (all blocks co-resident on half the chip: a block may wait for another's index)
+    setplan_kernel<false, true, true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, (i64*)unique_out, idx_out,
+                                                                 (i64*)d_num_unique);
+  } else {
+    setplan_kernel<false, true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count);
+    unique_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, (const i64*)ids, SetProbe{L.cur.ent, L.m2}, L.cur.ukeys, L.cur.count, (i64*)unique_out,
+                                                                 idx_out, (i64*)d_num_unique);
+  }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "unique_unordered: launch failed");
   return TFRA_OK;
 }

@@ -333,6 +333,11 @@ def test_overlapped_step_1e9_slots(env, cfg):
   ids = [batch(s) for s in range(steps + 2)]
   drv = de.OverlapAssignStep(t).prime(ids[0][0])
   written = {}
+  # an INDEPENDENT model of the row contents across steps (not the table itself): a sorted dictionary on the device of every key the
+  # steps have written with the row of its last write; a key no step wrote holds its closed-form pre-fill row
+  seen_k = torch.empty(0, dtype=torch.int64, device="cuda")
+  seen_v = torch.empty((0, dim), dtype=dtype, device="cuda")
+  n_from_dict = 0
   for s in range(steps):
     k, is_new = ids[s]
     vals = row_of(torch, k * 31 + (s + 1), dim, dtype) + (torch.arange(B, device="cuda")[:, None] % 5).to(dtype)   # position-dependent: WHICH occurrence is kept
@@ -342,7 +347,24 @@ def test_overlapped_step_1e9_slots(env, cfg):
     assert torch.equal(out, ref), "step %d" % s
     assert not bool(ex[is_new].any())                    # never-seen ids miss (a never-seen rank is drawn once)
     assert int(t.size().item()) <= capacity
+    want = row_of(torch, k, dim, dtype)                  # the pre-fill's row of the key ...
+    if seen_k.numel():
+      pos = torch.searchsorted(seen_k, k).clamp(max=seen_k.numel() - 1)
+      hit = seen_k[pos] == k
+      want = torch.where(hit[:, None], seen_v[pos], want)   # ... unless an earlier step wrote it: the row of its last write
+      n_from_dict += int((hit & ex).sum())
+    assert torch.equal(out[ex], want[ex]), "step %d: a present key does not hold the row of its last write" % s
+    assert bool((out[~ex] == 0).all()), "step %d: an absent key did not read the default row" % s
+    uk, inv = torch.unique(k, return_inverse=True)
+    lp = torch.zeros(uk.numel(), dtype=torch.long, device="cuda")
+    lp.scatter_reduce_(0, inv, torch.arange(B, device="cuda"), reduce="amax", include_self=False)
+    allk, allv = torch.cat([seen_k, uk]), torch.cat([seen_v, vals[lp]])
+    seen_k, inv2 = torch.unique(allk, return_inverse=True)
+    last = torch.zeros(seen_k.numel(), dtype=torch.long, device="cuda")
+    last.scatter_reduce_(0, inv2, torch.arange(allk.numel(), device="cuda"), reduce="amax", include_self=False)   # the newer entry wins
+    seen_v = allv[last]
     written[s] = (k, vals)
+  assert n_from_dict > steps * 1000                      # the hot ids recur: thousands of lookups per step were checked against earlier writes
   drv.flush()
   st = drv.stats()
   assert st["overlapped"] >= steps - 3 and st["deferred_evictions"] > 0 and st["rows_corrected"] > 0, st
