@@ -385,3 +385,44 @@ def test_overlap_all_distinct_ids(env):
   st = drv.stats()
   assert st["overlapped"] >= nsteps - 4 and st["lookups_listed"] >= nsteps - 6, st
   tbl.check_errors()
+
+
+@pytest.mark.parametrize("n", [1, 17, 63, 65, 1023, 1025])
+def test_overlap_tiny_and_ragged_batches(env, n):
+  """Batch sizes around the launch's granules (16 ids per lookup wave, 64 per block, 1024 per MAP segment / plan tile): one id, a
+  partial wave, one over a block, one under / over a segment — with repeats, the two sentinel key values and changing look-ahead."""
+  torch, de = env
+  dim, cap, nsteps = 64, 200_000, 9
+  rng = np.random.default_rng(100 + n)
+  imin = np.iinfo(np.int64).min
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  t = make_dense_table(torch, de, cap, dim, universe, "ovl_tiny_%d" % n)
+  tbl = t._table
+  latest = {int(k): float(int(k) % 1000) for k in universe}
+
+  def draw():
+    ids = universe[rng.integers(0, 40, size=n)].copy()          # forty hot ids: every batch shares most of them with the one before
+    if n > 2:
+      ids[rng.integers(0, n)] = imin
+      ids[rng.integers(0, n)] = imin + 1
+    if n > 8:
+      ids[rng.integers(0, n, size=n // 4)] = universe[rng.integers(0, universe.size, size=n // 4)]
+    return torch.from_numpy(ids).cuda()
+
+  batches = [draw() for _ in range(nsteps + 2)]
+  drv = de.OverlapAssignStep(t).prime(batches[0])
+  for s in range(nsteps):
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 1000.0 * (s + 1))[:, None].repeat(1, dim).contiguous()
+    nxt = batches[s + 1] if s % 4 != 3 else None
+    nx2 = batches[s + 2] if (nxt is not None and s % 3 != 1) else None
+    out, ex = drv.step(vals, nxt, nx2, return_exists=True)
+    if nxt is None:
+      drv.prime(batches[s + 1])
+    torch.cuda.synchronize()
+    _dict_check(torch, tbl, batches[s], out, ex, latest, ("tiny", n, s))
+    for i, k in enumerate(batches[s].cpu().numpy().tolist()):
+      latest[k] = 1000.0 * (s + 1) + i
+  drv.flush()
+  ek, ev = t.export()
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
+  tbl.check_errors()
