@@ -1095,6 +1095,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.patch_count = a.sync + 32 * 9 + 1; a.patch_count_next = a.sync_next + 32 * 9 + 1;   // (read with the tail's arrivals as one 8-byte word)
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
+    int map_slot_new = -1;
     if (list_ok) {
       a.find_list = reinterpret_cast<const uint4*>(d->mapbuf + (size_t)d->map_slot * d->map_cap * 16);
       d->n_find_listed += 1;
@@ -1114,7 +1115,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       const unsigned ms = a.find_list ? (d->map_slot ^ 1u) : 0u;
       a.map_n = (unsigned)n_next; a.map_ids = (const i64*)ids_next; a.map_blocks = (unsigned)((n_next + MAP_SEG - 1) / MAP_SEG);
       a.map_out = reinterpret_cast<uint4*>(d->mapbuf + (size_t)ms * d->map_cap * 16);
-      d->map_slot = ms; d->map_valid = true; d->map_ids = ids_next; d->map_n = n_next; d->map_plan = plan_cur; d->map_gen = plan_cur->gen;
+      map_slot_new = (int)ms;   // (the driver's record of the list is made behind the launch: an error return in between must not arm it)
     }
     // the next batch's plan: its pairs were scattered by the previous call's launch -> this launch builds the table; else a launch of its own, in front
     if (n_next) {
@@ -1161,6 +1162,9 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     }
     if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }
     if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "step_overlap: launch failed");
+    if (map_slot_new >= 0) {
+      d->map_slot = (unsigned)map_slot_new; d->map_valid = true; d->map_ids = ids_next; d->map_n = n_next; d->map_plan = plan_cur; d->map_gen = plan_cur->gen;
+    }
     if (plan_prev) step_epoch_public(t);
     d->n_overlapped += 1;
   }
