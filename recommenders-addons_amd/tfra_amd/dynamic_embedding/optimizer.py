@@ -684,9 +684,39 @@ def assign_step_driver_for(new_key_ratio):
   return "overlapped_step" if float(new_key_ratio) <= 0.25 else "look_ahead"
 
 
+class _LookAheadAssignStep:
+  """`PrefetchAssignStep` behind `OverlapAssignStep`'s call signature (prime / step(values, next_ids, next2_ids, return_exists) / flush),
+  so that code written against one driver runs on the other (assign_step_for)."""
+
+  def __init__(self, table):
+    self._ps = PrefetchAssignStep(table)
+    self._ids = None
+
+  def prime(self, ids):
+    self._ps.prime(ids)
+    self._ids = self._ps.ids[self._ps.cur]
+    return self
+
+  def step(self, values, next_ids=None, next2_ids=None, return_exists=False):
+    if self._ids is None:
+      raise RuntimeError("assign step: no batch is primed — call prime(ids) first")
+    ids = self._ids
+    if return_exists:   # the look-ahead call returns rows only: the flags come from a find of their own, in front of the write-back
+      rows, ex = self._ps.table.find(ids, return_exists=True)
+      self._ps.step(values, next_ids, lookup=False)
+    else:
+      rows, ex = self._ps.step(values, next_ids), None
+    self._ids = self._ps.ids[self._ps.cur] if next_ids is not None else None
+    return (rows, ex) if return_exists else rows
+
+  def flush(self):   # nothing is deferred: a step has written its batch back when it returns
+    pass
+
+
 def assign_step_for(table, new_key_ratio=0.0):
-  """The step driver object assign_step_driver_for() names (same prime / step / flush interface)."""
-  return OverlapAssignStep(table) if assign_step_driver_for(new_key_ratio) == "overlapped_step" else PrefetchAssignStep(table)
+  """The step driver object assign_step_driver_for() names, behind one interface: prime(ids) / step(values, next_ids, next2_ids,
+  return_exists) / flush()."""
+  return OverlapAssignStep(table) if assign_step_driver_for(new_key_ratio) == "overlapped_step" else _LookAheadAssignStep(table)
 
 
 class OverlapAssignStep:

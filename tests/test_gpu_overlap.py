@@ -426,3 +426,34 @@ def test_overlap_tiny_and_ragged_batches(env, n):
   ek, ev = t.export()
   np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
   tbl.check_errors()
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.5])
+def test_assign_step_for_picks_a_driver_by_rule_and_both_give_the_sequential_results(env, ratio):
+  """de.assign_step_for(table, new_key_ratio): the overlapped step up to a quarter never-seen ids per batch, the look-ahead driver
+  beyond — one interface, the same results (lookup i+1 sees write-back i)."""
+  torch, de = env
+  assert de.assign_step_driver_for(0.0) == de.assign_step_driver_for(0.25) == "overlapped_step" and de.assign_step_driver_for(0.26) == "look_ahead"
+  dim, cap, n, nsteps = 64, 300_000, 4000, 6
+  rng = np.random.default_rng(31)
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  t = make_dense_table(torch, de, cap, dim, universe, "ovl_rule_%d" % int(ratio * 10))
+  drv = de.assign_step_for(t, ratio)
+  assert type(drv).__name__ == ("OverlapAssignStep" if ratio <= 0.25 else "_LookAheadAssignStep")
+  latest = {int(k): float(int(k) % 1000) for k in universe}
+  batches = [torch.from_numpy(universe[(rng.zipf(1.15, size=n) * 37) % universe.size]).cuda() for _ in range(nsteps + 2)]
+  drv.prime(batches[0])
+  for s in range(nsteps):
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim).contiguous()
+    out, ex = drv.step(vals, batches[s + 1], batches[s + 2], return_exists=True)
+    torch.cuda.synchronize()
+    ids_np = batches[s].cpu().numpy()
+    want = np.array([latest.get(int(k), 0.0) for k in ids_np], np.float32)
+    exn = ex.cpu().numpy()
+    np.testing.assert_array_equal(out[:, 0].cpu().numpy()[exn], want[exn])
+    assert exn.mean() > 0.99
+    for i, k in enumerate(ids_np.tolist()):
+      latest[k] = 100000.0 * (s + 1) + i
+  drv.flush()
+  ek, ev = t.export()
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
