@@ -22,20 +22,22 @@
 // LRU-type scores on a bounded table at capacity — the metric's configuration.  Anything else takes the sequential fallback
 // inside the same entry point.
 //
-// ONE launch per step, five roles by block index (block-uniform branches; grid order = dispatch order):
+// ONE launch per step, six roles by block index (block-uniform branches; grid order = dispatch order):
 //   BUILD    one 2048-slot window of plan(i+2)'s table per block, in LDS, from the segments a SCATTER filled one launch ago
 //   SCATTER  one tile of 1024 ids of batch i+3 per block: distinct (id, last position) pairs into per-(window, tile) segments
 //            (a plan is built over two launches WITHOUT a global atomic; ids two batches ahead)
-//   OWN      write-back(i): own_batch16 over slices of plan(i)'s table, victims checked against plan(i+1)
-//   FIND     lookup(i+1) with forwarding from plan(i) / values_i
+//   MAP      (round 5) 1024 positions of the NEXT lookup per block, probed in this batch's plan and sorted by where their row will
+//            come from (forwarded / table): the next launch's lookup reads its entries instead of probing, whole waves of one kind
+//   OWN      write-back(i): own_batch16 over slices of plan(i)'s table (~40 keys per block), victims checked against plan(i+1)
+//   FIND     lookup(i+1) with forwarding from plan(i) / values_i, driven by the list the previous launch's MAP made
 //   TAIL     the last 32 blocks: wait for the OWN blocks (a counter), take the keys the pass left over (lost claims, deferred
 //            evictions) with the locked protocol, note every victim that batch i+1 looks up, and — if any — wait for the FIND
 //            blocks and correct their output rows.  Nothing a TAIL block waits for waits for anything itself.
 // One stream, no events, no host in the loop: the sequence is enqueued many steps ahead (tfra_table_steps_overlap).
-// Round-4 measurements on the metric's configuration (10^9 slots, 131 072 Zipf-1.2 ids, 22.7 K distinct): the launch 31-33 us
-// depending on the box; its roles ALONE (TFRA_STEP_ABLATE): builders 9.6 us, lookup + builders 19.8, write-back + tail 23.0 (30.6
-// while every key claimed its buckets up front and a dozen keys per step went through the tail).  27 K block-microseconds of waves that
-// wait on memory 78 % of their time, through 1280 block slots at ~70 %: DESIGN.md section 5.
+// Measurements on the metric's configuration (10^9 slots, 131 072 Zipf-1.2 ids, 22.5 K distinct): round 4 31-33 us per launch
+// (roles ALONE, TFRA_STEP_ABLATE: builders 9.6 us, lookup + builders 19.8, write-back + tail 23.0); round 5 21.3-21.5 us on average
+// under rocprofv3 — the MAP role (31.0 -> 26.0 us on one box) and 448-slot write-back slices (26.2 -> 20.8): 12 K waves that wait on
+// memory 75 % of their time, 92.4 MB of HBM traffic for 80.0 MB algorithmic; DESIGN.md sections 4.5 and 5.
 
 #ifdef TFRA_STEP_DEVICE_PART
 
@@ -984,7 +986,8 @@ static SetProbe probe_of(const tfra_sparse_plan* pl) { return SetProbe{pl->set_t
 static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 && pl->tab_state[pl->set_parity] == 2; }
 
 // variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0: 8 keys per wave in the write-back, 5 blocks per CU | 1: 4 keys | 2: 4 blocks per CU | 3: 6), 8 every plan as a launch of
-// its own, 16 time stamps, 64 the lookup reads the table's lines for every id
+// its own, 16 time stamps, 32 no MAP role (round 4's lookup), 64 the lookup reads the table's lines for every id.  TFRA_STEP_OWN_SLICE: a fixed
+// write-back slice (else sized from the batch's distinct-key count), TFRA_STEP_FIND_FIRST: lookup blocks in front of the write-back's
 static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {   // the overlapped step: one launch
   const int k = variant & 7;
   if (variant & 16) step_k_u2_t<<<grid, 256, 0, s>>>(a);
