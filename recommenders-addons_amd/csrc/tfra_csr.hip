@@ -1275,8 +1275,10 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
     // plain loads: everything written before this launch is visible, and nobody else writes a bucket this key owns
     kk[u][0] = key_line(v, b0[u])[sub];
     kk[u][1] = key_line(v, b1[u])[sub];
-    sc[u][0] = fl.spec ? (i64)score_line(v, b0[u])[sub] : 0;
-    sc[u][1] = fl.spec ? (i64)score_line(v, b1[u])[sub] : 0;
+    // (HF, the step launch: 96 % of the keys are hits, which write their score word and never read a score line — the lines are fetched
+    // below, and only by the waves that hold a key in need of a victim: 5.8 MB less random reads per launch on the metric's stream)
+    sc[u][0] = (fl.spec && !hf) ? (i64)score_line(v, b0[u])[sub] : 0;
+    sc[u][1] = (fl.spec && !hf) ? (i64)score_line(v, b1[u])[sub] : 0;
   }
   // ---- per key again, while the lines travel: count and last position from the plan record, input score ---
   if (SRC == SRC_PLAN) {
@@ -1305,7 +1307,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   }
   keep_live_u2<U>(kk, 0);
   keep_live_u2<U>(kk, 1);
-  if (fl.spec) {
+  if (fl.spec && !hf) {
     keep_live_u2<U>(sc, 0);
     keep_live_u2<U>(sc, 1);
   }
@@ -1316,8 +1318,30 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   bool flag_b0[U];   // the key goes to b1 although b0 never overflowed before: finds must go on to b1
   unsigned bxc[U];   // bucket beyond the home buckets the key was found in (it must be claimed too); ~0: none
   bool ex[U];        // ACC: the caller's exists flag
+  bool need_v[U], ovf0_u[U];   // HF: the key needs a victim (score lines fetched below); b0's overflow flag as the decision saw it
+  auto choose_victim = [&](int u, bool ovf0) {
+    u64 best_score, best_word;
+    select_victim_dpp(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word);
+    const u64 cmp = a.sp.strategy == TFRA_EVICT_EPOCHLFU ? ((a.sp.epoch << 32) | in_s[u]) : in_s[u];
+    if (fl.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
+      word[u] = best_word;
+      act[u] = 3;
+      flag_b0[u] = !ovf0 && (best_word >> 4) == b1[u];
+      if (CF) {
+        const int vsrc = gshift + (int)(best_word & 15u);
+        const i64 ka = shfl_i64(kk[u][0], vsrc), kb = shfl_i64(kk[u][1], vsrc);
+        const i64 vk = (best_word >> 4) == (u64)b1[u] ? kb : ka;
+        // (HF: nor may it be a key of THIS batch — those are written without a claim, see below)
+        if (vk != EMPTY_KEY && (hf ? set_contains_either_group(*cf, *own_plan, vk, sub, gshift) : set_contains_group(*cf, vk, sub, gshift))) {   // the next lookup wants it: deferred
+          act[u] = 0; why[u] = 3;
+          if (cf_stat && sub == 0) atomicAdd(cf_stat, 1u);
+        }
+      }
+    }
+  };
 #pragma unroll
   for (int u = 0; u < U; ++u) {
+    need_v[u] = false; ovf0_u[u] = false;
     ex[u] = ACC && __shfl((int)exreg, u * 4 + grp) != 0;
     in_s[u] = 1;
     if (!fl.lru_like) in_s[u] = (u64)shfl_i64((i64)insreg, u * 4 + grp);   // (LRU-type scores ignore the input score)
@@ -1353,26 +1377,27 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
         else if (emp1) { word[u] = (u64)b1[u] * 16 + (__ffs(emp1) - 1); act[u] = 2; flag_b0[u] = !ovf0; }
         else if (fl.spec) {
           // both home buckets full on a table that no longer walks: replace the minimum-score entry of the 30 slots
-          u64 best_score, best_word;
-          select_victim_dpp(b0[u], b1[u], kk[u], sc[u], sub, gshift, best_score, best_word);
-          const u64 cmp = a.sp.strategy == TFRA_EVICT_EPOCHLFU ? ((a.sp.epoch << 32) | in_s[u]) : in_s[u];
-          if (fl.lru_like || cmp >= best_score) {   // else: not admitted, dropped like HKV does
-            word[u] = best_word;
-            act[u] = 3;
-            flag_b0[u] = !ovf0 && (best_word >> 4) == b1[u];
-            if (CF) {
-              const int vsrc = gshift + (int)(best_word & 15u);
-              const i64 ka = shfl_i64(kk[u][0], vsrc), kb = shfl_i64(kk[u][1], vsrc);
-              const i64 vk = (best_word >> 4) == (u64)b1[u] ? kb : ka;
-              // (HF: nor may it be a key of THIS batch — those are written without a claim, see below)
-              if (vk != EMPTY_KEY && (hf ? set_contains_either_group(*cf, *own_plan, vk, sub, gshift) : set_contains_group(*cf, vk, sub, gshift))) {   // the next lookup wants it: deferred
-                act[u] = 0; why[u] = 3;
-                if (cf_stat && sub == 0) atomicAdd(cf_stat, 1u);
-              }
-            }
-          }
+          if (hf) need_v[u] = true;                   // (its score lines are not here yet: below)
+          else choose_victim(u, ovf0);
+          ovf0_u[u] = ovf0;
         } else why[u] = 2;   // a table that still walks (not at capacity / unbounded): placed further along by the general path
       }
+    }
+  }
+  if (hf && fl.spec) {
+    bool any_v = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) any_v = any_v || need_v[u];
+    if (__ballot(any_v)) {   // (wave-uniform) one more round trip, for the waves that hold a key in need of a victim
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        sc[u][0] = (i64)score_line(v, b0[u])[sub];
+        sc[u][1] = (i64)score_line(v, b1[u])[sub];
+      }
+      keep_live_u2<U>(sc, 0);
+      keep_live_u2<U>(sc, 1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (need_v[u]) choose_victim(u, ovf0_u[u]);
     }
   }
   // ---- now the claims -------------------------------------------------------------------------------------------
