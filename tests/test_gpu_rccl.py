@@ -83,7 +83,18 @@ def test_native_route_over_real_rccl(world, tmp_path):
   from oracle import optimizers as oopt
   if torch.cuda.device_count() < world:
     pytest.skip("%d GPUs needed, %d visible" % (world, torch.cuda.device_count()))
-  mp.spawn(_worker, args=(world, 29940 + world, str(tmp_path)), nprocs=world, join=True)
+  # (never wait forever for a collective that does not complete: a deadline, then the ranks are killed and the test fails)
+  ctx = mp.spawn(_worker, args=(world, 29940 + world, str(tmp_path)), nprocs=world, join=False)
+  import time
+  deadline = time.monotonic() + 300.0
+  done = False
+  while not done and time.monotonic() < deadline:
+    done = ctx.join(timeout=5.0)
+  if not done:
+    for pr in ctx.processes:
+      if pr.is_alive():
+        pr.kill()   # the exact processes started above
+    pytest.fail("the %d-rank RCCL run did not finish within 300 s" % world)
   res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
   tab = oracle.CpuTable(DIM)
   dflt = np.full(DIM, 0.5, np.float32)
