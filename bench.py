@@ -716,12 +716,12 @@ def run_bounded(args, torch, de, dev, cfg):
 
   def op_surface_fused(i):
     # what the registered fused TF ops issue (tf_ops/fused_ops_rocm.cc): TFRA>HkvHashTableEmbeddingLookup = Find of all B ids + the
-    # unique ids / inverse index for the backward pass, TFRA>HkvHashTableInsertN = Insert of the unique keys, count on the device —
+    # unique ids / inverse index for the backward pass in ONE launch (tfra_table_find_unique), TFRA>HkvHashTableInsertN = Insert of the unique keys, count on the device —
     # no host read anywhere (every output has the upper-bound shape [B])
-    _capi.check(lib.tfra_table_find(*finds[i]))
-    _capi.check(lib.tfra_unique_unordered(*uniqs2[i]))
+    _capi.check(lib.tfra_table_find_unique(*fus[i]))
     _capi.check(lib.tfra_table_insert_or_assign_n(tbl._h, B, cpin_p, P(ubuf), P(values), None, st))
 
+  fus = [(tbl._h, ws, B, P(ids[i]), P(out_buf), None, P(dflt_row), 0, P(ubuf), P(ibuf), cpin_p, st) for i in range(nsteps)]
   for i in range(W):
     op_surface_fused(i)
   secs_opfu, med_opfu, _ = timed_windows(torch, None, 1, dev, K, op_surface_fused, first=W)
@@ -928,8 +928,8 @@ def run_bounded(args, torch, de, dev, cfg):
                                   "rows) -> tfra_table_insert_or_assign_n (unique keys): Find and Insert read the count on the device and "
                                   "are enqueued BEFORE the one host read of it (tf.unique's output shape), which waits for the unique "
                                   "kernels only",
-              "value_op_surface_fused_ops": "the registered fused TF ops' call sequence (tf_ops/fused_ops_rocm.cc): tfra_table_find (B ids) + "
-                                            "tfra_unique_unordered (unique ids, inverse index, count on the device) = TFRA>HkvHashTableEmbeddingLookup, "
+              "value_op_surface_fused_ops": "the registered fused TF ops' call sequence (tf_ops/fused_ops_rocm.cc): tfra_table_find_unique = ONE launch with the find of "
+                                            "the B ids next to their de-duplication (unique ids, inverse index, count on the device) = TFRA>HkvHashTableEmbeddingLookup, "
                                             "tfra_table_insert_or_assign_n = TFRA>HkvHashTableInsertN; no host read",
               "value_op_surface_host_read_first": "the same ops with the host read in front of Find (tfra_table_find / "
                                                   "tfra_table_insert_or_assign called with the count): the calls of tf_ops/mi355x_table_ops.h",

@@ -423,6 +423,15 @@ int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* uni
 int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* unique_out,
                           int32_t* idx_out, int64_t* d_num_unique, tfra_stream_t stream);
 
+/* Find of all n ids AND tfra_unique_unordered of the same ids in ONE launch — the forward half of embedding_lookup as the fused TF op
+ * TFRA>HkvHashTableEmbeddingLookup issues it (tf_ops/fused_ops_rocm.cc; PY/dynamic_embedding_ops.py:99-117 needs the rows of every id,
+ * the distinct ids and the inverse index for the backward pass).  rows_out / exists / defaults / default_is_full as tfra_table_find,
+ * unique_out / idx_out / d_num_unique as tfra_unique_unordered; the same results as the two calls one after the other (which is what
+ * runs for n > 131072 ids or rows that are not 16-byte granules). */
+int tfra_table_find_unique(tfra_table_t* t, tfra_workspace_t* ws, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists,
+                           const void* defaults, int default_is_full, int64_t* unique_out, int32_t* idx_out,
+                           int64_t* d_num_unique, tfra_stream_t stream);
+
 /* out[idx[i],:] += in[i,:] in index order per segment is NOT guaranteed; sums are accumulated in
  * fp32 with a fixed tree per segment => deterministic. out is [num_segments, dim], zeroed here. */
 int tfra_segment_sum(tfra_workspace_t* ws, size_t n, int dim, const float* in, const int32_t* idx,

@@ -1593,22 +1593,22 @@ struct SetTab {   // one of the plan's two tables
 // finish, by ticket — its length into num_out.  A key's dense index exists once the block that INSTALLED the key has drawn its base
 // from the append counter; the other blocks holding the key poll the entry's index word (index + 1, 0 = not yet) — one poller per
 // block and distinct id (the block's ids share the answer through LDS), a wait of one atomic's round trip.
-template <bool COUNTS, bool INDEX = false, bool FUSED = false>
-__global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
-                                                        unsigned* next_use_count, i64* __restrict__ unique_out = nullptr,
-                                                        int* __restrict__ idx_out = nullptr, i64* __restrict__ num_out = nullptr) {
+template <bool COUNTS, bool INDEX, bool FUSED>
+__device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned nblk, size_t n, const i64* __restrict__ ids, unsigned m2,
+                                              const SetTab& cur, const SetTab& old, unsigned* next_use_count, i64* __restrict__ unique_out,
+                                              int* __restrict__ idx_out, i64* __restrict__ num_out) {
   static_assert(!FUSED || (INDEX && !COUNTS), "FUSED: the unique-with-index build");
   __shared__ i64 s_key[SP_LDS];
   __shared__ unsigned s_pos[SP_LDS + 2], s_cnt[SP_LDS + 2];
   __shared__ unsigned s_n, s_base;
   const unsigned tid = threadIdx.x;
   const unsigned n_old = *old.count;
-  if (blockIdx.x == 0 && tid == 0) { *next_use_count = 0; next_use_count[5] = 0; }   // ([5]: the next use's ticket of a FUSED build, beside its count)
+  if (bid == 0 && tid == 0) { *next_use_count = 0; next_use_count[5] = 0; }   // ([5]: the next use's ticket of a FUSED build, beside its count)
   for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS || FUSED) s_cnt[i] = 0; }
   if (tid == 0) s_n = 0;
   __syncthreads();
   // ---- A: equal ids of the block meet in LDS ---------------------------------------------------------------
-  const size_t gid = (size_t)blockIdx.x * SP_NT + tid;
+  const size_t gid = (size_t)bid * SP_NT + tid;
   unsigned lds_slot = 0;   // FUSED: where this thread's id sits in the block's LDS table
   if (gid < n) {
     const i64 id = ids[gid];
@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
   __syncthreads();
   if (tid == 0) s_base = s_n ? atomicAdd(cur.count, s_n) : 0u;
   // ---- C: empty the slots the previous build used in the OTHER table (while the counter add travels) -------------------
-  for (size_t i = gid; i < n_old; i += (size_t)gridDim.x * SP_NT) {
+  for (size_t i = gid; i < n_old; i += (size_t)nblk * SP_NT) {
     const unsigned sl = old.uslot[i];
     *reinterpret_cast<uint4*>(old.ent + sl) = make_uint4(0u, 0x80000000u, 0u, 0u);   // {EMPTY_KEY, 0, 0}
   }
@@ -1712,10 +1712,33 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
     __syncthreads();
     if (tid == 0) {
       unsigned* ticket = cur.count + 5;
-      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u)
         *num_out = (i64)__hip_atomic_load(cur.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+template <bool COUNTS, bool INDEX = false, bool FUSED = false>
+__global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
+                                                        unsigned* next_use_count, i64* __restrict__ unique_out = nullptr,
+                                                        int* __restrict__ idx_out = nullptr, i64* __restrict__ num_out = nullptr) {
+  setplan_block<COUNTS, INDEX, FUSED>(blockIdx.x, gridDim.x, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out);
+}
+
+// TFRA>HkvHashTableEmbeddingLookup in ONE launch (tfra_table_find_unique): the first `ublocks` blocks (<= 128: co-resident, see FUSED)
+// de-duplicate the ids — distinct ids, inverse index, count —, the blocks behind them look the SAME ids up in the table.  The
+// de-duplication waits (atomics' round trips: 85 % of its wave cycles), the lookup moves bytes: side by side they take the time of
+// the longer one instead of the sum plus a launch gap.  16 waves per block, the lookup's waves as in find_kernel.
+template <int G, bool PF1>
+__global__ __launch_bounds__(SP_NT) void find_unique_kernel(unsigned ublocks, size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
+                                                            unsigned* next_use_count, i64* __restrict__ unique_out, int* __restrict__ idx_out,
+                                                            i64* __restrict__ num_out, TableView v, unsigned char* __restrict__ rows_out,
+                                                            uint8_t* __restrict__ exists, const unsigned char* __restrict__ defaults, int full) {
+  if (blockIdx.x < ublocks) {
+    setplan_block<false, true, true>(blockIdx.x, ublocks, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out);
+    return;
+  }
+  find_wave<G, 4, G == 16, PF1>(v, n, ids, rows_out, exists, defaults, full, 0u, (blockIdx.x - ublocks) * (SP_NT / 64) + (threadIdx.x >> 6));
 }
 
 // tfra_unique_unordered, second launch: idx[i] = position of ids[i] in the plan's dense list (a probe of the plan's table);
@@ -2839,6 +2862,51 @@ extern "C" int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64
                                                                  idx_out, (i64*)d_num_unique);
   }
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "unique_unordered: launch failed");
+  return TFRA_OK;
+}
+
+// TFRA>HkvHashTableEmbeddingLookup (tf_ops/fused_ops_rocm.cc) as ONE launch: Find of all n ids (tfra_table_find's results, default fill
+// included) side by side with tfra_unique_unordered of the same ids (find_unique_kernel).  Shapes the one-launch de-duplication does
+// not take (n > 128 * 1024 ids) and rows that are not 16-byte granules go through the two calls one after the other: same results.
+extern "C" int tfra_table_find_unique(tfra_table_t* tp, tfra_workspace_t* ws, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists,
+                                      const void* defaults, int default_is_full, int64_t* unique_out, int32_t* idx_out,
+                                      int64_t* d_num_unique, tfra_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!tp || !ws || !d_num_unique) return set_error(TFRA_ERR_INVALID, "find_unique: null argument");
+  Table* t = reinterpret_cast<Table*>(tp);
+  if (t->device != ws->device) return set_error(TFRA_ERR_INVALID, "find_unique: table and workspace live on different devices");
+  bool one = n != 0 && n <= 128u * SP_NT && ids && rows_out && defaults && unique_out && idx_out;
+  if (one) {
+    const size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)rows_out | (size_t)(uintptr_t)defaults;
+    one = (x & 15) == 0;
+  }
+  if (!one) {
+    int rc = tfra_table_find(tp, n, ids, rows_out, exists, defaults, default_is_full, stream);
+    if (rc) return rc;
+    return tfra_unique_unordered(ws, n, ids, unique_out, idx_out, d_num_unique, stream);
+  }
+  std::lock_guard<std::mutex> lock(t->mu);
+  { int rc = t->enter(s); if (rc) return rc; }
+  if (!ws->uplan) {
+    tfra_sparse_plan* pl = nullptr;
+    int rc = tfra_sparse_plan_create(ws->device, &pl);
+    if (rc) return rc;
+    ws->uplan = pl;
+  }
+  tfra_sparse_plan* pl = reinterpret_cast<tfra_sparse_plan*>(ws->uplan);
+  SetPlanLaunch L;
+  int rc = setplan_prepare(pl, n, s, false, &L);
+  if (rc) return rc;
+  const TableView v = t->view_of(t->cur);
+  const unsigned fblocks = (unsigned)((n + 16 * (SP_NT / 64) - 1) / (16 * (SP_NT / 64)));   // 16 keys per wave, 16 waves per block
+  const unsigned grid = L.blocks + fblocks;
+  if (t->dense)
+    find_unique_kernel<16, true><<<grid, SP_NT, 0, s>>>(L.blocks, n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, (i64*)unique_out, idx_out,
+                                                        (i64*)d_num_unique, v, (unsigned char*)rows_out, exists, (const unsigned char*)defaults, default_is_full);
+  else
+    find_unique_kernel<16, false><<<grid, SP_NT, 0, s>>>(L.blocks, n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, (i64*)unique_out, idx_out,
+                                                         (i64*)d_num_unique, v, (unsigned char*)rows_out, exists, (const unsigned char*)defaults, default_is_full);
+  if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "find_unique: launch failed");
   return TFRA_OK;
 }
 

@@ -27,9 +27,7 @@ typedef tfra::AuxInitPod AuxInit;  // elem_bytes = sizeof(V); pattern[f] = aux_i
 // =============================== kernels ====================================================
 
 // ---- find (+ fused default fill, + exists) -------------------------------------------------
-// PF1: also put the SECOND home bucket's line of every key in flight with the first (a bounded table running
-// near capacity: most b0 lines are full and flagged, ~1/3 of the resident keys and every miss need b1, and on
-// a loaded memory round trip is ~2 us — two in flight beat two in a row).
+// (the work of a wave — 16 keys — is find_wave, tfra_device.h; PF1: both home-bucket lines of a key in flight together)
 template <int G, int U, bool WT = (G == 16), bool PF1 = false>
 __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const i64* __restrict__ keys,
                                                    unsigned char* __restrict__ out,
@@ -40,61 +38,7 @@ __global__ __launch_bounds__(256) void find_kernel(TableView v, size_t n, const 
     const long long dn = *d_n;
     n = dn < 0 ? 0 : min(n, (size_t)dn);
   }
-  const int lane = threadIdx.x & 63, sub = lane & 15, gshift = lane & 48;
-  const int grp = lane >> 4;
-  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  constexpr int KPW = 4 * U;
-  const unsigned base = wave * KPW;   // n < 2^32 (find_impl)
-  if (base >= n) return;
-  // Loads are kept UNCONDITIONAL (tail keys are clamped to the last valid index): a load inside an
-  // `if (valid)` block gets its own `s_waitcnt vmcnt(0)` and the U probes / U rows would be fetched
-  // one latency after the other instead of all in flight (measured 23 us -> 11 us per 131072 keys).
-  const unsigned last = (unsigned)n - 1;
-  // ONE LANE PER KEY for the scalar work: lane j (and j+16, j+32, j+48) holds key j of the wave's 16 and hashes it —
-  // one instruction stream for 16 keys; the groups then fetch key / b0 / b1 of "their" key by shuffle.  (Hashing per
-  // group cost 4x the instructions, and instruction issue, not HBM, is what bounds this kernel.)
-  const i64 kreg = keys[min(base + (unsigned)(lane & (KPW - 1)), last)];
-  u64 hreg;
-  const unsigned b0reg = (unsigned)bucket0(kreg, v.nb, hreg);
-  const unsigned b1reg = (unsigned)bucket1(hreg, b0reg, v.nb);
-  i64 key[U];
-  unsigned b0[U], b1[U], idx[U];
-  i64 k0[U], k1[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int j = u * 4 + grp;
-    key[u] = shfl_i64(kreg, j);
-    b0[u] = (unsigned)__shfl((int)b0reg, j);
-    b1[u] = (unsigned)__shfl((int)b1reg, j);
-    idx[u] = min(base + (unsigned)j, last);
-    k0[u] = key_line(v, b0[u])[sub];  // U probes in flight
-    k1[u] = PF1 ? key_line(v, b1[u])[sub] : 0;
-  }
-  static_assert(U == 4, "keep_live is written for U == 4");
-  keep_live(k0[0], k0[1], k0[2], k0[3]);
-  if (PF1) keep_live(k1[0], k1[1], k1[2], k1[3]);
-  const unsigned char* src[U];
-  unsigned char* dst[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const i64 word = probe_find_word(v, key[u], b0[u], b1[u], k0[u], sub, gshift, PF1 ? &k1[u] : nullptr);
-    if (exists && sub == 0) exists[idx[u]] = word >= 0;
-    src[u] = word >= 0 ? word_row_ptr(v, (u64)word) + field_off
-                       : defaults + (full ? (u64)idx[u] * (u64)v.field_bytes : 0);
-    dst[u] = out + (u64)idx[u] * (u64)v.field_bytes;
-  }
-  typedef typename Granule<G>::T T;
-  for (unsigned off = sub * G; off < v.field_bytes; off += 16 * G) {
-    T tmp[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) tmp[u] = *reinterpret_cast<const T*>(src[u] + off);  // U rows in flight
-    keep_live(tmp[0], tmp[1], tmp[2], tmp[3]);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {  // clamped tail: same bytes twice
-      if (G == 16 && WT) store_wt16(dst[u] + off, *reinterpret_cast<uint4*>(&tmp[u]));
-      else *reinterpret_cast<T*>(dst[u] + off) = tmp[u];
-    }
-  }
+  find_wave<G, U, WT, PF1>(v, n, keys, out, exists, defaults, full, field_off, (blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
 
 // ---- aux-field initialisation for a newly claimed row --------------------------------------

@@ -145,6 +145,7 @@ _SIGS = {
     "tfra_workspace_destroy": [_P],
     "tfra_unique": [_P, _SZ, _P, _P, _P, _P, _P],
     "tfra_unique_unordered": [_P, _SZ, _P, _P, _P, _P, _P],
+    "tfra_table_find_unique": [_P, _P, _SZ, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "tfra_segment_sum": [_P, _SZ, _I, _P, _P, _P, _SZ, _P, _P],
     "tfra_gather_rows": [_SZ, _SZ, _P, _P, _P, _P],
     "tfra_sparse_segment_combine": [_P, _SZ, _I, _P, _P, _P, _P, _I, _SZ, _P, _P],

@@ -194,6 +194,30 @@ class _DeviceTable:
                    _stream(self._device))
     return (out, exists) if return_exists else out
 
+  def find_unique(self, keys, dynamic_default_values=None, return_exists=False):
+    """find(keys) and the de-duplication of the same keys in ONE launch (tfra_table_find_unique: the forward half of embedding_lookup
+    as the fused TF op issues it): returns (rows [n, dim], unique [n] — the first `count` entries are the distinct keys, in no
+    particular order —, idx [n] int32 with unique[idx] == keys, count: device int64 scalar[, exists]).  Nothing is read on the host."""
+    from .device_ops import _workspace
+    keys = self._keys(keys).reshape(-1)
+    n = keys.numel()
+    d = self._default_value if dynamic_default_values is None else dynamic_default_values
+    d = torch.as_tensor(d, device=self._device) if not torch.is_tensor(d) else d.to(self._device)
+    if d.dtype != self._value_dtype:
+      raise TypeError("default values must be dtype %s, got %s" % (self._value_dtype, d.dtype))
+    d = d.contiguous()
+    out = torch.empty((n, self._dim), dtype=self._value_dtype, device=self._device)
+    full = int(out.numel() == d.numel())
+    if not full and d.numel() < self._dim:
+      raise ValueError("default value needs at least dim=%d elements, got %d" % (self._dim, d.numel()))
+    exists = torch.empty(n, dtype=torch.bool, device=self._device) if return_exists else None
+    uniq = torch.empty(n, dtype=torch.int64, device=self._device)
+    idx = torch.empty(n, dtype=torch.int32, device=self._device)
+    cnt = torch.zeros((), dtype=torch.int64, device=self._device)
+    _capi.call("tfra_table_find_unique", self._h, _workspace(self._device), n, _ptr(keys), _ptr(out), _ptr(exists), _ptr(d), full,
+               _ptr(uniq), _ptr(idx), _ptr(cnt), _stream(self._device))
+    return (out, uniq, idx, cnt, exists) if return_exists else (out, uniq, idx, cnt)
+
   def upsert(self, keys, values, scores=None, unique_keys=False, field=0):
     keys = self._keys(keys)
     values = self._values_for(keys, values)

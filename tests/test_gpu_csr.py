@@ -462,6 +462,54 @@ def test_unique_unordered_matches_numpy_as_a_set(env):
     np.testing.assert_array_equal(un[idxn], ids)
 
 
+@pytest.mark.parametrize("kind", ["bounded_dense_f32", "growing_f32", "bounded_f16_dim128", "rows_of_24_bytes"])
+def test_find_unique_equals_find_and_unique(env, kind):
+  """tfra_table_find_unique (ONE launch: the lookup of all ids next to their de-duplication — what the fused TF op
+  TFRA>HkvHashTableEmbeddingLookup issues) against tfra_table_find and numpy.unique: rows and exists flags bit-exact, the distinct ids
+  as a set with a consistent inverse index.  Sizes up and down on one workspace (the plan's two tables alternate and empty each other),
+  above 131072 ids and with rows that are not 16-byte granules the call runs the two launches one after the other — same results."""
+  torch, de, SparsePlan = env
+  rng = np.random.default_rng(5)
+  imin = np.iinfo(np.int64).min
+  dtype, dim, bounded = {"bounded_dense_f32": (torch.float32, 64, True), "growing_f32": (torch.float32, 64, False),
+                         "bounded_f16_dim128": (torch.float16, 128, True), "rows_of_24_bytes": (torch.float32, 6, True)}[kind]
+  cap = 1 << 18
+  if bounded:
+    t = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                        evict_strategy=de.HkvEvictStrategy.LRU, name="fu_" + kind)
+  else:
+    t = de.CuckooHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), device="cuda:0", dim=dim, name="fu_" + kind)
+  tbl = t._table
+  resident = np.arange(1, int(cap * 0.9) + 1, dtype=np.int64) * 7919 - 11     # a bounded table above 60 %: "dense" (both lines in flight)
+  for lo in range(0, resident.size, 1 << 16):
+    k = torch.from_numpy(resident[lo:lo + (1 << 16)]).cuda()
+    tbl.upsert(k, ((k % 1000).to(torch.float32)[:, None] + torch.arange(dim, device="cuda")[None, :] / 64.0).to(dtype), unique_keys=True)
+  tbl.upsert(torch.tensor([imin, imin + 1], device="cuda"), torch.full((2, dim), 7.0, dtype=dtype, device="cuda"), unique_keys=True)
+  one_row = torch.full((dim,), -3.0, dtype=dtype, device="cuda")
+  for n in (7, 50_000, 3, 131_072, 1000, 200_000, 131_072, 1, 17, 0):
+    ids = (rng.zipf(1.2, size=n) % max(2, n)).astype(np.int64) * 7919 - 11    # ~10 % beyond the resident range for the big sizes: misses
+    if n > 100:
+      ids[rng.integers(0, n, size=n // 40)] = imin
+      ids[rng.integers(0, n, size=n // 50)] = imin + 1
+      ids[rng.integers(0, n, size=n // 10)] = -5 - rng.integers(0, 1000, size=n // 10)   # never inserted
+      ids[n // 3: n // 2] = 5 * 7919 - 11
+    kt = torch.from_numpy(ids).cuda()
+    for full in (False, True):
+      dflt = (torch.arange(n * dim, device="cuda").reshape(n, dim) % 251).to(dtype) if (full and n) else one_row
+      rows, uniq, idx, cnt, ex = tbl.find_unique(kt, dflt, return_exists=True)
+      ref, rex = tbl.find(kt, dflt, return_exists=True)
+      assert torch.equal(ex, rex) and torch.equal(rows, ref), (kind, n, full)
+      if n > 100:
+        assert 0 < int((~ex).sum()) < n
+      want = np.unique(ids)
+      u = int(cnt.item())
+      un, idxn = uniq[:u].cpu().numpy(), idx.cpu().numpy()
+      assert u == want.size
+      np.testing.assert_array_equal(np.sort(un), want)
+      np.testing.assert_array_equal(un[idxn], ids)
+  tbl.check_errors()
+
+
 @pytest.mark.parametrize("owner_tags", [True, False])
 @pytest.mark.parametrize("driver", ["upsert_sparse", "step"])
 def test_sparse_write_back_lfu_scores_are_occurrence_counts(env, driver, owner_tags):

@@ -158,7 +158,7 @@ def test_fused_shim_binds_only_declared_abi_entry_points_and_reaches_the_fused_c
   used = set(re.findall(r"\b(tfra_[a-z_0-9]+)\(", open(SHIM_FUSED).read() + open(SHIM_COMMON).read()))
   used -= {"tfra_mi355x"}
   assert used <= declared, sorted(used - declared)
-  for fn in ("tfra_table_apply_sparse", "tfra_unique_unordered", "tfra_table_find", "tfra_table_insert_or_assign_n",
+  for fn in ("tfra_table_apply_sparse", "tfra_table_find_unique", "tfra_table_find", "tfra_table_insert_or_assign_n",
              "tfra_step_driver_create", "tfra_table_step_overlap", "tfra_table_step_overlap_flush", "tfra_workspace_create",
              "tfra_rccl_unique_id", "tfra_rccl_transport_create", "tfra_route_create", "tfra_route_feed", "tfra_route_lookup", "tfra_route_apply"):
     assert fn in used, fn

@@ -10,7 +10,8 @@
  *   TFRA>HkvHashTableEmbeddingLookup           ids [..] -> rows [.., dim], unique ids, inverse index, count: tf.unique + Find + tf.gather
  *                                              (PY/dynamic_embedding_ops.py:99-117) with NO host read in between — every output has
  *                                              the upper-bound shape [B], the count stays on the device; the rows come from ONE find of
- *                                              all B ids (repeats hit L2: cheaper than find(U) + gather(B))
+ *                                              all B ids (repeats hit L2: cheaper than find(U) + gather(B)), in the same kernel
+ *                                              launch as the de-duplication (tfra_table_find_unique)
  *   TFRA>HkvHashTableInsertN                   Insert of the first `num` of B keys (`num` a device scalar: the lookup's count)
  *   TFRA>HkvHashTableApplySparse{Sgd,Adam,Adagrad,Ftrl}
  *                                              ids WITH repeats + their gradient rows -> duplicate sums + one fused update per key on
@@ -266,7 +267,8 @@ static float HostScalar(OpKernelContext* ctx, int i) { return ctx->input(i).scal
 // ---- tf.unique + Find + tf.gather as one op, no host read (PY/dynamic_embedding_ops.py:99-117) ---------------------------
 // The reference de-duplicates BEFORE the lookup because a CPU (or HKV) find is paid per key; here a find of all B ids is one
 // 12-us kernel whose repeats hit L2, cheaper than find(U) + gather(B): values = Find(ids) directly, and the unique ids / inverse
-// index (what the backward pass and a cache-fill Insert need) come from tfra_unique_unordered next to it.  Same rows, bit for bit.
+// index (what the backward pass and a cache-fill Insert need) come from the de-duplication of the ids running IN THE SAME LAUNCH
+// (tfra_table_find_unique).  Same rows, bit for bit.
 class EmbeddingLookupOp : public OpKernel {
  public:
   using OpKernel::OpKernel;
@@ -285,10 +287,10 @@ class EmbeddingLookupOp : public OpKernel {
     tfra_workspace_t* ws = nullptr;
     OP_REQUIRES_OK(ctx, t->Workspace(&ws));
     OP_REQUIRES(ctx, dflt.NumElements() == dim, errors::InvalidArgument("EmbeddingLookup: default_value must be one row [dim]"));
-    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_find(t->raw(), static_cast<size_t>(n), In<int64_t>(ids), Out<char>(values), nullptr,
-                                                 dflt.tensor_data().data(), 0, st)));
-    OP_REQUIRES_OK(ctx, ToStatus(tfra_unique_unordered(ws, static_cast<size_t>(n), In<int64_t>(ids), Out<int64_t>(unique_ids), Out<int32_t>(idx),
-                                                       Out<int64_t>(num), st)));
+    // ONE launch: the lookup's blocks behind the de-duplication's (find_unique_kernel, csrc/tfra_csr.hip)
+    OP_REQUIRES_OK(ctx, ToStatus(tfra_table_find_unique(t->raw(), ws, static_cast<size_t>(n), In<int64_t>(ids), Out<char>(values), nullptr,
+                                                        dflt.tensor_data().data(), 0, Out<int64_t>(unique_ids), Out<int32_t>(idx),
+                                                        Out<int64_t>(num), st)));
   }
 };
 

@@ -67,7 +67,7 @@ def embedding_lookup_unique_fused(params, ids, name=None):
       embeddings_flat = array_ops.gather(unique_embeddings, idx)         # :109
 
   becomes ONE op whose outputs all have the upper-bound length B = ids.size (no host read; `num_unique` stays on the device):
-  tfra_unique_unordered + tfra_table_find_n + tfra_gather_rows.  Returns (embeddings [ids.shape + dim], unique_ids [B], idx [B],
+  tfra_table_find_unique — the lookup of all B ids and their de-duplication in one kernel launch.  Returns (embeddings [ids.shape + dim], unique_ids [B], idx [B],
   num_unique): the last three are what TrainableWrapper keeps for the backward pass (the optimizer op below takes the ids WITH
   repeats, so a graph that only trains needs `embeddings` alone)."""
   import tensorflow as tf
