@@ -426,8 +426,8 @@ int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64_t* ids, in
 /* Find of all n ids AND tfra_unique_unordered of the same ids in ONE launch — the forward half of embedding_lookup as the fused TF op
  * TFRA>HkvHashTableEmbeddingLookup issues it (tf_ops/fused_ops_rocm.cc; PY/dynamic_embedding_ops.py:99-117 needs the rows of every id,
  * the distinct ids and the inverse index for the backward pass).  rows_out / exists / defaults / default_is_full as tfra_table_find,
- * unique_out / idx_out / d_num_unique as tfra_unique_unordered; the same results as the two calls one after the other (which is what
- * runs for n > 131072 ids or rows that are not 16-byte granules). */
+ * unique_out / idx_out / d_num_unique as tfra_unique_unordered (n <= 2^18); the same results as the two calls one after the other (which
+ * is what runs for rows that are not 16-byte granules). */
 int tfra_table_find_unique(tfra_table_t* t, tfra_workspace_t* ws, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists,
                            const void* defaults, int default_is_full, int64_t* unique_out, int32_t* idx_out,
                            int64_t* d_num_unique, tfra_stream_t stream);

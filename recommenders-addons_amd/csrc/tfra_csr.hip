@@ -1593,48 +1593,58 @@ struct SetTab {   // one of the plan's two tables
 // finish, by ticket — its length into num_out.  A key's dense index exists once the block that INSTALLED the key has drawn its base
 // from the append counter; the other blocks holding the key poll the entry's index word (index + 1, 0 = not yet) — one poller per
 // block and distinct id (the block's ids share the answer through LDS), a wait of one atomic's round trip.
-template <bool COUNTS, bool INDEX, bool FUSED>
+// IPT ids per thread (1; 2 in find_unique_kernel: half the blocks — half the wave slots — for the same ids; the LDS table grows with it)
+template <bool COUNTS, bool INDEX, bool FUSED, int IPT = 1>
 __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned nblk, size_t n, const i64* __restrict__ ids, unsigned m2,
                                               const SetTab& cur, const SetTab& old, unsigned* next_use_count, i64* __restrict__ unique_out,
                                               int* __restrict__ idx_out, i64* __restrict__ num_out) {
   static_assert(!FUSED || (INDEX && !COUNTS), "FUSED: the unique-with-index build");
-  __shared__ i64 s_key[SP_LDS];
-  __shared__ unsigned s_pos[SP_LDS + 2], s_cnt[SP_LDS + 2];
+  constexpr unsigned LDSN = SP_LDS * IPT;   // slots of the block's LDS table: two per id
+  constexpr int NR = 2 * IPT;               // ... = NR per thread
+  __shared__ i64 s_key[LDSN];
+  __shared__ unsigned s_pos[LDSN + 2], s_cnt[LDSN + 2];
   __shared__ unsigned s_n, s_base;
   const unsigned tid = threadIdx.x;
   const unsigned n_old = *old.count;
   if (bid == 0 && tid == 0) { *next_use_count = 0; next_use_count[5] = 0; }   // ([5]: the next use's ticket of a FUSED build, beside its count)
-  for (unsigned i = tid; i < SP_LDS + 2; i += SP_NT) { if (i < SP_LDS) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS || FUSED) s_cnt[i] = 0; }
+  for (unsigned i = tid; i < LDSN + 2; i += SP_NT) { if (i < LDSN) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS || FUSED) s_cnt[i] = 0; }
   if (tid == 0) s_n = 0;
   __syncthreads();
   // ---- A: equal ids of the block meet in LDS ---------------------------------------------------------------
-  const size_t gid = (size_t)bid * SP_NT + tid;
-  unsigned lds_slot = 0;   // FUSED: where this thread's id sits in the block's LDS table
-  if (gid < n) {
-    const i64 id = ids[gid];
-    unsigned slot;
-    if (is_reserved_key(id)) slot = SP_LDS + (unsigned)reserved_index(id);
-    else {
-      slot = (unsigned)(fmix64((u64)id) >> 41) & (SP_LDS - 1);
-      for (;;) {
-        const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&s_key[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)id);
-        if (was == EMPTY_KEY || was == id) break;
-        slot = (slot + 1) & (SP_LDS - 1);
+  const size_t gid = (size_t)bid * SP_NT + tid;   // (phase C's start)
+  size_t gids[IPT];
+  unsigned lds_slot[IPT];   // FUSED: where each of this thread's ids sits in the block's LDS table
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    gids[q] = ((size_t)bid * IPT + q) * SP_NT + tid;
+    lds_slot[q] = 0;
+    if (gids[q] < n) {
+      const i64 id = ids[gids[q]];
+      unsigned slot;
+      if (is_reserved_key(id)) slot = LDSN + (unsigned)reserved_index(id);
+      else {
+        slot = (unsigned)(fmix64((u64)id) >> 41) & (LDSN - 1);
+        for (;;) {
+          const i64 was = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&s_key[slot]), (unsigned long long)EMPTY_KEY, (unsigned long long)id);
+          if (was == EMPTY_KEY || was == id) break;
+          slot = (slot + 1) & (LDSN - 1);
+        }
       }
+      atomicMax(&s_pos[slot], (unsigned)gids[q] + 1u);
+      if (COUNTS) atomicAdd(&s_cnt[slot], 1u);
+      lds_slot[q] = slot;
     }
-    atomicMax(&s_pos[slot], (unsigned)gid + 1u);
-    if (COUNTS) atomicAdd(&s_cnt[slot], 1u);
-    lds_slot = slot;
   }
   __syncthreads();
   // ---- B: the block's distinct ids into the global table: the first probes of both of a thread's keys travel together ----
-  i64 mykey[2];
-  unsigned myslot[2], myidx[2], p1[2], cn[2];
-  bool have[2], mine[2] = {false, false};
-  i64 was[2];
+  i64 mykey[NR];
+  unsigned myslot[NR], myidx[NR], p1[NR], cn[NR];
+  bool have[NR], mine[NR];
+  i64 was[NR];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const unsigned s = tid + (unsigned)r * SP_NT;   // 2048 hash slots; the two sentinel slots ride with threads 0 and 1 below
+  for (int r = 0; r < NR; ++r) {
+    const unsigned s = tid + (unsigned)r * SP_NT;   // 2048 hash slots per id of a thread; the two sentinel slots ride with threads 0 and 1 below
+    mine[r] = false;
     mykey[r] = s_key[s];
     p1[r] = s_pos[s]; cn[r] = COUNTS ? s_cnt[s] : 0u;
     have[r] = p1[r] != 0;
@@ -1643,7 +1653,7 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
     if (have[r]) was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
   }
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < NR; ++r) {
     if (have[r]) {
       for (;;) {
         if (was[r] == EMPTY_KEY) { mine[r] = true; break; }
@@ -1656,11 +1666,11 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
     }
     myidx[r] = mine[r] ? atomicAdd(&s_n, 1u) : 0u;
   }
-  if (tid < 2 && s_pos[SP_LDS + tid] != 0) {   // a sentinel key value occurred in this block
+  if (tid < 2 && s_pos[LDSN + tid] != 0) {   // a sentinel key value occurred in this block
     const unsigned sl = m2 + tid;
     const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[sl].key), (unsigned long long)EMPTY_KEY, 1ULL);
-    atomicMax(&cur.ent[sl].pos1, s_pos[SP_LDS + tid]);
-    if (COUNTS) atomicAdd(&cur.ent[sl].cnt, s_cnt[SP_LDS + tid]);
+    atomicMax(&cur.ent[sl].pos1, s_pos[LDSN + tid]);
+    if (COUNTS) atomicAdd(&cur.ent[sl].cnt, s_cnt[LDSN + tid]);
     if (w == EMPTY_KEY) {
       const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
       cur.ukeys[at] = EMPTY_KEY + (i64)tid;
@@ -1678,7 +1688,7 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < NR; ++r) {
     if (!mine[r]) continue;
     cur.ukeys[s_base + myidx[r]] = mykey[r];
     cur.uslot[s_base + myidx[r]] = myslot[r];
@@ -1689,7 +1699,7 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
     // the dense index of every distinct id of the block -> LDS (s_cnt is free here): drawn above for the keys this block installed,
     // polled from the entry for the others (their installer is a resident block: the grid is at most 128 blocks)
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
       if (!have[r]) continue;
       unsigned v = mine[r] ? s_base + myidx[r] + 1u : 0u;
       for (unsigned it = 0; !v && it < (1u << 24); ++it) {
@@ -1698,16 +1708,18 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
       }
       s_cnt[tid + (unsigned)r * SP_NT] = v;
     }
-    if (tid < 2 && s_pos[SP_LDS + tid] != 0) {   // a sentinel key value occurred in this block
+    if (tid < 2 && s_pos[LDSN + tid] != 0) {   // a sentinel key value occurred in this block
       unsigned v = 0;
       for (unsigned it = 0; !v && it < (1u << 24); ++it) {
         v = __hip_atomic_load(&cur.ent[m2 + tid].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!v) __builtin_amdgcn_s_sleep(2);
       }
-      s_cnt[SP_LDS + tid] = v;
+      s_cnt[LDSN + tid] = v;
     }
     __syncthreads();
-    if (gid < n) idx_out[gid] = (int)s_cnt[lds_slot] - 1;   // (-1 only after a poll that timed out: never seen)
+#pragma unroll
+    for (int q = 0; q < IPT; ++q)
+      if (gids[q] < n) idx_out[gids[q]] = (int)s_cnt[lds_slot[q]] - 1;   // (-1 only after a poll that timed out: never seen)
     // the list's length, once every block has added its share: the last block to get here writes it
     __syncthreads();
     if (tid == 0) {
@@ -1729,13 +1741,13 @@ __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __r
 // de-duplicate the ids — distinct ids, inverse index, count —, the blocks behind them look the SAME ids up in the table.  The
 // de-duplication waits (atomics' round trips: 85 % of its wave cycles), the lookup moves bytes: side by side they take the time of
 // the longer one instead of the sum plus a launch gap.  16 waves per block, the lookup's waves as in find_kernel.
-template <int G, bool PF1>
+template <int G, bool PF1, int FU_IPT>
 __global__ __launch_bounds__(SP_NT) void find_unique_kernel(unsigned ublocks, size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
                                                             unsigned* next_use_count, i64* __restrict__ unique_out, int* __restrict__ idx_out,
                                                             i64* __restrict__ num_out, TableView v, unsigned char* __restrict__ rows_out,
                                                             uint8_t* __restrict__ exists, const unsigned char* __restrict__ defaults, int full) {
   if (blockIdx.x < ublocks) {
-    setplan_block<false, true, true>(blockIdx.x, ublocks, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out);
+    setplan_block<false, true, true, FU_IPT>(blockIdx.x, ublocks, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out);
     return;
   }
   find_wave<G, 4, G == 16, PF1>(v, n, ids, rows_out, exists, defaults, full, 0u, (blockIdx.x - ublocks) * (SP_NT / 64) + (threadIdx.x >> 6));
@@ -2867,7 +2879,7 @@ extern "C" int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64
 
 // TFRA>HkvHashTableEmbeddingLookup (tf_ops/fused_ops_rocm.cc) as ONE launch: Find of all n ids (tfra_table_find's results, default fill
 // included) side by side with tfra_unique_unordered of the same ids (find_unique_kernel).  Shapes the one-launch de-duplication does
-// not take (n > 128 * 1024 ids) and rows that are not 16-byte granules go through the two calls one after the other: same results.
+// not take (rows that are not 16-byte granules) go through the two calls one after the other: same results.
 extern "C" int tfra_table_find_unique(tfra_table_t* tp, tfra_workspace_t* ws, size_t n, const int64_t* ids, void* rows_out, uint8_t* exists,
                                       const void* defaults, int default_is_full, int64_t* unique_out, int32_t* idx_out,
                                       int64_t* d_num_unique, tfra_stream_t stream) {
@@ -2875,7 +2887,7 @@ extern "C" int tfra_table_find_unique(tfra_table_t* tp, tfra_workspace_t* ws, si
   if (!tp || !ws || !d_num_unique) return set_error(TFRA_ERR_INVALID, "find_unique: null argument");
   Table* t = reinterpret_cast<Table*>(tp);
   if (t->device != ws->device) return set_error(TFRA_ERR_INVALID, "find_unique: table and workspace live on different devices");
-  bool one = n != 0 && n <= 128u * SP_NT && ids && rows_out && defaults && unique_out && idx_out;
+  bool one = n != 0 && n <= MAX_IDS && n <= 256u * SP_NT && ids && rows_out && defaults && unique_out && idx_out;
   if (one) {
     const size_t x = (size_t)t->field_bytes | (size_t)(uintptr_t)rows_out | (size_t)(uintptr_t)defaults;
     one = (x & 15) == 0;
@@ -2899,13 +2911,17 @@ extern "C" int tfra_table_find_unique(tfra_table_t* tp, tfra_workspace_t* ws, si
   if (rc) return rc;
   const TableView v = t->view_of(t->cur);
   const unsigned fblocks = (unsigned)((n + 16 * (SP_NT / 64) - 1) / (16 * (SP_NT / 64)));   // 16 keys per wave, 16 waves per block
-  const unsigned grid = L.blocks + fblocks;
-  if (t->dense)
-    find_unique_kernel<16, true><<<grid, SP_NT, 0, s>>>(L.blocks, n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, (i64*)unique_out, idx_out,
-                                                        (i64*)d_num_unique, v, (unsigned char*)rows_out, exists, (const unsigned char*)defaults, default_is_full);
-  else
-    find_unique_kernel<16, false><<<grid, SP_NT, 0, s>>>(L.blocks, n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, (i64*)unique_out, idx_out,
-                                                         (i64*)d_num_unique, v, (unsigned char*)rows_out, exists, (const unsigned char*)defaults, default_is_full);
+  // one id per thread of a de-duplicating block up to 131072 ids, two above (<= 128 blocks either way).  Two everywhere (TFRA_FU_IPT=2, tuning)
+  // makes this launch 0.3 us shorter and the Insert that follows 1.4 us longer (same box, twice): the order of the distinct ids changes
+  static const int ipt_env = [] { const char* e = getenv("TFRA_FU_IPT"); return e ? atoi(e) : 0; }();
+  const int ipt = ipt_env == 1 || ipt_env == 2 ? ipt_env : (n <= 128u * SP_NT ? 1 : 2);
+  const unsigned ublocks = (unsigned)((n + SP_NT * ipt - 1) / (SP_NT * ipt));   // <= 128: co-resident whatever the find's blocks do
+  const unsigned grid = ublocks + fblocks;
+#define FU_LAUNCH(PF1, IPT) find_unique_kernel<16, PF1, IPT><<<grid, SP_NT, 0, s>>>(ublocks, n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, \
+    (i64*)unique_out, idx_out, (i64*)d_num_unique, v, (unsigned char*)rows_out, exists, (const unsigned char*)defaults, default_is_full)
+  if (t->dense) { if (ipt == 1) FU_LAUNCH(true, 1); else FU_LAUNCH(true, 2); }
+  else { if (ipt == 1) FU_LAUNCH(false, 1); else FU_LAUNCH(false, 2); }
+#undef FU_LAUNCH
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "find_unique: launch failed");
   return TFRA_OK;
 }
