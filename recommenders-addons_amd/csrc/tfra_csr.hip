@@ -1590,7 +1590,7 @@ struct SetTab {   // one of the plan's two tables
 // INDEX: the occurrence-count word of a key's table entry receives the key's position in the dense list instead (tfra_unique_unordered)
 // FUSED (tfra_unique_unordered in ONE launch, INDEX only, grids of <= 128 blocks — all co-resident on half the chip): the kernel also
 // writes the inverse index idx_out[i] = position of ids[i] in the dense list, the list itself into unique_out and — the last block to
-// finish, by ticket — its length into num_out.  A key's dense index exists once the block that INSTALLED the key has drawn its base
+// add its share — its length into num_out.  A key's dense index exists once the block that INSTALLED the key has drawn its base
 // from the append counter; the other blocks holding the key poll the entry's index word (index + 1, 0 = not yet) — one poller per
 // block and distinct id (the block's ids share the answer through LDS), a wait of one atomic's round trip.
 // IPT ids per thread (1; 2 in find_unique_kernel: half the blocks — half the wave slots — for the same ids; the LDS table grows with it)
@@ -1606,7 +1606,7 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
   __shared__ unsigned s_n, s_base;
   const unsigned tid = threadIdx.x;
   const unsigned n_old = *old.count;
-  if (bid == 0 && tid == 0) { *next_use_count = 0; next_use_count[5] = 0; }   // ([5]: the next use's ticket of a FUSED build, beside its count)
+  if (bid == 0 && tid == 0) *next_use_count = 0;
   for (unsigned i = tid; i < LDSN + 2; i += SP_NT) { if (i < LDSN) s_key[i] = EMPTY_KEY; s_pos[i] = 0; if (COUNTS || FUSED) s_cnt[i] = 0; }
   if (tid == 0) s_n = 0;
   __syncthreads();
@@ -1680,7 +1680,21 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
     }
   }
   __syncthreads();
-  if (tid == 0) s_base = s_n ? atomicAdd(cur.count, s_n) : 0u;
+  if (tid == 0) {
+    if (FUSED) {
+      // the block's share and its ARRIVAL in one 64-bit add — the word in front of the count (always 0 otherwise: CsrKeys::d_counts[0])
+      // counts the blocks: the last one to arrive sees the others' shares in the value returned and knows the list's length there
+      // and then (a ticket of its own at the end of the kernel was one more round trip); it leaves the word at 0 again
+      const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long*>(cur.count - 1), ((unsigned long long)s_n << 32) | 1ULL);
+      s_base = (unsigned)(r >> 32);
+      if ((unsigned)r == nblk - 1u) {
+        *num_out = (i64)(s_base + s_n);
+        __hip_atomic_store(cur.count - 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      s_base = s_n ? atomicAdd(cur.count, s_n) : 0u;
+    }
+  }
   // ---- C: empty the slots the previous build used in the OTHER table (while the counter add travels) -------------------
   for (size_t i = gid; i < n_old; i += (size_t)nblk * SP_NT) {
     const unsigned sl = old.uslot[i];
@@ -1720,13 +1734,6 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
 #pragma unroll
     for (int q = 0; q < IPT; ++q)
       if (gids[q] < n) idx_out[gids[q]] = (int)s_cnt[lds_slot[q]] - 1;   // (-1 only after a poll that timed out: never seen)
-    // the list's length, once every block has added its share: the last block to get here writes it
-    __syncthreads();
-    if (tid == 0) {
-      unsigned* ticket = cur.count + 5;
-      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u)
-        *num_out = (i64)__hip_atomic_load(cur.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 
