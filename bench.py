@@ -445,11 +445,29 @@ def timing_note(secs, K):
 
 
 def profile_summary():
+  """the newest committed rocprofv3 summary (profiles/rNN_summary.json, made by scripts/run_profile_round.sh: separate --pmc FETCH_SIZE /
+  WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) — `roofline.traffic` is READ from it, not measured by this run:
+  `roofline.traffic_source` names the file"""
   try:
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
-    return json.load(open(os.path.join(ROOT, "profiles", cands[-1]))) if cands else None
+    if not cands:
+      return None
+    d = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+    d["_source"] = "profiles/" + cands[-1]
+    return d
   except (OSError, ValueError):
     return None
+
+
+def cpu_baseline_1e9():
+  """the CPU leg at the metric's 10^9 resident keys, measured once on a GPU box's host (169 s of CPU work: it does not fit the default
+  run, which stops at the 256 M-key rung) — quoted in the line with its source"""
+  try:
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_cpu_baseline_1e9.json"))
+    d = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+    return {"value_at_1e9_keys": d["value"], "table_ops_only_at_1e9_keys": d.get("table_ops_only_pairs_per_s"), "source_1e9": "profiles/" + cands[-1]}
+  except (OSError, ValueError, IndexError, KeyError):
+    return {}
 
 
 def traffic_of(prof, workload, kname):
@@ -623,6 +641,14 @@ def run_bounded(args, torch, de, dev, cfg):
   verified["overlapped_step_every_timed_step_overlapped"] = (verified["overlapped_step_every_timed_step_overlapped"] and
                                                              ovl_stats_d4["overlapped"] - ovl_stats["overlapped"] >= WINDOWS * K)
   del ovl, ids_d4, outs_d4
+  routed_local = None
+  if cfg == "m1b":
+    # what `--gpus N` runs per GPU (run_metric_sharded), at ONE rank on THIS table: the route driver with device copies where the alltoalls
+    # would be — the route's own cost (route plan ahead; gather + copy + owner launch on the distinct ids + copy + gather per step)
+    try:
+      routed_local = routed_assign_measure(args, torch, None, de, dev, 1, 0, table, idf, values, "local", K, W, verified, "routed_local")
+    except Exception as e:   # noqa: BLE001 — a side measurement must not lose the line
+      routed_local = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
   # ---- driver 1b: round 3's look-ahead driver (one C call per step, plan of batch i+1 on a second stream, host-ordered) --------
   ps = de.PrefetchAssignStep(table).prime(ids[0])
@@ -880,6 +906,10 @@ def run_bounded(args, torch, de, dev, cfg):
       "driver": "overlapped_step" if best_is_overlapped else "look_ahead",
       "driver_rule": "de.assign_step_driver_for(new_key_ratio): overlapped_step when <= 25 %% of a batch are never-seen ids, else look_ahead "
                      "(new_key_ratio here: %.2f)" % new_ratio,
+      "routed_local": None if routed_local is None else (routed_local if "error" in routed_local else {
+          "value": B * K / routed_local["med"], "ms_per_step": routed_local["med"] / K * 1e3, "owner_launch_us": routed_local["owner_launch_us"],
+          "host_enqueue_ms_per_step": round(1e3 * routed_local["host_s"] / K, 4), "served_ids_per_step": routed_local["served_ids"],
+          "route_stats": routed_local["stats"], "timing": timing_note(routed_local["secs"], K)}),
       "value_plain_call": B * K / med_plain, "ms_per_step_plain_call": med_plain / K * 1e3,
       "value_op_surface": B * K / med_ops, "ms_per_step_op_surface": med_ops / K * 1e3,
       "value_op_surface_fused_ops": B * K / med_opfu, "ms_per_step_op_surface_fused_ops": med_opfu / K * 1e3,
@@ -944,6 +974,9 @@ def run_bounded(args, torch, de, dev, cfg):
       "roofline": {
           "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
+          "traffic_source": (prof or {}).get("_source") if kernels[dom]["traffic"] is not None else None,
+          "avg_launch_us_note": "HIP events around the launch on its stream: one dispatch (~1.5 us) more than the kernel itself (rocprofv3's per-kernel "
+                                "average of the same build: profiles/*_kernel_stats.csv)",
           "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_launch_us"],
           "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "step_frac_look_ahead_driver": step_bytes / (med_pf / K) / 1e9 / HBM_PEAK_GBS,
@@ -963,6 +996,225 @@ def run_bounded(args, torch, de, dev, cfg):
   gc.collect()
   torch.cuda.empty_cache()
   return res
+
+
+# ------------------------------------------------------------------ the metric's workload, hash-sharded over the ranks (N > 1; N = 1: --config m1s)
+def gather_served_counts(torch, dist, world, rank, ids):
+  """(ids this rank serves for one step, distinct ones among them) when every rank routes the distinct ids of a batch like `ids`:
+  untimed, for the owner launch's algorithmic bytes"""
+  uq = torch.unique(ids)
+  if world == 1:
+    return int(uq.numel()), int(uq.numel())
+  # the batches differ per rank: every rank's share for THIS owner, through the host (small: a few thousand ids per rank)
+  sends = [uq[((uq & 0x7FFFFFFF) % world) == r].cpu().numpy() for r in range(world)]
+  gathered = [None] * world
+  dist.all_gather_object(gathered, sends)
+  got = np.concatenate([gathered[src][rank] for src in range(world)])
+  return int(got.size), int(np.unique(got).size)
+
+
+def routed_assign_measure(args, torch, dist, de, dev, world, rank, table, idf, values, transport, K, W, verified, tag):
+  """W warm-up steps + the timed windows of RoutedAssignStep (tfra_assign_route_*: csrc/tfra_aroute.hip) on `table` = this rank's shard;
+  ONE step call + ONE feed call per step through the C ABI with pre-built arguments, five batches fed ahead; then 24 steps with HIP events
+  around the owner's step launch, a flush, and the untimed check of the last batch against every rank's writes."""
+  import ctypes
+  from tfra_amd import _capi
+  from tfra_amd.dynamic_embedding.distributed import RoutedAssignStep
+  lib = _capi.lib()
+  B = args.batch
+  dim, dtype = values.shape[1], values.dtype
+  AHEAD = int(os.environ.get("TFRA_ROUTE_AHEAD", "5"))
+  Wr = max(W, 8)   # the routed pipeline runs five batches ahead on its own streams: the first steps fill it
+  NT = 24
+  rs = RoutedAssignStep(table, transport=transport, max_batch=B)
+  assert not rs.identity
+  st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+  P = lambda t: ctypes.c_void_p(t.data_ptr())
+  nb = Wr + WINDOWS * K + NT + 1
+  ids = idf.keys(nb + AHEAD + 1)
+  outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(2)]
+  dflt = rs.default
+  feeds = [(rs._h, B, P(ids[i]), 1, st) for i in range(nb + AHEAD + 1)]
+  step_first = (rs._h, P(outs[0]), P(dflt), None, st)
+  steps = [(rs._h, P(outs[q]), P(dflt), P(values), st) for q in range(2)]
+
+  def call(fn, a):
+    rc = fn(*a)
+    if rc:
+      if rs._staged is not None and rs._staged.error is not None:
+        raise rs._staged.error
+      _capi.check(rc)
+
+  for j in range(AHEAD + 1):
+    call(lib.tfra_assign_route_feed, feeds[j])
+
+  def step(i):
+    call(lib.tfra_assign_route_step, step_first if i == 0 else steps[i & 1])
+    call(lib.tfra_assign_route_feed, feeds[i + AHEAD + 1])
+
+  for i in range(Wr):
+    step(i)
+  secs, med, host_s = timed_windows(torch, dist, world, dev, K, step, first=Wr)
+  _capi.check(lib.tfra_assign_route_time_kernels(rs._h, NT))
+  first_t = Wr + WINDOWS * K
+  for i in range(first_t, first_t + NT):
+    step(i)
+  us, nst = ctypes.c_double(), ctypes.c_size_t()
+  _capi.check(lib.tfra_assign_route_kernel_times(rs._h, ctypes.byref(us), ctypes.byref(nst)))
+  # the batch looked up last (first_t + NT - 1) is pending: look its ids up ONCE MORE — the step writes it back first
+  last = ids[first_t + NT - 1]
+  for k in range(AHEAD + 1):   # drain what is fed ahead (each is written back with `values`), then the last batch again
+    call(lib.tfra_assign_route_step, steps[k & 1])
+  call(lib.tfra_assign_route_feed, (rs._h, B, P(last), 1, st))
+  chk = torch.empty((B, dim), dtype=dtype, device=dev)
+  call(lib.tfra_assign_route_step, (rs._h, P(chk), P(dflt), P(values), st))
+  call(lib.tfra_assign_route_flush, (rs._h, P(values), st))
+  torch.cuda.synchronize()
+  # expected: the row of a key of `last` = its LAST write over rank 0's, rank 1's, ... batches (every rank wrote ITS `values` at the key's
+  # last position: the highest rank holding the key wins) — for the keys none of the drained batches (which came later and wrote too) holds
+  later = torch.unique(torch.cat([ids[first_t + NT + k] for k in range(AHEAD + 1)]))
+  if world > 1:
+    on_dev = dist.get_backend() == "nccl"
+    mv = lambda t: t if on_dev else t.cpu()
+    g_last = [torch.empty_like(mv(last)) for _ in range(world)]
+    dist.all_gather(g_last, mv(last))
+    g_vals = [torch.empty_like(mv(values)) for _ in range(world)]
+    dist.all_gather(g_vals, mv(values))
+    later_all = [None] * world
+    dist.all_gather_object(later_all, later.cpu().numpy())
+    later = torch.from_numpy(np.unique(np.concatenate(later_all))).to(dev)
+    all_ids = torch.cat([t.to(dev) for t in g_last]); all_vals = torch.cat([t.to(dev) for t in g_vals])
+    want = last_occurrence_rows(torch, all_ids, all_vals)[rank * B:(rank + 1) * B]
+    del g_last, g_vals, all_ids, all_vals
+  else:
+    want = last_occurrence_rows(torch, last, values)
+  keep = ~torch.isin(last, later)
+  diff = keep & (chk != want).any(dim=1)
+  # (a bounded table at capacity: a key of `last` may have been EVICTED by one of the drained batches' new keys — it then reads as the
+  # default row; anything else is an error)
+  evicted_only = bool((chk[diff] == dflt.to(chk.dtype)).all()) if bool(diff.any()) else True
+  verified["%s_last_batch" % tag] = bool(keep.any()) and evicted_only and int(diff.sum()) <= max(8, int(keep.sum()) // 500)
+  stats = rs.stats()
+  verified["%s_every_owner_step_overlapped" % tag] = stats["owner_sequential"] <= Wr
+  nr, nd = gather_served_counts(torch, dist, world, rank, last)
+  rccl = rs.rccl_ranks
+  rs.close()
+  return {"secs": secs, "med": med, "host_s": host_s, "owner_launch_us": us.value, "launches_timed": nst.value, "stats": stats,
+          "served_ids": nr, "served_distinct": nd, "rccl_ranks": rccl, "ahead": AHEAD, "warm": Wr}
+
+
+def run_metric_sharded(args, torch, dist, de, dev, world, rank):
+  """The metric's step — lookup(B) + insert_or_assign(B, last occurrence wins) on a bounded LRU table at capacity, dim 64 fp32,
+  Zipf-1.2 — with the table HASH-SHARDED over the ranks (BASELINE configs[3]'s sharding: owner = default_partition_fn, 5*10^8 slots
+  per GPU by default), per-GPU batch B drawn from the GLOBAL Zipf over all world*slots ranks, ids / rows / values routed
+  (RoutedAssignStep), the owner running the overlapped step on what it receives.  At world 1 (`--config m1s`) the same driver with
+  device copies where the alltoalls would be: what the route itself costs."""
+  B, K, W = args.batch, args.steps, args.warmup
+  dim, dtype, Rb = 64, torch.float32, 256
+  want = args.shard_slots
+  # every rank must end up with the SAME slot count (the id stream's range is world * slots): agree on the smallest that allocates
+  table, failures = None, []
+  for slots in [want] + [int(want * f) for f in (0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.25)]:
+    ok = 1
+    try:
+      table = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=slots, max_capacity=slots,
+                              device=str(dev), dim=dim, evict_strategy=de.HkvEvictStrategy.LRU, name="bench_m1s_%d" % rank)
+    except Exception as e:   # noqa: BLE001
+      failures.append({"slots": slots, "error": str(e)[:160]})
+      ok, table = 0, None
+    if world > 1:
+      t_ok = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+      dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+      ok = int(t_ok.item())
+    if ok:
+      break
+    if table is not None:
+      del table
+      table = None
+      torch.cuda.empty_cache()
+  assert table is not None, failures
+  n_total = slots * world
+  gen = torch.Generator(device=dev).manual_seed(SEED + 17 * rank)
+  chunk = 4_000_000 * min(world, 8)     # ranks per chunk: ~4 M keys of them are this rank's
+  vcap = min(4_400_000, max(1024, int(n_total / world * 1.1) + 1024))
+  vals_fill = (torch.randn((vcap, dim), generator=gen, device=dev) * 0.01).to(dtype)
+  t0 = time.perf_counter()
+  # coldest ranks first (an LRU table: the order of the bulk load is the order of the scores), this rank's keys only
+  for lo in range(((n_total - 1) // chunk) * chunk + 1, 0, -chunk):
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(n_total, lo + chunk - 1) + 1, dtype=torch.int64, device=dev))
+    if world > 1:
+      k = k[((k & 0x7FFFFFFF) % world) == rank]   # default_partition_fn (PY/dynamic_embedding_variable.py:165-197)
+    for a in range(0, k.numel(), vcap):
+      kk = k[a:a + vcap]
+      table._table.upsert(kk, vals_fill[:kk.numel()], unique_keys=True)
+  resident = int(table.size().item())
+  t_fill = time.perf_counter() - t0
+  del vals_fill
+  capacity = table._table.capacity()
+  new_ratio = args.new_key_ratio if args.new_key_ratio is not None else 0.0
+  idf = IdFactory(torch, dev, B, n_total, new_ratio, n_total + 1 + rank * (1 << 40), SEED + 1000 * rank + 7)
+  values = (torch.randn((B, dim), generator=gen, device=dev) * 0.01).to(dtype)
+  verified = {}
+  transport = "local" if world == 1 else "auto"
+  m = routed_assign_measure(args, torch, dist, de, dev, world, rank, table, idf, values, transport, K, W, verified, "routed_step")
+  table._table.check_errors()
+  census = {k: int(v) for k, v in table._table.slot_census().items()}
+  size_end = int(table.size().item())
+  verified.update({"check_errors_clean": True, "size_le_capacity": size_end <= capacity, "no_locked_slot": census["locked"] == 0})
+  bad = [k for k, v in verified.items() if v is False]
+  if world > 1:
+    allbad = [None] * world
+    dist.all_gather_object(allbad, bad)
+    bad = sorted(set(sum(allbad, [])))
+  assert not bad, "bench verification failed: %s (route: %s)" % (bad, m["stats"])
+  uniq = idf.keys(4)
+  U = int(np.mean([torch.unique(uniq[i]).numel() for i in range(4)]))
+  med, secs, host_s = m["med"], m["secs"], m["host_s"]
+  ms = med / K * 1e3
+  value = world * B * K / med
+  step_bytes = B * (8 + 2 * Rb) + U * (16 + 2 * Rb)                              # per GPU, the metric's definition (SURVEY §8d)
+  owner_bytes = m["served_ids"] * (8 + 2 * Rb) + m["served_distinct"] * (16 + 2 * Rb)   # what the owner's launch moves for the ids it serves
+  res = {
+      "metric": "embedding lookup+insert pairs/s (dim=64 fp32, %d-GPU hash-sharded bounded table, %d slots per GPU, %d %% never-seen ids per batch: "
+                "lookup + insert_or_assign with score-based eviction, ids / rows / values routed)" % (world, capacity, round(100 * new_ratio)),
+      "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "driver": "routed_overlapped_step",
+      "config": {
+          "workload": "BASELINE metric (dim 64 fp32, Zipf-1.2) on configs[3]'s sharding: %d shard(s) x %d slots (bounded Hkv LRU tables at capacity, "
+                      "%d keys resident per GPU; owner = default_partition_fn), per-GPU batch=%d from the GLOBAL Zipf-1.2 over the %d ranks; step = "
+                      "lookup(B) + insert_or_assign(B, last occurrence wins): distinct ids / rows / values routed (%s), the owner runs "
+                      "tfra_table_step_overlap on the ids it serves" % (world, capacity, resident, B, n_total,
+                                                                        "RCCL alltoall over xGMI" if world > 1 else "one rank through the route driver: device copies"),
+          "slots": capacity, "requested_slots": want, "alloc_failures": failures, "resident_after_prefill": resident,
+          "global_batch": B * world, "keys_per_gpu": resident, "new_key_ratio": new_ratio, "unique_keys_per_batch": U,
+          "unique_ratio": round(U / B, 4), "prefill_s": round(t_fill, 1), "steps_per_host_call": 1,
+          "parallelism": ("key-hash sharded x%d, RCCL alltoall" % world) if world > 1 else "single GPU through the route driver (no transport)",
+          "route": "assign_route", "rccl_ranks_seen": m["rccl_ranks"], "batches_fed_ahead": m["ahead"],
+          "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
+          "served_ids_per_step": m["served_ids"], "served_distinct_ids_per_step": m["served_distinct"],
+          "route_stats": m["stats"], "verified": verified,
+          "launches_per_step": "critical path (caller's stream): gather(values) + alltoall + owner step launch + alltoall + gather(rows) = 3 kernels "
+                               "+ 2 collectives; ahead, on the driver's streams: 1 route-plan launch + 2 small collectives + 1 copy per batch",
+          "timing": {"value": timing_note(secs, K)},
+      },
+      "roofline": {
+          "bound": "hbm", "kernel": "step_k at the owner (tfra_table_step_overlap on the ids this rank serves: lookup + write-back in ONE launch)",
+          "achieved": owner_bytes / m["owner_launch_us"] / 1e3 if m["owner_launch_us"] else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": owner_bytes / m["owner_launch_us"] / 1e3 / HBM_PEAK_GBS if m["owner_launch_us"] else None,
+          "traffic": None, "traffic_source": None,
+          "algorithmic_bytes_per_launch": owner_bytes, "avg_launch_us": m["owner_launch_us"], "launches_timed": m["launches_timed"],
+          "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "step_algorithmic_bytes": step_bytes,
+          "step_bytes_definition": "per GPU: B*(8+2*Rb) for the lookup + U*(16+2*Rb) for the write-back of the batch's U distinct keys (SURVEY §8d)",
+          "timing": "HIP events the owner's step driver records around its launch (they include one dispatch), 24 launches on fresh batches",
+      },
+  }
+  del table
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
+  return res
+
 
 
 # ------------------------------------------------------------------ c2 / c4: growing table behind de.Variable, fused optimizer
@@ -1161,6 +1413,7 @@ def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
           "bound": "hbm", "kernel": "find_kernel<16,4> (embedding lookup, default fill fused)",
           "achieved": find_bytes / find_us / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": find_bytes / find_us / 1e3 / HBM_PEAK_GBS, "traffic": traffic_of(prof, cfg, "find_kernel"),
+          "traffic_source": (prof or {}).get("_source") if traffic_of(prof, cfg, "find_kernel") is not None else None,
           "algorithmic_bytes_per_launch": find_bytes, "avg_launch_us": find_us,
           "avg_launch_us_same_batch_back_to_back": find_b2b_us,
           "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
@@ -1406,14 +1659,26 @@ def compact_line(res, detail_path=None):
                      "dtype", "data"))
   line["metric"] = _short(res.get("metric"), 200)
   c = _pick(cfg, ("slots", "global_batch", "unique_ratio", "unique_keys_per_batch", "new_key_ratio", "steps_per_host_call",
-                  "host_enqueue_ms_per_step", "resident_after_prefill", "keys_per_gpu", "parallelism", "route", "tables", "rccl_ranks_seen"))
+                  "host_enqueue_ms_per_step", "resident_after_prefill", "keys_per_gpu", "parallelism", "route", "tables", "rccl_ranks_seen",
+                  "served_ids_per_step", "served_distinct_ids_per_step", "batches_fed_ahead"))
   c["workload"] = _short(cfg.get("workload"), 360)
   c["driver"] = res.get("driver") or cfg.get("driver")
   if res.get("driver_rule"):
     c["driver_rule"] = _short(res["driver_rule"], 170)
   line["config"] = c
-  r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "step_frac",
-                 "step_algorithmic_bytes"))
+  # the run's own untimed verification (config.verified: every flag in bench_detail.json): ONE bit here — the AND of all of them over the
+  # top-level workload and every secondary one that ran
+  flags = dict(cfg.get("verified") or {})
+  for name, rr in (res.get("secondary") or {}).items():
+    for k, v in ((rr.get("config") or {}).get("verified") or {}).items():
+      flags["%s.%s" % (name, k)] = v
+  bools = [v for v in flags.values() if isinstance(v, bool)]
+  line["verified"] = bool(bools) and all(bools)
+  line["verified_flags"] = len(bools)
+  r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_us",
+                 "step_frac", "step_algorithmic_bytes"))
+  if "avg_launch_us" in r:
+    r["avg_launch_us_is"] = "HIP events around the launch (incl. one dispatch)"
   r["kernel"] = _short(rf.get("kernel"), 150)
   if r.get("traffic") is not None and r.get("algorithmic_bytes_per_launch"):
     r["traffic_over_algorithmic"] = _num(r["traffic"] / r["algorithmic_bytes_per_launch"], 3)
@@ -1426,6 +1691,7 @@ def compact_line(res, detail_path=None):
       if k in po:
         b[k] = _num(po[k])
     b["sample"] = _short(cb.get("sample"), 330)
+    b.update({k: _num(v) if not isinstance(v, str) else v for k, v in cpu_baseline_1e9().items()})
     line["cpu_baseline"] = b
   sp = res.get("scaling_point")
   if sp:
@@ -1492,10 +1758,12 @@ def main():
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--c5-streams", type=int, default=4)
   ap.add_argument("--c5-workers", type=int, default=1)
-  ap.add_argument("--config", choices=["m1b", "c3", "c2", "c4", "c5"], default=None,
-                  help="default: m1b on one GPU (the metric's own configuration; c3 / c2 / c4 / c5 as secondary), c4 per GPU for N>1; "
-                       "c5 with --gpus N: 26 hash-sharded tables per GPU through the multi-table route")
+  ap.add_argument("--config", choices=["m1b", "m1s", "c3", "c2", "c4", "c5"], default=None,
+                  help="default: m1b on one GPU (the metric's own configuration; c3 / c2 / c4 / c5 as secondary), m1s per GPU for N>1 (the metric's "
+                       "step on a hash-sharded table, ids / rows / values routed; --config m1s --gpus 1: the same through the route driver at one rank); "
+                       "c4: configs[3] with the fused-SGD gradient route; c5 with --gpus N: 26 hash-sharded tables per GPU through the multi-table route")
   ap.add_argument("--slots", type=int, default=1_000_000_000, help="m1b / c3: slots of the bounded table")
+  ap.add_argument("--shard-slots", type=int, default=500_000_000, help="m1s: slots of the bounded table PER GPU (configs[3]: 4 B keys over 8 GPUs)")
   ap.add_argument("--keys", type=int, default=100_000_000, help="c2: resident keys")
   ap.add_argument("--c4-keys", type=int, default=500_000_000, help="c4: resident keys PER GPU")
   ap.add_argument("--batch", type=int, default=131072, help="ids per GPU per step")
@@ -1503,6 +1771,22 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-secondary", action="store_true", help="skip the secondary c3 / c2 / c4 measurements of the default invocation")
   args = ap.parse_args()
+
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # `python bench.py --gpus N` without a launcher: become one — re-run this command line under torch.distributed.run, one process per
+    # GPU (rank 0 prints the line to the inherited stdout), and leave with its exit code
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+      sk.bind(("127.0.0.1", 0))
+      port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: %s" % (args.gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
 
   import torch
   import torch.distributed as dist
@@ -1512,7 +1796,9 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if args.gpus > 1 or world > 1 or os.environ.get("TFRA_BENCH_FORCE_A2A") == "1":
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+      raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus N` — it starts its own ranks — or "
+                       "torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = os.environ.get("TFRA_BENCH_BACKEND", "nccl")  # "gloo": smoke-test the N>1 path on ONE GPU
     if backend == "gloo":
@@ -1523,8 +1809,10 @@ def main():
       dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
   dev = torch.device("cuda", local_rank)
   torch.cuda.set_device(dev)
-  cfg = args.config or ("m1b" if (world == 1 and not dist.is_initialized()) else "c4")
-  if cfg in ("c3", "m1b"):
+  cfg = args.config or ("m1b" if (world == 1 and not dist.is_initialized()) else "m1s")
+  if cfg == "m1s":
+    res = run_metric_sharded(args, torch, dist, de, dev, world, rank)
+  elif cfg in ("c3", "m1b"):
     assert world == 1, "%s is a single-GPU configuration" % cfg
     if args.config is None and not args.no_secondary:
       args._growth = measure_growth(torch, de, dev, 128, torch.float16, args.slots // 4)   # reported under secondary.c3
@@ -1546,12 +1834,15 @@ def main():
       res["secondary"] = sec
       # what a `--gpus N` run measures PER GPU is configs[3] through the route driver — not the metric's configuration above: the
       # N = 1 point of that curve, at the top level so that a scaling record is built from like workloads
-      c4r = sec.get("c4", {})
+      rl = res.get("routed_local") or {}
       res["scaling_point"] = {
-          "workload": c4r.get("config", {}).get("workload"), "value": c4r.get("value"), "ms_per_step": c4r.get("ms_per_step"), "n_gpus": 1,
-          "error": c4r.get("error"),
-          "note": "`bench.py --gpus N` (N > 1) runs THIS workload per GPU (configs[3]: hash-sharded table, ids / rows / gradients routed); "
-                  "compare its `value` with this one, not with the top-level `value` (the metric's single-GPU configuration).  No RCCL "
+          "workload": "the metric's step on THIS table THROUGH the route driver at one rank (tfra_assign_route_*: what every `--gpus N` rank runs, "
+                      "with device copies where the alltoalls would be): route plan ahead, per step gather + copy + owner step launch on the "
+                      "distinct ids + copy + gather", "value": rl.get("value"), "ms_per_step": rl.get("ms_per_step"), "n_gpus": 1,
+          "launches_per_step": 4, "error": rl.get("error"),
+          "note": "`bench.py --gpus N` (N > 1) runs the metric's step per GPU on a hash-sharded table (run_metric_sharded: lookup(B) + "
+                  "insert_or_assign(B), ids / rows / values routed, the owner running the overlapped step); at ONE rank the route is the identity "
+                  "and that step IS the top-level `value`; this entry is the same one-rank step with the route's kernels forced on.  No RCCL "
                   "communicator with more than one rank has been formed on the builder's side (one GPU per box): nothing is projected."}
   elif cfg == "c5":
     if world == 1 and not dist.is_initialized():

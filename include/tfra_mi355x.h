@@ -554,6 +554,44 @@ int tfra_route_apply(tfra_route_t* r, const tfra_opt_params* p, const float* d_g
 /* ids this rank serves for the oldest fed batch (device pointer valid until its apply; waits for the split sizes) */
 int tfra_route_served_ids(tfra_route_t* r, const int64_t** d_ids, size_t* n, size_t* n_distinct_local);
 
+/* -- the metric's step on a hash-sharded table: lookup(B) + insert_or_assign(B) with ids / rows / values routed ---------------
+ *    (csrc/tfra_aroute.hip).  Replaces, for a table sharded over the GPUs of one node, the reference's sequence
+ *      lookup : HvdAllToAllEmbedding.__alltoall_embedding_lookup__  (PY/shadow_embedding_ops.py:397-447: unique -> partition ->
+ *               hvd.alltoall(ids) -> local Find -> hvd.alltoall(rows) -> stitch)
+ *      insert : Variable.upsert on a sharded Variable            (PY/dynamic_embedding_variable.py:772-800: keys AND values
+ *               partitioned by owner, one Insert per shard; the last occurrence of a repeated key wins)
+ *    with ONE launch per batch for everything that depends on the ids alone (de-duplication, grouping by owner, last positions,
+ *    position -> row map: runs ahead, on the driver's own streams, followed by the count exchange, the one host read of the split
+ *    sizes and the id exchange) and, per step on the caller's stream: gather(values at the last positions) -> alltoall(values) ->
+ *    tfra_table_step_overlap at the owner (lookup of the ids it serves for THIS batch + write-back of the rows it received for the
+ *    PREVIOUS one, one launch) -> alltoall(rows) -> gather(rows -> positions).
+ *    Results = ONE table that sees, per step, lookup(every rank's ids) and then insert_or_assign(rank 0's batch, rank 1's, ...):
+ *    a key written by several ranks in one step keeps the highest rank's last occurrence; lookup i+1 sees every write of step i.
+ *      feed  : announce a batch (ids must stay valid and unchanged until the batch has been written back).  A batch moves one
+ *              stage of its route per step: keep FIVE batches fed ahead of the one being looked up and nothing waits on the
+ *              host (fewer works too: the missing stages then run, and stall, inside step; the owner's overlapped step then
+ *              builds its de-duplication plans by launches of their own).  At most six.
+ *      step  : rows_out[i,:] = row of ids[i] of the OLDEST fed batch not yet looked up (default_row for missing keys: one row);
+ *              values_prev [n_prev, dim] = the rows to assign to the ids of the batch the PREVIOUS step looked up (NULL on the
+ *              first step / after a flush); they must stay unchanged until this call's work has run.
+ *      flush : writes the last looked-up batch back.  Call it before the table is used through any other entry point.
+ *    transport NULL: one rank (device copies where the alltoalls would be).  Any value type; batches of at most max_batch <= 2^18
+ *    ids, at most 2^18 ids served per rank and batch, at most 64 ranks.  Every rank issues the same call sequence; one caller thread.
+ *    stats out6: steps, host stalls on split sizes, owner steps taken overlapped / one op after the other, distinct ids of the last
+ *    batch looked up, ids this rank served for it. */
+typedef struct tfra_assign_route tfra_assign_route_t;
+int tfra_assign_route_create(tfra_table_t* table, const tfra_transport* transport, int partition_mode, size_t max_batch,
+                             tfra_assign_route_t** out);
+int tfra_assign_route_destroy(tfra_assign_route_t* r);
+int tfra_assign_route_feed(tfra_assign_route_t* r, size_t n, const int64_t* d_ids, int ids_ready, tfra_stream_t stream);
+int tfra_assign_route_step(tfra_assign_route_t* r, void* d_rows_out, const void* default_row, const void* values_prev,
+                           tfra_stream_t stream);
+int tfra_assign_route_flush(tfra_assign_route_t* r, const void* values_prev, tfra_stream_t stream);
+int tfra_assign_route_stats(const tfra_assign_route_t* r, uint64_t* out6);
+/* measurement: tfra_step_driver_time_kernels / _kernel_times of the owner's step driver (the step launch of the next `steps` steps) */
+int tfra_assign_route_time_kernels(tfra_assign_route_t* r, size_t steps);
+int tfra_assign_route_kernel_times(tfra_assign_route_t* r, double* step_kernel_us, size_t* steps);
+
 #ifdef __cplusplus
 }
 #endif

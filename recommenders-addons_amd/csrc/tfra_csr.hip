@@ -1597,7 +1597,7 @@ struct SetTab {   // one of the plan's two tables
 template <bool COUNTS, bool INDEX, bool FUSED, int IPT = 1>
 __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned nblk, size_t n, const i64* __restrict__ ids, unsigned m2,
                                               const SetTab& cur, const SetTab& old, unsigned* next_use_count, i64* __restrict__ unique_out,
-                                              int* __restrict__ idx_out, i64* __restrict__ num_out) {
+                                              int* __restrict__ idx_out, i64* __restrict__ num_out, unsigned* err = nullptr) {
   static_assert(!FUSED || (INDEX && !COUNTS), "FUSED: the unique-with-index build");
   constexpr unsigned LDSN = SP_LDS * IPT;   // slots of the block's LDS table: two per id
   constexpr int NR = 2 * IPT;               // ... = NR per thread
@@ -1711,7 +1711,11 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
   }
   if (FUSED) {
     // the dense index of every distinct id of the block -> LDS (s_cnt is free here): drawn above for the keys this block installed,
-    // polled from the entry for the others (their installer is a resident block: the grid is at most 128 blocks)
+    // polled from the entry for the others (their installer is a resident block: at most 128 de-duplicating blocks — 256 with
+    // TFRA_FU_IPT=1 above 131072 ids, still co-resident: 1024 threads of 57 registers, four blocks per CU).  The poll is bounded; a
+    // timeout leaves idx_out = -1 for the block's positions of that id AND counts an error (`err`: the table's counter under
+    // tfra_table_find_unique, the workspace's under tfra_unique_unordered), so that nothing indexes with it unnoticed.
+    bool timed_out = false;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       if (!have[r]) continue;
@@ -1720,6 +1724,7 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
         v = __hip_atomic_load(&cur.ent[myslot[r]].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!v) __builtin_amdgcn_s_sleep(2);
       }
+      timed_out |= v == 0u;
       s_cnt[tid + (unsigned)r * SP_NT] = v;
     }
     if (tid < 2 && s_pos[LDSN + tid] != 0) {   // a sentinel key value occurred in this block
@@ -1728,20 +1733,23 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
         v = __hip_atomic_load(&cur.ent[m2 + tid].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!v) __builtin_amdgcn_s_sleep(2);
       }
+      timed_out |= v == 0u;
       s_cnt[LDSN + tid] = v;
     }
+    if (timed_out && err) atomicAdd(err, 1u);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < IPT; ++q)
-      if (gids[q] < n) idx_out[gids[q]] = (int)s_cnt[lds_slot[q]] - 1;   // (-1 only after a poll that timed out: never seen)
+      if (gids[q] < n) idx_out[gids[q]] = (int)s_cnt[lds_slot[q]] - 1;   // (-1 only after a poll that timed out: never seen; counted in *err)
   }
 }
 
 template <bool COUNTS, bool INDEX = false, bool FUSED = false>
 __global__ __launch_bounds__(SP_NT) void setplan_kernel(size_t n, const i64* __restrict__ ids, unsigned m2, SetTab cur, SetTab old,
                                                         unsigned* next_use_count, i64* __restrict__ unique_out = nullptr,
-                                                        int* __restrict__ idx_out = nullptr, i64* __restrict__ num_out = nullptr) {
-  setplan_block<COUNTS, INDEX, FUSED>(blockIdx.x, gridDim.x, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out);
+                                                        int* __restrict__ idx_out = nullptr, i64* __restrict__ num_out = nullptr,
+                                                        unsigned* err = nullptr) {
+  setplan_block<COUNTS, INDEX, FUSED>(blockIdx.x, gridDim.x, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out, err);
 }
 
 // TFRA>HkvHashTableEmbeddingLookup in ONE launch (tfra_table_find_unique): the first `ublocks` blocks (<= 128: co-resident, see FUSED)
@@ -1754,7 +1762,7 @@ __global__ __launch_bounds__(SP_NT) void find_unique_kernel(unsigned ublocks, si
                                                             i64* __restrict__ num_out, TableView v, unsigned char* __restrict__ rows_out,
                                                             uint8_t* __restrict__ exists, const unsigned char* __restrict__ defaults, int full) {
   if (blockIdx.x < ublocks) {
-    setplan_block<false, true, true, FU_IPT>(blockIdx.x, ublocks, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out);
+    setplan_block<false, true, true, FU_IPT>(blockIdx.x, ublocks, n, ids, m2, cur, old, next_use_count, unique_out, idx_out, num_out, v.err_count);
     return;
   }
   find_wave<G, 4, G == 16, PF1>(v, n, ids, rows_out, exists, defaults, full, 0u, (blockIdx.x - ublocks) * (SP_NT / 64) + (threadIdx.x >> 6));
@@ -2862,6 +2870,11 @@ extern "C" int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64
   if (n == 0) { if (hipMemsetAsync(d_num_unique, 0, sizeof(int64_t), s) != hipSuccess) return set_error(TFRA_ERR_HIP, "unique: memset"); return TFRA_OK; }
   if (!ids || !unique_out || !idx_out) return set_error(TFRA_ERR_INVALID, "unique: null buffer");
   if (n > MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "unique_unordered: at most 2^18 ids per call (tfra_unique takes more)");
+  if (!ws->h_err && hipHostMalloc(reinterpret_cast<void**>(&ws->h_err), 64, hipHostMallocDefault) == hipSuccess) *ws->h_err = 0;
+  if (ws->h_err && __atomic_load_n(ws->h_err, __ATOMIC_RELAXED)) {   // an EARLIER one-launch call gave up waiting for another block's index
+    __atomic_store_n(ws->h_err, 0u, __ATOMIC_RELAXED);
+    return set_error(TFRA_ERR_HIP, "unique_unordered: an earlier call on this workspace timed out waiting for a block's index (its idx_out holds -1 entries)");
+  }
   if (!ws->uplan) {
     tfra_sparse_plan* pl = nullptr;
     int rc = tfra_sparse_plan_create(ws->device, &pl);
@@ -2874,7 +2887,7 @@ extern "C" int tfra_unique_unordered(tfra_workspace_t* ws, size_t n, const int64
   if (rc) return rc;
   if (L.blocks <= 128) {   // ONE launch (all blocks co-resident on half the chip: a block may wait for another's index)
     setplan_kernel<false, true, true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, (i64*)unique_out, idx_out,
-                                                                 (i64*)d_num_unique);
+                                                                 (i64*)d_num_unique, ws->h_err);
   } else {
     setplan_kernel<false, true><<<L.blocks, SP_NT, 0, s>>>(n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count);
     unique_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, (const i64*)ids, SetProbe{L.cur.ent, L.m2}, L.cur.ukeys, L.cur.count, (i64*)unique_out,
@@ -2918,11 +2931,12 @@ extern "C" int tfra_table_find_unique(tfra_table_t* tp, tfra_workspace_t* ws, si
   if (rc) return rc;
   const TableView v = t->view_of(t->cur);
   const unsigned fblocks = (unsigned)((n + 16 * (SP_NT / 64) - 1) / (16 * (SP_NT / 64)));   // 16 keys per wave, 16 waves per block
-  // one id per thread of a de-duplicating block up to 131072 ids, two above (<= 128 blocks either way).  Two everywhere (TFRA_FU_IPT=2, tuning)
+  // one id per thread of a de-duplicating block up to 131072 ids, two above (<= 128 blocks by default; TFRA_FU_IPT=1 above 131072 ids: up to
+  // 256, still co-resident).  Two everywhere (TFRA_FU_IPT=2, tuning)
   // makes this launch 0.3 us shorter and the Insert that follows 1.4 us longer (same box, twice): the order of the distinct ids changes
   static const int ipt_env = [] { const char* e = getenv("TFRA_FU_IPT"); return e ? atoi(e) : 0; }();
   const int ipt = ipt_env == 1 || ipt_env == 2 ? ipt_env : (n <= 128u * SP_NT ? 1 : 2);
-  const unsigned ublocks = (unsigned)((n + SP_NT * ipt - 1) / (SP_NT * ipt));   // <= 128: co-resident whatever the find's blocks do
+  const unsigned ublocks = (unsigned)((n + SP_NT * ipt - 1) / (SP_NT * ipt));   // <= 128 (256 with TFRA_FU_IPT=1): dispatched first, co-resident whatever the find's blocks do
   const unsigned grid = ublocks + fblocks;
 #define FU_LAUNCH(PF1, IPT) find_unique_kernel<16, PF1, IPT><<<grid, SP_NT, 0, s>>>(ublocks, n, (const i64*)ids, L.m2, L.cur, L.old, L.next_use_count, \
     (i64*)unique_out, idx_out, (i64*)d_num_unique, v, (unsigned char*)rows_out, exists, (const unsigned char*)defaults, default_is_full)

@@ -648,6 +648,7 @@ int tfra_workspace_destroy(tfra_workspace_t* ws) {
   if (ws->buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->buf); }
   if (ws->unq_buf) { (void)hipDeviceSynchronize(); (void)hipFree(ws->unq_buf); }
   if (ws->unq_ev) (void)hipEventDestroy(ws->unq_ev);
+  if (ws->h_err) { (void)hipDeviceSynchronize(); (void)hipHostFree(ws->h_err); }
   tfra::destroy_workspace_plan(ws->plan);
   tfra::destroy_workspace_plan(ws->uplan);
   delete ws;

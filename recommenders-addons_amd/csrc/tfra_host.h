@@ -116,6 +116,7 @@ struct tfra_workspace {
   size_t bytes = 0;
   void* plan = nullptr;   // tfra_sparse_plan of tfra_reduce_by_key
   void* uplan = nullptr;  // tfra_sparse_plan of tfra_unique_unordered
+  unsigned* h_err = nullptr;   // pinned: polls of the one-launch unique that timed out (reported by the NEXT tfra_unique_unordered call)
   // tfra_unique (up to 2^20 ids): two persistent hash sets that alternate and empty each other (no fill kernel per call)
   void* unq_buf = nullptr;
   size_t unq_cap = 0, unq_nmax = 0;

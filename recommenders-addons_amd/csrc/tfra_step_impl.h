@@ -1098,6 +1098,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
     a.patch_count = a.sync + 32 * 9 + 1; a.patch_count_next = a.sync_next + 32 * 9 + 1;   // (read with the tail's arrivals as one 8-byte word)
     a.zero4 = plan_prev ? reinterpret_cast<unsigned*>(L.next_ctr) : nullptr;
     a.serial_probe = (d->variant & 64) ? 0 : 1;
+    a.ablate = (d->ablate && d->step_no >= d->ablate_after) ? d->ablate : 0;   // (tuning: TFRA_STEP_ABLATE / _AFTER; results are wrong)
     int map_slot_new = -1;
     if (list_ok) {
       a.find_list = reinterpret_cast<const uint4*>(d->mapbuf + (size_t)d->map_slot * d->map_cap * 16);

@@ -166,6 +166,14 @@ _SIGS = {
     "tfra_route_lookup": [_P, _P, _P, _P],
     "tfra_route_apply": [_P, ctypes.POINTER(OptParams), _P, _P, _P],
     "tfra_route_served_ids": [_P, ctypes.POINTER(_P), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)],
+    "tfra_assign_route_create": [_P, ctypes.POINTER(Transport), _I, _SZ, ctypes.POINTER(_P)],
+    "tfra_assign_route_destroy": [_P],
+    "tfra_assign_route_feed": [_P, _SZ, _P, _I, _P],
+    "tfra_assign_route_step": [_P, _P, _P, _P, _P],
+    "tfra_assign_route_flush": [_P, _P, _P],
+    "tfra_assign_route_stats": [_P, ctypes.POINTER(ctypes.c_uint64)],
+    "tfra_assign_route_time_kernels": [_P, _SZ],
+    "tfra_assign_route_kernel_times": [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_SZ)],
 }
 
 _lib = None

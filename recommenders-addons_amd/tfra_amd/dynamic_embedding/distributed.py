@@ -395,6 +395,46 @@ class _StagedTransport:
     self.struct = _capi.Transport(None, dist.get_rank(group), world, self._fn)
 
 
+def _open_transport(kind, group, dev, rank, world):
+  """The alltoallv transport of the C route drivers: 'rccl' = the driver's own pair of RCCL communicators (grouped ncclSend / ncclRecv
+  over xGMI; the unique ids travel through the host framework's broadcast), 'staged' = host-staged through the torch.distributed
+  group (tests: two ranks sharing ONE GPU cannot form an RCCL communicator).  Returns (staged, rccl_struct, rccl_ranks)."""
+  import ctypes
+  from .. import _capi
+  if kind == "staged":
+    return _StagedTransport(group, dev), None, None
+  if kind != "rccl":
+    raise ValueError("transport: 'auto', 'rccl', 'staged' or None")
+  lib = _loaded_librccl().encode()
+  # rank 0 makes the two unique ids; a status byte travels with them so that a failure there raises on EVERY rank
+  # instead of leaving the others waiting in the broadcast
+  ids = torch.zeros(2 * _capi.RCCL_ID_BYTES + 1, dtype=torch.uint8)
+  err0 = None
+  if rank == 0:
+    buf = (ctypes.c_char * (2 * _capi.RCCL_ID_BYTES))()
+    try:
+      for ch in range(2):
+        _capi.call("tfra_rccl_unique_id", lib, ctypes.byref(buf, ch * _capi.RCCL_ID_BYTES))
+      ids = torch.frombuffer(bytearray(buf.raw) + bytearray([1]), dtype=torch.uint8).clone()
+    except Exception as e:   # noqa: BLE001 — reported below, on every rank
+      err0 = e
+  on_dev = dist.get_backend(group) == "nccl"
+  ids_x = ids.to(dev) if on_dev else ids
+  if world > 1:
+    dist.broadcast(ids_x, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+  raw = bytes(ids_x.cpu().numpy().tobytes())
+  if raw[-1] != 1:
+    raise RuntimeError("route transport: rank 0 could not create the RCCL unique ids (%s)" % (err0 or "see rank 0"))
+  raw = raw[:-1]
+  rccl = _capi.Transport()
+  _capi.call("tfra_rccl_transport_create", lib, raw, rank, world, dev.index or 0, ctypes.byref(rccl))
+  n = ctypes.c_int(0)
+  _capi.call("tfra_rccl_transport_ranks", ctypes.byref(rccl), ctypes.byref(n))
+  if n.value != world:
+    raise RuntimeError("route transport: the RCCL communicators span %d ranks, the process group %d" % (n.value, world))
+  return None, rccl, n.value
+
+
 class NativeRoutedStep:
   """`RoutedPrefetchStep` with the whole sequence issued from C (`tfra_route_*`, csrc/tfra_route.hip): three ctypes
   calls per step instead of ~18 plus four torch.distributed calls, and the collectives are grouped ncclSend/ncclRecv on
@@ -432,49 +472,24 @@ class NativeRoutedStep:
     self._rccl = None
     self._owns_transport = True
     tr = None
+    self._transport_owner = None
+    self.rccl_ranks = None   # ranks of the RCCL communicators as RCCL reports them (None: no RCCL transport)
     if share_transport_of is not None:
       # many tables, ONE pair of communicators (MultiTableRoutedStep): the collectives of every route are issued by the calling
       # thread in call order, the same on every rank, so routes may share a transport; only the first one owns (and destroys) it
+      if threaded or getattr(share_transport_of, "_threaded", False):
+        raise ValueError("NativeRoutedStep: routes that share a transport must not use helper threads (threaded=False on all of them): "
+                         "one pair of communicators is only safe when every collective is issued by the calling thread")
       self._owns_transport = False
-      self._staged, self._rccl = share_transport_of._staged, share_transport_of._rccl
+      self._transport_owner = share_transport_of   # keeps the owner (and its communicators) alive as long as this route is
+      self._staged, self._rccl, self.rccl_ranks = share_transport_of._staged, share_transport_of._rccl, share_transport_of.rccl_ranks
       tr = ctypes.byref(self._rccl) if self._rccl is not None else (ctypes.byref(self._staged.struct) if self._staged is not None else None)
-    elif transport == "rccl":
-      lib = _loaded_librccl().encode()
-      # rank 0 makes the two unique ids; a status byte travels with them so that a failure there raises on EVERY rank
-      # instead of leaving the others waiting in the broadcast
-      ids = torch.zeros(2 * _capi.RCCL_ID_BYTES + 1, dtype=torch.uint8)
-      err0 = None
-      if self.rank == 0:
-        buf = (ctypes.c_char * (2 * _capi.RCCL_ID_BYTES))()
-        try:
-          for ch in range(2):
-            _capi.call("tfra_rccl_unique_id", lib, ctypes.byref(buf, ch * _capi.RCCL_ID_BYTES))
-          ids = torch.frombuffer(bytearray(buf.raw) + bytearray([1]), dtype=torch.uint8).clone()
-        except Exception as e:   # noqa: BLE001 — reported below, on every rank
-          err0 = e
-      on_dev = dist.get_backend(group) == "nccl"
-      ids_x = ids.to(self.dev) if on_dev else ids
-      if self.world > 1:
-        dist.broadcast(ids_x, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-      raw = bytes(ids_x.cpu().numpy().tobytes())
-      if raw[-1] != 1:
-        raise RuntimeError("NativeRoutedStep: rank 0 could not create the RCCL unique ids (%s)" % (err0 or "see rank 0"))
-      raw = raw[:-1]
-      self._rccl = _capi.Transport()
-      _capi.call("tfra_rccl_transport_create", lib, raw, self.rank, self.world, self.dev.index or 0, ctypes.byref(self._rccl))
-      tr = ctypes.byref(self._rccl)
-    elif transport == "staged":
-      self._staged = _StagedTransport(group, self.dev)
-      tr = ctypes.byref(self._staged.struct)
+    elif transport in ("rccl", "staged"):
+      self._staged, self._rccl, self.rccl_ranks = _open_transport(transport, group, self.dev, self.rank, self.world)
+      tr = ctypes.byref(self._rccl) if self._rccl is not None else ctypes.byref(self._staged.struct)
     elif transport is not None:
       raise ValueError("transport: 'auto', 'rccl', 'staged' or None")
-    self.rccl_ranks = None   # ranks of the RCCL communicators as RCCL reports them (None: no RCCL transport)
-    if self._rccl is not None:
-      n = ctypes.c_int(0)
-      _capi.call("tfra_rccl_transport_ranks", ctypes.byref(self._rccl), ctypes.byref(n))
-      self.rccl_ranks = n.value
-      if self.rccl_ranks != self.world:
-        raise RuntimeError("NativeRoutedStep: the RCCL communicators span %d ranks, the process group %d" % (self.rccl_ranks, self.world))
+    self._threaded = bool(threaded)
     self._h = ctypes.c_void_p()
     _capi.call("tfra_route_create", self.table._h, tr, int(partition_mode), int(max_batch),
                0 if threaded else _capi.ROUTE_NO_THREAD, ctypes.byref(self._h))
@@ -588,3 +603,168 @@ class MultiTableRoutedStep:
     for s_ in reversed(self.steps):   # the owner of the transport last
       s_.close()
     self.steps = []
+
+
+class RoutedAssignStep:
+  """The metric's step — lookup(B ids) + insert_or_assign(B ids, B rows), repeats: the last occurrence wins — on a table that is
+  hash-sharded over the ranks (one process per GPU, this rank's shard = `table`), driven from C (`tfra_assign_route_*`,
+  csrc/tfra_aroute.hip).  Same call pattern as `OverlapAssignStep`, with the batches announced ahead:
+
+      rs = RoutedAssignStep(table); for k in range(5): rs.feed(ids[k])
+      rows_0 = rs.step()                       # lookup(batch 0)
+      for i in 1, 2, ...:
+        rs.feed(ids[i + 4])
+        rows_i = rs.step(values_{i-1})         # write-back of batch i-1 (the owner sees it before lookup i), lookup(batch i)
+      rs.flush(values_last)
+
+  Route and results: the reference's `__alltoall_embedding_lookup__` (PY/shadow_embedding_ops.py:397-447) for the lookup and
+  `Variable.upsert`'s partitioning of keys AND values by owner (PY/dynamic_embedding_variable.py:772-800) for the write-back —
+  one table that sees, per step, every rank's lookup and then rank 0's, rank 1's, ... insert_or_assign.  Per batch ONE launch for all
+  id-only work (de-duplication, owner grouping, last positions, position map), ahead of the step; per step on the critical path:
+  gather -> alltoall(values) -> the owner's overlapped step launch -> alltoall(rows) -> gather.
+
+  With ONE rank and no forced collectives the route is the identity (as `dynamic_partition` with one shard is in the reference):
+  the calls go straight to `tfra_table_step_overlap` (identity=True; the fed batches are its look-ahead).
+  transport: "auto" | "rccl" | "staged" (tests) | "local" (one rank THROUGH the route driver, device copies where the alltoalls
+  would be: what the route itself costs)."""
+
+  def __init__(self, table, group=None, partition_mode=0, transport="auto", max_batch=1 << 18):
+    import ctypes
+    from .. import _capi
+    self.t = table
+    self.table = table._table if hasattr(table, "_table") else table
+    self.dev = self.table.device
+    self.dim, self.vdt = self.table.dim, self.table.value_dtype
+    self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if transport == "auto":
+      transport = None if self.world == 1 else ("rccl" if dist.get_backend(group) == "nccl" else "staged")
+    self.identity = transport is None
+    self._staged = self._rccl = None
+    self.rccl_ranks = None
+    self._capi, self._ctypes = _capi, ctypes
+    self._fed = []        # announced batches not yet looked up, oldest first
+    self._pending = None  # (ids, values) of the batch looked up last (kept alive until written back)
+    self._keep = None
+    self.default = self.table._default_value
+    if self.default.dtype != self.vdt or not self.default.is_contiguous():
+      self.default = self.default.to(self.vdt).contiguous()
+    self._h = None
+    if self.identity:
+      if self.world != 1:
+        raise ValueError("RoutedAssignStep: transport=None needs a single rank")
+      from .optimizer import OverlapAssignStep
+      self._ovl = OverlapAssignStep(table)
+      return
+    tr = None
+    if transport in ("rccl", "staged"):
+      self._staged, self._rccl, self.rccl_ranks = _open_transport(transport, group, self.dev, self.rank, self.world)
+      tr = ctypes.byref(self._rccl) if self._rccl is not None else ctypes.byref(self._staged.struct)
+    elif transport != "local":
+      raise ValueError("transport: 'auto', 'rccl', 'staged', 'local' or None")
+    elif self.world != 1:
+      raise ValueError("RoutedAssignStep: transport='local' needs a single rank")
+    self._h = ctypes.c_void_p()
+    _capi.call("tfra_assign_route_create", self.table._h, tr, int(partition_mode), int(max_batch), ctypes.byref(self._h))
+
+  def _call(self, name, *args):
+    try:
+      self._capi.call(name, *args)
+    except self._capi.TfraError:
+      if self._staged is not None and self._staged.error is not None:
+        e, self._staged.error = self._staged.error, None
+        raise e
+      raise
+
+  def _stream(self):
+    return self._ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(self.dev.index or 0))
+
+  def _as_ids(self, ids):
+    if torch.is_tensor(ids) and ids.dtype == torch.int64 and ids.dim() == 1 and ids.is_contiguous() and ids.device == self.dev:
+      return ids
+    return torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
+
+  def feed(self, ids, ids_ready=True):
+    ids = self._as_ids(ids)
+    if not self.identity:
+      self._call("tfra_assign_route_feed", self._h, ids.numel(), self._ctypes.c_void_p(ids.data_ptr()), 1 if ids_ready else 0, self._stream())
+    self._fed.append(ids)
+
+  def _values(self, values, n):
+    if values.dtype != self.vdt or not values.is_contiguous() or values.shape != (n, self.dim):
+      values = values.reshape(n, self.dim).to(self.vdt).contiguous()
+    return values
+
+  def step(self, values_prev=None, out=None):
+    """rows of the oldest announced batch; values_prev [n_prev, dim] = what the batch of the PREVIOUS step writes back."""
+    if not self._fed:
+      raise RuntimeError("RoutedAssignStep.step: no batch fed")
+    if self._pending is not None and values_prev is None:
+      raise ValueError("RoutedAssignStep.step: the previous step's batch has not been written back: values_prev is None")
+    ids = self._fed[0]
+    n = ids.numel()
+    vp = self._values(values_prev, self._pending[0].numel()) if self._pending is not None else None
+    if self.identity:
+      o = self._ovl
+      if o._ids is None:
+        o.prime(ids)
+      rows = o.step(vp, self._fed[1] if len(self._fed) > 1 else None, self._fed[2] if len(self._fed) > 2 else None) if vp is not None else \
+          self._identity_first(o)
+    else:
+      rows = out if out is not None else torch.empty((n, self.dim), dtype=self.vdt, device=self.dev)
+      self._call("tfra_assign_route_step", self._h, self._ctypes.c_void_p(rows.data_ptr()), self._ctypes.c_void_p(self.default.data_ptr()),
+                 self._ctypes.c_void_p(vp.data_ptr()) if vp is not None else None, self._stream())
+    self._keep = self._pending
+    self._pending = (ids, vp)
+    self._fed.pop(0)
+    return rows
+
+  def _identity_first(self, o):
+    # the first step of the identity route has nothing to write back: OverlapAssignStep.step wants values of the step's OWN batch (it
+    # defers them itself); here the values arrive one call later, so the driver is called directly
+    from .table_ops import _stream
+    ids = self._fed[0]
+    n = ids.numel()
+    out = torch.empty((n, self.dim), dtype=self.vdt, device=self.dev)
+    nxt = self._fed[1] if len(self._fed) > 1 else None
+    nx2 = self._fed[2] if len(self._fed) > 2 else None
+    c = self._ctypes
+    self._capi.check(o._fn(o._h, n, c.c_void_p(ids.data_ptr()), c.c_void_p(out.data_ptr()), None, o._default_p, 0, None, None,
+                           0 if nxt is None else nxt.numel(), c.c_void_p(nxt.data_ptr()) if nxt is not None else None,
+                           0 if nx2 is None else nx2.numel(), c.c_void_p(nx2.data_ptr()) if nx2 is not None else None, _stream(self.dev)))
+    return out
+
+  def flush(self, values_prev):
+    if self._pending is None:
+      return
+    vp = self._values(values_prev, self._pending[0].numel())
+    if self.identity:
+      from .table_ops import _stream
+      self._capi.call("tfra_table_step_overlap_flush", self._ovl._h, self._ctypes.c_void_p(vp.data_ptr()), None, _stream(self.dev))
+    else:
+      self._call("tfra_assign_route_flush", self._h, self._ctypes.c_void_p(vp.data_ptr()), self._stream())
+    self._keep = (self._pending, vp)
+    self._pending = None
+
+  def stats(self):
+    if self.identity:
+      st = self._ovl.stats()
+      return {"steps": st["overlapped"] + st["sequential"], "stalls": 0, "owner_overlapped": st["overlapped"], "owner_sequential": st["sequential"]}
+    buf = (self._ctypes.c_uint64 * 6)()
+    self._call("tfra_assign_route_stats", self._h, buf)
+    return {"steps": buf[0], "stalls": buf[1], "owner_overlapped": buf[2], "owner_sequential": buf[3], "distinct_ids_last_batch": buf[4],
+            "served_ids_last_batch": buf[5]}
+
+  def close(self):
+    if getattr(self, "_h", None):
+      self._capi.call("tfra_assign_route_destroy", self._h)
+      self._h = None
+    if self._rccl is not None:
+      self._capi.call("tfra_rccl_transport_destroy", self._ctypes.byref(self._rccl))
+      self._rccl = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

@@ -28,7 +28,7 @@ def _full_result():
                     "drivers": {"k%d" % i: long for i in range(8)}, "verified": {"k%d" % i: True for i in range(30)},
                     "timing": {"k%d" % i: {"ms_per_step_by_window": [0.0323] * 5} for i in range(8)}, "overlapped_step_stats": {"a": 1}},
          "roofline": {"bound": "hbm", "kernel": long, "achieved": 2450.9123, "peak": 8000.0, "unit": "GB/s", "frac": 0.306371234,
-                      "traffic": 89374562, "algorithmic_bytes_per_launch": 80162576, "avg_launch_us": 32.7071234, "step_frac": 0.3094212,
+                      "traffic": 89374562, "traffic_source": "profiles/r99_summary.json", "algorithmic_bytes_per_launch": 80162576, "avg_launch_us": 32.7071234, "step_frac": 0.3094212,
                       "step_algorithmic_bytes": 80162576, "kernels": kern, "timing": long, "step_bytes_definition": long},
          "cpu_baseline": {"value": 43980000.123, "unit": "lookup+insert pairs/s", "cores": 128, "kind": "reference", "resident_keys": 256000000,
                           "table_ops_only_pairs_per_s": 1002133618, "host_cores": 256, "host_ram_bytes": 3 << 40, "sample": long,
@@ -62,6 +62,46 @@ def test_compact_line_is_one_short_json_line_with_the_judged_keys():
   assert set(d["secondary"]) == {"c3", "c2", "c4"} and all("value" in v and "ms_per_step" in v for v in d["secondary"].values())
   assert d["variants_pairs_per_s"]["overlapped_step_4_steps_per_host_call"]
   assert d["detail"] == "bench_detail.json"
+  # the run's own verification reaches the parsed line as ONE bit (the AND of every flag, secondary workloads included) ...
+  assert d["verified"] is True and d["verified_flags"] == 30 + 3 * 20
+  # ... the traffic's provenance is named, and the event timing says what it includes
+  assert d["roofline"]["traffic_source"] == "profiles/r99_summary.json" and "dispatch" in d["roofline"]["avg_launch_us_is"]
+  # the CPU leg at the metric's 10^9 keys (measured once, committed under profiles/) is quoted with its source
+  assert d["cpu_baseline"]["value_at_1e9_keys"] > 1e6 and d["cpu_baseline"]["source_1e9"].startswith("profiles/")
+
+
+def test_compact_line_says_false_when_any_verification_flag_failed():
+  res = _full_result()
+  res["secondary"]["c2"] = dict(res["secondary"]["c2"], config=dict(res["secondary"]["c2"]["config"], verified={"a": True, "b": False}))
+  assert json.loads(bench.compact_line(res))["verified"] is False
+  res = _full_result()
+  res["config"]["verified"] = {}
+  for v in res["secondary"].values():
+    v["config"]["verified"] = {}
+  assert json.loads(bench.compact_line(res))["verified"] is False     # nothing checked is not "verified"
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+  """`python bench.py --gpus N` (the form the driver uses) must not die for want of torch.distributed.run: it re-executes itself under
+  the launcher.  Here: the command it would run, captured instead of run."""
+  import subprocess
+  seen = {}
+
+  def fake_call(cmd, env=None):
+    seen["cmd"], seen["env"] = cmd, env
+    return 0
+  monkeypatch.setattr(subprocess, "call", fake_call)
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+  try:
+    bench.main()
+    assert False, "main() should have exited with the launcher's code"
+  except SystemExit as e:
+    assert e.code == 0
+  cmd = seen["cmd"]
+  assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+  assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+  assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_compact_line_of_the_round4_result_that_the_driver_could_not_parse():

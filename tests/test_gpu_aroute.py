@@ -1,0 +1,278 @@
+"""GPU: the metric's step on a hash-sharded table — lookup(B) + insert_or_assign(B), ids / rows / values routed, the owner running
+the overlapped step (tfra_assign_route_*, csrc/tfra_aroute.hip; Python RoutedAssignStep).
+
+Reference: PY/shadow_embedding_ops.py:397-447 (__alltoall_embedding_lookup__: unique -> partition -> alltoall(ids) -> local lookup
+-> alltoall(rows) -> stitch), PY/dynamic_embedding_variable.py:772-800 (upsert on a sharded Variable partitions keys AND values;
+the last occurrence of a repeated key wins), K/hkv_hashtable_op_gpu.cu.cc:192-213,256-267 (Insert exclusive, Find shared: lookup
+i+1 sees update i), python/kernel_tests/horovod_sync_train_test.py:265-376 (the sharded run equals the single-table run).
+
+  * one rank THROUGH the route driver (transport 'local': device copies where the alltoalls would be) — every step's rows against a
+    plain find of the table right after the step call (the write-back of the previous batch is complete, this batch's has not
+    started) and against a dictionary; bounded LRU table at capacity (the owner's launch is the overlapped one), growing table
+    and fp16 rows (the owner runs the same sequence one op after the other); batch sizes up and down, sentinel keys, a hot id,
+    five / one / zero batches fed ahead;
+  * two ranks sharing cuda:0 (collectives host-staged through gloo: RCCL cannot pair two ranks on one GPU), each with the real HIP
+    table of its shard, against ONE oracle table (the reference's CPU semantics) that sees, per step, every rank's lookup and then
+    rank 0's, rank 1's insert_or_assign: rows bit-exact, final keys exact, every key on its owner's shard;
+  * the identity route of a single rank equals the overlapped step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "recommenders-addons_amd")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+IMIN = np.iinfo(np.int64).min
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import RoutedAssignStep
+  return torch, de, RoutedAssignStep
+
+
+def _dense_table(torch, de, cap, dim, fill_keys, name, dtype=None, device="cuda:0"):
+  dtype = dtype or torch.float32
+  t = de.HkvHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), init_capacity=cap, max_capacity=cap, device=device, dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name=name)
+  k = torch.from_numpy(fill_keys).to(device)
+  for lo in range(0, k.numel(), 20000):
+    kk = k[lo:lo + 20000]
+    t._table.upsert(kk, (kk % 1000).to(torch.float32)[:, None].repeat(1, dim).to(dtype), unique_keys=True)
+    torch.cuda.synchronize()
+  for _ in range(3):   # the host learns the density from an asynchronous size read
+    t._table.upsert(k[:16], (k[:16] % 1000).to(torch.float32)[:, None].repeat(1, dim).to(dtype), unique_keys=True)
+    torch.cuda.synchronize()
+  return t
+
+
+def _make_batches(rng, universe, sizes):
+  out = []
+  for n in sizes:
+    ids = universe[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % universe.size].astype(np.int64)
+    if n >= 200:
+      ids[rng.integers(0, n, size=n // 100)] = IMIN           # the two sentinel key values as ordinary keys
+      ids[rng.integers(0, n, size=n // 130)] = IMIN + 1
+      ids[: n // 6] = universe[7]                             # a hot id
+    rng.shuffle(ids)
+    out.append(ids)
+  return out
+
+
+@pytest.mark.parametrize("kind,ahead", [("dense_bounded", 5), ("dense_bounded", 1), ("dense_bounded", 0), ("growing", 5), ("f16_dim128", 3),
+                                        ("big_batches", 5)])
+def test_route_driver_single_rank_equals_table_and_dictionary(env, kind, ahead):
+  torch, de, RoutedAssignStep = env
+  import zlib
+  rng = np.random.default_rng(zlib.crc32(("%s/%d" % (kind, ahead)).encode()))
+  dtype, dim = (torch.float16, 128) if kind == "f16_dim128" else (torch.float32, 64)
+  big = kind == "big_batches"
+  cap = 1_200_000 if big else 120_000
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  resident = universe[: int(universe.size * 0.99)]
+  if kind == "growing":
+    t = de.CuckooHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), device="cuda:0", dim=dim, name="ar_grow")
+    k = torch.from_numpy(resident).cuda()
+    t._table.upsert(k, (k % 1000).to(torch.float32)[:, None].repeat(1, dim).to(dtype), unique_keys=True)
+  else:
+    t = _dense_table(torch, de, cap, dim, resident, "ar_%s_%d" % (kind, ahead), dtype)
+  tbl = t._table
+  latest = {int(k): float(int(k) % 1000) for k in resident}
+  sizes = [131072, 200000, 262144, 70000, 131072, 131072, 1000] if big else [5000, 5000, 700, 1, 9000, 5000, 333, 5000, 5000, 12000, 5000, 64]
+  nsteps = len(sizes)
+  batches = [torch.from_numpy(b).cuda() for b in _make_batches(rng, universe, sizes)]
+  rs = RoutedAssignStep(t, transport="local", max_batch=1 << 18)
+  assert not rs.identity
+  fed = 0
+  for _ in range(min(ahead + 1, nsteps)):
+    rs.feed(batches[fed]); fed += 1
+  prev_vals = None
+  n_evicted = 0
+  for s in range(nsteps):
+    if fed <= s:
+      rs.feed(batches[fed]); fed += 1
+    ids = batches[s]
+    n = ids.numel()
+    out = rs.step(prev_vals)
+    if fed < nsteps and fed <= s + ahead:
+      rs.feed(batches[fed]); fed += 1
+    torch.cuda.synchronize()
+    ref, rex = tbl.find(ids, return_exists=True)            # the table right now = what this lookup had to reflect
+    assert torch.equal(out, ref), "step %d" % s
+    ids_np = ids.cpu().numpy()
+    want = np.array([latest.get(int(k), 0.0) for k in ids_np], np.float32)
+    want_ex = np.array([int(k) in latest for k in ids_np])
+    exn, outn = rex.cpu().numpy(), out[:, 0].float().cpu().numpy()
+    assert not np.any(exn & ~want_ex)
+    n_evicted += int(np.sum(~exn & want_ex))
+    if dtype == torch.float32:
+      np.testing.assert_array_equal(outn[exn], want[exn])
+    else:
+      np.testing.assert_array_equal(outn[exn], want[exn].astype(np.float16).astype(np.float32))
+    assert bool((out == out[:, :1]).all())
+    if dtype == torch.float16:   # position mod 1024 + a step offset, as the half rounds it
+      v1 = ((torch.arange(n, device="cuda") % 1024).to(torch.float32) + 2048.0 * ((s % 15) + 1)).to(dtype).float()
+    else:
+      v1 = torch.arange(n, device="cuda", dtype=torch.float32) + 1000000.0 * (s + 1)
+    prev_vals = v1[:, None].repeat(1, dim).to(dtype)
+    v1n = v1.cpu().numpy()
+    for i, k in enumerate(ids_np.tolist()):
+      latest[k] = float(v1n[i])
+  assert n_evicted <= sum(sizes) // 100, n_evicted
+  rs.flush(prev_vals)
+  torch.cuda.synchronize()
+  st = rs.stats()
+  assert st["steps"] == nsteps, st
+  if kind == "growing":
+    assert st["owner_sequential"] >= nsteps - 1, st
+  else:
+    assert st["owner_overlapped"] >= nsteps and st["owner_sequential"] == 0, st    # every owner launch was the overlapped one
+  ek, ev = t.export()
+  assert ek.numel() == int(t.size().item()) <= len(latest) and ek.numel() >= 0.99 * len(latest)
+  np.testing.assert_array_equal(ev[:, 0].float().cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
+  tbl.check_errors()
+  rs.close()
+
+
+def test_identity_route_equals_overlapped_step(env):
+  """world 1, no forced route: RoutedAssignStep IS tfra_table_step_overlap on the announced batches (dynamic_partition with one
+  shard is the identity in the reference too) — same rows as the route driver run on a twin table."""
+  torch, de, RoutedAssignStep = env
+  rng = np.random.default_rng(3)
+  cap, dim = 120_000, 64
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
+  ta = _dense_table(torch, de, cap, dim, universe, "ar_id_a")
+  tb = _dense_table(torch, de, cap, dim, universe, "ar_id_b")
+  batches = [torch.from_numpy(b).cuda() for b in _make_batches(rng, universe, [4000] * 9)]
+  ra, rb = RoutedAssignStep(ta), RoutedAssignStep(tb, transport="local")
+  assert ra.identity and not rb.identity
+  for r in (ra, rb):
+    for k in range(3):
+      r.feed(batches[k])
+  pv = None
+  for s in range(9):
+    oa, ob = ra.step(pv), rb.step(pv)
+    assert torch.equal(oa, ob), "step %d" % s
+    for r in (ra, rb):
+      if s + 3 < 9:
+        r.feed(batches[s + 3])
+    pv = (torch.arange(4000, device="cuda", dtype=torch.float32) + 7000.0 * (s + 1))[:, None].repeat(1, dim)
+  ra.flush(pv); rb.flush(pv)
+  torch.cuda.synchronize()
+  assert ra.stats()["owner_overlapped"] >= 9
+  ka, va = ta.export(); kb, vb = tb.export()
+  oa, ob = torch.argsort(ka), torch.argsort(kb)
+  assert torch.equal(ka[oa], kb[ob]) and torch.equal(va[oa], vb[ob])
+  rb.close()
+
+
+# ---- two ranks on one GPU ----------------------------------------------------------------------------------------------------
+W2_DIM, W2_STEPS, W2_CAP = 16, 9, 60_000
+
+
+def _w2_universe():
+  rng = np.random.default_rng(77)
+  return rng.permutation(np.arange(1, int(2 * W2_CAP * 0.62) + 1, dtype=np.int64)) * 104729 - 999_999   # negative keys too
+
+
+def _w2_batch(rank, step, universe):
+  rng = np.random.default_rng(5000 * step + rank)
+  n = [3000, 2500, 1, 4000, 3000, 700, 3000, 3000, 2000][step] + 111 * rank
+  ids = universe[(rng.zipf(1.2, size=n) * 31 + rng.integers(0, 40, size=n)) % universe.size].astype(np.int64)
+  if n > 100:
+    ids[: n // 8] = universe[3]                  # a hot id both ranks write every step: the highest rank's last occurrence wins
+    ids[rng.integers(0, n, size=5)] = IMIN
+    ids[rng.integers(0, n, size=5)] = IMIN + 1
+  rng.shuffle(ids)
+  vals = (np.arange(n, dtype=np.float32) + 10000.0 * (step + 1) + 5000.0 * rank)[:, None].repeat(W2_DIM, 1)
+  return ids, vals
+
+
+def _w2_worker(rank, world, port, kind, out_dir):
+  import torch
+  import torch.distributed as dist
+  import tfra_amd.dynamic_embedding as de
+  from tfra_amd.dynamic_embedding.distributed import RoutedAssignStep
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    torch.cuda.set_device(0)
+    universe = _w2_universe()
+    mine = universe[((universe & 0x7FFFFFFF) % world) == rank]
+    sent = np.array([IMIN, IMIN + 1], np.int64)
+    mine = np.concatenate([mine, sent[((sent & 0x7FFFFFFF) % world) == rank]])   # the sentinel keys are resident too: nothing is ever inserted
+    if kind == "dense_bounded":
+      t = _dense_table(torch, de, W2_CAP, W2_DIM, mine, "ar_w2_%d" % rank)
+    else:
+      t = de.CuckooHashTable(torch.int64, torch.float32, torch.zeros(W2_DIM), device="cuda:0", dim=W2_DIM, name="ar_w2g_%d" % rank)
+      half = mine[: mine.size // 2]              # growing table: half the universe resident, the other half enters through the steps
+      k = torch.from_numpy(half).cuda()
+      t._table.upsert(k, (k % 1000).to(torch.float32)[:, None].repeat(1, W2_DIM), unique_keys=True)
+    rs = RoutedAssignStep(t, transport="staged", max_batch=1 << 16)
+    batches = [_w2_batch(rank, s, universe) for s in range(W2_STEPS)]
+    ids_t = [torch.from_numpy(b[0]).cuda() for b in batches]
+    vals_t = [torch.from_numpy(b[1]).cuda() for b in batches]
+    ahead = 4 if kind == "dense_bounded" else 2
+    fed = 0
+    for _ in range(min(ahead + 1, W2_STEPS)):
+      rs.feed(ids_t[fed]); fed += 1
+    looked = []
+    for s in range(W2_STEPS):
+      rows = rs.step(vals_t[s - 1] if s else None)
+      if fed < W2_STEPS:
+        rs.feed(ids_t[fed]); fed += 1
+      looked.append(rows.cpu().numpy())
+    rs.flush(vals_t[-1])
+    torch.cuda.synchronize()
+    st = rs.stats()
+    if kind == "dense_bounded":
+      assert st["owner_overlapped"] >= W2_STEPS and st["owner_sequential"] == 0, st
+    t._table.check_errors()
+    k, v = t.export()
+    k = k.cpu().numpy()
+    assert np.all(((k & 0x7FFFFFFF) % world) == rank)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), keys=k, vals=v.cpu().numpy(), **{"look%d" % i: x for i, x in enumerate(looked)})
+    rs.close()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dense_bounded", "growing"])
+def test_routed_assign_world2_real_shards_one_gpu_vs_one_oracle_table(kind, tmp_path):
+  import torch
+  import torch.multiprocessing as mp
+  import oracle
+  assert torch.cuda.is_available()
+  world, port = 2, 29930 + (kind == "growing")
+  mp.spawn(_w2_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
+  res = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+  universe = _w2_universe()
+  tab = oracle.CpuTable(W2_DIM)
+  sent = np.array([IMIN, IMIN + 1], np.int64)
+  if kind == "dense_bounded":
+    pre = np.concatenate([universe, sent])
+  else:
+    pre = np.concatenate([universe[((universe & 0x7FFFFFFF) % world) == r][: int(np.sum(((universe & 0x7FFFFFFF) % world) == r)) // 2] for r in range(world)])
+  tab.insert(pre, (pre % 1000).astype(np.float32)[:, None].repeat(W2_DIM, 1))
+  dflt = np.zeros(W2_DIM, np.float32)
+  for step in range(W2_STEPS):
+    batches = [_w2_batch(r, step, universe) for r in range(world)]
+    for r, (ids, _) in enumerate(batches):            # every rank looks up first ...
+      np.testing.assert_array_equal(res[r]["look%d" % step], tab.find(ids, dflt), err_msg="rank %d step %d" % (r, step))
+    for ids, vals in batches:                         # ... then rank 0's insert_or_assign, then rank 1's (sequential: the last occurrence wins)
+      tab.insert(ids, vals)
+  ek, ev = tab.export_sorted()
+  gk = np.concatenate([r["keys"] for r in res])
+  gv = np.concatenate([r["vals"] for r in res])
+  o = np.argsort(gk)
+  np.testing.assert_array_equal(gk[o], ek)            # every key lives on exactly one shard
+  np.testing.assert_array_equal(gv[o], ev)

@@ -467,7 +467,8 @@ def test_find_unique_equals_find_and_unique(env, kind):
   """tfra_table_find_unique (ONE launch: the lookup of all ids next to their de-duplication — what the fused TF op
   TFRA>HkvHashTableEmbeddingLookup issues) against tfra_table_find and numpy.unique: rows and exists flags bit-exact, the distinct ids
   as a set with a consistent inverse index.  Sizes up and down on one workspace (the plan's two tables alternate and empty each other),
-  above 131072 ids and with rows that are not 16-byte granules the call runs the two launches one after the other — same results."""
+  up to 262144 ids in ONE launch (two ids per de-duplicating thread above 131072); with rows that are not 16-byte granules the call
+  runs the two launches one after the other — same results."""
   torch, de, SparsePlan = env
   rng = np.random.default_rng(5)
   imin = np.iinfo(np.int64).min

@@ -146,7 +146,7 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   env = dict(os.environ, TFRA_BENCH_BACKEND="gloo", TFRA_BENCH_ROUTE=route, HSA_ENABLE_IPC_MODE_LEGACY="0", TFRA_BENCH_DETAIL_DIR=str(tmp_path))
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", str(29990 + (route == "native")), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-         "--c4-keys", "300000", "--batch", "8192", "--no-cpu-baseline"]
+         "--config", "c4", "--c4-keys", "300000", "--batch", "8192", "--no-cpu-baseline"]
   p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
   assert p.returncode == 0, p.stderr[-3000:]
   lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -155,11 +155,38 @@ def test_bench_two_ranks_one_gpu(route, tmp_path):
   assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
   assert d["config"]["global_batch"] == 2 * 8192
   assert "roofline" in d and d["unit"] == "pairs/s"
-  # every N runs ONE per-GPU workload, BASELINE configs[3] (hash-sharded, per-GPU batch from the global Zipf, routed)
+  # `--config c4`: BASELINE configs[3] with the gradient route (hash-sharded, per-GPU batch from the global Zipf, fused SGD at the owner)
   assert d["config"]["workload"].startswith("BASELINE configs[3]") and d["config"]["route"] == route
   assert len(lines[0]) < 6000          # the driver keeps an ~8 KB tail of stdout: the line must fit whole
   full = json.load(open(os.path.join(str(tmp_path), "bench_detail.json")))   # everything else: the detail file
   assert full["config"]["timing"]["value"]["windows"] == 5 and full["config"]["timing"]["value"]["steps_per_window"] == 6
+
+
+def test_bench_gpus2_without_a_launcher_runs_the_metric_step_sharded(tmp_path):
+  """`python bench.py --gpus 2` exactly as the driver starts it (NO torch.distributed.run in front): bench.py starts its own two ranks
+  (here sharing cuda:0, collectives host-staged through gloo) and measures, per GPU, the METRIC's workload — lookup(B) +
+  insert_or_assign(B) on a bounded LRU shard at capacity, ids / rows / values routed, the owner running the overlapped step — the
+  same step the one-GPU line reports.  One JSON line from rank 0, its in-run verification true."""
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+  env.update(TFRA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", TFRA_BENCH_DETAIL_DIR=str(tmp_path))
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--shard-slots", "300000",
+         "--batch", "8192", "--no-cpu-baseline"]
+  p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-3000:]
+  lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, p.stdout[-2000:]
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "pairs/s"
+  assert d["config"]["global_batch"] == 2 * 8192 and d["config"]["route"] == "assign_route" and d["config"]["driver"] == "routed_overlapped_step"
+  assert d["config"]["workload"].startswith("BASELINE metric") and "lookup+insert pairs/s" in d["metric"]
+  assert d["verified"] is True and d["roofline"]["step_frac"] > 0 and d["roofline"]["avg_launch_us"] > 0
+  assert len(lines[0]) < 6000
+  full = json.load(open(os.path.join(str(tmp_path), "bench_detail.json")))
+  st = full["config"]["route_stats"]
+  assert st["owner_overlapped"] >= 5 * 6 and full["config"]["verified"]["routed_step_last_batch"] is True
 
 
 # ---- configs[4] across ranks: several tables, each hash-sharded, one route per table on ONE shared transport, fused FTRL ----------

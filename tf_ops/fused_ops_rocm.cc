@@ -274,6 +274,9 @@ class EmbeddingLookupOp : public OpKernel {
   using OpKernel::OpKernel;
   void Compute(OpKernelContext* ctx) override {
     TFRA_TABLE_OR_RETURN(ctx, t);
+    // the outputs are allocated with the op's attr dtypes, the library writes the TABLE's row size: the two must be one
+    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype()},
+                                            {t->value_dtype(), t->key_dtype(), DT_INT32, DT_INT64}));
     const Tensor& ids = ctx->input(1);
     const Tensor& dflt = ctx->input(2);
     const int64_t n = ids.NumElements(), dim = static_cast<int64_t>(t->dim());
@@ -282,11 +285,11 @@ class EmbeddingLookupOp : public OpKernel {
     OP_REQUIRES_OK(ctx, ctx->allocate_output("unique_ids", TensorShape({n}), &unique_ids));   // upper bound: the first num_unique are valid
     OP_REQUIRES_OK(ctx, ctx->allocate_output("idx", TensorShape({n}), &idx));
     OP_REQUIRES_OK(ctx, ctx->allocate_output("num_unique", TensorShape({}), &num));
-    if (n == 0) return;
     tfra_stream_t st = StreamOf(ctx);
     tfra_workspace_t* ws = nullptr;
     OP_REQUIRES_OK(ctx, t->Workspace(&ws));
     OP_REQUIRES(ctx, dflt.NumElements() == dim, errors::InvalidArgument("EmbeddingLookup: default_value must be one row [dim]"));
+    // (no early return for an empty batch: the call zeroes num_unique, a device scalar a downstream InsertN reads)
     // ONE launch: the lookup's blocks behind the de-duplication's (find_unique_kernel, csrc/tfra_csr.hip)
     OP_REQUIRES_OK(ctx, ToStatus(tfra_table_find_unique(t->raw(), ws, static_cast<size_t>(n), In<int64_t>(ids), Out<char>(values), nullptr,
                                                         dflt.tensor_data().data(), 0, Out<int64_t>(unique_ids), Out<int32_t>(idx),
@@ -301,6 +304,9 @@ class InsertNOp : public OpKernel {
     TFRA_TABLE_OR_RETURN(ctx, t);
     OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->key_dtype(), t->value_dtype(), DT_INT64}, {}));
     const Tensor& keys = ctx->input(1);
+    OP_REQUIRES(ctx, ctx->input(2).NumElements() == keys.NumElements() * static_cast<int64_t>(t->dim()),
+                errors::InvalidArgument("InsertN: values must hold one row [dim] per key (the upper-bound shape of keys)"));
+    OP_REQUIRES(ctx, ctx->input(3).NumElements() == 1, errors::InvalidArgument("InsertN: num must be a scalar"));
     OP_REQUIRES_OK(ctx, ToStatus(tfra_table_insert_or_assign_n(t->raw(), static_cast<size_t>(keys.NumElements()), In<int64_t>(ctx->input(3)),
                                                                In<int64_t>(keys), ctx->input(2).tensor_data().data(), nullptr, StreamOf(ctx))));
   }
@@ -361,6 +367,9 @@ class LookupAssignStepOp : public OpKernel {
   explicit LookupAssignStepOp(OpKernelConstruction* ctx) : OpKernel(ctx) { OP_REQUIRES_OK(ctx, ctx->GetAttr("ids_were_announced", &announced_)); }
   void Compute(OpKernelContext* ctx) override {
     TFRA_TABLE_OR_RETURN(ctx, t);
+    OP_REQUIRES(ctx, t->key_dtype() == DT_INT64, errors::InvalidArgument("LookupAssignStep: int64 keys"));
+    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, DT_INT64, t->value_dtype(), t->value_dtype(), DT_INT64, DT_INT64},
+                                            {t->value_dtype(), DT_BOOL}));
     MI355XHashTable::StepState* s = nullptr;
     OP_REQUIRES_OK(ctx, t->Step(&s));
     mutex_lock l(s->mu);
@@ -409,6 +418,7 @@ class LookupAssignFlushOp : public OpKernel {
   using OpKernel::OpKernel;
   void Compute(OpKernelContext* ctx) override {
     TFRA_TABLE_OR_RETURN(ctx, t);
+    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, t->value_dtype()}, {}));
     MI355XHashTable::StepState* s = nullptr;
     OP_REQUIRES_OK(ctx, t->Step(&s));
     mutex_lock l(s->mu);
