@@ -1195,7 +1195,7 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
           "served_ids_per_step": m["served_ids"], "served_distinct_ids_per_step": m["served_distinct"],
           "route_stats": m["stats"], "verified": verified,
           "launches_per_step": "critical path (caller's stream): gather(values) + alltoall + owner step launch + alltoall + gather(rows) = 3 kernels "
-                               "+ 2 collectives; ahead, on the driver's streams: 1 route-plan launch + 2 small collectives + 1 copy per batch",
+                               "+ 2 collectives; ahead, on the driver's own stream: 2 route-plan launches + 2 small collectives + 1 copy per batch",
           "timing": {"value": timing_note(secs, K)},
       },
       "roofline": {

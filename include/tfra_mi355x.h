@@ -560,7 +560,7 @@ int tfra_route_served_ids(tfra_route_t* r, const int64_t** d_ids, size_t* n, siz
  *               hvd.alltoall(ids) -> local Find -> hvd.alltoall(rows) -> stitch)
  *      insert : Variable.upsert on a sharded Variable            (PY/dynamic_embedding_variable.py:772-800: keys AND values
  *               partitioned by owner, one Insert per shard; the last occurrence of a repeated key wins)
- *    with ONE launch per batch for everything that depends on the ids alone (de-duplication, grouping by owner, last positions,
+ *    with TWO launches per batch (route plan: insert + emit) for everything that depends on the ids alone (de-duplication, grouping by owner, last positions,
  *    position -> row map: runs ahead, on the driver's own streams, followed by the count exchange, the one host read of the split
  *    sizes and the id exchange) and, per step on the caller's stream: gather(values at the last positions) -> alltoall(values) ->
  *    tfra_table_step_overlap at the owner (lookup of the ids it serves for THIS batch + write-back of the rows it received for the

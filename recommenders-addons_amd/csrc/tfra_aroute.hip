@@ -6,8 +6,8 @@
 // What is different here (MI355X-first, not the reference's call pattern):
 //   * the OWNER's half of a step is the overlapped step of tfra_step_impl.h — lookup of the ids it serves for batch i+1 and
 //     write-back of the rows it received for batch i in ONE launch (ids the two share are forwarded from the received rows);
-//   * everything that depends on the ids alone runs AHEAD of the step, off its critical path, and is ONE launch per batch:
-//     `routeplan_kernel` de-duplicates the batch (the distinct ids are what travels: a Zipf-1.2 batch of 131 072 ids has ~22 K),
+//   * everything that depends on the ids alone runs AHEAD of the step, off its critical path, and is TWO launches per batch:
+//     the route plan (routeplan_insert_kernel + routeplan_emit_kernel) de-duplicates the batch (the distinct ids are what travels: a Zipf-1.2 batch of 131 072 ids has ~22 K),
 //     groups the distinct ids by owner, records the last position of every distinct id (insert_or_assign: the last occurrence
 //     wins) and the position -> returned-row map.  The route of tfra_route.hip needs 11 launches for the same (CSR plan 3,
 //     partition 3, position map 2, plan of the served ids 3);
@@ -23,7 +23,7 @@
 // K/hkv_hashtable_op_gpu.cu.cc:192-213,256-267).
 //
 // Collectives: every alltoall of both channels is issued by the CALLING thread at points that depend on the call sequence
-// alone — identical on every rank.  No helper thread: the id-only half is one launch.
+// alone — identical on every rank.  No helper thread: the id-only half is two launches.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -41,39 +41,43 @@ namespace {
 
 int hip_fail(const char* what) { return set_error(TFRA_ERR_HIP, std::string("assign route: ") + what); }
 
-// ------------------------------------------------------------------------------------------- the id-only half: ONE launch
-// routeplan_kernel: for a batch of n ids (<= 2^18)
+// ------------------------------------------------------------------------------------------- the id-only half: TWO launches
+// For a batch of n ids (<= 2^18):
 //   keys_out[0 .. U)   the distinct ids grouped by owner (owner 0's first), order inside a group unspecified
 //   lastpos[j]         the LAST position of keys_out[j] in the batch
 //   pos2row[p]         the row j with keys_out[j] == ids[p]
 //   d_counts[w]        distinct ids owned by rank w (int64: what the count exchange sends)
-// Phases (blocks of 1024 threads, at most 128 of them, all co-resident — the kernel holds one grid-wide meeting):
+// routeplan_insert_kernel (blocks of 1024 threads, one or two ids per thread):
 //   A  equal ids of a block meet in an LDS hash table (compare-and-swap on the key, max on position + 1);
 //   B  every distinct id of the block goes into a global open-addressing table (compare-and-swap; max on position + 1); the block
-//      whose swap installed a key counts it under its owner (LDS), then draws the block's base per owner from the per-owner
-//      counters (one returned add per block and owner) and ARRIVES;
-//   C  while thread 0 waits for the other blocks' arrival, the block empties its share of the slots the PREVIOUS build used in
-//      the other of the two tables (they alternate: no fill launch between builds);
-//   D  all counts are final: prefix over the owners -> the row of every installed key = prefix[owner] + block base + index in
-//      the block; the installer writes key / last position (final: every block's max came before its arrival) / slot and
-//      publishes row + 1 in the entry; the other blocks holding the key poll that word (their installer is resident);
-//   E  pos2row from the block's LDS table.
+//      whose swap installed a key counts it under its owner in LDS, draws the block's base per owner from the per-owner counters
+//      (ONE returned add per block and owner: 128 x world adds per batch, not one per key) and stores (owner, base + index) in
+//      the key's entry: the key's row inside its owner's group.
+// routeplan_emit_kernel (256 threads per block; launched behind it: every count is final, no block waits for another):
+//   position blocks: probe the table for ids[p] -> pos2row[p] = prefix[owner] + row inside the group;
+//   slot blocks: one table slot per thread -> keys_out / lastpos of the key it holds; the same thread empties its slot of the OTHER
+//      of the two tables (they alternate: the table of the build before is clean again when the next build needs it).
+// (A first form did all of this in ONE launch with a grid-wide meeting — every block co-resident, thread 0 of each polling an arrival
+// counter.  Its 2048 waves held a quarter of the chip's wave slots while they waited, beside the step launch they are meant to stay
+// out of the way of, and a kernel that needs all its blocks resident at once is one more thing that can go wrong on a GPU shared
+// with foreign work.  Two plain launches cost one more enqueue on a stream that is not the critical path.)
 // The two sentinel key values (EMPTY_KEY, LOCKED_KEY) have slots of their own behind the table.
 constexpr int RP_NT = 1024;
 constexpr unsigned RP_MAX_WORLD = 64;
 constexpr size_t RP_MAX_IDS = (size_t)1 << 18;
-struct RpEnt { i64 key; unsigned pos1, row1; };   // key (EMPTY_KEY = free) | last position + 1 | row + 1 (0 = not yet known)
-// control words of one use of one table (512 B): [0] blocks arrived, [1] distinct ids in total (left for the next build: the list
-// it walks to empty this table), [32 .. 32 + world) distinct ids per owner
-constexpr unsigned RP_CTL_WORDS = 128;
+struct RpEnt { i64 key; unsigned pos1, row1; };   // key (EMPTY_KEY = free) | last position + 1 | owner << 20 | (row inside the owner's group + 1)
+constexpr unsigned RP_ROW_BITS = 20, RP_ROW_MASK = (1u << RP_ROW_BITS) - 1u;
 
 struct RpArgs {
-  unsigned n, m2, world, mode, nblk;
+  unsigned n, m2, world, mode;
   const i64* ids;
-  RpEnt* ent; unsigned* slots; unsigned* ctl; unsigned* ctl_next_use;
-  RpEnt* old_ent; const unsigned* old_slots; const unsigned* old_total;
+  RpEnt* ent;            // this build's table
+  RpEnt* old_ent;        // the other one: emptied by the emit kernel
+  unsigned* gcount;      // [RP_MAX_WORLD] distinct ids per owner of this build (zero before it)
+  unsigned* gcount_next; // the counters of the NEXT build (two sets alternate): zeroed by the emit kernel
   i64* keys_out; int* lastpos; int* pos2row; i64* d_counts;
-  unsigned* err;   // pinned: meetings / polls that timed out (never seen; reported by the next call)
+  i64* h_counts;         // pinned: the same counts for the host (the split sizes of the id exchange) — no copy command
+  unsigned pos_blocks;   // emit: blocks that map positions (the rest scan slots)
 };
 
 __device__ __forceinline__ int rp_owner_of(i64 key, unsigned num, unsigned mode) {   // default_partition_fn, PY/dynamic_embedding_variable.py:165-197
@@ -81,28 +85,25 @@ __device__ __forceinline__ int rp_owner_of(i64 key, unsigned num, unsigned mode)
   if (mode == 1) { i64 m = key % (i64)num; return (int)(m < 0 ? m + (i64)num : m); }
   return (int)__umul64hi(fmix64((u64)key), (u64)num);
 }
+__device__ __forceinline__ unsigned rp_home(i64 key, unsigned m2) { return (unsigned)(fmix64((u64)key) >> 20) & (m2 - 1); }
 
 template <int IPT>
-__global__ __launch_bounds__(RP_NT) void routeplan_kernel(const RpArgs a) {
+__global__ __launch_bounds__(RP_NT) void routeplan_insert_kernel(const RpArgs a) {
   constexpr unsigned LDSN = 2048u * IPT;   // slots of the block's LDS table: two per id
   constexpr int NR = 2 * IPT;
   __shared__ i64 s_key[LDSN];
-  __shared__ unsigned s_pos[LDSN + 2], s_row[LDSN + 2];
-  __shared__ unsigned s_own[RP_MAX_WORLD], s_obase[RP_MAX_WORLD], s_pref[RP_MAX_WORLD];
+  __shared__ unsigned s_pos[LDSN + 2];
+  __shared__ unsigned s_own[RP_MAX_WORLD], s_obase[RP_MAX_WORLD];
   const unsigned tid = threadIdx.x, bid = blockIdx.x, m2 = a.m2;
-  const unsigned n_old = *a.old_total;
-  for (unsigned i = tid; i < LDSN + 2; i += RP_NT) { if (i < LDSN) s_key[i] = EMPTY_KEY; s_pos[i] = 0; s_row[i] = 0; }
+  for (unsigned i = tid; i < LDSN + 2; i += RP_NT) { if (i < LDSN) s_key[i] = EMPTY_KEY; s_pos[i] = 0; }
   if (tid < RP_MAX_WORLD) { s_own[tid] = 0; s_obase[tid] = 0; }
-  if (bid == 0 && tid < RP_CTL_WORDS) a.ctl_next_use[tid] = 0;   // (its last reader — the other table's build after this table's previous use — is over)
   __syncthreads();
   // ---- A ------------------------------------------------------------------------------------------------------------
-  unsigned gids[IPT], lds_slot[IPT];
 #pragma unroll
   for (int q = 0; q < IPT; ++q) {
-    gids[q] = (bid * IPT + q) * RP_NT + tid;
-    lds_slot[q] = 0;
-    if (gids[q] < a.n) {
-      const i64 id = a.ids[gids[q]];
+    const unsigned g = (bid * IPT + q) * RP_NT + tid;
+    if (g < a.n) {
+      const i64 id = a.ids[g];
       unsigned slot;
       if (is_reserved_key(id)) slot = LDSN + (unsigned)reserved_index(id);
       else {
@@ -113,107 +114,89 @@ __global__ __launch_bounds__(RP_NT) void routeplan_kernel(const RpArgs a) {
           slot = (slot + 1) & (LDSN - 1);
         }
       }
-      atomicMax(&s_pos[slot], gids[q] + 1u);
-      lds_slot[q] = slot;
+      atomicMax(&s_pos[slot], g + 1u);
     }
   }
   __syncthreads();
-  // ---- B ------------------------------------------------------------------------------------------------------------
-  // NR + 1 items per thread: the block's LDS slots tid, tid + 1024, ...; threads 0 and 1 also carry the two sentinel slots
-  i64 mykey[NR + 1];
-  unsigned myslot[NR + 1], myidx[NR + 1], myown[NR + 1], lslot[NR + 1];
-  bool have[NR + 1], mine[NR + 1];
+  // ---- B: NR + 1 items per thread — the block's LDS slots tid, tid + 1024, ...; threads 0 and 1 also carry the two sentinel slots -----
+  unsigned myslot[NR + 1], myidx[NR + 1], myown[NR + 1];
+  bool mine[NR + 1];
 #pragma unroll
   for (int r = 0; r <= NR; ++r) {
     const bool sentinel = r == NR;
-    lslot[r] = sentinel ? LDSN + (tid & 1u) : tid + (unsigned)r * RP_NT;
-    have[r] = (!sentinel || tid < 2) && s_pos[lslot[r]] != 0;
+    const unsigned ls = sentinel ? LDSN + (tid & 1u) : tid + (unsigned)r * RP_NT;
+    const bool have = (!sentinel || tid < 2) && s_pos[ls] != 0;
     mine[r] = false; myidx[r] = 0; myown[r] = 0; myslot[r] = 0;
-    mykey[r] = sentinel ? EMPTY_KEY + (i64)(tid & 1u) : s_key[lslot[r]];
-    if (!have[r]) continue;
-    const unsigned p1 = s_pos[lslot[r]];
+    if (!have) continue;
+    const i64 key = sentinel ? EMPTY_KEY + (i64)(tid & 1u) : s_key[ls];
     if (sentinel) {
       myslot[r] = m2 + (tid & 1u);
       const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&a.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, 1ULL);
       mine[r] = w == EMPTY_KEY;
     } else {
-      unsigned sl = (unsigned)(fmix64((u64)mykey[r]) >> 20) & (m2 - 1);
+      unsigned sl = rp_home(key, m2);
       for (;;) {
-        const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&a.ent[sl].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
+        const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&a.ent[sl].key), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
         if (w == EMPTY_KEY) { mine[r] = true; break; }
-        if (w == mykey[r]) break;
+        if (w == key) break;
         sl = (sl + 1) & (m2 - 1);
       }
       myslot[r] = sl;
     }
-    atomicMax(&a.ent[myslot[r]].pos1, p1);
+    atomicMax(&a.ent[myslot[r]].pos1, s_pos[ls]);
     if (mine[r]) {
-      myown[r] = (unsigned)rp_owner_of(mykey[r], a.world, a.mode);
+      myown[r] = (unsigned)rp_owner_of(key, a.world, a.mode);
       myidx[r] = atomicAdd(&s_own[myown[r]], 1u);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's max-es are acknowledged before the block arrives
   __syncthreads();
-  if (tid < a.world && s_own[tid]) s_obase[tid] = atomicAdd(a.ctl + 32 + tid, s_own[tid]);   // (returned: performed when the value is here)
+  if (tid < a.world && s_own[tid]) s_obase[tid] = atomicAdd(a.gcount + tid, s_own[tid]);
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(a.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- C: empty the slots the previous build used in the OTHER table ----------------------------------------------------
-  for (unsigned i = bid * RP_NT + tid; i < n_old; i += a.nblk * RP_NT) {
-    const unsigned sl = a.old_slots[i];
-    *reinterpret_cast<uint4*>(a.old_ent + sl) = make_uint4(0u, 0x80000000u, 0u, 0u);   // {EMPTY_KEY, 0, 0}
-  }
-  // ---- the meeting ---------------------------------------------------------------------------------------------------
-  if (tid == 0) {
-    bool ok = false;
-    for (unsigned it = 0; it < (1u << 24); ++it) {
-      if (__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.nblk) { ok = true; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    if (!ok) atomicAdd(a.err, 1u);
-  }
-  __syncthreads();
-  // ---- D ------------------------------------------------------------------------------------------------------------
-  if (tid < a.world) s_pref[tid] = __hip_atomic_load(a.ctl + 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int r = 0; r <= NR; ++r)
+    if (mine[r]) a.ent[myslot[r]].row1 = (myown[r] << RP_ROW_BITS) | (s_obase[myown[r]] + myidx[r] + 1u);
+}
+
+__global__ __launch_bounds__(256) void routeplan_emit_kernel(const RpArgs a) {
+  __shared__ unsigned s_pref[RP_MAX_WORLD];
+  const unsigned tid = threadIdx.x, bid = blockIdx.x, m2 = a.m2;
+  if (tid < a.world) s_pref[tid] = a.gcount[tid];
   __syncthreads();
   if (tid == 0) {
     unsigned run = 0;
     for (unsigned w = 0; w < a.world; ++w) {
       const unsigned c = s_pref[w];
-      if (bid == 0) a.d_counts[w] = (i64)c;
+      if (bid == 0) { a.d_counts[w] = (i64)c; __hip_atomic_store(a.h_counts + w, (i64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       s_pref[w] = run;
       run += c;
     }
-    if (bid == 0) a.ctl[1] = run;
   }
+  if (bid == 0 && tid < RP_MAX_WORLD) a.gcount_next[tid] = 0;
   __syncthreads();
-  bool timed_out = false;
-#pragma unroll
-  for (int r = 0; r <= NR; ++r) {
-    if (!have[r] || !mine[r]) continue;
-    const unsigned row = s_pref[myown[r]] + s_obase[myown[r]] + myidx[r];
-    a.keys_out[row] = mykey[r];
-    a.slots[row] = myslot[r];
-    a.lastpos[row] = (int)__hip_atomic_load(&a.ent[myslot[r]].pos1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
-    __hip_atomic_store(&a.ent[myslot[r]].row1, row + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_row[lslot[r]] = row + 1u;
-  }
-#pragma unroll
-  for (int r = 0; r <= NR; ++r) {
-    if (!have[r] || mine[r]) continue;
-    unsigned v = 0;
-    for (unsigned it = 0; !v && it < (1u << 24); ++it) {
-      v = __hip_atomic_load(&a.ent[myslot[r]].row1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!v) __builtin_amdgcn_s_sleep(2);
+  if (bid < a.pos_blocks) {
+    const unsigned p = bid * 256u + tid;
+    if (p >= a.n) return;
+    const i64 id = a.ids[p];
+    unsigned sl;
+    if (is_reserved_key(id)) sl = m2 + (unsigned)reserved_index(id);
+    else {
+      sl = rp_home(id, m2);
+      for (unsigned it = 0; it < m2 && a.ent[sl].key != id; ++it) sl = (sl + 1) & (m2 - 1);   // (present: the insert kernel put it there)
     }
-    timed_out |= v == 0u;
-    s_row[lslot[r]] = v;
+    const unsigned v = a.ent[sl].row1;
+    a.pos2row[p] = (int)(s_pref[v >> RP_ROW_BITS] + (v & RP_ROW_MASK)) - 1;
+    return;
   }
-  if (timed_out) atomicAdd(a.err, 1u);
-  __syncthreads();
-  // ---- E ------------------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int q = 0; q < IPT; ++q)
-    if (gids[q] < a.n) a.pos2row[gids[q]] = (int)s_row[lds_slot[q]] - 1;
+  const unsigned i = (bid - a.pos_blocks) * 256u + tid;
+  if (i >= m2 + 2) return;
+  const uint4 e = *reinterpret_cast<const uint4*>(a.ent + i);
+  const i64 k = (i64)(((u64)e.y << 32) | e.x);
+  if (k != EMPTY_KEY) {
+    const unsigned row = s_pref[e.w >> RP_ROW_BITS] + (e.w & RP_ROW_MASK) - 1u;
+    a.keys_out[row] = i >= m2 ? EMPTY_KEY + (i64)(i - m2) : k;
+    a.lastpos[row] = (int)e.z - 1;
+  }
+  *reinterpret_cast<uint4*>(a.old_ent + i) = make_uint4(0u, 0x80000000u, 0u, 0u);   // {EMPTY_KEY, 0, 0}
 }
 
 __global__ __launch_bounds__(256) void rp_fill_kernel(RpEnt* e, size_t n) {
@@ -230,10 +213,11 @@ int dmalloc(T** p, size_t count) {
 
 // ------------------------------------------------------------------------------------------- the driver
 constexpr int NS = 8;   // batches in flight: the one being written back, the one looked up, up to five fed ahead, one spare
-// A batch moves through these stages (who issues what: everything the calling thread, in call order):
-//   FED      routeplan_kernel                                                                [side stream]
-//   COUNTED  alltoall of the per-owner counts, copy to pinned memory                         [coll stream]
-//   ROUTED   split sizes read on the host, alltoall of the distinct ids                      [coll stream]
+// A batch moves through these stages (everything is issued by the calling thread, in call order; the id-only half on ONE stream of the
+// driver's own, `ahead`, in order — route plan, count exchange, copy of the split sizes, id exchange need no events between them):
+//   FED      the route plan's two launches                                                   [ahead]
+//   COUNTED  alltoall of the per-owner counts, copy to pinned memory                         [ahead]
+//   ROUTED   split sizes read on the host, alltoall of the distinct ids                      [ahead]
 //   LOOKED   its lookup has been issued; the next step writes it back and retires it
 enum { ST_FREE = 0, ST_FED = 1, ST_COUNTED = 2, ST_ROUTED = 3, ST_LOOKED = 4 };
 
@@ -246,9 +230,11 @@ struct ASlot {
   int* pos2row = nullptr;       // [max_n] position -> owner-major row
   i64* d_counts = nullptr;      // [2 * world] per-owner send counts | per-source receive counts
   i64* h_counts = nullptr;      // pinned copy
-  i64* recv_ids = nullptr;      // [rcap] the ids this rank serves for the batch, source-major
-  size_t rcap = 0;
-  hipEvent_t src_ev = nullptr, plan_ev = nullptr, counts_ev = nullptr, ids_ev = nullptr, done = nullptr;
+  i64* recv_buf = nullptr;      // [rcap] the ids this rank serves for the batch, source-major (one rank without a transport: unused,
+  size_t rcap = 0;              //  what is sent IS what is received: recv_ids = owner_major)
+  i64* recv_ids = nullptr;
+  hipEvent_t src_ev = nullptr, done = nullptr;
+  hipEvent_t counts_ev = nullptr, ids_ev = nullptr;   // borrowed from the driver's ring of marks (mark_ahead)
   bool done_recorded = false, wait_src = false, main_waited = false;
   std::vector<size_t> send, recv;   // ids per peer
 };
@@ -263,18 +249,19 @@ struct tfra_assign_route {
   tfra_transport tr{};
   int world = 1, rank = 0, mode = 0, device = 0;
   size_t max_n = 0, row_bytes = 0;
-  hipStream_t side = nullptr, coll = nullptr;
-  // routeplan scratch: two tables that alternate and empty each other, each with two control blocks that alternate per use
+  hipStream_t ahead = nullptr;
+  static constexpr int NMARK = 4 * NS;   // a mark is referenced for at most ~3 steps, at most two are recorded per call
+  hipEvent_t marks[NMARK] = {};
+  int mark_next = 0;
+  // route-plan scratch: two tables that alternate (the emit kernel of a build empties the other one), two sets of per-owner counters
   RpEnt* ent[2] = {nullptr, nullptr};
-  unsigned* uslots[2] = {nullptr, nullptr};
-  unsigned* ctl = nullptr;        // [2 tables][2 uses][RP_CTL_WORDS]
-  unsigned m2 = 0, builds = 0, uses[2] = {0, 0};
-  unsigned* h_err = nullptr;      // pinned
+  unsigned* gcount = nullptr;     // [2][RP_MAX_WORLD]
+  unsigned m2 = 0, builds = 0;
   ASlot slots[NS];
   int head = 0, look = 0, tail = 0;   // oldest live slot (looked up, not yet written back — or == look), next to look up, next free
   int live = 0;                        // slots between head and tail
   bool pending = false;                // slots[head] has been looked up and awaits its write-back
-  // critical-path buffers (caller's stream only)
+  // critical-path buffers (caller's stream only).  One rank without a transport: vrecv = vsend and rows_back = rows_served
   unsigned char* vsend = nullptr; unsigned char* rows_back = nullptr;            // [max_n rows]
   unsigned char* vrecv = nullptr; unsigned char* rows_served = nullptr; size_t served_cap = 0;   // [served_cap rows]
   std::vector<size_t> sb, rb;
@@ -285,16 +272,13 @@ namespace {
 
 int a2a(tfra_assign_route* r, int channel, const void* send, const std::vector<size_t>& sc, void* recv, const std::vector<size_t>& rc, size_t elem,
         hipStream_t s) {
-  if (!r->has_tr) {   // one rank: what it sends is what it receives
-    if (sc[0] && hipMemcpyAsync(recv, send, sc[0] * elem, hipMemcpyDeviceToDevice, s) != hipSuccess) return hip_fail("local copy");
-    return TFRA_OK;
-  }
+  if (!r->has_tr) return TFRA_OK;   // one rank: the receive buffer IS the send buffer (see create)
   for (int i = 0; i < r->world; ++i) { r->sb[i] = sc[i] * elem; r->rb[i] = rc[i] * elem; }
   return r->tr.alltoallv(r->tr.ctx, channel, send, r->sb.data(), recv, r->rb.data(), (tfra_stream_t)s);
 }
 
 int ensure_served(tfra_assign_route* r, size_t nr) {
-  if (nr <= r->served_cap) return TFRA_OK;
+  if (!r->has_tr || nr <= r->served_cap) return TFRA_OK;
   if (hipDeviceSynchronize() != hipSuccess) return hip_fail("synchronize before growing");
   (void)hipFree(r->vrecv); (void)hipFree(r->rows_served);
   r->vrecv = r->rows_served = nullptr; r->served_cap = 0;
@@ -306,69 +290,58 @@ int ensure_served(tfra_assign_route* r, size_t nr) {
   return TFRA_OK;
 }
 
-int check_err_word(tfra_assign_route* r) {
-  if (r->h_err && __atomic_load_n(r->h_err, __ATOMIC_RELAXED)) {
-    __atomic_store_n(r->h_err, 0u, __ATOMIC_RELAXED);
-    return set_error(TFRA_ERR_HIP, "assign route: a route-plan launch timed out waiting for its other blocks (the GPU did not keep <= 128 blocks resident)");
-  }
-  return TFRA_OK;
-}
-
-// FED: the one launch of the id-only half
+// FED: the two launches of the id-only half
 int issue_plan(tfra_assign_route* r, ASlot& sl) {
-  hipStream_t side = r->side;
-  if (sl.wait_src && hipStreamWaitEvent(side, sl.src_ev, 0) != hipSuccess) return hip_fail("event wait");
-  // the slot's buffers were last read by the step that wrote its previous batch back
-  if (sl.done_recorded && hipEventQuery(sl.done) != hipSuccess && hipStreamWaitEvent(side, sl.done, 0) != hipSuccess) return hip_fail("event wait");
+  hipStream_t st = r->ahead;
+  if (sl.wait_src && hipStreamWaitEvent(st, sl.src_ev, 0) != hipSuccess) return hip_fail("event wait");
+  // the slot's buffers were last read by the step that wrote its previous batch back (NS - 1 steps ago: normally complete)
+  if (sl.done_recorded && hipEventQuery(sl.done) != hipSuccess && hipStreamWaitEvent(st, sl.done, 0) != hipSuccess) return hip_fail("event wait");
   const unsigned p = r->builds & 1u;
   r->builds += 1;
-  const unsigned use = ++r->uses[p];
   RpArgs a{};
   a.n = (unsigned)sl.n; a.m2 = r->m2; a.world = (unsigned)r->world; a.mode = (unsigned)r->mode;
-  const int ipt = sl.n <= (size_t)128 * RP_NT ? 1 : 2;
-  a.nblk = (unsigned)((sl.n + (size_t)RP_NT * ipt - 1) / ((size_t)RP_NT * ipt));
   a.ids = (const i64*)sl.ids;
-  a.ent = r->ent[p]; a.slots = r->uslots[p];
-  a.ctl = r->ctl + (size_t)(2 * p + (use & 1u)) * RP_CTL_WORDS;
-  a.ctl_next_use = r->ctl + (size_t)(2 * p + ((use + 1) & 1u)) * RP_CTL_WORDS;
-  a.old_ent = r->ent[p ^ 1u]; a.old_slots = r->uslots[p ^ 1u];
-  a.old_total = r->ctl + (size_t)(2 * (p ^ 1u) + (r->uses[p ^ 1u] & 1u)) * RP_CTL_WORDS + 1;   // (never used yet: a zeroed word)
-  a.keys_out = sl.owner_major; a.lastpos = sl.lastpos; a.pos2row = sl.pos2row; a.d_counts = sl.d_counts;
-  a.err = r->h_err;
-  if (ipt == 1) routeplan_kernel<1><<<a.nblk, RP_NT, 0, side>>>(a);
-  else routeplan_kernel<2><<<a.nblk, RP_NT, 0, side>>>(a);
+  a.ent = r->ent[p]; a.old_ent = r->ent[p ^ 1u];
+  a.gcount = r->gcount + (size_t)p * RP_MAX_WORLD; a.gcount_next = r->gcount + (size_t)(p ^ 1u) * RP_MAX_WORLD;
+  a.keys_out = sl.owner_major; a.lastpos = sl.lastpos; a.pos2row = sl.pos2row; a.d_counts = sl.d_counts; a.h_counts = sl.h_counts;
+  a.pos_blocks = (unsigned)((sl.n + 255) / 256);
+  static const int ipt_env = [] { const char* e = getenv("TFRA_RP_IPT"); return e ? atoi(e) : 0; }();
+  const int ipt = (ipt_env == 1 || ipt_env == 2 || ipt_env == 4) ? ipt_env : (sl.n <= (size_t)32 * RP_NT ? 1 : 4);
+  const unsigned iblk = (unsigned)((sl.n + (size_t)RP_NT * ipt - 1) / ((size_t)RP_NT * ipt));
+  if (ipt == 1) routeplan_insert_kernel<1><<<iblk, RP_NT, 0, st>>>(a);
+  else if (ipt == 2) routeplan_insert_kernel<2><<<iblk, RP_NT, 0, st>>>(a);
+  else routeplan_insert_kernel<4><<<iblk, RP_NT, 0, st>>>(a);
+  routeplan_emit_kernel<<<a.pos_blocks + (r->m2 + 2 + 255) / 256, 256, 0, st>>>(a);
   if (hipGetLastError() != hipSuccess) return hip_fail("route-plan launch failed");
-  if (hipEventRecord(sl.plan_ev, side) != hipSuccess) return hip_fail("event record");
   sl.state = ST_FED;
   return TFRA_OK;
 }
 
 // FED -> COUNTED
 int issue_counts(tfra_assign_route* r, ASlot& sl) {
-  hipStream_t c = r->coll;
-  if (hipStreamWaitEvent(c, sl.plan_ev, 0) != hipSuccess) return hip_fail("event wait");
+  hipStream_t c = r->ahead;
   if (r->has_tr) {
     for (int i = 0; i < r->world; ++i) r->sb[i] = r->rb[i] = sizeof(int64_t);
     int rc = r->tr.alltoallv(r->tr.ctx, 1, sl.d_counts, r->sb.data(), sl.d_counts + r->world, r->rb.data(), (tfra_stream_t)c);
     if (rc) return rc;
-  } else if (hipMemcpyAsync(sl.d_counts + 1, sl.d_counts, sizeof(int64_t), hipMemcpyDeviceToDevice, c) != hipSuccess) {
-    return hip_fail("local copy");
   }
-  if (hipMemcpyAsync(sl.h_counts, sl.d_counts, (size_t)2 * r->world * sizeof(int64_t), hipMemcpyDeviceToHost, c) != hipSuccess ||
-      hipEventRecord(sl.counts_ev, c) != hipSuccess)
+  // the send counts reach pinned memory from the route plan itself; what arrived from the other ranks is copied (one rank: the receive
+  // count is the send count, filled in on the host)
+  if (r->has_tr && hipMemcpyAsync(sl.h_counts + r->world, sl.d_counts + r->world, (size_t)r->world * sizeof(int64_t), hipMemcpyDeviceToHost, c) != hipSuccess)
     return hip_fail("split sizes copy");
+  sl.counts_ev = nullptr;   // = the event the caller records behind this stage (mark_ahead)
   sl.state = ST_COUNTED;
   return TFRA_OK;
 }
 
 // COUNTED -> ROUTED: the ONE host read of a batch (the split sizes, as hvd.alltoall(ids, splits) needs them too), then the ids
 int issue_ids(tfra_assign_route* r, ASlot& sl) {
+  if (!sl.counts_ev) return set_error(TFRA_ERR_HIP, "assign route: internal: stage without an event");
   if (hipEventQuery(sl.counts_ev) != hipSuccess) {
     r->n_stalls += 1;
     if (hipEventSynchronize(sl.counts_ev) != hipSuccess) return hip_fail("waiting for the split sizes");
   }
-  int rc = check_err_word(r);
-  if (rc) return rc;
+  if (!r->has_tr) sl.h_counts[1] = sl.h_counts[0];
   size_t u = 0, nr = 0;
   for (int i = 0; i < r->world; ++i) {
     sl.send[i] = (size_t)sl.h_counts[i]; sl.recv[i] = (size_t)sl.h_counts[r->world + i];
@@ -377,28 +350,46 @@ int issue_ids(tfra_assign_route* r, ASlot& sl) {
   if (u > sl.n || u == 0) return set_error(TFRA_ERR_INVALID, "assign route: impossible split sizes (ranks out of step?)");
   if (nr > RP_MAX_IDS) return set_error(TFRA_ERR_UNSUPPORTED, "assign route: a rank serves at most 2^18 ids per batch");
   sl.u = u; sl.nr = nr;
-  if (nr > sl.rcap) {
+  int rc = TFRA_OK;
+  if (r->has_tr && nr > sl.rcap) {
     if (hipDeviceSynchronize() != hipSuccess) return hip_fail("synchronize before growing");
-    (void)hipFree(sl.recv_ids); sl.recv_ids = nullptr; sl.rcap = 0;
+    (void)hipFree(sl.recv_buf); sl.recv_buf = nullptr; sl.rcap = 0;
     const size_t cap = std::min(RP_MAX_IDS, nr + nr / 4 + 1024);
-    rc = dmalloc(&sl.recv_ids, cap);
+    rc = dmalloc(&sl.recv_buf, cap);
     if (rc) return rc;
     sl.rcap = cap;
   }
+  sl.recv_ids = r->has_tr ? sl.recv_buf : sl.owner_major;
   rc = ensure_served(r, nr);
   if (rc) return rc;
-  rc = a2a(r, 1, sl.owner_major, sl.send, sl.recv_ids, sl.recv, sizeof(int64_t), r->coll);
+  rc = a2a(r, 1, sl.owner_major, sl.send, sl.recv_ids, sl.recv, sizeof(int64_t), r->ahead);
   if (rc) return rc;
-  if (hipEventRecord(sl.ids_ev, r->coll) != hipSuccess) return hip_fail("event record");
+  sl.ids_ev = nullptr;   // = the event the caller records behind this stage (mark_ahead)
   sl.main_waited = false;
   sl.state = ST_ROUTED;
   return TFRA_OK;
 }
 
+// ONE event behind everything a call put into the ahead stream: it stands for the end of every stage issued since the last one
+// (the stream is in order; a stage's consumer waits a little longer than it must — two steps ahead of its use, it does not matter)
+int mark_ahead(tfra_assign_route* r) {
+  bool any = false;
+  for (ASlot& sl : r->slots) any = any || (sl.state == ST_COUNTED && !sl.counts_ev) || (sl.state == ST_ROUTED && !sl.ids_ev);
+  if (!any) return TFRA_OK;
+  hipEvent_t e = r->marks[r->mark_next];
+  r->mark_next = (r->mark_next + 1) % tfra_assign_route::NMARK;
+  if (hipEventRecord(e, r->ahead) != hipSuccess) return hip_fail("event record");
+  for (ASlot& sl : r->slots) {
+    if (sl.state == ST_COUNTED && !sl.counts_ev) sl.counts_ev = e;
+    if (sl.state == ST_ROUTED && !sl.ids_ev) sl.ids_ev = e;
+  }
+  return TFRA_OK;
+}
+
 int ensure_routed(tfra_assign_route* r, ASlot& sl) {
   int rc = TFRA_OK;
-  if (sl.state == ST_FED) rc = issue_counts(r, sl);
-  if (!rc && sl.state == ST_COUNTED) rc = issue_ids(r, sl);
+  if (sl.state == ST_FED) { rc = issue_counts(r, sl); if (!rc) rc = mark_ahead(r); }
+  if (!rc && sl.state == ST_COUNTED) { rc = issue_ids(r, sl); if (!rc) rc = mark_ahead(r); }
   return rc;
 }
 
@@ -409,7 +400,7 @@ int advance_ahead(tfra_assign_route* r) {
     if (sl.state == ST_COUNTED) { int rc = issue_ids(r, sl); if (rc) return rc; }
     else if (sl.state == ST_FED) { int rc = issue_counts(r, sl); if (rc) return rc; }
   }
-  return TFRA_OK;
+  return mark_ahead(r);
 }
 
 // write-back half of a step: the rows of the batch in slots[head] (looked up by the previous step) travel to their owners
@@ -438,16 +429,16 @@ int tfra_assign_route_destroy(tfra_assign_route_t* r) {
   (void)hipDeviceSynchronize();
   if (r->drv) (void)tfra_step_driver_destroy(r->drv);
   for (ASlot& sl : r->slots) {
-    (void)hipFree(sl.owner_major); (void)hipFree(sl.lastpos); (void)hipFree(sl.pos2row); (void)hipFree(sl.d_counts); (void)hipFree(sl.recv_ids);
+    (void)hipFree(sl.owner_major); (void)hipFree(sl.lastpos); (void)hipFree(sl.pos2row); (void)hipFree(sl.d_counts); (void)hipFree(sl.recv_buf);
     if (sl.h_counts) (void)hipHostFree(sl.h_counts);
-    for (hipEvent_t e : {sl.src_ev, sl.plan_ev, sl.counts_ev, sl.ids_ev, sl.done}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {sl.src_ev, sl.done}) if (e) (void)hipEventDestroy(e);
   }
-  for (int p = 0; p < 2; ++p) { (void)hipFree(r->ent[p]); (void)hipFree(r->uslots[p]); }
-  (void)hipFree(r->ctl);
-  if (r->h_err) (void)hipHostFree(r->h_err);
-  (void)hipFree(r->vsend); (void)hipFree(r->rows_back); (void)hipFree(r->vrecv); (void)hipFree(r->rows_served);
-  if (r->side) (void)hipStreamDestroy(r->side);
-  if (r->coll) (void)hipStreamDestroy(r->coll);
+  for (hipEvent_t e : r->marks) if (e) (void)hipEventDestroy(e);
+  for (int p = 0; p < 2; ++p) (void)hipFree(r->ent[p]);
+  (void)hipFree(r->gcount);
+  (void)hipFree(r->vsend); (void)hipFree(r->rows_served);
+  if (r->has_tr) { (void)hipFree(r->rows_back); (void)hipFree(r->vrecv); }   // (aliases of the two above otherwise)
+  if (r->ahead) (void)hipStreamDestroy(r->ahead);
   delete r;
   return TFRA_OK;
 }
@@ -470,8 +461,7 @@ int tfra_assign_route_create(tfra_table_t* table, const tfra_transport* transpor
   if (r->device < 0 && hipGetDevice(&r->device) != hipSuccess) { delete r; return hip_fail("no device"); }
   r->sb.resize(r->world); r->rb.resize(r->world);
   int rc = hipSetDevice(r->device) == hipSuccess ? TFRA_OK : hip_fail("hipSetDevice");
-  if (!rc && (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess ||
-              hipStreamCreateWithFlags(&r->coll, hipStreamNonBlocking) != hipSuccess)) rc = hip_fail("stream create");
+  if (!rc && hipStreamCreateWithFlags(&r->ahead, hipStreamNonBlocking) != hipSuccess) rc = hip_fail("stream create");
   if (!rc) rc = tfra_step_driver_create(table, &r->drv);
   const size_t n = max_batch;
   unsigned m2 = 4096;
@@ -479,13 +469,10 @@ int tfra_assign_route_create(tfra_table_t* table, const tfra_transport* transpor
   r->m2 = m2;
   for (int p = 0; p < 2 && !rc; ++p) {
     rc = dmalloc(&r->ent[p], (size_t)m2 + 2);
-    if (!rc) rc = dmalloc(&r->uslots[p], n);
     if (!rc) rp_fill_kernel<<<256, 256, 0, nullptr>>>(r->ent[p], (size_t)m2 + 2);
   }
-  if (!rc) rc = dmalloc(&r->ctl, (size_t)4 * RP_CTL_WORDS);
-  if (!rc && hipMemset(r->ctl, 0, (size_t)4 * RP_CTL_WORDS * sizeof(unsigned)) != hipSuccess) rc = hip_fail("memset");
-  if (!rc && hipHostMalloc(reinterpret_cast<void**>(&r->h_err), 64, hipHostMallocDefault) != hipSuccess) { r->h_err = nullptr; rc = hip_fail("pinned allocation"); }
-  if (!rc) *r->h_err = 0;
+  if (!rc) rc = dmalloc(&r->gcount, (size_t)2 * RP_MAX_WORLD);
+  if (!rc && hipMemset(r->gcount, 0, (size_t)2 * RP_MAX_WORLD * sizeof(unsigned)) != hipSuccess) rc = hip_fail("memset");
   for (ASlot& sl : r->slots) {
     if (rc) break;
     sl.send.assign(r->world, 0); sl.recv.assign(r->world, 0);
@@ -493,16 +480,22 @@ int tfra_assign_route_create(tfra_table_t* table, const tfra_transport* transpor
     if (!rc) rc = dmalloc(&sl.lastpos, n);
     if (!rc) rc = dmalloc(&sl.pos2row, n);
     if (!rc) rc = dmalloc(&sl.d_counts, (size_t)2 * r->world);
-    if (!rc) rc = dmalloc(&sl.recv_ids, n);
-    if (!rc) sl.rcap = n;
+    if (!rc && r->has_tr) { rc = dmalloc(&sl.recv_buf, n); if (!rc) sl.rcap = n; }
     if (!rc && hipHostMalloc(reinterpret_cast<void**>(&sl.h_counts), (size_t)2 * r->world * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
       rc = hip_fail("pinned allocation");
-    for (hipEvent_t* e : {&sl.src_ev, &sl.plan_ev, &sl.counts_ev, &sl.ids_ev, &sl.done})
+    for (hipEvent_t* e : {&sl.src_ev, &sl.done})
       if (!rc && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = hip_fail("event create");
   }
+  for (hipEvent_t& e : r->marks)
+    if (!rc && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = hip_fail("event create");
   if (!rc) rc = dmalloc(&r->vsend, n * r->row_bytes);
-  if (!rc) rc = dmalloc(&r->rows_back, n * r->row_bytes);
-  if (!rc) rc = ensure_served(r, n);
+  if (r->has_tr) {
+    if (!rc) rc = dmalloc(&r->rows_back, n * r->row_bytes);
+    if (!rc) rc = ensure_served(r, n);
+  } else {   // one rank: a rank's own send buffers are its receive buffers (nr == u <= max_batch)
+    if (!rc) rc = dmalloc(&r->rows_served, n * r->row_bytes);
+    r->vrecv = r->vsend; r->rows_back = r->rows_served; r->served_cap = n;
+  }
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = hip_fail("synchronize");
   if (rc) { std::string keep = tfra::g_last_error; (void)tfra_assign_route_destroy(r); tfra::g_last_error = keep; return rc; }
   *out = r;
@@ -541,7 +534,7 @@ int tfra_assign_route_step(tfra_assign_route_t* r, void* d_rows_out, const void*
   if (nxt && nxt->state != ST_ROUTED) nxt = nullptr;
   ASlot* nx2 = (nxt && fed_ahead >= 3) ? &r->slots[(r->look + 2) % NS] : nullptr;
   if (nx2 && nx2->state != ST_ROUTED) nx2 = nullptr;
-  // the coll stream is in order: waiting for the newest batch's ids covers the older ones (and their route plans)
+  // the ahead stream is in order: waiting for the newest batch's ids covers the older ones (and every route plan before them)
   ASlot* newest = nx2 ? nx2 : (nxt ? nxt : &cur);
   if (!newest->main_waited && hipStreamWaitEvent(s, newest->ids_ev, 0) != hipSuccess) return hip_fail("event wait");
   cur.main_waited = true;

@@ -1975,8 +1975,13 @@ static int setplan_prepare(tfra_sparse_plan* pl, size_t n, hipStream_t s, bool c
 }
 // The same for a build WITHOUT the dense list and without atomics (the overlapped step: scatter launch + build launch): the
 // table that takes the build (every slot of it is written by the build launch), the scatter buffers sized for n ids.
+// (The table is sized for at least 131 072 ids — 128 windows — whatever the batch: a scatter tile holds up to 1024 DISTINCT ids, spread over
+// the windows into segments of SEG_CAP = 32 entries.  A batch of 22 K all-distinct ids — what one rank of a sharded table serves —
+// sized by its own length had 32 windows: 32 ids per segment on average, half the segments overflowed, and the launch took 36 us
+// instead of 17: scripts/mb_owner_step.py.)
+constexpr size_t LISTLESS_MIN_IDS = 131072;
 static int setplan_prepare_listless(tfra_sparse_plan* pl, size_t n, hipStream_t s) {
-  int rc = setplan_ensure(pl, n, s);
+  int rc = setplan_ensure(pl, std::max(n, LISTLESS_MIN_IDS), s);
   if (rc) return rc;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   if (pl->seg_cap_ids < pl->set_cap) {

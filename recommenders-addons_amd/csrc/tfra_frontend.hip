@@ -355,6 +355,27 @@ __global__ __launch_bounds__(256) void move_rows_kernel(size_t n, unsigned row_b
   copy_bytes16<G>(dst, src, row_bytes, sub);
 }
 
+// gather of 16-byte-granule rows with U rows of a 16-lane group in flight (the row -> position gather behind a lookup of de-duplicated
+// ids moves B rows: one row per group was one dependent idx -> row -> store chain per group, 9-13 us for 131 072 rows of 256 B)
+template <int U>
+__global__ __launch_bounds__(256) void gather_rows16_kernel(size_t n, unsigned row_bytes, const unsigned char* __restrict__ in,
+                                                            const int* __restrict__ idx, unsigned char* __restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  const size_t base = ((((size_t)blockIdx.x * 256) + threadIdx.x) >> 4) * U;
+  if (base >= n) return;
+  size_t j[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) j[u] = base + u < n ? (size_t)idx[base + u] : 0;
+  for (unsigned off = (unsigned)sub * 16u; off < row_bytes; off += 256u) {
+    uint4 t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = *reinterpret_cast<const uint4*>(in + j[u] * (size_t)row_bytes + off);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + u < n) *reinterpret_cast<uint4*>(out + (base + u) * (size_t)row_bytes + off) = t[u];
+  }
+}
+
 template <bool SCATTER>
 int move_rows(size_t n, size_t row_bytes, const void* in, const int32_t* idx, void* out, hipStream_t s) {
   if (n == 0) return TFRA_OK;
@@ -365,6 +386,11 @@ int move_rows(size_t n, size_t row_bytes, const void* in, const int32_t* idx, vo
   const unsigned char* i8 = (const unsigned char*)in;
   unsigned char* o8 = (unsigned char*)out;
   unsigned rb = (unsigned)row_bytes;
+  if (!SCATTER && g == 16 && n >= 4096) {
+    gather_rows16_kernel<4><<<(unsigned)(((n + 3) / 4 * 16 + 255) / 256), block, 0, s>>>(n, rb, i8, idx, o8);
+    HIP_TRY(hipGetLastError());
+    return TFRA_OK;
+  }
   switch (g) {
     case 16: move_rows_kernel<16, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;
     case 8: move_rows_kernel<8, SCATTER><<<grid, block, 0, s>>>(n, rb, i8, idx, o8); break;

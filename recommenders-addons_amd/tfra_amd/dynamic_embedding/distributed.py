@@ -619,7 +619,7 @@ class RoutedAssignStep:
 
   Route and results: the reference's `__alltoall_embedding_lookup__` (PY/shadow_embedding_ops.py:397-447) for the lookup and
   `Variable.upsert`'s partitioning of keys AND values by owner (PY/dynamic_embedding_variable.py:772-800) for the write-back —
-  one table that sees, per step, every rank's lookup and then rank 0's, rank 1's, ... insert_or_assign.  Per batch ONE launch for all
+  one table that sees, per step, every rank's lookup and then rank 0's, rank 1's, ... insert_or_assign.  Per batch TWO launches (the route plan) for all
   id-only work (de-duplication, owner grouping, last positions, position map), ahead of the step; per step on the critical path:
   gather -> alltoall(values) -> the owner's overlapped step launch -> alltoall(rows) -> gather.
 
@@ -705,11 +705,7 @@ class RoutedAssignStep:
     n = ids.numel()
     vp = self._values(values_prev, self._pending[0].numel()) if self._pending is not None else None
     if self.identity:
-      o = self._ovl
-      if o._ids is None:
-        o.prime(ids)
-      rows = o.step(vp, self._fed[1] if len(self._fed) > 1 else None, self._fed[2] if len(self._fed) > 2 else None) if vp is not None else \
-          self._identity_first(o)
+      rows = self._identity_step(vp, out)
     else:
       rows = out if out is not None else torch.empty((n, self.dim), dtype=self.vdt, device=self.dev)
       self._call("tfra_assign_route_step", self._h, self._ctypes.c_void_p(rows.data_ptr()), self._ctypes.c_void_p(self.default.data_ptr()),
@@ -719,20 +715,21 @@ class RoutedAssignStep:
     self._fed.pop(0)
     return rows
 
-  def _identity_first(self, o):
-    # the first step of the identity route has nothing to write back: OverlapAssignStep.step wants values of the step's OWN batch (it
-    # defers them itself); here the values arrive one call later, so the driver is called directly
+  def _identity_step(self, vp, out):
+    # one rank, no route: tfra_table_step_overlap itself — the announced batches are its look-ahead (the values of a batch arrive one
+    # call later, as in the routed form: the driver defers the write-back)
     from .table_ops import _stream
+    o, c = self._ovl, self._ctypes
     ids = self._fed[0]
     n = ids.numel()
-    out = torch.empty((n, self.dim), dtype=self.vdt, device=self.dev)
+    rows = out if out is not None else torch.empty((n, self.dim), dtype=self.vdt, device=self.dev)
     nxt = self._fed[1] if len(self._fed) > 1 else None
     nx2 = self._fed[2] if len(self._fed) > 2 else None
-    c = self._ctypes
-    self._capi.check(o._fn(o._h, n, c.c_void_p(ids.data_ptr()), c.c_void_p(out.data_ptr()), None, o._default_p, 0, None, None,
+    self._capi.check(o._fn(o._h, n, c.c_void_p(ids.data_ptr()), c.c_void_p(rows.data_ptr()), None, o._default_p, 0,
+                           c.c_void_p(vp.data_ptr()) if vp is not None else None, None,
                            0 if nxt is None else nxt.numel(), c.c_void_p(nxt.data_ptr()) if nxt is not None else None,
                            0 if nx2 is None else nx2.numel(), c.c_void_p(nx2.data_ptr()) if nx2 is not None else None, _stream(self.dev)))
-    return out
+    return rows
 
   def flush(self, values_prev):
     if self._pending is None:

@@ -142,36 +142,41 @@ def test_route_driver_single_rank_equals_table_and_dictionary(env, kind, ahead):
   rs.close()
 
 
-def test_identity_route_equals_overlapped_step(env):
+def test_identity_route_is_the_overlapped_step(env):
   """world 1, no forced route: RoutedAssignStep IS tfra_table_step_overlap on the announced batches (dynamic_partition with one
-  shard is the identity in the reference too) — same rows as the route driver run on a twin table."""
+  shard is the identity in the reference too): every step's rows equal a plain find of the table right after the step call, every
+  launch was the overlapped one, and the final table holds every batch's last writes."""
   torch, de, RoutedAssignStep = env
   rng = np.random.default_rng(3)
-  cap, dim = 120_000, 64
+  cap, dim, n, nsteps = 120_000, 64, 4000, 9
   universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
-  ta = _dense_table(torch, de, cap, dim, universe, "ar_id_a")
-  tb = _dense_table(torch, de, cap, dim, universe, "ar_id_b")
-  batches = [torch.from_numpy(b).cuda() for b in _make_batches(rng, universe, [4000] * 9)]
-  ra, rb = RoutedAssignStep(ta), RoutedAssignStep(tb, transport="local")
-  assert ra.identity and not rb.identity
-  for r in (ra, rb):
-    for k in range(3):
-      r.feed(batches[k])
+  t = _dense_table(torch, de, cap, dim, universe, "ar_id")
+  batches = [torch.from_numpy(b).cuda() for b in _make_batches(rng, universe, [n] * nsteps)]
+  rs = RoutedAssignStep(t)
+  assert rs.identity
+  for k in range(3):
+    rs.feed(batches[k])
+  latest = {}
   pv = None
-  for s in range(9):
-    oa, ob = ra.step(pv), rb.step(pv)
-    assert torch.equal(oa, ob), "step %d" % s
-    for r in (ra, rb):
-      if s + 3 < 9:
-        r.feed(batches[s + 3])
-    pv = (torch.arange(4000, device="cuda", dtype=torch.float32) + 7000.0 * (s + 1))[:, None].repeat(1, dim)
-  ra.flush(pv); rb.flush(pv)
+  for s in range(nsteps):
+    out = rs.step(pv)
+    if s + 3 < nsteps:
+      rs.feed(batches[s + 3])
+    torch.cuda.synchronize()
+    assert torch.equal(out, t._table.find(batches[s])), "step %d" % s
+    pv = (torch.arange(n, device="cuda", dtype=torch.float32) + 7000.0 * (s + 1))[:, None].repeat(1, dim)
+    for i, k in enumerate(batches[s].cpu().numpy().tolist()):
+      latest[k] = 7000.0 * (s + 1) + i
+  rs.flush(pv)
   torch.cuda.synchronize()
-  assert ra.stats()["owner_overlapped"] >= 9
-  ka, va = ta.export(); kb, vb = tb.export()
-  oa, ob = torch.argsort(ka), torch.argsort(kb)
-  assert torch.equal(ka[oa], kb[ob]) and torch.equal(va[oa], vb[ob])
-  rb.close()
+  st = rs.stats()
+  assert st["owner_overlapped"] >= nsteps and st["owner_sequential"] == 0, st
+  keys = torch.tensor(list(latest), dtype=torch.int64, device="cuda")
+  rows, ex = t._table.find(keys, return_exists=True)
+  exn = ex.cpu().numpy()
+  assert exn.mean() > 0.99
+  np.testing.assert_array_equal(rows[:, 0].cpu().numpy()[exn], np.array(list(latest.values()), np.float32)[exn])
+  t._table.check_errors()
 
 
 # ---- two ranks on one GPU ----------------------------------------------------------------------------------------------------
@@ -264,15 +269,31 @@ def test_routed_assign_world2_real_shards_one_gpu_vs_one_oracle_table(kind, tmp_
     pre = np.concatenate([universe[((universe & 0x7FFFFFFF) % world) == r][: int(np.sum(((universe & 0x7FFFFFFF) % world) == r)) // 2] for r in range(world)])
   tab.insert(pre, (pre % 1000).astype(np.float32)[:, None].repeat(W2_DIM, 1))
   dflt = np.zeros(W2_DIM, np.float32)
+  n_absent = n_rows = 0
   for step in range(W2_STEPS):
     batches = [_w2_batch(r, step, universe) for r in range(world)]
     for r, (ids, _) in enumerate(batches):            # every rank looks up first ...
-      np.testing.assert_array_equal(res[r]["look%d" % step], tab.find(ids, dflt), err_msg="rank %d step %d" % (r, step))
+      got, want = res[r]["look%d" % step], tab.find(ids, dflt)
+      bad = np.any(got != want, axis=1)
+      # a BOUNDED shard at 62 % load does evict now and then (a key whose two home buckets are both full — the reference tests pin only
+      # size <= capacity): such a key reads as the default row until it is written again; anything else is an error.  Never on the
+      # growing table.
+      assert kind == "dense_bounded" or not bad.any(), "rank %d step %d" % (r, step)
+      assert np.all(got[bad] == 0.0), "rank %d step %d: a row that is neither the oracle's nor the default" % (r, step)
+      n_absent += int(bad.sum()); n_rows += ids.size
     for ids, vals in batches:                         # ... then rank 0's insert_or_assign, then rank 1's (sequential: the last occurrence wins)
       tab.insert(ids, vals)
+  assert n_absent <= n_rows // 500, (n_absent, n_rows)
   ek, ev = tab.export_sorted()
   gk = np.concatenate([r["keys"] for r in res])
   gv = np.concatenate([r["vals"] for r in res])
   o = np.argsort(gk)
-  np.testing.assert_array_equal(gk[o], ek)            # every key lives on exactly one shard
-  np.testing.assert_array_equal(gv[o], ev)
+  gk, gv = gk[o], gv[o]
+  assert np.all(np.diff(gk) > 0)                      # every key lives on exactly one shard
+  if kind == "growing":
+    np.testing.assert_array_equal(gk, ek)
+    np.testing.assert_array_equal(gv, ev)
+  else:
+    pos = np.searchsorted(ek, gk)
+    assert np.all(ek[np.minimum(pos, ek.size - 1)] == gk) and gk.size >= ek.size - max(8, ek.size // 500)   # the shards hold nothing the oracle does not
+    np.testing.assert_array_equal(gv, ev[pos])
