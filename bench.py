@@ -438,6 +438,12 @@ def timed_windows(torch, dist, world, dev, K, step, first=0, windows=WINDOWS):
   return secs, secs[med], hosts[med]
 
 
+def note(msg):
+  """progress to stderr (short lines: a driver may keep one merged tail) — where a run was when something went wrong"""
+  if os.environ.get("RANK", "0") == "0":
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def timing_note(secs, K):
   return {"windows": len(secs), "steps_per_window": K, "reported": "median window",
           "ms_per_step_min": round(min(secs) / K * 1e3, 5), "ms_per_step_max": round(max(secs) / K * 1e3, 5),
@@ -641,6 +647,7 @@ def run_bounded(args, torch, de, dev, cfg):
   verified["overlapped_step_every_timed_step_overlapped"] = (verified["overlapped_step_every_timed_step_overlapped"] and
                                                              ovl_stats_d4["overlapped"] - ovl_stats["overlapped"] >= WINDOWS * K)
   del ovl, ids_d4, outs_d4
+  note("%s: overlapped step timed (%.2f us/step)" % (cfg, med / K * 1e6))
   routed_local = None
   if cfg == "m1b":
     # what `--gpus N` runs per GPU (run_metric_sharded), at ONE rank on THIS table: the route driver with device copies where the alltoalls
@@ -649,6 +656,7 @@ def run_bounded(args, torch, de, dev, cfg):
       routed_local = routed_assign_measure(args, torch, None, de, dev, 1, 0, table, idf, values, "local", K, W, verified, "routed_local")
     except Exception as e:   # noqa: BLE001 — a side measurement must not lose the line
       routed_local = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    note("m1b: route driver at one rank timed")
 
   # ---- driver 1b: round 3's look-ahead driver (one C call per step, plan of batch i+1 on a second stream, host-ordered) --------
   ps = de.PrefetchAssignStep(table).prime(ids[0])
@@ -660,6 +668,7 @@ def run_bounded(args, torch, de, dev, cfg):
   verified["look_ahead_driver_last_batch"] = bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, last, values)))
   del ps, ids, got, ex, outs
 
+  note("%s: look-ahead driver timed" % cfg)
   # ---- driver 2: no look-ahead, two calls: Find, then the fused extra that de-duplicates inside the call --------------
   ids = idf.keys(nsteps)
 
@@ -807,6 +816,7 @@ def run_bounded(args, torch, de, dev, cfg):
   verified["op_surface_table_ops_only_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:uq[nsteps - 1].numel()]))
   del got, ex
 
+  note("%s: op-surface variants timed" % cfg)
   # ---- per-kernel timings (HIP events on the launching stream), fresh batches each launch ----------------------
   rc = raw_calls(torch, dev)
   NP = 24                                     # write-back launches timed, every one on its own batch (6 were too few: +-10 %)
@@ -1034,6 +1044,7 @@ def routed_assign_measure(args, torch, dist, de, dev, world, rank, table, idf, v
   ids = idf.keys(nb + AHEAD + 1)
   outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(2)]
   dflt = rs.default
+  torch.cuda.synchronize()   # the ids are complete: the route's own stream reads them without an event (ids_ready = 1)
   feeds = [(rs._h, B, P(ids[i]), 1, st) for i in range(nb + AHEAD + 1)]
   step_first = (rs._h, P(outs[0]), P(dflt), None, st)
   steps = [(rs._h, P(outs[q]), P(dflt), P(values), st) for q in range(2)]
@@ -1822,6 +1833,7 @@ def main():
               "value_op_surface_table_ops_only", "ms_per_step",
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}
+      note("m1b done; secondary workloads")
       for name, fn in (("c3", lambda: run_bounded(args, torch, de, dev, "c3")),       # configs[2]
                        ("c2", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c2")),   # configs[1]
                        ("c4", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c4")),   # configs[3] at N=1: the first point of the N-GPU curve
@@ -1829,6 +1841,7 @@ def main():
         try:
           r = fn()
           sec[name] = {k: r[k] for k in keep if k in r}
+          note("secondary %s done" % name)
         except Exception as e:   # noqa: BLE001 — a secondary measurement must not lose the line
           sec[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
       res["secondary"] = sec

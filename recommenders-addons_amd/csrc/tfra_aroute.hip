@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void routeplan_emit_kernel(const RpArgs a) {
       for (unsigned it = 0; it < m2 && a.ent[sl].key != id; ++it) sl = (sl + 1) & (m2 - 1);   // (present: the insert kernel put it there)
     }
     const unsigned v = a.ent[sl].row1;
-    a.pos2row[p] = (int)(s_pref[v >> RP_ROW_BITS] + (v & RP_ROW_MASK)) - 1;
+    // (v == 0 or a foreign entry: the ids changed between the two launches — a caller that fed a buffer still being written without saying
+    // so (ids_ready = 0).  The results are then undefined, but the row stays inside the buffers.)
+    const unsigned own = min(v >> RP_ROW_BITS, a.world - 1u), loc = v & RP_ROW_MASK;
+    a.pos2row[p] = loc ? (int)min(s_pref[own] + loc - 1u, a.n - 1u) : 0;
     return;
   }
   const unsigned i = (bid - a.pos_blocks) * 256u + tid;

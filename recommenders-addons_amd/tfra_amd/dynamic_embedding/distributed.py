@@ -684,7 +684,9 @@ class RoutedAssignStep:
       return ids
     return torch.as_tensor(ids, device=self.dev).reshape(-1).to(torch.int64).contiguous()
 
-  def feed(self, ids, ids_ready=True):
+  def feed(self, ids, ids_ready=False):
+    """ids_ready=False (default): the ids may still be in flight on the current stream — the driver's own stream waits for them (one
+    event); True: they are complete (a host synchronisation lies between their producer and this call)."""
     ids = self._as_ids(ids)
     if not self.identity:
       self._call("tfra_assign_route_feed", self._h, ids.numel(), self._ctypes.c_void_p(ids.data_ptr()), 1 if ids_ready else 0, self._stream())
