@@ -457,3 +457,94 @@ def test_assign_step_for_picks_a_driver_by_rule_and_both_give_the_sequential_res
   drv.flush()
   ek, ev = t.export()
   np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(k)] for k in ek.cpu().numpy()], np.float32))
+
+
+def _foreign_hog(seconds, ready, stop):
+  """second process: keeps cuda:0 busy with long kernels (large fp32 matrix products, queued deep) for `seconds`"""
+  import time
+  import torch
+  a = torch.randn((6144, 6144), device="cuda")
+  b = torch.randn((6144, 6144), device="cuda")
+  torch.cuda.synchronize()
+  ready.set()
+  t0 = time.time()
+  while time.time() - t0 < seconds and not stop.is_set():
+    for _ in range(8):
+      a = torch.mm(a, b) * 1e-4
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("foreign", ["second_stream", "second_process"])
+def test_overlap_steps_beside_foreign_work_on_the_gpu(env, foreign):
+  """The step launch's tail blocks wait (bounded) for the write-back blocks of the SAME launch; the launch assumes that its blocks
+  get onto the chip in grid order.  Foreign work — another stream of this process queued deep with long kernels, or ANOTHER PROCESS
+  doing the same — takes CUs away and delays residency: 400 overlapped steps next to it must still equal the ops run one after the
+  other, with no bounded wait timing out (tfra_table_check_errors counts every one) and nothing left locked.
+  Reference semantics: K/hkv_hashtable_op_gpu.cu.cc:192-213,256-267 (Insert exclusive, Find shared)."""
+  torch, de = env
+  import threading
+  dim, cap, n, nsteps = 64, 2_000_000, 20000, 400
+  rng = np.random.default_rng(21)
+  universe = rng.permutation(np.arange(1, int(cap * 0.9) + 1, dtype=np.int64)) * 7919 + 3
+  t = make_dense_table(torch, de, cap, dim, universe[: int(universe.size * 0.95)], "ovl_foreign_" + foreign)
+  tbl = t._table
+  batches = []
+  for s in range(nsteps + 2):
+    ids = universe[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 5000, size=n)) % universe.size].astype(np.int64)
+    batches.append(torch.from_numpy(ids).cuda())
+  vals = [(torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (k + 1))[:, None].repeat(1, dim) for k in range(4)]
+  stop_flag = threading.Event()
+  proc = None
+  if foreign == "second_stream":
+    side = torch.cuda.Stream()
+    a = torch.randn((6144, 6144), device="cuda")
+    b = torch.randn((6144, 6144), device="cuda")
+
+    def hog():
+      with torch.cuda.stream(side):
+        x = a
+        while not stop_flag.is_set():
+          for _ in range(8):
+            x = torch.mm(x, b) * 1e-4
+          side.synchronize()
+    th = threading.Thread(target=hog, daemon=True)
+    th.start()
+  else:
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ready, stop = ctx.Event(), ctx.Event()
+    proc = ctx.Process(target=_foreign_hog, args=(60.0, ready, stop))
+    proc.start()
+    assert ready.wait(120), "the foreign process did not come up"
+  try:
+    drv = de.OverlapAssignStep(t).prime(batches[0])
+    mism = 0
+    for s in range(nsteps):
+      out, ex = drv.step(vals[s % 4], batches[s + 1], batches[s + 2], return_exists=True)
+      if s % 8 == 7:    # (every step would serialise the two workloads at the host: the foreign queue must stay deep while steps run)
+        ref, rex = tbl.find(batches[s], return_exists=True)
+        mism += int((ex != rex).sum()) + int((out != ref).any(dim=1).sum())
+    drv.flush()
+    torch.cuda.synchronize()
+  finally:
+    stop_flag.set()
+    if proc is not None:
+      stop.set()
+      proc.join(90)
+      if proc.is_alive():
+        proc.kill()
+    else:
+      th.join(60)
+  assert mism == 0, mism
+  st = drv.stats()
+  assert st["overlapped"] >= nsteps - 8, st
+  tbl.check_errors()                       # a tail block that gave up waiting would have counted an error
+  assert tbl.slot_census()["locked"] == 0
+  # the last batch's writes are all there (nothing dropped)
+  last = batches[nsteps - 1]
+  got, ex = tbl.find(last, return_exists=True)
+  lastv = vals[(nsteps - 1) % 4]
+  uk, inv = torch.unique(last, return_inverse=True)
+  lp = torch.zeros(uk.numel(), dtype=torch.long, device="cuda")
+  lp.scatter_reduce_(0, inv, torch.arange(n, device="cuda"), reduce="amax", include_self=False)
+  assert bool(ex.all()) and torch.equal(got, lastv[lp][inv])
