@@ -1166,7 +1166,10 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
   idf = IdFactory(torch, dev, B, n_total, new_ratio, n_total + 1 + rank * (1 << 40), SEED + 1000 * rank + 7)
   values = (torch.randn((B, dim), generator=gen, device=dev) * 0.01).to(dtype)
   verified = {}
-  transport = "local" if world == 1 else "auto"
+  # one rank: the route driver with device copies ("local"); TFRA_BENCH_FORCE_A2A=1 under torch.distributed.run --nproc-per-node 1:
+  # the REAL transport with a one-rank RCCL communicator pair (grouped ncclSend / ncclRecv to itself: what the collectives' launches cost)
+  forced = world == 1 and os.environ.get("TFRA_BENCH_FORCE_A2A") == "1" and dist is not None and dist.is_initialized()
+  transport = ("rccl" if dist.get_backend() == "nccl" else "staged") if forced else ("local" if world == 1 else "auto")
   m = routed_assign_measure(args, torch, dist, de, dev, world, rank, table, idf, values, transport, K, W, verified, "routed_step")
   table._table.check_errors()
   census = {k: int(v) for k, v in table._table.slot_census().items()}
@@ -1200,7 +1203,8 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
           "slots": capacity, "requested_slots": want, "alloc_failures": failures, "resident_after_prefill": resident,
           "global_batch": B * world, "keys_per_gpu": resident, "new_key_ratio": new_ratio, "unique_keys_per_batch": U,
           "unique_ratio": round(U / B, 4), "prefill_s": round(t_fill, 1), "steps_per_host_call": 1,
-          "parallelism": ("key-hash sharded x%d, RCCL alltoall" % world) if world > 1 else "single GPU through the route driver (no transport)",
+          "parallelism": ("key-hash sharded x%d, RCCL alltoall" % world) if world > 1 else
+                         ("single GPU through the route driver, transport %s (one-rank communicators)" % transport if forced else "single GPU through the route driver (no transport)"),
           "route": "assign_route", "rccl_ranks_seen": m["rccl_ranks"], "batches_fed_ahead": m["ahead"],
           "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
           "served_ids_per_step": m["served_ids"], "served_distinct_ids_per_step": m["served_distinct"],
