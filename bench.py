@@ -649,7 +649,7 @@ def run_bounded(args, torch, de, dev, cfg):
   del ovl, ids_d4, outs_d4
   note("%s: overlapped step timed (%.2f us/step)" % (cfg, med / K * 1e6))
   routed_local = None
-  if cfg == "m1b":
+  if cfg == "m1b" and os.environ.get("TFRA_BENCH_SKIP_ROUTED_LOCAL") != "1":   # (the profile runs skip it: its step launches would mix into the trace's step_k average)
     # what `--gpus N` runs per GPU (run_metric_sharded), at ONE rank on THIS table: the route driver with device copies where the alltoalls
     # would be — the route's own cost (route plan ahead; gather + copy + owner launch on the distinct ids + copy + gather per step)
     try:

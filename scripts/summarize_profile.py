@@ -18,8 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ["find_kernel", "upsert_own_kernel", "upsert_rest_kernel", "setplan_kernel", "insert_unique_kernel",
            "insert_evict_kernel", "export_kernel", "csr_tile_kernel", "csr_bucket_kernel", "csr_scatter_kernel", "hot_sums_kernel",
            "apply_csr_kernel", "apply_kernel", "density_kernel", "unique_idx_kernel", "unq_insert_kernel", "gather_csr_kernel", "plan_dest_bins_kernel",
-           "plan_dest_keys_kernel", "part_scatter_kernel", "accum_kernel", "step_k"]
-WORKLOADS = ("m1b", "c3", "c2", "c4")
+           "plan_dest_keys_kernel", "part_scatter_kernel", "accum_kernel", "step_k", "routeplan_insert_kernel", "routeplan_emit_kernel",
+           "gather_rows16_kernel", "move_rows_kernel"]
+WORKLOADS = ("m1b", "m1s", "c3", "c2", "c4")
 COMMANDS = {w: "python bench.py --config %s --no-secondary --no-cpu-baseline" % w for w in WORKLOADS}
 SRC_NAMES = {"0": "plan", "1": "direct", "2": "set"}   # upsert_own_kernel<G, SIMPLE, SRC> / upsert_rest_kernel<G, SRC>: where the keys come from
 
