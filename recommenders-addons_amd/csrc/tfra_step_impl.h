@@ -615,13 +615,17 @@ __device__ __forceinline__ void step_body(const StepArgs& a) {
 }
 // Instantiations (the budgets are attributes, not template arguments): 256-thread blocks are admitted per CU up to
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) — ~106 scalar registers (what the big argument block costs) allow 6, 96 allow 7, 80 allow 8.
-#define TFRA_STEP_KERNEL(NAME, UU, TIMING, W)                                                                        \
-  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(104), amdgpu_waves_per_eu(W, W))) void NAME(const StepArgs a) { step_body<true, UU, TIMING, W>(a); }
-TFRA_STEP_KERNEL(step_k_u2, 2, false, 5)
-TFRA_STEP_KERNEL(step_k_u2_t, 2, true, 5)
-TFRA_STEP_KERNEL(step_k_u1, 1, false, 5)        // (tuning) 4 keys per wave in the write-back
-TFRA_STEP_KERNEL(step_k_u2_w4, 2, false, 4)     // (tuning) no spills, 4 blocks per CU
-TFRA_STEP_KERNEL(step_k_u2_w6, 2, false, 6)     // (tuning) 6 blocks per CU
+#define TFRA_STEP_KERNEL(NAME, SIMPLE, UU, TIMING, W)                                                                \
+  __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(104), amdgpu_waves_per_eu(W, W))) void NAME(const StepArgs a) { step_body<SIMPLE, UU, TIMING, W>(a); }
+TFRA_STEP_KERNEL(step_k_u2, true, 2, false, 5)
+TFRA_STEP_KERNEL(step_k_u2_t, true, 2, true, 5)
+TFRA_STEP_KERNEL(step_k_u1, true, 1, false, 5)        // (tuning) 4 keys per wave in the write-back
+TFRA_STEP_KERNEL(step_k_u2_w4, true, 2, false, 4)     // (tuning) no spills, 4 blocks per CU
+TFRA_STEP_KERNEL(step_k_u2_w6, true, 2, false, 6)     // (tuning) 6 blocks per CU
+// Round 6: the strategy read at run time (SIMPLE = false: own_setup takes it from the table's ScoreP) — EPOCHLRU tables, whose scores
+// are (epoch << 32 | clock): like LRU a new key is ALWAYS admitted (it carries the highest score of its buckets), which is what the
+// forwarding rests on; LFU / EPOCHLFU / CUSTOMIZED may refuse a key and stay on the sequential path.  4 blocks per CU (no spills).
+TFRA_STEP_KERNEL(step_k_gen, false, 2, false, 4)
 #undef TFRA_STEP_KERNEL
 
 // ---- TAIL role: the remainder of a step INSIDE its launch ------------------------------------------------------------------
@@ -988,9 +992,10 @@ static bool plan_is_listless(const tfra_sparse_plan* pl) { return pl->kind == 1 
 // variant (TFRA_STEP_VARIANT, tuning): bits 0-2 kernel (0: 8 keys per wave in the write-back, 5 blocks per CU | 1: 4 keys | 2: 4 blocks per CU | 3: 6), 8 every plan as a launch of
 // its own, 16 time stamps, 32 no MAP role (round 4's lookup), 64 the lookup reads the table's lines for every id.  TFRA_STEP_OWN_SLICE: a fixed
 // write-back slice (else sized from the batch's distinct-key count), TFRA_STEP_FIND_FIRST: lookup blocks in front of the write-back's
-static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a) {   // the overlapped step: one launch
+static void launch_step(int variant, unsigned grid, hipStream_t s, const StepArgs& a, bool lru) {   // the overlapped step: one launch
   const int k = variant & 7;
-  if (variant & 16) step_k_u2_t<<<grid, 256, 0, s>>>(a);
+  if (!lru) step_k_gen<<<grid, 256, 0, s>>>(a);
+  else if (variant & 16) step_k_u2_t<<<grid, 256, 0, s>>>(a);
   else if (k == 1) step_k_u1<<<grid, 256, 0, s>>>(a);
   else if (k == 2) step_k_u2_w4<<<grid, 256, 0, s>>>(a);
   else if (k == 3) step_k_u2_w6<<<grid, 256, 0, s>>>(a);
@@ -1037,7 +1042,8 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
   plan_next2->scat_ids = nullptr; plan_next2->scat_n = 0;
   unsigned* tags = t->ensure_own_tags(s);
   // what the TABLE must be for the overlap (constant over its life, but for `dense`) and what this CALL must be
-  const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && t->opts.strategy == TFRA_EVICT_LRU) ? 0u : 8u) |
+  const bool lru_like = t->opts.strategy == TFRA_EVICT_LRU || t->opts.strategy == TFRA_EVICT_EPOCHLRU;   // a new key is always admitted
+  const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && lru_like) ? 0u : 8u) |
                              (t->at_max_capacity() ? 0u : 16u) | (t->dense ? 0u : 32u) | (t->capture_safe ? 128u : 0u) | ((t->field_bytes & 15u) ? 2u : 0u);
   const bool aligned = (((uintptr_t)rows_out | (uintptr_t)defaults | (uintptr_t)values_prev) & 15) == 0;
   const unsigned why = why_table | (aligned ? 0u : 2u) | (scores_prev ? 8u : 0u) | ((!plan_prev || plan_prev->n > 0) ? 0u : 64u);
@@ -1165,7 +1171,7 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
       // builders, no forwarding — 52 us per step against 33: the write-back alone in its launch still takes 25 us.)
       const unsigned grid = a.build_blocks + a.scat_blocks + a.map_blocks + a.own_blocks + a.find_blocks + a.tail_blocks;
       if (d->tbuf) { unsigned* ti = d->tinfo[step % TIMING_SLOTS]; ti[0] = a.build_blocks; ti[1] = a.scat_blocks; ti[2] = a.own_blocks; ti[3] = a.find_blocks; ti[4] = grid; ti[5] = a.map_blocks; ti[6] = a.find_first; }
-      launch_step(d->variant, grid, s, a);
+      launch_step(d->variant, grid, s, a, t->opts.strategy == TFRA_EVICT_LRU);
       if (timed) (void)hipEventRecord(d->kev[d->kev_used * 3 + 1], s);
     }
     if (timed) { (void)hipEventRecord(d->kev[d->kev_used * 3 + 2], s); d->kev_used += 1; d->kev_left -= 1; }

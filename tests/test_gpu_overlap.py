@@ -548,3 +548,51 @@ def test_overlap_steps_beside_foreign_work_on_the_gpu(env, foreign):
   lp = torch.zeros(uk.numel(), dtype=torch.long, device="cuda")
   lp.scatter_reduce_(0, inv, torch.arange(n, device="cuda"), reduce="amax", include_self=False)
   assert bool(ex.all()) and torch.equal(got, lastv[lp][inv])
+
+
+def test_overlap_step_on_an_epoch_lru_table(env):
+  """Round 6: EPOCHLRU tables take the overlapped launch too (score = epoch << 32 | clock: like LRU a new key is always admitted —
+  the premise of the forwarding; T/hkv_hashtable_evict_test.py:481-525 for the strategy).  Every step equals a plain find of the
+  table right after the call; every launch was the overlapped one; and the EPOCH a key's score carries is the epoch of its last
+  write, exactly as on a twin table driven one op after the other (same step_per_epoch: the epoch advances per write-back)."""
+  torch, de = env
+  dim, cap, n, nsteps, spe = 64, 200_000, 6000, 26, 3
+  rng = np.random.default_rng(77)
+  universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 6151 + 1
+
+  def make(name):
+    t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                        evict_strategy=de.HkvEvictStrategy.EPOCHLRU, step_per_epoch=spe, name=name)
+    k = torch.from_numpy(universe).cuda()
+    for lo in range(0, k.numel(), 20000):      # (the same number of upserts on both tables: the same epoch when the steps start)
+      kk = k[lo:lo + 20000]
+      t._table.upsert(kk, (kk % 1000).to(torch.float32)[:, None].repeat(1, dim), unique_keys=True)
+      torch.cuda.synchronize()
+    for _ in range(3):
+      t._table.upsert(k[:16], (k[:16] % 1000).to(torch.float32)[:, None].repeat(1, dim), unique_keys=True)
+      torch.cuda.synchronize()
+    return t
+
+  ta, tb = make("ovl_elru_a"), make("ovl_elru_b")
+  batches = [torch.from_numpy(universe[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % universe.size]).cuda() for _ in range(nsteps + 2)]
+  drv = de.OverlapAssignStep(ta).prime(batches[0])
+  for s in range(nsteps):
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
+    out, ex = drv.step(vals, batches[s + 1], batches[s + 2], return_exists=True)
+    ref, rex = ta._table.find(batches[s], return_exists=True)
+    assert torch.equal(ex, rex) and torch.equal(out, ref), "step %d" % s
+    tb._table.find(batches[s])                       # the twin: one op after the other
+    tb._table.upsert_sparse(batches[s], vals)
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] >= nsteps - 8 and st["why_sequential"] in (0, 32), st     # (32: not yet known dense — the first steps only)
+  ka, _, sa = ta.export_with_scores(1)
+  kb, _, sb = tb.export_with_scores(1)
+  da = dict(zip(ka.cpu().numpy().tolist(), (sa.cpu().numpy().astype(np.uint64) >> np.uint64(32)).tolist()))
+  db = dict(zip(kb.cpu().numpy().tolist(), (sb.cpu().numpy().astype(np.uint64) >> np.uint64(32)).tolist()))
+  both = [k for k in da if k in db]
+  assert len(both) >= 0.99 * max(len(da), len(db))
+  assert all(da[k] == db[k] for k in both)
+  assert max(da.values()) >= nsteps // spe           # the epoch really advanced while the steps ran
+  ta._table.check_errors()
+  assert ta._table.slot_census()["locked"] == 0
