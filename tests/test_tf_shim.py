@@ -132,7 +132,11 @@ def test_fused_shim_registers_the_fused_paths_as_ops_with_gpu_kernels():
   for o in ("Sgd", "Adam", "Adagrad", "Ftrl"):
     assert "TFRA>HkvHashTableApplySparse" + o in names and "TFRA>RouteApply" + o in names
   assert {"TFRA>HkvHashTableOfTensorsWithSlots", "TFRA>HkvHashTableEmbeddingLookup", "TFRA>HkvHashTableInsertN", "TFRA>HkvHashTableLookupAssignStep",
-          "TFRA>HkvHashTableLookupAssignFlush", "TFRA>RcclUniqueId", "TFRA>RouteCreate", "TFRA>RouteFeed", "TFRA>RouteLookup"} <= names
+          "TFRA>HkvHashTableLookupAssignFlush", "TFRA>RcclUniqueId", "TFRA>RouteCreate", "TFRA>RouteFeed", "TFRA>RouteLookup",
+          "TFRA>AssignRouteCreate", "TFRA>AssignRouteFeed", "TFRA>AssignRouteStep", "TFRA>AssignRouteFlush"} <= names
+  # the routed assign step moves rows of the table's own value type (any of the GPU value types), one Step = lookup + the previous write-back
+  assert got["TFRA>AssignRouteStep"]["inputs"] == ["route_handle: resource", "default_value: value_dtype", "prev_values: value_dtype"]
+  assert got["TFRA>AssignRouteStep"]["outputs"] == ["values: value_dtype"] and kernels["TFRA>AssignRouteStep"] == ["value_dtype"]
   ref = set(json.load(open(GOLDEN))["ops"]) | set(json.load(open(GOLDEN_CUCKOO))["ops"])
   assert not (names & ref)                                         # loaded next to the reference's ops: no name registered twice
   # the creator with slots = the reference creator's attrs + the two new ones, so TFRA's Python wrapper passes the same kwargs
@@ -160,7 +164,8 @@ def test_fused_shim_binds_only_declared_abi_entry_points_and_reaches_the_fused_c
   assert used <= declared, sorted(used - declared)
   for fn in ("tfra_table_apply_sparse", "tfra_table_find_unique", "tfra_table_find", "tfra_table_insert_or_assign_n",
              "tfra_step_driver_create", "tfra_table_step_overlap", "tfra_table_step_overlap_flush", "tfra_workspace_create",
-             "tfra_rccl_unique_id", "tfra_rccl_transport_create", "tfra_route_create", "tfra_route_feed", "tfra_route_lookup", "tfra_route_apply"):
+             "tfra_rccl_unique_id", "tfra_rccl_transport_create", "tfra_route_create", "tfra_route_feed", "tfra_route_lookup", "tfra_route_apply",
+             "tfra_assign_route_create", "tfra_assign_route_feed", "tfra_assign_route_step", "tfra_assign_route_flush"):
     assert fn in used, fn
 
 
@@ -190,5 +195,6 @@ def test_tfra_side_binding_calls_registered_ops_with_their_signatures():
   for want in ("TFRA>HkvHashTableOfTensorsWithSlots", "TFRA>HkvHashTableEmbeddingLookup", "TFRA>HkvHashTableApplySparseAdam",
                "TFRA>HkvHashTableApplySparseSgd", "TFRA>HkvHashTableApplySparseAdagrad", "TFRA>HkvHashTableApplySparseFtrl",
                "TFRA>HkvHashTableLookupAssignStep", "TFRA>HkvHashTableLookupAssignFlush", "TFRA>RcclUniqueId", "TFRA>RouteCreate",
-               "TFRA>RouteFeed", "TFRA>RouteLookup", "TFRA>RouteApplyAdam"):
+               "TFRA>RouteFeed", "TFRA>RouteLookup", "TFRA>RouteApplyAdam", "TFRA>AssignRouteCreate", "TFRA>AssignRouteFeed",
+               "TFRA>AssignRouteStep", "TFRA>AssignRouteFlush"):
     assert want in seen, want

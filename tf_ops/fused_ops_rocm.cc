@@ -22,6 +22,7 @@
  *                                              (csrc/tfra_step_impl.h), results those of the two ops in order
  *                                              (K/hkv_hashtable_op_gpu.cu.cc:192-213,256-267)
  *   TFRA>RcclUniqueId, TFRA>RouteCreate, TFRA>RouteFeed, TFRA>RouteLookup, TFRA>RouteApply{Sgd,Adam,Adagrad,Ftrl}
+ *   TFRA>AssignRouteCreate, TFRA>AssignRouteFeed, TFRA>AssignRouteStep, TFRA>AssignRouteFlush   (round 6: lookup + insert_or_assign routed)
  *                                              HvdAllToAllEmbedding's exchange (PY/shadow_embedding_ops.py:397-447) for one table shard
  *                                              per rank, the id-only half prepared ahead, collectives = grouped ncclSend/ncclRecv
  *
@@ -254,6 +255,49 @@ REGISTER_OP("TFRA>RouteApplyFtrl")
     .Input("l1: float")
     .Input("l2: float")
     .Input("lr_power: float")
+    .SetShapeFn(FusedScalarHandle);
+
+// ---- the metric's step on a hash-sharded table: lookup + insert_or_assign with ids / rows / values routed (csrc/tfra_aroute.hip) ----
+// AssignRouteStep = HvdAllToAllEmbedding's lookup of the OLDEST fed batch (PY/shadow_embedding_ops.py:397-447) + the sharded
+// Variable.upsert of the batch the previous Step looked up (PY/dynamic_embedding_variable.py:772-800), the owner's half as ONE launch.
+REGISTER_OP("TFRA>AssignRouteCreate")
+    .Input("table_handle: resource")
+    .Input("rccl_ids: uint8")
+    .Output("route_handle: resource")
+    .Attr("container: string = ''")
+    .Attr("shared_name: string = ''")
+    .Attr("rank: int >= 0 = 0")
+    .Attr("world: int >= 1 = 1")
+    .Attr("partition_mode: int = 0")
+    .Attr("max_batch: int >= 1 = 262144")
+    .Attr("librccl_path: string = 'librccl.so'")
+    .SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      c->set_output(0, c->Scalar());
+      return OkStatus();
+    });
+
+REGISTER_OP("TFRA>AssignRouteFeed")
+    .Input("route_handle: resource")
+    .Input("ids: int64")
+    .SetShapeFn(FusedScalarHandle);
+
+REGISTER_OP("TFRA>AssignRouteStep")
+    .Input("route_handle: resource")
+    .Input("default_value: value_dtype")
+    .Input("prev_values: value_dtype")
+    .Output("values: value_dtype")
+    .Attr("value_dtype: type")
+    .SetShapeFn([](InferenceContext* c) {
+      TF_RETURN_IF_ERROR(FusedScalarHandle(c));
+      c->set_output(0, c->UnknownShapeOfRank(2));
+      return OkStatus();
+    });
+
+REGISTER_OP("TFRA>AssignRouteFlush")
+    .Input("route_handle: resource")
+    .Input("prev_values: value_dtype")
+    .Attr("value_dtype: type")
     .SetShapeFn(FusedScalarHandle);
 
 // =========================================== op kernels ===========================================
@@ -581,6 +625,144 @@ class RouteApplyOp : public OpKernel {
   bool use_epsilon_ = true;
 };
 
+// ---- the routed assign step (tfra_assign_route_*) ---------------------------------------------------------------------------------
+class AssignRouteResource final : public ResourceBase {
+ public:
+  AssignRouteResource() = default;
+  ~AssignRouteResource() override {
+    if (route) tfra_assign_route_destroy(route);
+    if (has_transport) tfra_rccl_transport_destroy(&transport);
+    if (table) table->Unref();
+  }
+  std::string DebugString() const override { return "TFRA MI355X assign route"; }
+  tfra_assign_route_t* route = nullptr;
+  tfra_transport transport = {};
+  bool has_transport = false;
+  MI355XHashTable* table = nullptr;           // one reference held: the shard outlives its route
+  int64_t dim = 0;
+  mutex mu;
+  std::vector<Tensor> fed;                    // ids of the batches fed and not yet looked up (the driver reads them on its own stream)
+  Tensor pending_ids, keep_ids, keep_values;  // the batch looked up last (written back by the next Step) and what the launch in flight reads
+  bool pending = false;
+  int64_t pending_n = 0;
+};
+
+class AssignRouteCreateOp : public OpKernel {
+ public:
+  explicit AssignRouteCreateOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("rank", &rank_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("world", &world_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("partition_mode", &mode_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("max_batch", &max_batch_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("librccl_path", &path_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    mutex_lock l(mu_);
+    if (!created_) OP_REQUIRES_OK(ctx, cinfo_.Init(ctx->resource_manager(), def(), true));
+    AssignRouteResource* res = nullptr;
+    OP_REQUIRES_OK(ctx, cinfo_.resource_manager()->LookupOrCreate<AssignRouteResource>(
+                            cinfo_.container(), cinfo_.name(), &res, [ctx, this](AssignRouteResource** ret) {
+                              MI355XHashTable* t = nullptr;
+                              core::RefCountPtr<lookup::LookupInterface> hold;
+                              TF_RETURN_IF_ERROR(TableOf(ctx, &t, &hold));
+                              AssignRouteResource* r = new AssignRouteResource();
+                              t->Ref();
+                              r->table = t;
+                              r->dim = static_cast<int64_t>(t->dim());
+                              if (world_ > 1) {
+                                const Tensor& ids = ctx->input(1);
+                                if (ids.NumElements() != 2 * TFRA_RCCL_ID_BYTES) { r->Unref(); return errors::InvalidArgument("AssignRouteCreate: rccl_ids must be TFRA>RcclUniqueId's output (256 bytes)"); }
+                                Status s = ToStatus(tfra_rccl_transport_create(path_.c_str(), ids.tensor_data().data(), static_cast<int>(rank_),
+                                                                               static_cast<int>(world_), -1, &r->transport));
+                                if (!s.ok()) { r->Unref(); return s; }
+                                r->has_transport = true;
+                              }
+                              Status s = ToStatus(tfra_assign_route_create(t->raw(), r->has_transport ? &r->transport : nullptr, static_cast<int>(mode_),
+                                                                           static_cast<size_t>(max_batch_), &r->route));
+                              if (!s.ok()) { r->Unref(); return s; }
+                              *ret = r;
+                              return OkStatus();
+                            }));
+    core::ScopedUnref unref(res);
+    created_ = true;
+    Tensor* handle = nullptr;
+    AllocatorAttributes host;
+    host.set_on_host(true);
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({}), &handle, host));
+    handle->scalar<ResourceHandle>()() = MakeResourceHandle<AssignRouteResource>(ctx, cinfo_.container(), cinfo_.name());
+  }
+
+ private:
+  mutex mu_;
+  bool created_ = false;
+  ContainerInfo cinfo_;
+  int64_t rank_ = 0, world_ = 1, mode_ = 0, max_batch_ = 262144;
+  std::string path_;
+};
+
+#define TFRA_AROUTE_OR_RETURN(ctx, r)                                                  \
+  AssignRouteResource* r = nullptr;                                                    \
+  OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, 0), &r));               \
+  core::ScopedUnref r##_unref(r)
+
+class AssignRouteFeedOp : public OpKernel {   // from the input pipeline's prefetch stage, up to five batches ahead of their Step
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    TFRA_AROUTE_OR_RETURN(ctx, r);
+    mutex_lock l(r->mu);
+    const Tensor& ids = ctx->input(1);
+    OP_REQUIRES_OK(ctx, ToStatus(tfra_assign_route_feed(r->route, static_cast<size_t>(ids.NumElements()), In<int64_t>(ids), /*ids_ready=*/0, StreamOf(ctx))));
+    r->fed.push_back(ids);
+  }
+};
+
+class AssignRouteStepOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    TFRA_AROUTE_OR_RETURN(ctx, r);
+    mutex_lock l(r->mu);
+    OP_REQUIRES(ctx, !r->fed.empty(), errors::InvalidArgument("AssignRouteStep: no batch has been fed"));
+    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, r->table->value_dtype(), r->table->value_dtype()}, {r->table->value_dtype()}));
+    const Tensor& dflt = ctx->input(1);
+    const Tensor& prev_values = ctx->input(2);
+    OP_REQUIRES(ctx, dflt.NumElements() == r->dim, errors::InvalidArgument("AssignRouteStep: default_value must be one row [dim]"));
+    OP_REQUIRES(ctx, !r->pending || prev_values.NumElements() == r->pending_n * r->dim,
+                errors::InvalidArgument("AssignRouteStep: prev_values must hold one row per id of the batch the previous Step looked up"));
+    const Tensor ids = r->fed.front();
+    Tensor* values = nullptr;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output("values", TensorShape({ids.NumElements(), r->dim}), &values));
+    OP_REQUIRES_OK(ctx, ToStatus(tfra_assign_route_step(r->route, Out<char>(values), dflt.tensor_data().data(),
+                                                        r->pending ? prev_values.tensor_data().data() : nullptr, StreamOf(ctx))));
+    // alive until the launches that read them have run: the ids written back by this call, its values; this batch's ids until the next
+    r->keep_ids = r->pending_ids;
+    r->keep_values = prev_values;
+    r->pending_ids = ids;
+    r->pending = true;
+    r->pending_n = ids.NumElements();
+    r->fed.erase(r->fed.begin());
+  }
+};
+
+class AssignRouteFlushOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    TFRA_AROUTE_OR_RETURN(ctx, r);
+    mutex_lock l(r->mu);
+    if (!r->pending) return;
+    OP_REQUIRES_OK(ctx, ctx->MatchSignature({DT_RESOURCE, r->table->value_dtype()}, {}));
+    const Tensor& prev_values = ctx->input(1);
+    OP_REQUIRES(ctx, prev_values.NumElements() == r->pending_n * r->dim,
+                errors::InvalidArgument("AssignRouteFlush: prev_values must hold one row per id of the batch the last Step looked up"));
+    OP_REQUIRES_OK(ctx, ToStatus(tfra_assign_route_flush(r->route, prev_values.tensor_data().data(), StreamOf(ctx))));
+    r->keep_ids = r->pending_ids;
+    r->keep_values = prev_values;
+    r->pending = false;
+  }
+};
+
 // =========================================== kernel registrations ===========================================
 // The table-typed ops for K = int64 x the reference's GPU value types (hkv_hashtable_op_gpu.cu.cc:1133-1138); the optimizer ops
 // are float32 (the planned write-back), hyper-parameters and RCCL ids in host memory.
@@ -595,7 +777,9 @@ class RouteApplyOp : public OpKernel {
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableLookupAssignStep").Device(DEVICE_GPU).TypeConstraint<V>("value_dtype"),         \
                           LookupAssignStepOp);                                                                                  \
   REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableLookupAssignFlush").Device(DEVICE_GPU).TypeConstraint<V>("value_dtype"),        \
-                          LookupAssignFlushOp);
+                          LookupAssignFlushOp);                                                                                 \
+  REGISTER_KERNEL_BUILDER(Name("TFRA>AssignRouteStep").Device(DEVICE_GPU).TypeConstraint<V>("value_dtype"), AssignRouteStepOp); \
+  REGISTER_KERNEL_BUILDER(Name("TFRA>AssignRouteFlush").Device(DEVICE_GPU).TypeConstraint<V>("value_dtype"), AssignRouteFlushOp);
 
 TFRA_REGISTER_FUSED(float);
 TFRA_REGISTER_FUSED(int8_t);
@@ -616,6 +800,8 @@ REGISTER_KERNEL_BUILDER(Name("TFRA>HkvHashTableApplySparseFtrl").Device(DEVICE_G
 
 REGISTER_KERNEL_BUILDER(Name("TFRA>RcclUniqueId").Device(DEVICE_GPU).HostMemory("ids"), RcclUniqueIdOp);
 REGISTER_KERNEL_BUILDER(Name("TFRA>RouteCreate").Device(DEVICE_GPU).HostMemory("rccl_ids").HostMemory("route_handle"), RouteCreateOp);
+REGISTER_KERNEL_BUILDER(Name("TFRA>AssignRouteCreate").Device(DEVICE_GPU).HostMemory("rccl_ids").HostMemory("route_handle"), AssignRouteCreateOp);
+REGISTER_KERNEL_BUILDER(Name("TFRA>AssignRouteFeed").Device(DEVICE_GPU), AssignRouteFeedOp);
 REGISTER_KERNEL_BUILDER(Name("TFRA>RouteFeed").Device(DEVICE_GPU), RouteFeedOp);
 REGISTER_KERNEL_BUILDER(Name("TFRA>RouteLookup").Device(DEVICE_GPU), RouteLookupOp);
 REGISTER_KERNEL_BUILDER(Name("TFRA>RouteApplySgd").Device(DEVICE_GPU).HostMemory("lr"), RouteApplyOp<TFRA_OPT_SGD>);

@@ -200,3 +200,38 @@ class AllToAllRoute:
 
   def apply_ftrl(self, grads, default_row, lr, l1, l2, lr_power):
     return self.ops.tfra_route_apply_ftrl(self.handle, grads, default_row, lr, l1, l2, lr_power)
+
+
+class AllToAllAssignRoute:
+  """The metric's step — lookup(ids) + insert_or_assign(ids, rows), repeats: the last occurrence wins — on one table shard per rank:
+  the lookup half is `__alltoall_embedding_lookup__` (R/shadow_embedding_ops.py:397-447), the write-back half the sharded
+  `Variable.upsert` (R/dynamic_embedding_variable.py:772-800: keys AND values partitioned by owner), issued by the C driver
+  (tfra_assign_route_*): per batch two launches for everything that depends on the ids alone, ahead of the step; per step
+  gather -> alltoall(values) -> ONE launch at the owner (lookup of this batch + write-back of the previous one) -> alltoall(rows)
+  -> gather.
+
+      route = AllToAllAssignRoute(table, hvd.rank(), hvd.size(), max_batch, value_dtype)
+      for k in range(5): route.feed(next(batches))            # the dataset's prefetch stage: five batches ahead
+      rows = route.step(default_row, zero_rows)               # first step: nothing to write back (prev_values is ignored)
+      loop: route.feed(next(batches)); rows = route.step(default_row, new_rows_of_the_previous_batch)
+      route.flush(new_rows_of_the_last_batch)"""
+
+  def __init__(self, table, rank, world, max_batch, value_dtype, librccl_path="librccl.so"):
+    import horovod.tensorflow as hvd
+    import tensorflow as tf
+    self.ops = load_ops()
+    self.vdt = value_dtype
+    ids = self.ops.tfra_rccl_unique_id(librccl_path=librccl_path) if rank == 0 else tf.zeros([256], tf.uint8)
+    ids = hvd.broadcast(ids, root_rank=0)     # 2 x 128 bytes through the host framework
+    self.handle = self.ops.tfra_assign_route_create(table.resource_handle, ids, rank=rank, world=world, partition_mode=0,
+                                                    max_batch=max_batch, librccl_path=librccl_path,
+                                                    shared_name="assign_route_" + str(table.name))
+
+  def feed(self, ids):
+    return self.ops.tfra_assign_route_feed(self.handle, ids)
+
+  def step(self, default_row, prev_values):    # rows of the OLDEST fed batch; prev_values = what the previous step's batch writes back
+    return self.ops.tfra_assign_route_step(self.handle, default_row, prev_values, value_dtype=self.vdt)
+
+  def flush(self, prev_values):
+    return self.ops.tfra_assign_route_flush(self.handle, prev_values, value_dtype=self.vdt)
