@@ -195,3 +195,31 @@ class RestrictPolicyOracle:
       table.pop(int(k), None)
       self.status.pop(int(k), None)
     return [int(k) for k in gone]
+
+
+# ---- the metric's step on a sharded table (csrc/tfra_aroute.hip restated) ----------------------------
+def route_plan(ids, world, partition_fn=default_partition_fn):
+  """What the route plan of one batch holds (tfra_aroute.hip: routeplan_insert_kernel + routeplan_emit_kernel): the distinct
+  ids grouped by owner (order inside a group unspecified: here sorted), the LAST position of each, the position -> row map and
+  the per-owner counts.  PY/shadow_embedding_ops.py:316,397-422 does unique then dynamic_partition."""
+  ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+  uniq, inv = np.unique(ids, return_inverse=True)
+  last = np.zeros(uniq.size, dtype=np.int64)
+  np.maximum.at(last, inv, np.arange(ids.size))
+  owner = partition_fn(uniq, world)
+  order = np.argsort(owner, kind="stable")
+  row_of_uniq = np.empty(uniq.size, dtype=np.int64)
+  row_of_uniq[order] = np.arange(uniq.size)
+  counts = np.bincount(owner, minlength=world).astype(np.int64)
+  return uniq[order], last[order], row_of_uniq[inv], counts
+
+
+def routed_assign_model(table, ids_per_rank, values_per_rank, defaults):
+  """ONE table, one step of every rank: all lookups first, then rank 0's insert_or_assign, rank 1's, ... (the last occurrence of
+  a repeated key wins: sequential insert).  Returns the rows every rank's lookup returns.  What RoutedAssignStep must equal
+  (PY/shadow_embedding_ops.py:397-447 for the lookup, PY/dynamic_embedding_variable.py:772-800 for the sharded upsert)."""
+  rows = [table.find(np.asarray(i, np.int64).reshape(-1), defaults) for i in ids_per_rank]
+  for i, v in zip(ids_per_rank, values_per_rank):
+    if v is not None:
+      table.insert(np.asarray(i, np.int64).reshape(-1), v)
+  return rows

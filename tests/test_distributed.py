@@ -181,3 +181,89 @@ def test_alltoall_lookup_and_write_back_world2(dedup):
     ek, ev = tabs[owner_rank].export_sorted()
     np.testing.assert_array_equal(res[owner_rank][1], ek)
     np.testing.assert_allclose(res[owner_rank][2], ev, rtol=1e-6, atol=1e-6)
+
+
+# ---- the routed assign step (csrc/tfra_aroute.hip) restated with numpy doubles over gloo ------------------------------------------
+def _ra_batch(rank, step):
+  rng = np.random.default_rng(40 * step + rank)
+  n = 300 + 17 * rank + (step % 3) * 5
+  ids = (rng.zipf(1.3, size=n).astype(np.int64) % 400) * 7919 - 1234
+  ids[: n // 6] = 7919 * 3 - 1234                       # a hot id both ranks write every step
+  rng.shuffle(ids)
+  vals = (np.arange(n, dtype=np.float32) + 1000.0 * (step + 1) + 500.0 * rank)[:, None].repeat(DIM, 1)
+  return ids, vals
+
+
+def _ra_worker(rank, world, port, q, steps):
+  """One rank of the route as the C driver issues it, the device pieces replaced by the numpy restatement (oracle/frontends.py
+  route_plan) and the shard by the CPU oracle: per step gather(values at the last positions) -> alltoall(values) -> the owner writes
+  the PREVIOUS batch back (source-major: the highest rank's row wins) and looks THIS batch's ids up -> alltoall(rows) -> gather."""
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  import oracle
+  from oracle import frontends as ofe
+  shard = oracle.CpuTable(DIM)
+  dflt = np.zeros(DIM, np.float32)
+
+  def a2a(send, counts_send, width, dtype):
+    cs = torch.tensor(counts_send, dtype=torch.int64)
+    cr = torch.empty(world, dtype=torch.int64)
+    dist.all_to_all_single(cr, cs)
+    recv = torch.empty((int(cr.sum()),) + ((width,) if width else ()), dtype=dtype)
+    dist.all_to_all_single(recv, torch.from_numpy(np.ascontiguousarray(send)), cr.tolist(), cs.tolist())
+    return recv.numpy(), cr.numpy()
+
+  prev = None        # (last positions, send counts, values, received ids) of the batch looked up by the previous step
+  looked = []
+  for s in range(steps + 1):
+    if prev is not None:                                  # write-back half of the step
+      lastpos, counts, vals, recv_ids_prev = prev
+      got, _ = a2a(vals[lastpos], counts.tolist(), DIM, torch.float32)
+      shard.insert(recv_ids_prev, got)                    # source-major, sequential: the last one wins
+    if s == steps:
+      break
+    ids, vals = _ra_batch(rank, s)
+    owner_major, lastpos, pos2row, counts = ofe.route_plan(ids, world)
+    recv_ids, rc = a2a(owner_major, counts.tolist(), 0, torch.int64)
+    rows = shard.find(recv_ids, dflt)                     # the owner's lookup (after the write-back above: lookup i+1 sees update i)
+    back, _ = a2a(rows, rc.tolist(), DIM, torch.float32)
+    looked.append(back[pos2row])
+    prev = (lastpos, counts, vals, recv_ids)
+  k, v = shard.export_sorted()
+  q.put((rank, looked, k, v))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_routed_assign_step_world2_equals_one_table():
+  world, steps, port = 2, 5, 29811 + (os.getpid() % 150)
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  procs = [ctx.Process(target=_ra_worker, args=(r, world, port, q, steps)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = {}
+  for _ in range(world):
+    r, looked, k, v = q.get(timeout=120)
+    res[r] = (looked, k, v)
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  import oracle
+  from oracle import frontends as ofe
+  tab = oracle.CpuTable(DIM)
+  dflt = np.zeros(DIM, np.float32)
+  for s in range(steps):
+    batches = [_ra_batch(r, s) for r in range(world)]
+    rows = ofe.routed_assign_model(tab, [b[0] for b in batches], [b[1] for b in batches], dflt)
+    for r in range(world):
+      np.testing.assert_array_equal(res[r][0][s], rows[r], err_msg="rank %d step %d" % (r, s))
+  ek, ev = tab.export_sorted()
+  gk = np.concatenate([res[r][1] for r in range(world)])
+  gv = np.concatenate([res[r][2] for r in range(world)])
+  o = np.argsort(gk)
+  np.testing.assert_array_equal(gk[o], ek)                # every key on exactly one shard
+  np.testing.assert_array_equal(gv[o], ev)
+  for r in range(world):
+    assert np.all(ofe.default_partition_fn(res[r][1], world) == r)
