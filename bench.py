@@ -1186,6 +1186,7 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
   med, secs, host_s = m["med"], m["secs"], m["host_s"]
   ms = med / K * 1e3
   value = world * B * K / med
+  prof = profile_summary()
   step_bytes = B * (8 + 2 * Rb) + U * (16 + 2 * Rb)                              # per GPU, the metric's definition
   owner_bytes = m["served_ids"] * (8 + 2 * Rb) + m["served_distinct"] * (16 + 2 * Rb)   # what the owner's launch moves for the ids it serves
   res = {
@@ -1217,7 +1218,8 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
           "bound": "hbm", "kernel": "step_k at the owner (tfra_table_step_overlap on the ids this rank serves: lookup + write-back in ONE launch)",
           "achieved": owner_bytes / m["owner_launch_us"] / 1e3 if m["owner_launch_us"] else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": owner_bytes / m["owner_launch_us"] / 1e3 / HBM_PEAK_GBS if m["owner_launch_us"] else None,
-          "traffic": None, "traffic_source": None,
+          "traffic": traffic_of(prof, "m1s", "step_k") if world == 1 and not forced else None,
+          "traffic_source": (prof or {}).get("_source") if (world == 1 and not forced and traffic_of(prof, "m1s", "step_k") is not None) else None,
           "algorithmic_bytes_per_launch": owner_bytes, "avg_launch_us": m["owner_launch_us"], "launches_timed": m["launches_timed"],
           "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "step_algorithmic_bytes": step_bytes,
           "step_bytes_definition": "per GPU: B*(8+2*Rb) for the lookup + U*(16+2*Rb) for the write-back of the batch's U distinct keys (SURVEY §8d)",
