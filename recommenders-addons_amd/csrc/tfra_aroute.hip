@@ -215,7 +215,11 @@ int dmalloc(T** p, size_t count) {
 }
 
 // ------------------------------------------------------------------------------------------- the driver
-constexpr int NS = 8;   // batches in flight: the one being written back, the one looked up, up to five fed ahead, one spare
+constexpr int NS = 12;  // slots of the ring.  At most MAX_LIVE batches are in flight (the one being written back, the one looked up, up to
+                        // five fed ahead); the other slots are slack: a slot is reused NS - MAX_LIVE + 1 steps after its batch was written
+                        // back, so the route plan of a new batch — which waits for that write-back — finds it complete although the host
+                        // runs a few steps ahead of the GPU (with 8 slots the split sizes of 9 batches in 10 were waited for on the host)
+constexpr int MAX_LIVE = 7;
 // A batch moves through these stages (everything is issued by the calling thread, in call order; the id-only half on ONE stream of the
 // driver's own, `ahead`, in order — route plan, count exchange, copy of the split sizes, id exchange need no events between them):
 //   FED      the route plan's two launches                                                   [ahead]
@@ -507,7 +511,7 @@ int tfra_assign_route_create(tfra_table_t* table, const tfra_transport* transpor
 
 int tfra_assign_route_feed(tfra_assign_route_t* r, size_t n, const int64_t* d_ids, int ids_ready, tfra_stream_t stream) {
   if (!r) return set_error(TFRA_ERR_INVALID, "assign_route_feed: null route");
-  if (r->live >= NS - 1) return set_error(TFRA_ERR_INVALID, "assign_route_feed: six batches are fed ahead already");
+  if (r->live >= MAX_LIVE) return set_error(TFRA_ERR_INVALID, "assign_route_feed: six batches are fed ahead already");
   if (n == 0 || n > r->max_n || !d_ids) return set_error(TFRA_ERR_INVALID, "assign_route_feed: 1 <= n <= max_batch ids expected");
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != r->device) { if (hipSetDevice(r->device) != hipSuccess) return hip_fail("hipSetDevice"); } }
   ASlot& sl = r->slots[r->tail];
