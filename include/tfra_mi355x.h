@@ -173,7 +173,10 @@ int tfra_table_export_batch(tfra_table_t* t, size_t n, size_t offset, size_t* d_
  *    keeps using ONE stream.  Scratch buffers must have been sized by an identical warm-up call.
  *    TFRA_OPTION_NO_OWNER_TAGS = 1 makes the planned write-backs take the general two-kernel path
  *    (the one used when the 4 B/bucket owner-tag array cannot be allocated); same results.      */
-typedef enum { TFRA_OPTION_CAPTURE_SAFE = 1, TFRA_OPTION_NO_OWNER_TAGS = 2 } tfra_option;
+typedef enum { TFRA_OPTION_CAPTURE_SAFE = 1, TFRA_OPTION_NO_OWNER_TAGS = 2, TFRA_OPTION_KEY_BYTES_ON_DISK = 3 } tfra_option;
+/*    TFRA_OPTION_KEY_BYTES_ON_DISK = 4 | 8 (default 8): the width of a key in `<prefix>-keys` files.  4 = tables whose OP-LEVEL key type
+ *    is int32 (the reference's (int32, float) GPU kernels, K/cuckoo_hashtable_op_gpu.cu.cc:1058: its files hold raw int32 keys): save
+ *    narrows, load widens (sign-extending); a key outside the int32 range fails the save. */
 int tfra_table_set_option(tfra_table_t* t, int option, int64_t value);
 
 /* -- set_global_epoch (lookup_table_op_hkv.h:499,507,533) --------------------------------- */
@@ -464,6 +467,12 @@ int tfra_plan_reduce_to(const tfra_sparse_plan_t* plan, const float* grads, cons
 int tfra_plan_partition(const tfra_sparse_plan_t* plan, tfra_workspace_t* ws, int num_shards, int mode,
                         int64_t* keys_out, int32_t* perm_out, int64_t* d_counts, tfra_stream_t stream);
 int tfra_plan_positions_to(const tfra_sparse_plan_t* plan, const int32_t* perm, int32_t* dest_out, tfra_stream_t stream);
+
+/* int32 <-> int64 keys on the device (sign-extending / truncating): the engine's keys are int64; a caller whose op-level key type is
+ * int32 (K/cuckoo_hashtable_op_gpu.cu.cc:1058 REGISTER_KERNEL(int32, float)) widens in front of every table call and narrows the keys
+ * an export returns.  tfra_keys_narrow_i32 counts the keys that do not fit into *d_overflow (device int64, may be NULL). */
+int tfra_keys_widen_i32(size_t n, const int32_t* keys_in, int64_t* keys_out, tfra_stream_t stream);
+int tfra_keys_narrow_i32(size_t n, const int64_t* keys_in, int32_t* keys_out, int64_t* d_overflow, tfra_stream_t stream);
 
 /* out[i,:] = rows[idx[i],:] (tf.gather after unique). row_bytes = dim*sizeof(V). */
 int tfra_gather_rows(size_t n, size_t row_bytes, const void* rows, const int32_t* idx, void* out,

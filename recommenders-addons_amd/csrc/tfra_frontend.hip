@@ -342,6 +342,20 @@ __global__ __launch_bounds__(256) void unq2_scatter_kernel(size_t n, const i64* 
   }
 }
 
+// ------------------------------------ int32 <-> int64 keys ------------------------------------
+__global__ __launch_bounds__(256) void widen_keys_kernel(size_t n, const int* __restrict__ in, i64* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (i64)in[i];
+}
+__global__ __launch_bounds__(256) void narrow_keys_kernel(size_t n, const i64* __restrict__ in, int* __restrict__ out, i64* overflow) {
+  unsigned bad = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const i64 k = in[i];
+    out[i] = (int)k;
+    bad += (i64)(int)k != k;
+  }
+  if (overflow && bad) atomicAdd(reinterpret_cast<unsigned long long*>(overflow), (unsigned long long)bad);
+}
+
 // ------------------------------------ row gather / scatter ------------------------------------
 template <int G, bool SCATTER>
 __global__ __launch_bounds__(256) void move_rows_kernel(size_t n, unsigned row_bytes, const unsigned char* __restrict__ in,
@@ -708,6 +722,23 @@ int tfra_unique(tfra_workspace_t* ws, size_t n, const int64_t* ids, int64_t* uni
   scan_counts_kernel<<<1, 1024, 0, s>>>(bcnt, tiles, (i64*)d_num_unique);
   unq_scatter_kernel<<<(unsigned)tiles, 256, 0, s>>>(n, (const i64*)ids, hfirst, slot_of, bcnt, (i64*)unique_out, hrank);
   unq_idx_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, slot_of, hrank, idx_out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_keys_widen_i32(size_t n, const int32_t* keys_in, int64_t* keys_out, tfra_stream_t stream) {
+  if (n == 0) return TFRA_OK;
+  if (!keys_in || !keys_out) return set_error(TFRA_ERR_INVALID, "keys_widen_i32: null buffer");
+  widen_keys_kernel<<<(unsigned)std::min<size_t>(4096, (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(n, keys_in, (i64*)keys_out);
+  HIP_TRY(hipGetLastError());
+  return TFRA_OK;
+}
+
+int tfra_keys_narrow_i32(size_t n, const int64_t* keys_in, int32_t* keys_out, int64_t* d_overflow, tfra_stream_t stream) {
+  if (d_overflow) HIP_TRY(hipMemsetAsync(d_overflow, 0, sizeof(int64_t), (hipStream_t)stream));
+  if (n == 0) return TFRA_OK;
+  if (!keys_in || !keys_out) return set_error(TFRA_ERR_INVALID, "keys_narrow_i32: null buffer");
+  narrow_keys_kernel<<<(unsigned)std::min<size_t>(4096, (n + 255) / 256), 256, 0, (hipStream_t)stream>>>(n, (const i64*)keys_in, keys_out, (i64*)d_overflow);
   HIP_TRY(hipGetLastError());
   return TFRA_OK;
 }

@@ -74,6 +74,7 @@ struct Table {
   bool dense = false;        // a table that cannot grow any more holds > 60 % of its slots (async size reads)
   bool capture_safe = false;  // TFRA_OPTION_CAPTURE_SAFE
   bool no_owner_tags = false; // TFRA_OPTION_NO_OWNER_TAGS
+  int key_file_bytes = 8;     // TFRA_OPTION_KEY_BYTES_ON_DISK
   uint64_t global_epoch = 0;
   int64_t curr_step = 1;
   bool epoch_hold = false;   // see step_epoch (tfra_optim.hip)

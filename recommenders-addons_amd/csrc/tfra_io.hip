@@ -1,7 +1,8 @@
 // KV-file save / load for the MI355X table (N2 row of SURVEY.md §8f).
 //
 // On-disk format = the reference's, byte for byte: `<prefix>-keys` is a raw native-endian
-// int64 array, `<prefix>-values` a raw V[n*dim] array in the same order
+// K array (int64; int32 for tables whose op-level key type is int32: TFRA_OPTION_KEY_BYTES_ON_DISK = 4, narrowed / widened on
+// the host side of the staging buffers), `<prefix>-values` a raw V[n*dim] array in the same order
 // (R/kernels/cuckoo_hashtable_op.cc:310-391 SaveToFileSystemImpl, :393-505 LoadFromFileSystemImpl;
 // GPU twin R/kernels/lookup_impl/lookup_table_op_hkv.h:132-273 RandomKVFile, :602-717).
 // Streaming: `buffer_keys` slots are exported per chunk through pinned staging buffers, so a
@@ -78,7 +79,15 @@ static int save_impl(tfra_table_t* tp, int field, const char* prefix, size_t buf
     (void)hipMemcpyAsync(h_keys, d_keys, got * sizeof(i64), hipMemcpyDeviceToHost, s);
     (void)hipMemcpyAsync(h_vals, d_vals, got * fb, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) { cleanup(); return set_error(TFRA_ERR_HIP, "save: copy"); }
-    if (fwrite(h_keys, sizeof(i64), got, kf.f) != got || fwrite(h_vals, fb, got, vf.f) != got) {
+    if (t->key_file_bytes == 4) {   // int32 keys on disk: narrowed in place (the staging buffer is ours)
+      int* k32 = reinterpret_cast<int*>(h_keys);
+      for (size_t i = 0; i < got; ++i) {
+        const i64 k = h_keys[i];
+        if ((i64)(int)k != k) { cleanup(); return set_error(TFRA_ERR_INVALID, "save: a key does not fit the table's 4-byte key files"); }
+        k32[i] = (int)k;
+      }
+    }
+    if (fwrite(h_keys, (size_t)t->key_file_bytes, got, kf.f) != got || fwrite(h_vals, fb, got, vf.f) != got) {
       cleanup();
       return set_error(TFRA_ERR_IO, "save: short write");
     }
@@ -121,9 +130,10 @@ static int load_impl(tfra_table_t* tp, int field, const char* prefix, size_t buf
   fseek(vf.f, 0, SEEK_END);
   size_t val_bytes = (size_t)ftell(vf.f);
   fseek(vf.f, 0, SEEK_SET);
-  size_t nkeys = key_bytes / sizeof(i64);
+  const size_t kb = (size_t)t->key_file_bytes;
+  size_t nkeys = key_bytes / kb;
   // LoadFromFileSystemImpl checks the two files describe the same number of entries (:431-441)
-  if (key_bytes % sizeof(i64) || nkeys * fb != val_bytes)
+  if (key_bytes % kb || nkeys * fb != val_bytes)
     return set_error(TFRA_ERR_IO, "load: " + kp + " and " + vp + " sizes do not match dim");
   size_t chunk = std::max<size_t>(1, std::min(buffer_keys, nkeys));
   i64 *d_keys = nullptr, *h_keys = nullptr;
@@ -139,9 +149,13 @@ static int load_impl(tfra_table_t* tp, int field, const char* prefix, size_t buf
   size_t done = 0;
   while (done < nkeys) {
     size_t len = std::min(chunk, nkeys - done);
-    if (fread(h_keys, sizeof(i64), len, kf.f) != len || fread(h_vals, fb, len, vf.f) != len) {
+    if (fread(h_keys, kb, len, kf.f) != len || fread(h_vals, fb, len, vf.f) != len) {
       cleanup();
       return set_error(TFRA_ERR_IO, "load: short read");
+    }
+    if (kb == 4) {   // int32 keys on disk: widened in place, back to front
+      const int* k32 = reinterpret_cast<const int*>(h_keys);
+      for (size_t i = len; i-- > 0;) h_keys[i] = (i64)k32[i];
     }
     (void)hipMemcpyAsync(d_keys, h_keys, len * sizeof(i64), hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(d_vals, h_vals, len * fb, hipMemcpyHostToDevice, s);

@@ -1620,6 +1620,11 @@ int tfra_table_set_option(tfra_table_t* tp, int option, int64_t value) {
   std::lock_guard<std::mutex> lock(t->mu);
   if (option == TFRA_OPTION_CAPTURE_SAFE) { t->capture_safe = value != 0; return TFRA_OK; }
   if (option == TFRA_OPTION_NO_OWNER_TAGS) { t->no_owner_tags = value != 0; return TFRA_OK; }
+  if (option == TFRA_OPTION_KEY_BYTES_ON_DISK) {
+    if (value != 4 && value != 8) return set_error(TFRA_ERR_INVALID, "TFRA_OPTION_KEY_BYTES_ON_DISK: 4 or 8");
+    t->key_file_bytes = (int)value;
+    return TFRA_OK;
+  }
   return set_error(TFRA_ERR_INVALID, "unknown option");
 }
 

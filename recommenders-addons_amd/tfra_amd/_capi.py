@@ -15,6 +15,7 @@ FLAG_UNIQUE_KEYS = 1
 OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_FTRL = range(4)
 OPTION_CAPTURE_SAFE = 1
 OPTION_NO_OWNER_TAGS = 2
+OPTION_KEY_BYTES_ON_DISK = 3
 
 
 class TfraError(RuntimeError):
@@ -148,6 +149,8 @@ _SIGS = {
     "tfra_table_find_unique": [_P, _P, _SZ, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "tfra_segment_sum": [_P, _SZ, _I, _P, _P, _P, _SZ, _P, _P],
     "tfra_gather_rows": [_SZ, _SZ, _P, _P, _P, _P],
+    "tfra_keys_widen_i32": [_SZ, _P, _P, _P],
+    "tfra_keys_narrow_i32": [_SZ, _P, _P, _P, _P],
     "tfra_sparse_segment_combine": [_P, _SZ, _I, _P, _P, _P, _P, _I, _SZ, _P, _P],
     "tfra_partition": [_P, _SZ, _P, _P, _I, _I, _P, _P, _P, _P],
     "tfra_partition_by_owner": [_P, _SZ, _P, _I, _P, _P, _P],

@@ -89,9 +89,11 @@ class _DeviceTable:
   def __init__(self, key_dtype, value_dtype, default_value, name, device, dim=None, aux_fields=0,
                init_capacity=0, max_capacity=0, max_hbm_for_values=0, strategy=-1, step_per_epoch=0,
                reserved_key_start_bit=0, max_load_factor=0.0, aux_init=(0.0, 0.0, 0.0, 0.0)):
-    if key_dtype != torch.int64:
-      # GPU ops are registered for K=int64 only (R/kernels/hkv_hashtable_op_gpu.cu.cc:1133-1138)
-      raise TypeError("key_dtype must be torch.int64 on GPU tables, got %s" % key_dtype)
+    if key_dtype not in (torch.int64, torch.int32):
+      # GPU ops: K = int64 (R/kernels/hkv_hashtable_op_gpu.cu.cc:1133-1138) and, for the cuckoo ops, (int32, float)
+      # (R/kernels/cuckoo_hashtable_op_gpu.cu.cc:1058).  The engine's keys are int64: int32 keys are widened on the device in
+      # front of every call (tfra_keys_widen_i32), exports narrow them, and the key files hold 4-byte keys like the reference's.
+      raise TypeError("key_dtype must be torch.int64 or torch.int32 on GPU tables, got %s" % key_dtype)
     if value_dtype not in _TORCH2DT:
       raise TypeError("unsupported value_dtype %s" % value_dtype)
     self._key_dtype = key_dtype
@@ -126,6 +128,8 @@ class _DeviceTable:
     h = ctypes.c_void_p()
     _capi.call("tfra_table_create", ctypes.byref(o), None, ctypes.byref(h))
     self._h = h
+    if key_dtype == torch.int32:
+      _capi.call("tfra_table_set_option", self._h, _capi.OPTION_KEY_BYTES_ON_DISK, 4)
 
   def __del__(self):
     h = getattr(self, "_h", None)
@@ -157,7 +161,12 @@ class _DeviceTable:
     keys = torch.as_tensor(keys, device=self._device) if not torch.is_tensor(keys) else keys
     if keys.dtype != self._key_dtype:
       raise TypeError("Signature mismatch. Keys must be dtype %s, got %s." % (self._key_dtype, keys.dtype))
-    return keys.to(self._device).contiguous()
+    keys = keys.to(self._device).contiguous()
+    if self._key_dtype == torch.int32:   # the engine's keys are int64
+      wide = torch.empty(keys.shape, dtype=torch.int64, device=self._device)
+      _capi.call("tfra_keys_widen_i32", keys.numel(), _ptr(keys), _ptr(wide), _stream(self._device))
+      return wide
+    return keys
 
   def _values_for(self, keys, values, what="values"):
     values = torch.as_tensor(values, device=self._device) if not torch.is_tensor(values) else values
@@ -345,6 +354,10 @@ class _DeviceTable:
     got = int(counter.item())
     if got != n:
       raise RuntimeError("export: table changed during export (%d vs %d)" % (got, n))
+    if self._key_dtype == torch.int32:
+      narrow = torch.empty(n, dtype=torch.int32, device=self._device)
+      _capi.call("tfra_keys_narrow_i32", n, _ptr(keys), _ptr(narrow), None, _stream(self._device))
+      keys = narrow
     return keys, vals, scores
 
   def save(self, prefix, buffer_size=4194304, append_to_file=False, field=0):

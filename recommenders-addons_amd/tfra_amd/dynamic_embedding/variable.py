@@ -151,7 +151,11 @@ class Variable:
     if self.shard_num <= 1:
       return [flat], None, [flat.numel()]
     if self.partition_fn is default_partition_fn:
-      owner_major, perm, counts = device_ops.partition(flat, self.shard_num, device_ops.PARTITION_MASK_MOD)
+      if flat.dtype == torch.int32:   # the partition kernel reads int64 keys; sign extension keeps (key & 0x7fffffff) % n
+        owner_major, perm, counts = device_ops.partition(flat.to(torch.int64), self.shard_num, device_ops.PARTITION_MASK_MOD)
+        owner_major = owner_major.to(torch.int32)
+      else:
+        owner_major, perm, counts = device_ops.partition(flat, self.shard_num, device_ops.PARTITION_MASK_MOD)
     else:
       owner = self.partition_fn(flat, self.shard_num)
       perm, counts = device_ops.partition_by_owner(owner, self.shard_num)

@@ -48,6 +48,8 @@ def parse_cuckoo_gpu_types(text):
     pairs.add((norm.get(m.group(1), m.group(1)), norm.get(m.group(2), m.group(2))))
   for m in re.finditer(r"^\s*TFRA_REGISTER_CUCKOO\(\s*([\w:]+)\s*\)\s*;", text, re.M):
     pairs.add(("int64_t", norm.get(m.group(1), m.group(1))))
+  for m in re.finditer(r"^\s*TFRA_REGISTER_CUCKOO_KV\(\s*([\w:]+)\s*,\s*([\w:]+)\s*\)\s*;", text, re.M):
+    pairs.add((norm.get(m.group(1), m.group(1)), norm.get(m.group(2), m.group(2))))
   return sorted(list(p) for p in pairs)
 
 

@@ -79,8 +79,10 @@ class MI355XHashTable final : public lookup::LookupInterface {
     OP_REQUIRES_OK(ctx, GetNodeAttr(def, "value_shape", &value_shape_));
     OP_REQUIRES(ctx, TensorShapeUtils::IsVector(value_shape_),
                 errors::InvalidArgument("Default value must be a vector, got shape ", value_shape_.DebugString()));
-    OP_REQUIRES(ctx, key_dtype_ == DT_INT64 && TfraDtypeOf(value_dtype_) >= 0,
-                errors::InvalidArgument("hash table on MI355X: int64 keys and float / half / bfloat16 / int8 / int32 / int64 values"));
+    // int32 keys (the reference's (int32, float) cuckoo kernels, cuckoo_hashtable_op_gpu.cu.cc:1058): widened on the device in front of
+    // every engine call, narrowed behind an export, 4-byte keys in the key files (Keys64 / Export / TFRA_OPTION_KEY_BYTES_ON_DISK)
+    OP_REQUIRES(ctx, (key_dtype_ == DT_INT64 || key_dtype_ == DT_INT32) && TfraDtypeOf(value_dtype_) >= 0,
+                errors::InvalidArgument("hash table on MI355X: int64 / int32 keys and float / half / bfloat16 / int8 / int32 / int64 values"));
     int64_t init_capacity = 0, max_capacity = 0, max_hbm = 0, step_per_epoch = 0;
     int strategy = -1, reserved_bit = 0;
     if (cuckoo) {   // cuckoo_hashtable_op_gpu.cu.cc:58-75: init_size, 0 -> TF_HASHTABLE_INIT_SIZE, default 8192
@@ -137,6 +139,7 @@ class MI355XHashTable final : public lookup::LookupInterface {
     const char* from = std::getenv("TFRA_TABLE_ALLOCATOR");
     const bool hip_bytes = from != nullptr && std::string(from) == "hip";
     OP_REQUIRES_OK(ctx, ToStatus(tfra_table_create(&o, hip_bytes ? nullptr : &bridge, &table_)));
+    if (key_dtype_ == DT_INT32) OP_REQUIRES_OK(ctx, ToStatus(tfra_table_set_option(table_, TFRA_OPTION_KEY_BYTES_ON_DISK, 4)));
   }
   ~MI355XHashTable() override {
     if (step_.driver) tfra_step_driver_destroy(step_.driver);
@@ -187,17 +190,26 @@ class MI355XHashTable final : public lookup::LookupInterface {
   // `scores` = the op's int64 input, nullptr / empty tensor = none (hkv_hashtable_op_gpu.cu.cc:758-762)
   Status InsertWithScores(OpKernelContext* ctx, const Tensor& keys, const Tensor& values, const Tensor* scores) {
     const size_t n = static_cast<size_t>(keys.NumElements());
-    return ToStatus(tfra_table_insert_or_assign(table_, n, Data<int64_t>(keys), values.tensor_data().data(), ScoresOf(scores),
+    Tensor wide;
+    const int64_t* k = nullptr;
+    TF_RETURN_IF_ERROR(Keys64(ctx, keys, &wide, &k));
+    return ToStatus(tfra_table_insert_or_assign(table_, n, k, values.tensor_data().data(), ScoresOf(scores),
                                                 UniqueFlag(), StreamOf(ctx)));
   }
   Status Accum(OpKernelContext* ctx, const Tensor& keys, const Tensor& values_or_deltas, const Tensor& exists, const Tensor* scores) {
     const size_t n = static_cast<size_t>(keys.NumElements());
-    return ToStatus(tfra_table_accum_or_assign(table_, n, Data<int64_t>(keys), values_or_deltas.tensor_data().data(),
+    Tensor wide;
+    const int64_t* k = nullptr;
+    TF_RETURN_IF_ERROR(Keys64(ctx, keys, &wide, &k));
+    return ToStatus(tfra_table_accum_or_assign(table_, n, k, values_or_deltas.tensor_data().data(),
                                                reinterpret_cast<const uint8_t*>(exists.tensor_data().data()), ScoresOf(scores),
                                                UniqueFlag(), StreamOf(ctx)));
   }
   Status Remove(OpKernelContext* ctx, const Tensor& keys) override {
-    return ToStatus(tfra_table_erase(table_, static_cast<size_t>(keys.NumElements()), Data<int64_t>(keys), StreamOf(ctx)));
+    Tensor wide;
+    const int64_t* k = nullptr;
+    TF_RETURN_IF_ERROR(Keys64(ctx, keys, &wide, &k));
+    return ToStatus(tfra_table_erase(table_, static_cast<size_t>(keys.NumElements()), k, StreamOf(ctx)));
   }
   Status Clear(OpKernelContext* ctx) { return ToStatus(tfra_table_clear(table_, StreamOf(ctx))); }
   Status SizeToDevice(OpKernelContext* ctx, int64_t* d_out) { return ToStatus(tfra_table_size_to_device(table_, d_out, StreamOf(ctx))); }
@@ -224,9 +236,17 @@ class MI355XHashTable final : public lookup::LookupInterface {
     size_t* d_counter = reinterpret_cast<size_t*>(const_cast<char*>(counter.tensor_data().data()));
     if (hipMemsetAsync(d_counter, 0, sizeof(size_t), static_cast<hipStream_t>(stream)) != hipSuccess)
       return errors::Internal("export: hipMemsetAsync failed");
-    return ToStatus(tfra_table_export_batch(table_, capacity, 0, d_counter, MutableData<int64_t>(keys),
-                                            values ? const_cast<char*>(values->tensor_data().data()) : nullptr,
-                                            scores ? MutableData<uint64_t>(scores) : nullptr, stream));
+    Tensor wide;   // int32 keys: the engine exports int64 keys, narrowed into the op's output behind it
+    int64_t* k64 = MutableData<int64_t>(keys);
+    if (key_dtype_ == DT_INT32) {
+      TF_RETURN_IF_ERROR(ctx->allocate_temp(DT_INT64, TensorShape({size}), &wide));
+      k64 = MutableData<int64_t>(&wide);
+    }
+    TF_RETURN_IF_ERROR(ToStatus(tfra_table_export_batch(table_, capacity, 0, d_counter, k64,
+                                                        values ? const_cast<char*>(values->tensor_data().data()) : nullptr,
+                                                        scores ? MutableData<uint64_t>(scores) : nullptr, stream)));
+    if (key_dtype_ == DT_INT32) return ToStatus(tfra_keys_narrow_i32(n, k64, MutableData<int32_t>(keys), nullptr, stream));
+    return OkStatus();
   }
   Status SaveToFile(OpKernelContext* ctx, const std::string& prefix, size_t buffer_keys, bool append) {
     size_t saved = 0;
@@ -257,6 +277,13 @@ class MI355XHashTable final : public lookup::LookupInterface {
   static const T* Data(const Tensor& t) { return reinterpret_cast<const T*>(t.tensor_data().data()); }
   template <class T>
   static T* MutableData(Tensor* t) { return reinterpret_cast<T*>(const_cast<char*>(t->tensor_data().data())); }
+  // the engine's int64 keys of an op's key tensor: the tensor itself, or — int32 keys — a widened temporary (freed in stream order)
+  Status Keys64(OpKernelContext* ctx, const Tensor& keys, Tensor* wide, const int64_t** out) {
+    if (key_dtype_ == DT_INT64) { *out = Data<int64_t>(keys); return OkStatus(); }
+    TF_RETURN_IF_ERROR(ctx->allocate_temp(DT_INT64, keys.shape(), wide));
+    *out = MutableData<int64_t>(wide);
+    return ToStatus(tfra_keys_widen_i32(static_cast<size_t>(keys.NumElements()), Data<int32_t>(keys), MutableData<int64_t>(wide), StreamOf(ctx)));
+  }
   static const uint64_t* ScoresOf(const Tensor* scores) {
     return (scores && scores->NumElements() > 0) ? Data<uint64_t>(*scores) : nullptr;
   }
@@ -265,7 +292,10 @@ class MI355XHashTable final : public lookup::LookupInterface {
     if (n == 0) return OkStatus();
     // is_full_default = (value.size() == default.size()) (hkv_hashtable_op_gpu.cu.cc:186-190)
     const int full = values->NumElements() == default_value.NumElements() ? 1 : 0;
-    return ToStatus(tfra_table_find(table_, n, Data<int64_t>(keys), const_cast<char*>(values->tensor_data().data()),
+    Tensor wide;
+    const int64_t* k = nullptr;
+    TF_RETURN_IF_ERROR(Keys64(ctx, keys, &wide, &k));
+    return ToStatus(tfra_table_find(table_, n, k, const_cast<char*>(values->tensor_data().data()),
                                     exists ? MutableData<uint8_t>(exists) : nullptr, default_value.tensor_data().data(), full,
                                     StreamOf(ctx)));
   }
