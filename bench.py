@@ -1204,7 +1204,8 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
           "slots": capacity, "requested_slots": want, "alloc_failures": failures, "resident_after_prefill": resident,
           "global_batch": B * world, "keys_per_gpu": resident, "new_key_ratio": new_ratio, "unique_keys_per_batch": U,
           "unique_ratio": round(U / B, 4), "prefill_s": round(t_fill, 1), "steps_per_host_call": 1,
-          "parallelism": ("key-hash sharded x%d, RCCL alltoall" % world) if world > 1 else
+          "parallelism": ("key-hash sharded x%d, %s" % (world, "RCCL alltoall over xGMI (the driver's own communicator pair)" if m["rccl_ranks"] else
+                                                        "alltoall STAGED THROUGH THE HOST (gloo: a functional run, ranks sharing a GPU — not a measurement)")) if world > 1 else
                          ("single GPU through the route driver, transport %s (one-rank communicators)" % transport if forced else "single GPU through the route driver (no transport)"),
           "route": "assign_route", "rccl_ranks_seen": m["rccl_ranks"], "batches_fed_ahead": m["ahead"],
           "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4),
