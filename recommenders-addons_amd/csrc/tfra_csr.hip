@@ -2155,6 +2155,10 @@ static void launch_apply_csr(Table* t, hipStream_t s, const tfra_sparse_plan* pl
   TableView v = t->view_of(t->cur);
   const float a0 = t->opts.aux_init[0], a1 = t->opts.aux_init[1];
   const unsigned gen = ++pl->use_gen;
+  // one RESIDENT grid (the kernel is grid-stride: 125 registers = 4 blocks per CU x 256 CUs): a batch's 33 K keys as 2075 blocks were two
+  // rounds of dispatch plus a third of 27 blocks; 1024 blocks looping twice: configs[1] 55.2 -> 53.7 us per step (A/B on one box, twice)
+  static const unsigned grid_cap = [] { const char* e = getenv("TFRA_APPLY_GRID_CAP"); return e ? (unsigned)atoi(e) : 1024u; }();
+  if (grid_cap) key_blocks = std::min(key_blocks, grid_cap);
   apply_csr_kernel<KIND, false><<<key_blocks, 256, 0, s>>>(v, o, pl->dim, grads, pl->partial, keys_of(pl), default_row, a0, a1, sp,
                                                            pl->dflag, pl->any_deferred, gen);
   if (sp.bounded)
