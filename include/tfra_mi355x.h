@@ -527,6 +527,10 @@ typedef struct {
   int rank, world;
   int (*alltoallv)(void* ctx, int channel, const void* send, const size_t* send_bytes, void* recv,
                    const size_t* recv_bytes, tfra_stream_t stream);
+  /* optional (NULL: the driver issues two alltoallv): TWO independent alltoallv as ONE exchange — the RCCL transport groups all their
+   * sends / recvs into one ncclGroup, one kernel instead of two (the count exchange of one batch with the id exchange of another) */
+  int (*alltoallv2)(void* ctx, int channel, const void* send_a, const size_t* send_bytes_a, void* recv_a, const size_t* recv_bytes_a,
+                    const void* send_b, const size_t* send_bytes_b, void* recv_b, const size_t* recv_bytes_b, tfra_stream_t stream);
 } tfra_transport;
 #define TFRA_RCCL_ID_BYTES 128
 int tfra_rccl_unique_id(const char* librccl_path, void* id_out /* TFRA_RCCL_ID_BYTES, host */);

@@ -271,7 +271,7 @@ struct tfra_assign_route {
   // critical-path buffers (caller's stream only).  One rank without a transport: vrecv = vsend and rows_back = rows_served
   unsigned char* vsend = nullptr; unsigned char* rows_back = nullptr;            // [max_n rows]
   unsigned char* vrecv = nullptr; unsigned char* rows_served = nullptr; size_t served_cap = 0;   // [served_cap rows]
-  std::vector<size_t> sb, rb;
+  std::vector<size_t> sb, rb, cb;
   unsigned long long n_steps = 0, n_stalls = 0;
 };
 
@@ -324,10 +324,10 @@ int issue_plan(tfra_assign_route* r, ASlot& sl) {
   return TFRA_OK;
 }
 
-// FED -> COUNTED
-int issue_counts(tfra_assign_route* r, ASlot& sl) {
+// FED -> COUNTED.  defer_exchange: the caller issues the count exchange itself, together with another batch's id exchange (one group)
+int issue_counts(tfra_assign_route* r, ASlot& sl, bool defer_exchange = false) {
   hipStream_t c = r->ahead;
-  if (r->has_tr) {
+  if (r->has_tr && !defer_exchange) {
     for (int i = 0; i < r->world; ++i) r->sb[i] = r->rb[i] = sizeof(int64_t);
     int rc = r->tr.alltoallv(r->tr.ctx, 1, sl.d_counts, r->sb.data(), sl.d_counts + r->world, r->rb.data(), (tfra_stream_t)c);
     if (rc) return rc;
@@ -341,8 +341,9 @@ int issue_counts(tfra_assign_route* r, ASlot& sl) {
   return TFRA_OK;
 }
 
-// COUNTED -> ROUTED: the ONE host read of a batch (the split sizes, as hvd.alltoall(ids, splits) needs them too), then the ids
-int issue_ids(tfra_assign_route* r, ASlot& sl) {
+// COUNTED -> ROUTED: the ONE host read of a batch (the split sizes, as hvd.alltoall(ids, splits) needs them too), then the ids.
+// with_counts_of: a FED batch whose count exchange travels in the same group as this batch's ids (tfra_transport::alltoallv2)
+int issue_ids(tfra_assign_route* r, ASlot& sl, ASlot* with_counts_of = nullptr) {
   if (!sl.counts_ev) return set_error(TFRA_ERR_HIP, "assign route: internal: stage without an event");
   if (hipEventQuery(sl.counts_ev) != hipSuccess) {
     r->n_stalls += 1;
@@ -369,7 +370,18 @@ int issue_ids(tfra_assign_route* r, ASlot& sl) {
   sl.recv_ids = r->has_tr ? sl.recv_buf : sl.owner_major;
   rc = ensure_served(r, nr);
   if (rc) return rc;
-  rc = a2a(r, 1, sl.owner_major, sl.send, sl.recv_ids, sl.recv, sizeof(int64_t), r->ahead);
+  if (with_counts_of && r->has_tr && r->tr.alltoallv2) {
+    std::vector<size_t>& cb = r->cb;
+    for (int i = 0; i < r->world; ++i) { r->sb[i] = sl.send[i] * sizeof(int64_t); r->rb[i] = sl.recv[i] * sizeof(int64_t); cb[i] = sizeof(int64_t); }
+    rc = r->tr.alltoallv2(r->tr.ctx, 1, sl.owner_major, r->sb.data(), sl.recv_ids, r->rb.data(), with_counts_of->d_counts, cb.data(),
+                          with_counts_of->d_counts + r->world, cb.data(), (tfra_stream_t)r->ahead);
+  } else {
+    rc = a2a(r, 1, sl.owner_major, sl.send, sl.recv_ids, sl.recv, sizeof(int64_t), r->ahead);
+    if (!rc && with_counts_of && r->has_tr) {
+      for (int i = 0; i < r->world; ++i) r->sb[i] = r->rb[i] = sizeof(int64_t);
+      rc = r->tr.alltoallv(r->tr.ctx, 1, with_counts_of->d_counts, r->sb.data(), with_counts_of->d_counts + r->world, r->rb.data(), (tfra_stream_t)r->ahead);
+    }
+  }
   if (rc) return rc;
   sl.ids_ev = nullptr;   // = the event the caller records behind this stage (mark_ahead)
   sl.main_waited = false;
@@ -402,6 +414,24 @@ int ensure_routed(tfra_assign_route* r, ASlot& sl) {
 
 // after a step: every batch fed ahead moves one stage.  Depends on the call sequence alone (the same on every rank).
 int advance_ahead(tfra_assign_route* r) {
+  // the normal case of a full pipeline: ONE batch has its split sizes and gets its ids routed, the NEXT one gets its counts exchanged —
+  // both exchanges as one group (one RCCL kernel instead of two)
+  ASlot* to_route = nullptr;
+  ASlot* to_count = nullptr;
+  int n_route = 0, n_count = 0;
+  for (int k = 0, i = r->head; k < r->live; ++k, i = (i + 1) % NS) {
+    ASlot& sl = r->slots[i];
+    if (sl.state == ST_COUNTED) { if (!to_route) to_route = &sl; n_route += 1; }
+    else if (sl.state == ST_FED) { if (!to_count) to_count = &sl; n_count += 1; }
+  }
+  if (n_route == 1 && n_count == 1) {
+    // (the received counts are copied to pinned memory BEHIND the exchange: issue_counts with the exchange deferred puts only that copy
+    // into the stream, so it comes after the group below)
+    int rc = issue_ids(r, *to_route, to_count);
+    if (!rc) rc = issue_counts(r, *to_count, /*defer_exchange=*/true);
+    if (rc) return rc;
+    return mark_ahead(r);
+  }
   for (int k = 0, i = r->head; k < r->live; ++k, i = (i + 1) % NS) {
     ASlot& sl = r->slots[i];
     if (sl.state == ST_COUNTED) { int rc = issue_ids(r, sl); if (rc) return rc; }
@@ -466,7 +496,7 @@ int tfra_assign_route_create(tfra_table_t* table, const tfra_transport* transpor
   r->mode = partition_mode; r->row_bytes = t->field_bytes; r->max_n = max_batch;
   r->device = t->opts.device;
   if (r->device < 0 && hipGetDevice(&r->device) != hipSuccess) { delete r; return hip_fail("no device"); }
-  r->sb.resize(r->world); r->rb.resize(r->world);
+  r->sb.resize(r->world); r->rb.resize(r->world); r->cb.resize(r->world);
   int rc = hipSetDevice(r->device) == hipSuccess ? TFRA_OK : hip_fail("hipSetDevice");
   if (!rc && hipStreamCreateWithFlags(&r->ahead, hipStreamNonBlocking) != hipSuccess) rc = hip_fail("stream create");
   if (!rc) rc = tfra_step_driver_create(table, &r->drv);

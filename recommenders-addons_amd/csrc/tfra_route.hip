@@ -105,6 +105,36 @@ int rccl_alltoallv(void* vctx, int channel, const void* send, const size_t* send
   return TFRA_OK;
 }
 
+int rccl_alltoallv2(void* vctx, int channel, const void* send_a, const size_t* sb_a, void* recv_a, const size_t* rb_a, const void* send_b,
+                    const size_t* sb_b, void* recv_b, const size_t* rb_b, tfra_stream_t stream) {
+  RcclCtx* c = static_cast<RcclCtx*>(vctx);
+  if (!c || channel < 0 || channel > 1) return set_error(TFRA_ERR_INVALID, "rccl transport: bad channel");
+  hipStream_t s = (hipStream_t)stream;
+  ncclResult_t r = c->api.group_start();
+  if (r != ncclSuccess) return rccl_fail(c->api, r, "ncclGroupStart");
+  for (int set = 0; set < 2; ++set) {   // (a peer's two sends / receives are matched in the order they are issued: set a, then set b, on every rank)
+    const char* sp = static_cast<const char*>(set ? send_b : send_a);
+    char* rp = static_cast<char*>(set ? recv_b : recv_a);
+    const size_t* sb = set ? sb_b : sb_a;
+    const size_t* rb = set ? rb_b : rb_a;
+    for (int peer = 0; peer < c->world; ++peer) {
+      if (sb[peer]) {
+        r = c->api.send(sp, sb[peer], ncclInt8, peer, c->comm[channel], s);
+        if (r != ncclSuccess) { (void)c->api.group_end(); return rccl_fail(c->api, r, "ncclSend"); }
+      }
+      if (rb[peer]) {
+        r = c->api.recv(rp, rb[peer], ncclInt8, peer, c->comm[channel], s);
+        if (r != ncclSuccess) { (void)c->api.group_end(); return rccl_fail(c->api, r, "ncclRecv"); }
+      }
+      sp += sb[peer];
+      rp += rb[peer];
+    }
+  }
+  r = c->api.group_end();
+  if (r != ncclSuccess) return rccl_fail(c->api, r, "ncclGroupEnd");
+  return TFRA_OK;
+}
+
 constexpr int NSLOTS = 5;   // up to four batches fed ahead of the one being applied
 
 // A batch moves through these stages; who issues what:
@@ -399,7 +429,7 @@ int tfra_rccl_transport_create(const char* librccl_path, const void* ids, int ra
       return rc;
     }
   }
-  out->ctx = c; out->rank = rank; out->world = world; out->alltoallv = rccl_alltoallv;
+  out->ctx = c; out->rank = rank; out->world = world; out->alltoallv = rccl_alltoallv; out->alltoallv2 = rccl_alltoallv2;
   return TFRA_OK;
 }
 

@@ -86,7 +86,8 @@ ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, cty
 
 class Transport(ctypes.Structure):
   """tfra_transport (include/tfra_mi355x.h): the alltoallv the routed step driver exchanges buffers through."""
-  _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int), ("alltoallv", ALLTOALLV_FN)]
+  _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int), ("alltoallv", ALLTOALLV_FN),
+              ("alltoallv2", ctypes.c_void_p)]   # optional: NULL for the host-staged test transport
 
 
 RCCL_ID_BYTES = 128
