@@ -189,6 +189,23 @@ def test_bench_gpus2_without_a_launcher_runs_the_metric_step_sharded(tmp_path):
   assert st["owner_overlapped"] >= 5 * 6 and full["config"]["verified"]["routed_step_last_batch"] is True
 
 
+def test_bench_m1s_one_rank_through_the_route_driver(tmp_path):
+  """`python bench.py --config m1s` (one rank): the per-GPU workload of every `--gpus N` run THROUGH the route driver, device buffers
+  aliased where the alltoalls would be — the line's `scaling_point` on a table of its own."""
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+  env.update(TFRA_BENCH_DETAIL_DIR=str(tmp_path))
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "m1s", "--steps", "6", "--warmup", "2", "--shard-slots", "400000",
+         "--batch", "8192", "--no-cpu-baseline"]
+  p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-3000:]
+  d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+  assert d["n_gpus"] == 1 and d["verified"] is True and d["config"]["route"] == "assign_route" and d["value"] > 0
+  assert "no transport" in d["config"]["parallelism"] and d["roofline"]["avg_launch_us"] > 0
+
+
 # ---- configs[4] across ranks: several tables, each hash-sharded, one route per table on ONE shared transport, fused FTRL ----------
 MT_DIMS, MT_STEPS = (8, 16, 4), 4
 
