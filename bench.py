@@ -1884,7 +1884,7 @@ def main():
   else:
     res = run_sharded(args, torch, dist, de, dev, world, rank, "c4")
   if rank == 0:
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # (the CPU leg belongs to the one-GPU line: at N > 1 the other ranks would sit in the final barrier for its 45 s)
       res["cpu_baseline"] = cpu_baseline(args.batch)
     emit(res)
   if dist.is_initialized():
