@@ -359,7 +359,8 @@ int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n
  *       four entries when ids_next2 is used); a batch that was announced but is never stepped is forgotten by the next call.
  *   tfra_table_step_overlap_flush(d, values_prev, scores_prev, stream) writes the last batch back: call it before the table
  *     is used through any other entry point.
- * Tables or calls the overlap does not cover (not a bounded LRU / EPOCHLRU table at capacity, caller scores, optimizer slots, rows
+ * Tables or calls the overlap does not cover (neither a bounded LRU / EPOCHLRU table at capacity nor a growing table without an eviction
+ * strategy — the cuckoo flavour —, caller scores, optimizer slots, rows
  * that are not multiples of 16 bytes) run the same sequence one op after the other inside the same entry points. */
 typedef struct tfra_step_driver tfra_step_driver_t;
 int tfra_step_driver_create(tfra_table_t* t, tfra_step_driver_t** out);

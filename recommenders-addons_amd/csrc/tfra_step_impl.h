@@ -1043,8 +1043,15 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
   unsigned* tags = t->ensure_own_tags(s);
   // what the TABLE must be for the overlap (constant over its life, but for `dense`) and what this CALL must be
   const bool lru_like = t->opts.strategy == TFRA_EVICT_LRU || t->opts.strategy == TFRA_EVICT_EPOCHLRU;   // a new key is always admitted
-  const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && lru_like) ? 0u : 8u) |
-                             (t->at_max_capacity() ? 0u : 16u) | (t->dense ? 0u : 32u) | (t->capture_safe ? 128u : 0u) | ((t->field_bytes & 15u) ? 2u : 0u);
+  // Round 6: a GROWING table (the cuckoo flavour: no eviction strategy, no max_capacity — what TFRA's default creator instantiates) qualifies
+  // too: every key of a batch ends up in it (it grows — own_prepare's prepare_insert, in stream order in front of the launch — instead of
+  // refusing or evicting), a new key that finds no free slot in its two home buckets goes to the tail's general (walking) path like any
+  // left-over key, and nothing is ever evicted under the lookup.  TFRA_STEP_GROWING=0 keeps such tables on the sequential path.
+  static const bool growing_ok = [] { const char* e = std::getenv("TFRA_STEP_GROWING"); return !e || std::atoi(e) != 0; }();
+  const bool growing = growing_ok && t->opts.strategy == TFRA_EVICT_NONE && t->opts.max_capacity == 0;
+  const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && (lru_like || growing)) ? 0u : 8u) |
+                             ((growing || t->at_max_capacity()) ? 0u : 16u) | ((growing || t->dense) ? 0u : 32u) | (t->capture_safe ? 128u : 0u) |
+                             ((t->field_bytes & 15u) ? 2u : 0u);
   const bool aligned = (((uintptr_t)rows_out | (uintptr_t)defaults | (uintptr_t)values_prev) & 15) == 0;
   const unsigned why = why_table | (aligned ? 0u : 2u) | (scores_prev ? 8u : 0u) | ((!plan_prev || plan_prev->n > 0) ? 0u : 64u);
   const bool eligible = why == 0 && (n > 0 || plan_prev);

@@ -178,7 +178,7 @@ def test_overlap_step_evictions_and_forced_conflicts(env):
 
 def test_overlap_many_steps_one_host_call_and_fallback(env):
   """tfra_table_steps_overlap: 8 steps enqueued by ONE host call equal the same steps issued one by one; and a table the
-  overlap does not cover (not at capacity: it still walks and grows) runs the same entry points one op after the other."""
+  overlap does not cover (LFU scores: a key may be refused) runs the same entry points one op after the other."""
   torch, de = env
   dim, cap, n = 64, 200_000, 8192
   rng = np.random.default_rng(9)
@@ -208,8 +208,9 @@ def test_overlap_many_steps_one_host_call_and_fallback(env):
   assert common.size >= max(ka.size, kb.size) - 16
   ck = torch.from_numpy(common).cuda()
   assert torch.equal(tabs[0].lookup(ck), tabs[1].lookup(ck))
-  # fallback: a growing table (CuckooHashTable) through the same driver
-  g = de.CuckooHashTable(torch.int64, torch.float32, torch.zeros(dim), device="cuda:0", dim=dim, name="ovl_fallback")
+  # fallback: a table the overlap does not cover (LFU scores: a key may be refused) through the same driver
+  g = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=1 << 20, max_capacity=1 << 22, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LFU, name="ovl_fallback")
   dg = de.OverlapAssignStep(g).prime(ids[0])
   ref = {}
   for k in range(4):
@@ -596,3 +597,62 @@ def test_overlap_step_on_an_epoch_lru_table(env):
   assert max(da.values()) >= nsteps // spe           # the epoch really advanced while the steps ran
   ta._table.check_errors()
   assert ta._table.slot_census()["locked"] == 0
+
+
+@pytest.mark.parametrize("new_share", [0.02, 0.3])
+def test_overlap_step_on_a_growing_table_dictionary_exact(env, new_share):
+  """Round 6: a GROWING table (CuckooHashTable: no eviction, no max_capacity — TFRA's default creator) takes the overlapped launch:
+  every key of a batch ends up in the table, so the forwarding premise holds; new keys that find no free slot at home go to the tail's
+  walking path; the table GROWS in front of a launch when it must (here several times: it starts at 8192 slots' worth).  Nothing is
+  ever evicted, so a dictionary is the exact oracle (the reference's CPU cuckoo table semantics: K/cuckoo_hashtable_op.cc:111-150,
+  last occurrence wins; lookup i+1 sees update i): every step's rows AND exists flags, and the final export, key for key."""
+  torch, de = env
+  dim, n, nsteps = 64, 20000, 40
+  rng = np.random.default_rng(int(new_share * 100))
+  t = de.CuckooHashTable(torch.int64, torch.float32, torch.full((dim,), -1.0), device="cuda:0", dim=dim, name="ovl_grow_%d" % int(new_share * 100))
+  tbl = t._table
+  resident = rng.permutation(np.arange(1, 60001, dtype=np.int64)) * 7919 + 3
+  k = torch.from_numpy(resident).cuda()
+  tbl.upsert(k, (k % 1000).to(torch.float32)[:, None].repeat(1, dim), unique_keys=True)
+  latest = {int(x): float(int(x) % 1000) for x in resident}
+  fresh = 10_000_000
+  imin = np.iinfo(np.int64).min
+  batches = []
+  for s in range(nsteps + 2):
+    ids = resident[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % resident.size].astype(np.int64)
+    m = int(n * new_share)
+    ids[rng.choice(n, size=m, replace=False)] = np.arange(fresh, fresh + m, dtype=np.int64) * 31 + 5     # never-seen keys
+    fresh += m
+    ids[rng.integers(0, n, size=3)] = imin
+    ids[rng.integers(0, n, size=3)] = imin + 1
+    batches.append(torch.from_numpy(ids).cuda())
+  cap0 = tbl.capacity()
+  drv = de.OverlapAssignStep(t).prime(batches[0])
+  for s in range(nsteps):
+    ids = batches[s]
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
+    nxt = batches[s + 1] if s % 7 != 6 else None
+    nx2 = batches[s + 2] if (nxt is not None and s % 5 != 4) else None
+    out, ex = drv.step(vals, nxt, nx2, return_exists=True)
+    if nxt is None:
+      drv.prime(batches[s + 1])
+    ids_np = ids.cpu().numpy()
+    want = np.array([latest.get(int(x), -1.0) for x in ids_np], np.float32)
+    want_ex = np.array([int(x) in latest for x in ids_np])
+    np.testing.assert_array_equal(ex.cpu().numpy(), want_ex, err_msg="step %d" % s)
+    np.testing.assert_array_equal(out[:, 0].cpu().numpy(), want, err_msg="step %d" % s)
+    assert bool((out == out[:, :1]).all())
+    for i, x in enumerate(ids_np.tolist()):
+      latest[x] = 100000.0 * (s + 1) + i
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] >= nsteps and st["sequential"] <= 1, st
+  assert int(t.size().item()) == len(latest)
+  if new_share > 0.1:
+    assert tbl.capacity() > cap0                                  # it really grew while the steps ran
+  ek, ev = t.export()
+  ekn = ek.cpu().numpy()
+  assert np.unique(ekn).size == ekn.size == len(latest)
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(x)] for x in ekn], np.float32))
+  assert bool((ev == ev[:, :1]).all())
+  tbl.check_errors()
