@@ -1235,6 +1235,62 @@ def run_metric_sharded(args, torch, dist, de, dev, world, rank):
 
 
 
+# ------------------------------------------------------------------ m1g: the metric's step on a GROWING table (TFRA's default creator)
+def run_growing_assign(args, torch, de, dev):
+  """lookup(B) + insert_or_assign(B) of Zipf-1.2 batches on a CuckooHashTable (no eviction, no max_capacity: what `CuckooHashTableCreator`,
+  TFRA's default, instantiates) with `--keys` (10^8) resident keys, dim 64 fp32: round 6 — the overlapped step takes such tables too."""
+  B, K, W = args.batch, args.steps, args.warmup
+  dim, dtype, Rb = 64, torch.float32, 256
+  n_keys = args.keys
+  new_ratio = args.new_key_ratio if args.new_key_ratio is not None else 0.0
+  table = de.CuckooHashTable(torch.int64, dtype, torch.zeros(dim, dtype=dtype), device=str(dev), dim=dim, name="bench_m1g", init_size=int(n_keys * 1.4))
+  gen = torch.Generator(device=dev).manual_seed(SEED + 3)
+  chunk = 4_000_000
+  vals_fill = torch.randn((chunk, dim), generator=gen, device=dev) * 0.01
+  for lo in range(1, n_keys + 1, chunk):
+    k = keys_of_ranks_torch(torch, torch.arange(lo, min(n_keys, lo + chunk - 1) + 1, dtype=torch.int64, device=dev))
+    table._table.upsert(k, vals_fill[:k.numel()], unique_keys=True)
+  del vals_fill
+  idf = IdFactory(torch, dev, B, n_keys, new_ratio, n_keys + 1, SEED + 11)
+  values = torch.randn((B, dim), generator=gen, device=dev) * 0.01
+  nsteps = W + WINDOWS * K
+  ids = idf.keys(nsteps + 3)
+  U = int(np.mean([torch.unique(ids[i]).numel() for i in range(4)]))
+  outs = [torch.empty((B, dim), dtype=dtype, device=dev) for _ in range(2)]
+  ovl = de.OverlapAssignStep(table)
+  ovl.prime(ids[0])
+  for i in range(W):
+    ovl.step(values, ids[i + 1], ids[i + 2])
+  runs = [ovl.make_run([ids[W + c]], [values], [outs[c & 1]], ids_after=ids[W + c + 1], values_before=values if (W + c) else None, ids_after2=ids[W + c + 2])
+          for c in range(WINDOWS * K)]
+  secs, med, host_s = timed_windows(torch, None, 1, dev, K, lambda i: runs[i - W](), first=W)
+  ovl.flush()
+  st = ovl.stats()
+  last = ids[nsteps - 1]
+  got, ex = table.lookup(last, return_exists=True)
+  verified = {"growing_table_last_batch": bool(ex.all()) and bool(torch.equal(got, last_occurrence_rows(torch, last, values))),
+              "growing_table_every_timed_step_overlapped": st["sequential"] <= W, "check_errors_clean": True}
+  table._table.check_errors()
+  bad = [k for k, v in verified.items() if v is False]
+  assert not bad, "bench verification failed: %s (%s)" % (bad, st)
+  ms = med / K * 1e3
+  step_bytes = B * (8 + 2 * Rb) + U * (16 + 2 * Rb)
+  res = {"metric": "embedding lookup+insert pairs/s (dim=64 fp32, GROWING table, %d resident keys, %d %% never-seen ids per batch)" % (n_keys, round(100 * new_ratio)),
+         "value": B * K / med, "unit": "pairs/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms, "driver": "overlapped_step",
+         "config": {"workload": "the metric's step on a growing table (CuckooHashTable: no eviction strategy, no max_capacity — TFRA's default creator), %d resident "
+                                "keys, batch=%d Zipf-1.2, %d %% never-seen ids" % (n_keys, B, round(100 * new_ratio)),
+                    "host_enqueue_ms_per_step": round(1e3 * host_s / K, 4), "unique_keys_per_batch": U, "verified": verified,
+                    "overlapped_step_stats": st, "timing": {"value": timing_note(secs, K)}},
+         "roofline": {"bound": "hbm", "kernel": "step_k_gen (the step's ONE launch, strategy read at run time)", "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "step_algorithmic_bytes": step_bytes}}
+  del table, ovl, runs
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
+  return res
+
+
+
 # ------------------------------------------------------------------ c2 / c4: growing table behind de.Variable, fused optimizer
 def run_sharded(args, torch, dist, de, dev, world, rank, cfg):
   """cfg 'c2' (configs[1], one GPU): 100 M keys, rows [p|m|v], 10 % never-seen ids, lookup + fused sparse Adam; look-ahead
@@ -1776,7 +1832,7 @@ def main():
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--c5-streams", type=int, default=4)
   ap.add_argument("--c5-workers", type=int, default=1)
-  ap.add_argument("--config", choices=["m1b", "m1s", "c3", "c2", "c4", "c5"], default=None,
+  ap.add_argument("--config", choices=["m1b", "m1s", "m1g", "c3", "c2", "c4", "c5"], default=None,
                   help="default: m1b on one GPU (the metric's own configuration; c3 / c2 / c4 / c5 as secondary), m1s per GPU for N>1 (the metric's "
                        "step on a hash-sharded table, ids / rows / values routed; --config m1s --gpus 1: the same through the route driver at one rank); "
                        "c4: configs[3] with the fused-SGD gradient route; c5 with --gpus N: 26 hash-sharded tables per GPU through the multi-table route")
@@ -1830,6 +1886,10 @@ def main():
   cfg = args.config or ("m1b" if (world == 1 and not dist.is_initialized()) else "m1s")
   if cfg == "m1s":
     res = run_metric_sharded(args, torch, dist, de, dev, world, rank)
+  elif cfg == "m1g":
+    assert world == 1, "m1g is a single-GPU configuration"
+    res = run_growing_assign(args, torch, de, dev)
+    res.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
   elif cfg in ("c3", "m1b"):
     assert world == 1, "%s is a single-GPU configuration" % cfg
     if args.config is None and not args.no_secondary:
@@ -1841,7 +1901,8 @@ def main():
               "ms_per_step_plain_call", "ms_per_step_op_surface", "config", "roofline")
       sec = {}
       note("m1b done; secondary workloads")
-      for name, fn in (("c3", lambda: run_bounded(args, torch, de, dev, "c3")),       # configs[2]
+      for name, fn in (("m1g", lambda: run_growing_assign(args, torch, de, dev)),     # the metric's step on TFRA's DEFAULT table type (growing)
+                       ("c3", lambda: run_bounded(args, torch, de, dev, "c3")),       # configs[2]
                        ("c2", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c2")),   # configs[1]
                        ("c4", lambda: run_sharded(args, torch, dist, de, dev, 1, 0, "c4")),   # configs[3] at N=1: the first point of the N-GPU curve
                        ("c5", lambda: run_c5_routed(args, torch, dist, de, dev, 1, 0, budget_frac=0.2))):   # configs[4] at N=1 through the sharded multi-table route
