@@ -359,8 +359,7 @@ int tfra_multi_step_prefetch(size_t n_tables, const tfra_step_desc* descs, int n
  *       four entries when ids_next2 is used); a batch that was announced but is never stepped is forgotten by the next call.
  *   tfra_table_step_overlap_flush(d, values_prev, scores_prev, stream) writes the last batch back: call it before the table
  *     is used through any other entry point.
- * Tables or calls the overlap does not cover (neither a bounded LRU / EPOCHLRU table at capacity nor a growing table without an eviction
- * strategy — the cuckoo flavour —, caller scores, optimizer slots, rows
+ * Tables or calls the overlap does not cover (LFU / EPOCHLFU / CUSTOMIZED scores — a key may be refused —, caller scores, optimizer slots, rows
  * that are not multiples of 16 bytes) run the same sequence one op after the other inside the same entry points. */
 typedef struct tfra_step_driver tfra_step_driver_t;
 int tfra_step_driver_create(tfra_table_t* t, tfra_step_driver_t** out);
@@ -404,8 +403,8 @@ int tfra_step_driver_lookups_listed(const tfra_step_driver_t* d, uint64_t* out);
 /* plans_built[2] (optional): plans of a next batch built inside the step launch (from pairs scattered one launch earlier: ids
  * known TWO batches ahead) / built by a launch of their own in front of the step (ids known one batch ahead only, or not at all) */
 /* why_sequential (optional): why the last step that ran one op after the other did — 1 empty batch, 2 a buffer or the row
- * size is not a multiple of 16 bytes, 4 no owner tags, 8 optimizer slots / neither LRU nor EPOCHLRU / caller scores, 16 the table can still
- * grow, 32 the table is not yet known to be dense (> 60 % of its slots, learned from asynchronous size reads), 64 the
+ * size is not a multiple of 16 bytes, 4 no owner tags, 8 optimizer slots / a strategy that may refuse a key / caller scores, 16 and 32
+ * (round 5: the table can still grow / is not yet dense) are no longer reasons unless TFRA_STEP_GROWING=0, 64 the
  * previous batch was empty, 128 TFRA_OPTION_CAPTURE_SAFE */
 
 /* -- front-end helpers (N1/N3 rows of SURVEY.md §8f) ------------------------------------- */

@@ -1049,9 +1049,14 @@ static int step_overlap_one(tfra_step_driver* d, size_t n, const int64_t* ids, v
   // left-over key, and nothing is ever evicted under the lookup.  TFRA_STEP_GROWING=0 keeps such tables on the sequential path.
   static const bool growing_ok = [] { const char* e = std::getenv("TFRA_STEP_GROWING"); return !e || std::atoi(e) != 0; }();
   const bool growing = growing_ok && t->opts.strategy == TFRA_EVICT_NONE && t->opts.max_capacity == 0;
+  // ... and so does a BOUNDED LRU / EPOCHLRU table that is not (yet) at its max_capacity or not yet dense: below max_capacity it grows like
+  // the cuckoo flavour; at max_capacity but sparse a new key walks four buckets and an eviction — if it comes to one — is the tail's (after
+  // every write-back block, victims the lookup asked for corrected as always).  An Hkv table whose max_capacity is never reached — a common
+  // deployment — used to stay on the sequential path for ever (reasons 16 / 32).
+  const bool any_fill = growing_ok && lru_like;
   const unsigned why_table = (tags ? 0u : 4u) | ((t->opts.aux_fields == 0 && (lru_like || growing)) ? 0u : 8u) |
-                             ((growing || t->at_max_capacity()) ? 0u : 16u) | ((growing || t->dense) ? 0u : 32u) | (t->capture_safe ? 128u : 0u) |
-                             ((t->field_bytes & 15u) ? 2u : 0u);
+                             ((growing || any_fill || t->at_max_capacity()) ? 0u : 16u) | ((growing || any_fill || t->dense) ? 0u : 32u) |
+                             (t->capture_safe ? 128u : 0u) | ((t->field_bytes & 15u) ? 2u : 0u);
   const bool aligned = (((uintptr_t)rows_out | (uintptr_t)defaults | (uintptr_t)values_prev) & 15) == 0;
   const unsigned why = why_table | (aligned ? 0u : 2u) | (scores_prev ? 8u : 0u) | ((!plan_prev || plan_prev->n > 0) ? 0u : 64u);
   const bool eligible = why == 0 && (n > 0 || plan_prev);

@@ -656,3 +656,90 @@ def test_overlap_step_on_a_growing_table_dictionary_exact(env, new_share):
   np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(x)] for x in ekn], np.float32))
   assert bool((ev == ev[:, :1]).all())
   tbl.check_errors()
+
+
+def test_overlap_step_on_a_bounded_table_that_never_fills(env):
+  """An Hkv LRU table whose max_capacity is far away (a common deployment) grows like the cuckoo flavour and never evicts: the
+  overlapped launch from the first step on, a dictionary the exact oracle, growth while the steps run."""
+  torch, de = env
+  dim, n, nsteps = 64, 12000, 30
+  rng = np.random.default_rng(8)
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.full((dim,), -1.0), init_capacity=1 << 16, max_capacity=1 << 24, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name="ovl_never_full")
+  tbl = t._table
+  resident = rng.permutation(np.arange(1, 20001, dtype=np.int64)) * 7919 + 3
+  k = torch.from_numpy(resident).cuda()
+  tbl.upsert(k, (k % 1000).to(torch.float32)[:, None].repeat(1, dim), unique_keys=True)
+  latest = {int(x): float(int(x) % 1000) for x in resident}
+  fresh = 5_000_000
+  batches = []
+  for s in range(nsteps + 2):
+    ids = resident[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % resident.size].astype(np.int64)
+    m = n // 2                                           # 6 K never-seen keys per step: past the first growth mark after ~20 steps
+    ids[rng.choice(n, size=m, replace=False)] = np.arange(fresh, fresh + m, dtype=np.int64) * 31 + 5
+    fresh += m
+    batches.append(torch.from_numpy(ids).cuda())
+  cap0 = tbl.capacity()
+  drv = de.OverlapAssignStep(t).prime(batches[0])
+  for s in range(nsteps):
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
+    out, ex = drv.step(vals, batches[s + 1], batches[s + 2], return_exists=True)
+    ids_np = batches[s].cpu().numpy()
+    np.testing.assert_array_equal(ex.cpu().numpy(), np.array([int(x) in latest for x in ids_np]), err_msg="step %d" % s)
+    np.testing.assert_array_equal(out[:, 0].cpu().numpy(), np.array([latest.get(int(x), -1.0) for x in ids_np], np.float32), err_msg="step %d" % s)
+    for i, x in enumerate(ids_np.tolist()):
+      latest[x] = 100000.0 * (s + 1) + i
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] >= nsteps and st["sequential"] <= 1, st
+  assert int(t.size().item()) == len(latest) and tbl.capacity() > cap0
+  ek, ev = t.export()
+  ekn = ek.cpu().numpy()
+  assert np.unique(ekn).size == ekn.size == len(latest)
+  np.testing.assert_array_equal(ev[:, 0].cpu().numpy(), np.array([latest[int(x)] for x in ekn], np.float32))
+  tbl.check_errors()
+
+
+def test_overlap_step_while_a_bounded_table_fills_up_and_starts_evicting(env):
+  """From a third full to beyond capacity through the SAME driver: growing phase, at max_capacity but sparse (new keys walk), dense
+  (evictions in the launch, deferred evictions, corrections).  Every step equals a plain find of the table right after the call; the
+  size never passes the capacity; nothing locked, no error."""
+  torch, de = env
+  dim, n, nsteps, cap = 64, 8000, 60, 1 << 17
+  rng = np.random.default_rng(12)
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap // 2, max_capacity=cap, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name="ovl_fills_up")
+  tbl = t._table
+  resident = rng.permutation(np.arange(1, cap // 3 + 1, dtype=np.int64)) * 7919 + 3
+  k = torch.from_numpy(resident).cuda()
+  tbl.upsert(k, (k % 1000).to(torch.float32)[:, None].repeat(1, dim), unique_keys=True)
+  fresh = 9_000_000
+  batches = []
+  for s in range(nsteps + 2):
+    ids = resident[(rng.zipf(1.15, size=n) * 37 + rng.integers(0, 50, size=n)) % resident.size].astype(np.int64)
+    m = n // 3                                           # 2.7 K never-seen keys per step: the table is full after ~35 steps
+    ids[rng.choice(n, size=m, replace=False)] = np.arange(fresh, fresh + m, dtype=np.int64) * 31 + 5
+    fresh += m
+    batches.append(torch.from_numpy(ids).cuda())
+  drv = de.OverlapAssignStep(t).prime(batches[0])
+  for s in range(nsteps):
+    vals = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * (s + 1))[:, None].repeat(1, dim)
+    out, ex = drv.step(vals, batches[s + 1], batches[s + 2], return_exists=True)
+    ref, rex = tbl.find(batches[s], return_exists=True)
+    assert torch.equal(ex, rex) and torch.equal(out, ref), "step %d" % s
+    assert int(t.size().item()) <= tbl.capacity()
+  drv.flush()
+  st = drv.stats()
+  assert st["overlapped"] >= nsteps - 2, st
+  assert int(t.size().item()) > 0.9 * tbl.capacity()      # it did fill up
+  assert st["deferred_evictions"] + st["victims_noted"] >= 0
+  tbl.check_errors()
+  assert tbl.slot_census()["locked"] == 0
+  # the last batch's writes are there
+  last = batches[nsteps - 1]
+  got, ex = tbl.find(last, return_exists=True)
+  lastv = (torch.arange(n, device="cuda", dtype=torch.float32) + 100000.0 * nsteps)[:, None].repeat(1, dim)
+  uk, inv = torch.unique(last, return_inverse=True)
+  lp = torch.zeros(uk.numel(), dtype=torch.long, device="cuda")
+  lp.scatter_reduce_(0, inv, torch.arange(n, device="cuda"), reduce="amax", include_self=False)
+  assert bool(ex.all()) and torch.equal(got, lastv[lp][inv])
