@@ -465,6 +465,71 @@ def profile_summary():
     return None
 
 
+def live_traffic(args):
+  """`roofline.traffic` measured BY THIS RUN when rocprofv3 is here: two short child runs of the headline workload alone
+  (`--config m1b --no-secondary --no-cpu-baseline --steps 10 --warmup 5`), one per counter as MI355X_MICROARCH.md prescribes
+  (`rocprofv3 --pmc FETCH_SIZE --kernel-trace`, then `--pmc WRITE_SIZE --kernel-trace`: PMC passes on their own, never with API
+  tracing), BEFORE this process touches the GPU (the table takes 273 of the 288 GB).  Per launch of the step kernel:
+  (2 x FETCH_SIZE + WRITE_SIZE) KiB — gfx950 reports half of the wide coalesced reads.  Returns {"step_k": bytes, "source": ...} or None
+  (no rocprofv3, a pass failed or ran into its limit: the line then quotes the committed profile summary and says so).
+  TFRA_BENCH_LIVE_TRAFFIC=0 skips it."""
+  import csv
+  import glob
+  import re
+  import shutil
+  import signal
+  import subprocess
+  import tempfile
+  if os.environ.get("TFRA_BENCH_LIVE_TRAFFIC", "1") == "0":
+    return None
+  exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+  if not exe:
+    return None
+  tmp = tempfile.mkdtemp(prefix="tfra_live_", dir="/tmp")
+  env = dict(os.environ)
+  env.update({"TMPDIR": "/tmp", "TFRA_BENCH_LIVE_TRAFFIC": "0", "TFRA_BENCH_SKIP_ROUTED_LOCAL": "1"})
+  per = {}
+  try:
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+      d = os.path.join(tmp, c)
+      cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "live", "--", sys.executable, os.path.abspath(__file__),
+             "--config", "m1b", "--no-secondary", "--no-cpu-baseline", "--steps", "10", "--warmup", "5", "--slots", str(args.slots),
+             "--batch", str(args.batch)]
+      t0 = time.perf_counter()
+      pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+      try:
+        rc = pr.wait(timeout=float(os.environ.get("TFRA_BENCH_LIVE_TRAFFIC_LIMIT_S", "240")))
+      except subprocess.TimeoutExpired:
+        os.killpg(pr.pid, signal.SIGKILL)   # the process group started above (rocprofv3 and the bench under it), nothing else
+        pr.wait()
+        note("live traffic: the %s pass ran into its limit" % c)
+        return None
+      if rc != 0:
+        note("live traffic: the %s pass ended with code %d" % (c, rc))
+        return None
+      tot, disp = 0.0, set()
+      for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+          for row in csv.DictReader(fh):
+            if row.get("Counter_Name") == c and re.search(r"\bstep_k_u\d", row.get("Kernel_Name", "")):
+              tot += float(row["Counter_Value"])
+              disp.add(row["Dispatch_Id"])
+      if not disp:
+        note("live traffic: no step launches in the %s pass" % c)
+        return None
+      per[c] = (tot / len(disp), len(disp))
+      note("live traffic: %s %.1f KiB per step launch (%d launches, %.0f s)" % (c, per[c][0], per[c][1], time.perf_counter() - t0))
+  except (OSError, ValueError, KeyError) as e:
+    note("live traffic: %s" % e)
+    return None
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+  return {"step_k": int((2 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]) * 1024),
+          "FETCH_SIZE_KiB_raw": round(per["FETCH_SIZE"][0], 1), "WRITE_SIZE_KiB": round(per["WRITE_SIZE"][0], 1), "launches": per["FETCH_SIZE"][1],
+          "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of THIS run (bench.live_traffic), (2 x FETCH + WRITE) KiB "
+                    "per step launch, %d launches" % per["FETCH_SIZE"][1]}
+
+
 def cpu_baseline_1e9():
   """the CPU leg at the metric's 10^9 resident keys, measured once on a GPU box's host (169 s of CPU work: it does not fit the default
   run, which stops at the 256 M-key rung) — quoted in the line with its source"""
@@ -882,11 +947,12 @@ def run_bounded(args, torch, de, dev, cfg):
   upsert_bytes = U * (8 + Rb + Rb + 8)                 # per unique key: key, value row read, row written, key stored
   step_bytes = step_bytes_ = lookup_bytes + upsert_bytes
   prof = profile_summary()
+  live = getattr(args, "_live_traffic", None) if cfg == "m1b" else None
   kernels = {
       "step_k (the step's ONE launch: lookup of batch i+1 with store-to-load forwarding + ownership write-back of batch i + its tail + plan builders)": {
           "avg_launch_us": ktimes["step_kernel_us"], "algorithmic_bytes_per_launch": step_bytes_, "unique_keys": U,
           "achieved_GBps": step_bytes_ / ktimes["step_kernel_us"] / 1e3, "frac": step_bytes_ / ktimes["step_kernel_us"] / 1e3 / HBM_PEAK_GBS,
-          "traffic": traffic_of(prof, cfg, "step_k"), "launches_timed": ktimes["steps"]},
+          "traffic": (live or {}).get("step_k") or traffic_of(prof, cfg, "step_k"), "launches_timed": ktimes["steps"]},
       "find_kernel<16,4,WT,PF1> (lookup; both home-bucket lines in flight)": {
           "avg_launch_us": find_us, "algorithmic_bytes_per_launch": lookup_bytes,
           "achieved_GBps": lookup_bytes / find_us / 1e3, "frac": lookup_bytes / find_us / 1e3 / HBM_PEAK_GBS,
@@ -984,7 +1050,9 @@ def run_bounded(args, torch, de, dev, cfg):
       "roofline": {
           "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
           "frac": kernels[dom]["frac"], "traffic": kernels[dom]["traffic"],
-          "traffic_source": (prof or {}).get("_source") if kernels[dom]["traffic"] is not None else None,
+          "traffic_source": ((live["source"] if (live and dom.startswith("step_k")) else (prof or {}).get("_source"))
+                             if kernels[dom]["traffic"] is not None else None),
+          "traffic_profile_summary": traffic_of(prof, cfg, "step_k") if (live and dom.startswith("step_k")) else None,
           "avg_launch_us_note": "HIP events around the launch on its stream: one dispatch (~1.5 us) more than the kernel itself (rocprofv3's per-kernel "
                                 "average of the same build: profiles/*_kernel_stats.csv)",
           "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"], "avg_launch_us": kernels[dom]["avg_launch_us"],
@@ -1749,8 +1817,10 @@ def compact_line(res, detail_path=None):
   bools = [v for v in flags.values() if isinstance(v, bool)]
   line["verified"] = bool(bools) and all(bools)
   line["verified_flags"] = len(bools)
-  r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_us",
-                 "step_frac", "step_algorithmic_bytes"))
+  r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_profile_summary", "algorithmic_bytes_per_launch",
+                 "avg_launch_us", "step_frac", "step_algorithmic_bytes"))
+  if r.get("traffic_profile_summary") is None:
+    r.pop("traffic_profile_summary", None)
   if "avg_launch_us" in r:
     r["avg_launch_us_is"] = "HIP events around the launch (incl. one dispatch)"
   r["kernel"] = _short(rf.get("kernel"), 150)
@@ -1861,6 +1931,9 @@ def main():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     sys.exit(subprocess.call(cmd, env=env))
+
+  if args.config is None and args.gpus == 1 and "WORLD_SIZE" not in os.environ and os.environ.get("TFRA_BENCH_FORCE_A2A") != "1":
+    args._live_traffic = live_traffic(args)   # (before this process allocates anything on the GPU)
 
   import torch
   import torch.distributed as dist

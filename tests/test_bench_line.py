@@ -131,3 +131,47 @@ def test_emit_prints_the_line_last_and_writes_the_detail_file(tmp_path, monkeypa
   assert d["detail"] == "bench_detail.json"
   full = json.load(open(tmp_path / "bench_detail.json"))
   assert "kernels" in full["roofline"] and len(json.dumps(full)) > 6000
+
+
+def test_live_traffic_reads_the_two_pmc_passes_of_a_rocprofv3_on_path(tmp_path, monkeypatch):
+  """bench.live_traffic(): `roofline.traffic` measured by the run itself — two child passes under rocprofv3 (--pmc FETCH_SIZE, then
+  --pmc WRITE_SIZE, each with --kernel-trace only), the step kernel's launches averaged, (2 x FETCH + WRITE) KiB.  Here a stand-in
+  `rocprofv3` on PATH that writes the counter file the real one writes (several rows per dispatch: one per counter instance; other
+  kernels beside the step's); switched off, absent, failing or over its limit, the function returns None and the line falls back to
+  the committed profile summary."""
+  import argparse
+  import stat
+  fake = tmp_path / "bin" / "rocprofv3"
+  fake.parent.mkdir()
+  fake.write_text("""#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+c = a[a.index("--pmc") + 1]
+d = a[a.index("-d") + 1]
+assert "--kernel-trace" in a and "--sys-trace" not in a and "--hip-trace" not in a and "-s" not in a     # PMC passes on their own
+child = a[a.index("--") + 1:]
+assert "--config" in child and child[child.index("--config") + 1] == "m1b" and "--no-secondary" in child and "--no-cpu-baseline" in child
+assert os.environ.get("TFRA_BENCH_LIVE_TRAFFIC") == "0"      # the child does not start passes of its own
+if os.environ.get("FAKE_ROCPROF_FAIL"):
+  sys.exit(3)
+os.makedirs(os.path.join(d, "host", "1234"), exist_ok=True)
+v = {"FETCH_SIZE": 20000.0, "WRITE_SIZE": 44000.0}[c]
+with open(os.path.join(d, "host", "1234", "live_counter_collection.csv"), "w") as f:
+  f.write("Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\\n")
+  for disp in (1, 2, 3, 4):
+    for part in range(2):   # two instances of the counter per dispatch: summed
+      f.write('%d,%d,1,1,1,1,1,1,"void (anonymous namespace)::step_k_u2(StepArgs)",256,0,0,96,0,100,%s,%f,0,0\\n' % (disp, disp, c, v / 2))
+  f.write('9,9,1,1,1,1,1,1,"void find_kernel<16, 4, true, true>(tfra::TableView)",256,0,0,57,0,100,%s,%f,0,0\\n' % (c, 1e9))
+""")
+  fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+  monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + os.environ.get("PATH", ""))
+  monkeypatch.delenv("TFRA_BENCH_LIVE_TRAFFIC", raising=False)
+  args = argparse.Namespace(slots=1000, batch=64)
+  got = bench.live_traffic(args)
+  assert got is not None and got["step_k"] == int((2 * 20000.0 + 44000.0) * 1024) and got["launches"] == 4
+  assert got["source"].startswith("live: rocprofv3 --pmc FETCH_SIZE")
+  monkeypatch.setenv("FAKE_ROCPROF_FAIL", "1")
+  assert bench.live_traffic(args) is None
+  monkeypatch.delenv("FAKE_ROCPROF_FAIL")
+  monkeypatch.setenv("TFRA_BENCH_LIVE_TRAFFIC", "0")
+  assert bench.live_traffic(args) is None
