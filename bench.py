@@ -724,6 +724,10 @@ def run_bounded(args, torch, de, dev, cfg):
     note("m1b: route driver at one rank timed")
 
   # ---- driver 1b: round 3's look-ahead driver (one C call per step, plan of batch i+1 on a second stream, host-ordered) --------
+  # (FRESH batches here too: until round 6 this driver ran on the overlapped step's batches, whose never-seen ids were resident by then —
+  # configs[2]'s write-back found every key and evicted nothing, and the line's c3 value was that of a stream without new keys)
+  del ids
+  ids = idf.keys(nsteps + 1)
   ps = de.PrefetchAssignStep(table).prime(ids[0])
   for i in range(W):
     ps.step(values, ids[i + 1])
@@ -822,6 +826,9 @@ def run_bounded(args, torch, de, dev, cfg):
     _capi.check(lib.tfra_table_insert_or_assign_n(tbl._h, B, cpin_p, P(ubuf), P(values), None, st))
 
   fus = [(tbl._h, ws, B, P(ids[i]), P(out_buf), None, P(dflt_row), 0, P(ubuf), P(ibuf), cpin_p, st) for i in range(nsteps)]
+  # (every variant on batches of its own — new never-seen ids where the workload has them: the argument blocks point into `ids`, which is
+  # refilled in place)
+  ids.copy_(idf.keys(nsteps))
   for i in range(W):
     op_surface_fused(i)
   secs_opfu, med_opfu, _ = timed_windows(torch, None, 1, dev, K, op_surface_fused, first=W)
@@ -829,10 +836,12 @@ def run_bounded(args, torch, de, dev, cfg):
   u = int(cpin[0])
   got, ex = table.lookup(ubuf[:u], return_exists=True)
   verified["op_surface_fused_ops_last_batch"] = bool(ex.all()) and bool(torch.equal(got, values[:u]))
+  ids.copy_(idf.keys(nsteps))
   for i in range(W):
     op_surface(i)
   secs_ops, med_ops, _ = timed_windows(torch, None, 1, dev, K, op_surface, first=W)
   torch.cuda.synchronize()
+  ids.copy_(idf.keys(nsteps))
   for i in range(W):
     op_surface_sync(i)
   secs_ops_sync, med_ops_sync, _ = timed_windows(torch, None, 1, dev, K, op_surface_sync, first=W)

@@ -1087,6 +1087,8 @@ struct OwnArgs {
   unsigned item_cap;
   const uint8_t* exists;   // ACC (insert_or_accum of unique keys, SRC_DIRECT): the caller's exists flag per key
   int acc_dt;              // ACC: tfra_dtype of the rows
+  SetProbe own_set;        // HF outside the step launch (SRC_SET): the launch's own SET plan, as something to probe
+  unsigned* stats_host;    // pinned (Table::own_stats_host) or null: where the remainder kernel leaves the pass's sample
 };
 // (OwnArgs stays a read-only kernel argument: a private, modified copy would live in scratch memory — its aux_init
 // pattern is indexed dynamically — and every field access of the hot loop would become a scratch load.)
@@ -1126,6 +1128,10 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
   unsigned total = 0;
   if (!slow_ctr) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned counted = slow_ctr ? *slow_ctr : total;
+  if (SRC == SRC_SET && slow_ctr && a.stats_host && blockIdx.x == 0 && threadIdx.x == 0) {   // the pass's sample -> the host (launch_own)
+    __hip_atomic_store(a.stats_host, slow_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.stats_host + 1, slow_ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
   if (counted == 0) return;
   const bool listed = slow_ctr && counted <= a.item_cap;
@@ -1236,9 +1242,8 @@ __device__ __forceinline__ void keep_live_u2(T (&x)[U][2], int k) {
 template <int G, bool SIMPLE, int SRC, int U, bool CF = false, bool ACC = false, bool HF = false>
 __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl, unsigned gj, bool valid, unsigned gen, unsigned* slow_ctr,
                                             int lane, int& fresh, const SetProbe* cf = nullptr, unsigned* cf_stat = nullptr,
-                                            i64 kgiven = 0, unsigned lastgiven = 0, const SetProbe* own_plan = nullptr) {
-  static_assert(!HF || CF, "HF: only with the plans of the overlapped step");
-  constexpr bool hf = HF;
+                                            i64 kgiven = 0, unsigned lastgiven = 0, const SetProbe* own_plan = nullptr, int* not_hits = nullptr) {
+  constexpr bool hf = HF;   // (CF && HF: the overlapped step's launch; HF alone: upsert_own_kernel over a SET plan, victims checked against that plan)
   const u64* const scores = SIMPLE ? nullptr : a.scores;
   const TableView& v = a.v;
   const CsrKeys& ks = a.ks;
@@ -1327,12 +1332,18 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
       word[u] = best_word;
       act[u] = 3;
       flag_b0[u] = !ovf0 && (best_word >> 4) == b1[u];
-      if (CF) {
+      if (CF || HF) {
         const int vsrc = gshift + (int)(best_word & 15u);
         const i64 ka = shfl_i64(kk[u][0], vsrc), kb = shfl_i64(kk[u][1], vsrc);
         const i64 vk = (best_word >> 4) == (u64)b1[u] ? kb : ka;
-        // (HF: nor may it be a key of THIS batch — those are written without a claim, see below)
-        if (vk != EMPTY_KEY && (hf ? set_contains_either_group(*cf, *own_plan, vk, sub, gshift) : set_contains_group(*cf, vk, sub, gshift))) {   // the next lookup wants it: deferred
+        // CF: the next lookup wants it; HF: nor may it be a key of THIS batch — those are written without a claim, see below
+        bool wanted = false;
+        if (vk != EMPTY_KEY) {
+          if (CF && HF) wanted = set_contains_either_group(*cf, *own_plan, vk, sub, gshift);
+          else if (CF) wanted = set_contains_group(*cf, vk, sub, gshift);
+          else wanted = set_contains_group(*own_plan, vk, sub, gshift);
+        }
+        if (wanted) {   // deferred to the remainder
           act[u] = 0; why[u] = 3;
           if (cf_stat && sub == 0) atomicAdd(cf_stat, 1u);
         }
@@ -1452,6 +1463,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
     if (act[u] && flag_b0[u] && sub == 15) atomicOr((u64*)(key_line(v, b0[u]) + 15), META_OVF0);   // finds go on to b1
     if (sub == 0 && why[u]) { if (CF) __hip_atomic_store(a.dflag + gk[u], (uint8_t)4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else a.dflag[gk[u]] = 4; }
     fresh += (act[u] == 2 && sub == 0);
+    if (not_hits) *not_hits += (real && act[u] != 1 && sub == 0);   // (a new key, an eviction, a key handed to the remainder)
   }
   {   // left-over keys of the wave -> the list: one atomic add for all of them
     u64 sm[U];
@@ -1531,14 +1543,20 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
   }
 }
 
-template <int G, bool SIMPLE, int SRC, int U = 4, bool ACC = false>
+// HF (SRC_SET, round 6 — what the overlapped step's write-back role has done since round 5): a HIT claims nothing and reads no score
+// line; a key that changes a bucket claims behind its decision, and a victim that is a key of this very batch (a probe of the batch's own
+// SET plan) sends the new key to the remainder.  On a Zipf batch over resident ids (96 % hits) a key then touches its two key lines, its
+// value row and its row instead of four lines, two claim words and the rows; a batch of mostly NEW keys pays one more dependent trip per
+// wave (the score lines, then the claims) — the host picks the form from a sample of the previous write-back (launch_own).
+template <int G, bool SIMPLE, int SRC, int U = 4, bool ACC = false, bool HF = false>
 __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, unsigned own_gen, unsigned* progress,
                                                          unsigned progress_val) {
   const int lane = threadIdx.x & 63;
   const unsigned total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  int fresh = 0;
+  int fresh = 0, not_hits = 0, looked = 0;
+  const bool sampled = SRC == SRC_SET && (wave & 15u) == 0;   // every 16th wave tells how many of its keys were not plain hits
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (progress) {   // see hot_sums_kernel; [1]: the keys of this write-back — the host sizes the next one's grid from it
       __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1549,10 +1567,17 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
   const OwnFlags fl = own_setup<SIMPLE>(a);
   for (unsigned wbase = wave * (4 * U); wbase < total; wbase += nwaves * (4 * U)) {
     const unsigned i = wbase + (unsigned)(lane & 15);
-    own_batch16<G, SIMPLE, SRC, U, false, ACC>(a, fl, min(i, total - 1), (lane & 15) < 4 * U && i < total, own_gen, &ctr->n_a, lane, fresh);
+    const bool valid = (lane & 15) < 4 * U && i < total;
+    own_batch16<G, SIMPLE, SRC, U, false, ACC, HF>(a, fl, min(i, total - 1), valid, own_gen, &ctr->n_a, lane, fresh, nullptr, nullptr, 0, 0,
+                                                   HF ? &a.own_set : nullptr, sampled ? &not_hits : nullptr);
+    looked += (valid && lane < 16);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(a.v, wave, fresh);
+  if (sampled) {
+    for (int off = 32; off > 0; off >>= 1) { not_hits += __shfl_xor(not_hits, off); looked += __shfl_xor(looked, off); }
+    if (lane == 0 && looked) { atomicAdd(&ctr->spare[0], (unsigned)not_hits); atomicAdd(&ctr->spare[1], (unsigned)looked); }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2238,6 +2263,25 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
   } else {                                                                                                    \
     upsert_rest_kernel<GG, SRC><<<(unsigned)std::max<size_t>(1, (nkeys + 15) / 16), 256, 0, s>>>(a, nullptr, nullptr); \
   }
+  // The form of the pass over a SET plan's keys (16-byte granules): HF when the last write-back that has ended was mostly plain hits —
+  // fewer than a quarter of the keys its sample looked at were new, evicting or left over — (TFRA_OWN_HF=1: always, 0: never; tuning, tests)
+  if (SRC == SRC_SET && g == 16 && a.tags && a.own_set.ent) {
+    const char* e = getenv("TFRA_OWN_HF");
+    bool hf = false;
+    if (e && *e) hf = atoi(e) != 0;
+    else if (a.stats_host) {
+      const unsigned nh = reinterpret_cast<const volatile unsigned*>(a.stats_host)[0], lk = reinterpret_cast<const volatile unsigned*>(a.stats_host)[1];
+      hf = lk >= 64 && (size_t)nh * 4 < (size_t)lk;
+    }
+    if (hf) {
+#define TFRA_OWN_HF_LAUNCH(SS, UU) upsert_own_kernel<16, SS, SRC_SET, UU, false, true><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val)
+      if (simple) { if (half) TFRA_OWN_HF_LAUNCH(true, 2); else TFRA_OWN_HF_LAUNCH(true, 4); }
+      else { if (half) TFRA_OWN_HF_LAUNCH(false, 2); else TFRA_OWN_HF_LAUNCH(false, 4); }
+#undef TFRA_OWN_HF_LAUNCH
+      upsert_rest_kernel<16, SRC><<<rest_blocks, 256, 0, s>>>(a, &ctr->n_a, reinterpret_cast<unsigned*>(next_ctr));
+      return;
+    }
+  }
   switch (g) {
     case 16:
       if (simple) { if (half) { TFRA_OWN(16, true, 2); } else { TFRA_OWN(16, true, 4); } }
@@ -2324,6 +2368,13 @@ static int own_prepare(Table* t, const tfra_sparse_plan_t* pl, const void* value
   a.v = t->view_of(t->cur); a.vals = (const unsigned char*)values; a.scores = (const u64*)scores; a.ks = keys_of(pl); a.keys = nullptr; a.nkeys = 0;
   a.ai = t->aux; a.sp = sp;
   a.dflag = pl->dflag; a.tags = tags; a.items = pl->slow_items; a.item_cap = SLOW_CAP;
+  if (pl->kind == 1) {   // a SET plan: its table as something to probe (HF), and where the pass's sample goes
+    const SetTab& tb = pl->set_tab[pl->set_parity];
+    a.own_set = SetProbe{tb.ent, pl->set_m2};
+    if (!t->own_stats_host && hipHostMalloc((void**)&t->own_stats_host, 64, hipHostMallocDefault) == hipSuccess) { t->own_stats_host[0] = 0; t->own_stats_host[1] = 0; }
+    else if (!t->own_stats_host) t->own_stats_host = nullptr;
+    a.stats_host = t->own_stats_host;
+  }
   return TFRA_OK;
 }
 

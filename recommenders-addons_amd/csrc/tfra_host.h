@@ -42,6 +42,8 @@ struct Table {
   i64* d_scalar = nullptr;
   i64* h_scalar = nullptr;  // pinned
   unsigned* progress_host = nullptr;  // tfra_table_step_prefetch: pinned progress counter of the main stream
+  unsigned* own_stats_host = nullptr; // pinned: [0] keys that were NOT plain hits, [1] keys looked at — a sample (every 16th wave) of the last
+                                      // ownership write-back of a SET plan that has ended: picks the pass's form for the next one (launch_own)
   unsigned step_gen = 0;
   std::mutex step_mu;
   uint8_t* evict_flags = nullptr;  // phase-2 flags of a fused write-back on a bounded table

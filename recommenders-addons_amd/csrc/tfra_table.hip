@@ -1367,6 +1367,7 @@ int tfra_table_destroy(tfra_table_t* tp) {
   t->dfree(t->size_shards, s); t->dfree(t->reserved_present, s);
   t->dfree(t->winner, s); t->dfree(t->scratch, s); t->dfree(t->evict_flags, s); t->dfree(t->own_tags, s); t->dfree(t->own_ws, s);
   if (t->progress_host) (void)hipHostFree(t->progress_host);
+  if (t->own_stats_host) (void)hipHostFree(t->own_stats_host);
   if (t->h_scalar) (void)hipHostFree(t->h_scalar);
   if (t->chain_event) (void)hipEventDestroy(t->chain_event);
   if (t->size_event) (void)hipEventDestroy(t->size_event);
