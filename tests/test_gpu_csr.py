@@ -251,6 +251,53 @@ def test_upsert_sparse_bounded_table_at_capacity(env, owner_tags):
   assert np.all(v == v[:, :1])
 
 
+@pytest.mark.parametrize("form", ["auto", "hf", "claims"])
+def test_upsert_sparse_both_forms_of_the_pass_on_a_table_at_capacity(env, monkeypatch, form):
+  """The ownership pass over a SET plan's keys has two forms (upsert_own_kernel<…, HF>): every key claims its two home buckets up front, or
+  only the keys that CHANGE a bucket claim them behind their decision and a victim that is a key of the same batch defers the new key to
+  the remainder.  Forced either way (TFRA_OWN_HF) and picked from the previous write-back's sample ("auto": the stream alternates
+  between batches of resident keys and batches that are half new, so both forms run): after EVERY step each key of the batch holds the
+  row of its last occurrence (a hit that claims nothing must never lose its slot to an eviction of the same launch), size <= capacity,
+  and the export is a dictionary of last writes."""
+  torch, de, SparsePlan = env
+  if form == "auto":
+    monkeypatch.delenv("TFRA_OWN_HF", raising=False)
+  else:
+    monkeypatch.setenv("TFRA_OWN_HF", "1" if form == "hf" else "0")
+  dim, cap, B = 16, 60_000, 40_000
+  t = de.HkvHashTable(torch.int64, torch.float32, torch.zeros(dim), init_capacity=cap, max_capacity=cap, device="cuda:0", dim=dim,
+                      evict_strategy=de.HkvEvictStrategy.LRU, name="ups_forms_" + form)
+  rng = np.random.default_rng(11)
+  latest = {}
+  fresh = 1
+  zero = torch.zeros(dim, device="cuda")
+  for step in range(16):
+    hot = (rng.zipf(1.2, size=B) % 20_000).astype(np.int64)
+    if step % 4 >= 2:   # two steps of resident keys only, then two with half of the batch never seen before (evictions at capacity)
+      keys = hot
+      keys[: B // 2] = np.arange(fresh, fresh + B // 2, dtype=np.int64) + 1_000_000
+      fresh += B // 2
+      rng.shuffle(keys)
+    else:
+      keys = hot
+    vals = np.tile((np.arange(B, dtype=np.float32) + step * B)[:, None], (1, dim))
+    kt = torch.from_numpy(keys).cuda()
+    t._table.upsert_sparse(kt, torch.from_numpy(vals).cuda())
+    for i in range(B):
+      latest[int(keys[i])] = float(vals[i, 0])
+    got, ex = t._table.find(kt, zero, return_exists=True)
+    assert bool(ex.all()), (form, step, int((~ex).sum()))
+    np.testing.assert_array_equal(got[:, 0].cpu().numpy(), np.array([latest[int(x)] for x in keys], np.float32))
+    assert int(t.size().item()) <= cap
+  assert int(t.size().item()) > cap * 0.9
+  k, v = t.export()
+  k, v = k.cpu().numpy(), v.cpu().numpy()
+  assert np.unique(k).size == k.size
+  np.testing.assert_array_equal(v[:, 0], np.array([latest[int(x)] for x in k], np.float32))
+  assert np.all(v == v[:, :1])
+  t._table.check_errors()
+
+
 def test_multi_table_step_matches_per_table_steps(env):
   """tfra_multi_step_prefetch (host-thread pool, several stream pairs) == one PrefetchStep per table, bit for bit: the
   tables are independent, only who issues the launches differs.  26-table shape of BASELINE configs[4] in small."""
