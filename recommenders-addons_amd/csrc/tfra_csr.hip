@@ -2371,8 +2371,6 @@ static int own_prepare(Table* t, const tfra_sparse_plan_t* pl, const void* value
   if (pl->kind == 1) {   // a SET plan: its table as something to probe (HF), and where the pass's sample goes
     const SetTab& tb = pl->set_tab[pl->set_parity];
     a.own_set = SetProbe{tb.ent, pl->set_m2};
-    if (!t->own_stats_host && hipHostMalloc((void**)&t->own_stats_host, 64, hipHostMallocDefault) == hipSuccess) { t->own_stats_host[0] = 0; t->own_stats_host[1] = 0; }
-    else if (!t->own_stats_host) t->own_stats_host = nullptr;
     a.stats_host = t->own_stats_host;
   }
   return TFRA_OK;

@@ -1343,6 +1343,8 @@ int tfra_table_create(const tfra_table_opts* o, const tfra_allocator* alloc, tfr
   t->d_dense = t->reserved_present + 10;
   t->d_scalar = (i64*)(t->reserved_present + 12);
   if (hipHostMalloc((void**)&t->h_scalar, 64) != hipSuccess) return fail(set_error(TFRA_ERR_OOM, "pinned scalar"));
+  if (hipHostMalloc((void**)&t->own_stats_host, 64) != hipSuccess) { t->own_stats_host = nullptr; return fail(set_error(TFRA_ERR_OOM, "pinned sample words")); }
+  t->own_stats_host[0] = t->own_stats_host[1] = 0;   // (allocated here, not at the first write-back: that one may run under stream capture)
   if (hipEventCreateWithFlags(&t->chain_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
   if (hipEventCreateWithFlags(&t->size_event, hipEventDisableTiming) != hipSuccess) return fail(set_error(TFRA_ERR_HIP, "event"));
   t->h_size = t->h_scalar + 4;
