@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
   unsigned total = 0;
   if (!slow_ctr) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned counted = slow_ctr ? *slow_ctr : total;
-  if (SRC == SRC_SET && slow_ctr && a.stats_host && blockIdx.x == 0 && threadIdx.x == 0) {   // the pass's sample -> the host (launch_own)
+  if ((SRC == SRC_SET || SRC == SRC_DIRECT) && !ACC && slow_ctr && a.stats_host && blockIdx.x == 0 && threadIdx.x == 0) {   // the pass's sample -> the host (launch_own)
     __hip_atomic_store(a.stats_host, slow_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.stats_host + 1, slow_ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
         if (vk != EMPTY_KEY) {
           if (CF && HF) wanted = set_contains_either_group(*cf, *own_plan, vk, sub, gshift);
           else if (CF) wanted = set_contains_group(*cf, vk, sub, gshift);
-          else wanted = set_contains_group(*own_plan, vk, sub, gshift);
+          else wanted = own_plan ? set_contains_group(*own_plan, vk, sub, gshift) : true;   // (no plan to ask: defer — launch_own never picks HF then)
         }
         if (wanted) {   // deferred to the remainder
           act[u] = 0; why[u] = 3;
@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int fresh = 0, not_hits = 0, looked = 0;
-  const bool sampled = SRC == SRC_SET && (wave & 15u) == 0;   // every 16th wave tells how many of its keys were not plain hits
+  const bool sampled = (SRC == SRC_SET || SRC == SRC_DIRECT) && !ACC && (wave & 15u) == 0;   // every 16th wave tells how many of its keys were not plain hits
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (progress) {   // see hot_sums_kernel; [1]: the keys of this write-back — the host sizes the next one's grid from it
       __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1569,7 +1569,7 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
     const unsigned i = wbase + (unsigned)(lane & 15);
     const bool valid = (lane & 15) < 4 * U && i < total;
     own_batch16<G, SIMPLE, SRC, U, false, ACC, HF>(a, fl, min(i, total - 1), valid, own_gen, &ctr->n_a, lane, fresh, nullptr, nullptr, 0, 0,
-                                                   HF ? &a.own_set : nullptr, sampled ? &not_hits : nullptr);
+                                                   (HF && a.own_set.ent) ? &a.own_set : nullptr, sampled ? &not_hits : nullptr);
     looked += (valid && lane < 16);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
@@ -2263,9 +2263,12 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
   } else {                                                                                                    \
     upsert_rest_kernel<GG, SRC><<<(unsigned)std::max<size_t>(1, (nkeys + 15) / 16), 256, 0, s>>>(a, nullptr, nullptr); \
   }
-  // The form of the pass over a SET plan's keys (16-byte granules): HF when the last write-back that has ended was mostly plain hits —
-  // fewer than a quarter of the keys its sample looked at were new, evicting or left over — (TFRA_OWN_HF=1: always, 0: never; tuning, tests)
-  if (SRC == SRC_SET && g == 16 && a.tags && a.own_set.ent) {
+  // The form of the pass (16-byte granules): HF when the last write-back that has ended was mostly plain hits — fewer than a quarter of
+  // the keys its sample looked at were new, evicting or left over — (TFRA_OWN_HF=1: always, 0: never; tuning, tests).  Where it may be
+  // taken: over a SET plan's keys (a victim is checked against the plan), and over ANY keys — a caller's unique keys included: the
+  // reference's Insert op — on a table that never evicts (unbounded: TFRA's default cuckoo flavour), where the only thing a hit's claim
+  // protected it from does not exist.
+  if ((SRC == SRC_SET || SRC == SRC_DIRECT) && g == 16 && a.tags && ((SRC == SRC_SET && a.own_set.ent) || a.sp.bounded == 0)) {
     const char* e = getenv("TFRA_OWN_HF");
     bool hf = false;
     if (e && *e) hf = atoi(e) != 0;
@@ -2274,7 +2277,7 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
       hf = lk >= 64 && (size_t)nh * 4 < (size_t)lk;
     }
     if (hf) {
-#define TFRA_OWN_HF_LAUNCH(SS, UU) upsert_own_kernel<16, SS, SRC_SET, UU, false, true><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val)
+#define TFRA_OWN_HF_LAUNCH(SS, UU) upsert_own_kernel<16, SS, SRC, UU, false, true><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val)
       if (simple) { if (half) TFRA_OWN_HF_LAUNCH(true, 2); else TFRA_OWN_HF_LAUNCH(true, 4); }
       else { if (half) TFRA_OWN_HF_LAUNCH(false, 2); else TFRA_OWN_HF_LAUNCH(false, 4); }
 #undef TFRA_OWN_HF_LAUNCH
@@ -2441,6 +2444,7 @@ int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const 
   a.ai = t->aux; a.sp = sp; a.dflag = (uint8_t*)t->own_ws + head; a.tags = tags;
   a.items = reinterpret_cast<OwnItem*>((unsigned char*)t->own_ws + 256); a.item_cap = SLOW_CAP;
   a.exists = accum_exists; a.acc_dt = t->opts.value_dtype; a.d_nkeys = (const long long*)d_n;
+  a.stats_host = t->own_stats_host;
   if (accum_exists) launch_own_accum(s, simple, a, n, ctr, next_ctr, og, 32u);
   else launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, 32u, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: launch failed");

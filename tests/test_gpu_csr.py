@@ -298,6 +298,47 @@ def test_upsert_sparse_both_forms_of_the_pass_on_a_table_at_capacity(env, monkey
   t._table.check_errors()
 
 
+@pytest.mark.parametrize("form", ["auto", "hf", "claims"])
+def test_insert_of_unique_keys_both_forms_of_the_pass_on_a_growing_table(env, monkeypatch, form):
+  """The reference's Insert op (insert_or_assign of a caller's UNIQUE keys) on a table that never evicts (the cuckoo flavour, TFRA's
+  default): the pass may take the form in which a hit claims nothing — there is no eviction a claim would protect it from.  Forced both
+  ways and auto-picked; batches of resident keys, batches with a third of new keys (the table grows under the stream), the sentinel
+  keys: the table is a dictionary of last writes after every step."""
+  torch, de, SparsePlan = env
+  if form == "auto":
+    monkeypatch.delenv("TFRA_OWN_HF", raising=False)
+  else:
+    monkeypatch.setenv("TFRA_OWN_HF", "1" if form == "hf" else "0")
+  dim = 16
+  t = de.CuckooHashTable(torch.int64, torch.float32, torch.zeros(dim), device="cuda:0", dim=dim, name="ins_forms_" + form, init_size=200_000)
+  rng = np.random.default_rng(19)
+  imin = np.iinfo(np.int64).min
+  latest = {}
+  fresh = 1
+  zero = torch.zeros(dim, device="cuda")
+  for step in range(14):
+    keys = np.unique((rng.zipf(1.2, size=60_000) % 50_000).astype(np.int64) * 7919 - 11)
+    if step % 3 == 2:
+      new = np.arange(fresh, fresh + keys.size // 2, dtype=np.int64) * 7919 - 11 + 7919 * 1_000_000
+      fresh += new.size
+      keys = np.concatenate([keys, new, np.array([imin, imin + 1], np.int64)])
+    rng.shuffle(keys)
+    vals = np.tile((np.arange(keys.size, dtype=np.float32) + step * 100_000)[:, None], (1, dim))
+    kt = torch.from_numpy(keys).cuda()
+    t._table.upsert(kt, torch.from_numpy(vals).cuda(), unique_keys=True)
+    for i in range(keys.size):
+      latest[int(keys[i])] = float(vals[i, 0])
+    got, ex = t._table.find(kt, zero, return_exists=True)
+    assert bool(ex.all()), (form, step, int((~ex).sum()))
+    np.testing.assert_array_equal(got[:, 0].cpu().numpy(), vals[:, 0])
+    assert int(t.size().item()) == len(latest)
+  k, v = t.export()
+  k, v = k.cpu().numpy(), v.cpu().numpy()
+  assert np.unique(k).size == k.size == len(latest)
+  np.testing.assert_array_equal(v[:, 0], np.array([latest[int(x)] for x in k], np.float32))
+  t._table.check_errors()
+
+
 def test_multi_table_step_matches_per_table_steps(env):
   """tfra_multi_step_prefetch (host-thread pool, several stream pairs) == one PrefetchStep per table, bit for bit: the
   tables are independent, only who issues the launches differs.  26-table shape of BASELINE configs[4] in small."""
