@@ -1686,7 +1686,9 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
         myslot[r] = set_at(myslot[r], 1u, set_wmask(m2));
         was[r] = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[myslot[r]].key), (unsigned long long)EMPTY_KEY, (unsigned long long)mykey[r]);
       }
-      atomicMax(&cur.ent[myslot[r]].pos1, p1[r]);
+      // (INDEX — tf.unique: nobody reads a last position, and the entry's other word is what the other blocks POLL for the key's index:
+      // an atomic on the line they are reading is the slow kind, NOTEBOOK round 2)
+      if (!INDEX) atomicMax(&cur.ent[myslot[r]].pos1, p1[r]);
       if (COUNTS) atomicAdd(&cur.ent[myslot[r]].cnt, cn[r]);
     }
     myidx[r] = mine[r] ? atomicAdd(&s_n, 1u) : 0u;
@@ -1694,7 +1696,7 @@ __device__ __forceinline__ void setplan_block(const unsigned bid, const unsigned
   if (tid < 2 && s_pos[LDSN + tid] != 0) {   // a sentinel key value occurred in this block
     const unsigned sl = m2 + tid;
     const i64 w = (i64)atomicCAS(reinterpret_cast<unsigned long long*>(&cur.ent[sl].key), (unsigned long long)EMPTY_KEY, 1ULL);
-    atomicMax(&cur.ent[sl].pos1, s_pos[LDSN + tid]);
+    if (!INDEX) atomicMax(&cur.ent[sl].pos1, s_pos[LDSN + tid]);
     if (COUNTS) atomicAdd(&cur.ent[sl].cnt, s_cnt[LDSN + tid]);
     if (w == EMPTY_KEY) {
       const unsigned at = atomicAdd(cur.count, 1u);   // (rare: its own add)
