@@ -1129,8 +1129,8 @@ __global__ __launch_bounds__(256) void upsert_rest_kernel(const OwnArgs a, const
   if (!slow_ctr) total = SRC != SRC_DIRECT ? a.ks.d_counts[0] + a.ks.d_counts[1] : direct_count(a);
   const unsigned counted = slow_ctr ? *slow_ctr : total;
   if ((SRC == SRC_SET || SRC == SRC_DIRECT) && !ACC && slow_ctr && a.stats_host && blockIdx.x == 0 && threadIdx.x == 0) {   // the pass's sample -> the host (launch_own)
-    __hip_atomic_store(a.stats_host, slow_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(a.stats_host + 1, slow_ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.stats_host, slow_ctr[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // not plain hits
+    __hip_atomic_store(a.stats_host + 1, slow_ctr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // keys looked at
   }
   if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;   // last kernel of this use: arm the next use's counters
   if (counted == 0) return;
@@ -1548,7 +1548,8 @@ __device__ __forceinline__ void own_batch16(const OwnArgs& a, const OwnFlags fl,
 // SET plan) sends the new key to the remainder.  On a Zipf batch over resident ids (96 % hits) a key then touches its two key lines, its
 // value row and its row instead of four lines, two claim words and the rows; a batch of mostly NEW keys pays one more dependent trip per
 // wave (the score lines, then the claims) — the host picks the form from a sample of the previous write-back (launch_own).
-template <int G, bool SIMPLE, int SRC, int U = 4, bool ACC = false, bool HF = false>
+// SAMPLE: the launch leaves the sample described below (compiled out where nobody reads it: a caller's keys on a table that evicts)
+template <int G, bool SIMPLE, int SRC, int U = 4, bool ACC = false, bool HF = false, bool SAMPLE = false>
 __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtrs* ctr, unsigned own_gen, unsigned* progress,
                                                          unsigned progress_val) {
   const int lane = threadIdx.x & 63;
@@ -1556,7 +1557,9 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
   const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int fresh = 0, not_hits = 0, looked = 0;
-  const bool sampled = (SRC == SRC_SET || SRC == SRC_DIRECT) && !ACC && (wave & 15u) == 0;   // every 16th wave tells how many of its keys were not plain hits
+  // every 128th wave tells how many of its keys were not plain hits — ONE 64-bit add per such wave (every 16th wave with two adds: ~180
+  // same-line atomics piling up at the end of a one-round kernel, 9.9 -> 12.4 us for the DIRECT pass of 22 K keys under rocprofv3)
+  const bool sampled = SAMPLE && (wave & 127u) == 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (progress) {   // see hot_sums_kernel; [1]: the keys of this write-back — the host sizes the next one's grid from it
       __hip_atomic_store(progress, progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1569,14 +1572,15 @@ __global__ __launch_bounds__(256) void upsert_own_kernel(const OwnArgs a, OwnCtr
     const unsigned i = wbase + (unsigned)(lane & 15);
     const bool valid = (lane & 15) < 4 * U && i < total;
     own_batch16<G, SIMPLE, SRC, U, false, ACC, HF>(a, fl, min(i, total - 1), valid, own_gen, &ctr->n_a, lane, fresh, nullptr, nullptr, 0, 0,
-                                                   (HF && a.own_set.ent) ? &a.own_set : nullptr, sampled ? &not_hits : nullptr);
-    looked += (valid && lane < 16);
+                                                   (HF && a.own_set.ent) ? &a.own_set : nullptr, (SAMPLE && sampled) ? &not_hits : nullptr);
+    if (SAMPLE) looked += (valid && lane < 16);
   }
   for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
   if (lane == 0 && fresh) size_add(a.v, wave, fresh);
-  if (sampled) {
+  if (SAMPLE && sampled) {
     for (int off = 32; off > 0; off >>= 1) { not_hits += __shfl_xor(not_hits, off); looked += __shfl_xor(looked, off); }
-    if (lane == 0 && looked) { atomicAdd(&ctr->spare[0], (unsigned)not_hits); atomicAdd(&ctr->spare[1], (unsigned)looked); }
+    if (lane == 0 && looked)   // spare[1] (low word: keys looked at) | spare[2] (high word: not plain hits), 8-byte aligned
+      atomicAdd(reinterpret_cast<unsigned long long*>(&ctr->spare[1]), ((unsigned long long)(unsigned)not_hits << 32) | (unsigned long long)(unsigned)looked);
   }
 }
 
@@ -2258,9 +2262,11 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
   const bool half = g == 16 && nkeys <= 131072;
   const unsigned blocks = (unsigned)std::max<size_t>(1, half ? (nkeys + 31) / 32 : (nkeys + 63) / 64);
   // a.tags == nullptr (TFRA_OPTION_NO_OWNER_TAGS, or the tags did not allocate): the locked protocol for every key
+  const bool smp = a.stats_host != nullptr && (SRC == SRC_SET || SRC == SRC_DIRECT) && g == 16;   // somebody reads the sample
 #define TFRA_OWN(GG, SS, UU)                                                                                  \
   if (a.tags) {                                                                                               \
-    upsert_own_kernel<GG, SS, SRC, UU><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val);            \
+    if (GG == 16 && smp) upsert_own_kernel<GG, SS, SRC, UU, false, false, GG == 16><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val); \
+    else upsert_own_kernel<GG, SS, SRC, UU><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val);       \
     upsert_rest_kernel<GG, SRC><<<rest_blocks, 256, 0, s>>>(a, &ctr->n_a, reinterpret_cast<unsigned*>(next_ctr)); \
   } else {                                                                                                    \
     upsert_rest_kernel<GG, SRC><<<(unsigned)std::max<size_t>(1, (nkeys + 15) / 16), 256, 0, s>>>(a, nullptr, nullptr); \
@@ -2282,10 +2288,10 @@ static void launch_own(hipStream_t s, int g, bool simple, const OwnArgs& a, size
     if (e && *e) hf = atoi(e) != 0;
     else if (a.stats_host) {
       const unsigned nh = reinterpret_cast<const volatile unsigned*>(a.stats_host)[0], lk = reinterpret_cast<const volatile unsigned*>(a.stats_host)[1];
-      hf = lk >= 64 && (size_t)nh * 4 < (size_t)lk;
+      hf = lk >= 32 && (size_t)nh * 4 < (size_t)lk;
     }
     if (hf) {
-#define TFRA_OWN_HF_LAUNCH(SS, UU) upsert_own_kernel<16, SS, SRC, UU, false, true><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val)
+#define TFRA_OWN_HF_LAUNCH(SS, UU) upsert_own_kernel<16, SS, SRC, UU, false, true, true><<<blocks, 256, 0, s>>>(a, ctr, og, progress, progress_val)
       if (simple) { if (half) TFRA_OWN_HF_LAUNCH(true, 2); else TFRA_OWN_HF_LAUNCH(true, 4); }
       else { if (half) TFRA_OWN_HF_LAUNCH(false, 2); else TFRA_OWN_HF_LAUNCH(false, 4); }
 #undef TFRA_OWN_HF_LAUNCH
@@ -2452,7 +2458,7 @@ int own_upsert_unique(Table* t, hipStream_t s, size_t n, const i64* keys, const 
   a.ai = t->aux; a.sp = sp; a.dflag = (uint8_t*)t->own_ws + head; a.tags = tags;
   a.items = reinterpret_cast<OwnItem*>((unsigned char*)t->own_ws + 256); a.item_cap = SLOW_CAP;
   a.exists = accum_exists; a.acc_dt = t->opts.value_dtype; a.d_nkeys = (const long long*)d_n;
-  a.stats_host = t->own_stats_host;
+  a.stats_host = sp.bounded == 0 ? t->own_stats_host : nullptr;   // (a table that evicts never takes the other form for a caller's keys: nothing to sample for)
   if (accum_exists) launch_own_accum(s, simple, a, n, ctr, next_ctr, og, 32u);
   else launch_own<SRC_DIRECT>(s, g, simple, a, n, ctr, next_ctr, og, 32u, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return set_error(TFRA_ERR_HIP, "insert: launch failed");
