@@ -69,6 +69,9 @@ using namespace tfra::red;
 
 namespace {
 
+#ifndef TFRA_HOT_SUMS_HALVES
+#define TFRA_HOT_SUMS_HALVES 1   // hot_sums_kernel: 8 rows in flight, twice (0: 16 at once, the form of rounds 2-5; A/B)
+#endif
 constexpr int DIRECT = 8;                 // occurrences the update kernel gathers by itself
 constexpr int SEG = 512;                  // entries of a hot bin = rows one hot_sums block reduces
 constexpr unsigned E_SKIP = 1u << 31, E_HEAD = 1u << 30, E_POS = (1u << 18) - 1;
@@ -596,15 +599,31 @@ __global__ __launch_bounds__(NTA) void hot_sums_kernel(const float* __restrict__
     for (int k = 0; k < NCH; ++k) {
       const int col = k * 64 + sub * 4;
       const int cc = col < dim ? col : 0;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (TFRA_HOT_SUMS_HALVES && NCH == 1) {   // (rows of more than 64 floats keep 16 in flight: their kernels are at 122-128 registers either way)
+      // 8 rows in flight, twice, instead of 16 at once: 76 registers instead of 106 => 6 waves per SIMD instead of 4 => the ~680 bins of
+      // a Zipf batch (512-thread blocks) are resident in ONE round instead of two; the second batch of loads costs a trip, the second round
+      // cost more: 10.0 -> 9.2 us under rocprofv3, configs[1]'s step 56.7-57.3 -> 55.6-55.7 us (A/B on one box, twice).  Same adds, same order.
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4*>(grads + rows[h * 8 + j] + cc);
+        keep_live(x[0], x[1], x[2], x[3]); keep_live(x[4], x[5], x[6], x[7]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if ((live >> (h * 8 + j)) & 1u) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+      }
+      } else {
       float4 x[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const float4*>(grads + rows[j] + cc);   // 16 rows in flight
       keep_live(x[0], x[1], x[2], x[3]); keep_live(x[4], x[5], x[6], x[7]);
       keep_live(x[8], x[9], x[10], x[11]); keep_live(x[12], x[13], x[14], x[15]);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < 16; ++j)
         if ((live >> j) & 1u) { acc.x += x[j].x; acc.y += x[j].y; acc.z += x[j].z; acc.w += x[j].w; }
+      }
       if (k) __syncthreads();   // the owners of the previous chunk have read s_sum
       *reinterpret_cast<float4*>(&s_sum[g][sub * 4]) = acc;
       __syncthreads();
