@@ -946,7 +946,7 @@ def run_bounded(args, torch, de, dev, cfg):
 
   # `value` = ONE driver per workload, chosen by RULE (de.assign_step_driver_for: the stream's share of never-seen ids), not by
   # result: the overlapped step for streams that mostly revisit resident keys (the metric's), the look-ahead driver when more than
-  # a quarter of a batch are never-seen ids (configs[2]: the write-back with its evictions is the long pole and runs faster as
+  # a tenth of a batch are never-seen ids (configs[2]: the write-back with its evictions is the long pole and runs faster as
   # kernels of its own).  The other driver's number is reported beside it.
   best_is_overlapped = de.assign_step_driver_for(new_ratio) == "overlapped_step"
   med_best = med if best_is_overlapped else med_pf
@@ -989,7 +989,7 @@ def run_bounded(args, torch, de, dev, cfg):
       "value_overlapped_step_4_steps_per_host_call": B * K / med_d4, "ms_per_step_overlapped_step_4_steps_per_host_call": med_d4 / K * 1e3,
       "value_look_ahead_driver": B * K / med_pf, "ms_per_step_look_ahead_driver": med_pf / K * 1e3,
       "driver": "overlapped_step" if best_is_overlapped else "look_ahead",
-      "driver_rule": "de.assign_step_driver_for(new_key_ratio): overlapped_step when <= 25 %% of a batch are never-seen ids, else look_ahead "
+      "driver_rule": "de.assign_step_driver_for(new_key_ratio): overlapped_step when <= 10 %% of a batch are never-seen ids, else look_ahead "
                      "(new_key_ratio here: %.2f)" % new_ratio,
       "routed_local": None if routed_local is None else (routed_local if "error" in routed_local else {
           "value": B * K / routed_local["med"], "ms_per_step": routed_local["med"] / K * 1e3, "owner_launch_us": routed_local["owner_launch_us"],

@@ -678,10 +678,12 @@ class PrefetchAssignStep:
 
 def assign_step_driver_for(new_key_ratio):
   """Which of the table's two step drivers a lookup + insert_or_assign stream should use, by RULE: 'overlapped_step'
-  (OverlapAssignStep: lookup i+1 and write-back i in one launch, shared ids forwarded) when at most a quarter of a batch's ids are
+  (OverlapAssignStep: lookup i+1 and write-back i in one launch, shared ids forwarded) when at most a tenth of a batch's ids are
   never-seen keys; 'look_ahead' (PrefetchAssignStep) beyond — every never-seen key on a full bounded table is an eviction, the
-  write-back becomes the long pole and runs faster as kernels of its own with the whole chip and its own register budget."""
-  return "overlapped_step" if float(new_key_ratio) <= 0.25 else "look_ahead"
+  write-back becomes the long pole and runs faster as kernels of its own with the whole chip and its own register budget.
+  (Where the two cross on the metric's table, profiles/r06_m1b_new_key_ratio_sweep.log: 0 % never-seen ids 21.5 vs 36.3 us per step,
+  1 % 29.2 vs 37.3, 5 % 43.6 vs 43.1, 10 % 46.8 vs 46.9, 25 % 58.5 vs 53.2 — until round 6 the rule said a quarter.)"""
+  return "overlapped_step" if float(new_key_ratio) <= 0.10 else "look_ahead"
 
 
 class _LookAheadAssignStep:

@@ -434,7 +434,7 @@ def test_assign_step_for_picks_a_driver_by_rule_and_both_give_the_sequential_res
   """de.assign_step_for(table, new_key_ratio): the overlapped step up to a quarter never-seen ids per batch, the look-ahead driver
   beyond — one interface, the same results (lookup i+1 sees write-back i)."""
   torch, de = env
-  assert de.assign_step_driver_for(0.0) == de.assign_step_driver_for(0.25) == "overlapped_step" and de.assign_step_driver_for(0.26) == "look_ahead"
+  assert de.assign_step_driver_for(0.0) == de.assign_step_driver_for(0.10) == "overlapped_step" and de.assign_step_driver_for(0.11) == "look_ahead"
   dim, cap, n, nsteps = 64, 300_000, 4000, 6
   rng = np.random.default_rng(31)
   universe = rng.permutation(np.arange(1, int(cap * 0.62) + 1, dtype=np.int64)) * 7919 + 3
